@@ -1,0 +1,194 @@
+/*
+ * oak_hip.h -- C ABI of the MI355X-native OAK Gram / SGPR-ELBO / predict / Sobol path.
+ *
+ * This is the drop-in boundary.  The reference (amzn/orthogonal-additive-gaussian-processes)
+ * is pure Python and has no FFI of its own; the path sits behind the GPflow `Kernel` protocol and
+ * the GPflow SGPR/GPR model methods.  Each entry point below names the reference interface it
+ * replaces (file:line relative to the upstream repo root).  The only caller is the ctypes layer
+ * `orthogonal-additive-gaussian-processes_amd/oak/_capi.py`; INTEGRATION.md shows the binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - every function returns an int status (OAK_OK == 0, negative == error) and records a
+ *     thread-local message retrievable with oak_last_error();
+ *   - all host buffers are caller-owned, C-contiguous, row-major, float64 (int32 where stated);
+ *   - the library owns all device memory behind an opaque oak_ctx (one per device, one HIP
+ *     stream); a ctx is not thread-safe, distinct ctxs are independent;
+ *   - there is NO CPU fallback: without a usable HIP device every compute call fails with
+ *     OAK_E_HIP.
+ */
+#ifndef OAK_HIP_H
+#define OAK_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OAK_OK        0
+#define OAK_E_ARG    -1   /* bad argument / unsupported configuration            */
+#define OAK_E_HIP    -2   /* HIP runtime error (no device, OOM, launch failure)   */
+#define OAK_E_NOTPD  -3   /* Cholesky met a non-positive pivot (tf InvalidArgumentError analogue) */
+#define OAK_E_NCCL   -4   /* RCCL error                                           */
+#define OAK_E_STATE  -5   /* call order violated (e.g. predict before posterior)  */
+
+#define OAK_MAX_DIMS   64  /* sub-kernels per OAK kernel                          */
+#define OAK_MAX_DEPTH   8  /* max_interaction_depth supported by the fused kernels */
+
+/* dim_type: which constrained base kernel a sub-kernel is */
+#define OAK_DIM_RBF          0  /* oak/ortho_rbf_kernel.py:20-177         */
+#define OAK_DIM_BINARY       1  /* oak/ortho_binary_kernel.py:13-59       */
+#define OAK_DIM_CATEGORICAL  2  /* oak/ortho_categorical_kernel.py:14-74  */
+
+/* measure: input measure of an RBF sub-kernel (oak/input_measures.py:16-78) */
+#define OAK_MEAS_NONE       0   /* unconstrained RBF (constrain_orthogonal=False, oak_kernel.py:199-210) */
+#define OAK_MEAS_GAUSSIAN   1   /* p0 = mu, p1 = var                      */
+#define OAK_MEAS_UNIFORM    2   /* p0 = a,  p1 = b                        */
+#define OAK_MEAS_EMPIRICAL  3   /* data: K locations then K weights       */
+#define OAK_MEAS_MOG        4   /* data: K means, K variances, K weights  */
+
+/*
+ * Plain-old-data description of an OAKKernel (oak/oak_kernel.py:59-221) at its current
+ * (constrained) parameter values.  All pointers are host pointers, read during the call only.
+ */
+typedef struct oak_kernel_desc {
+    int32_t num_dims;           /* D = len(kernel.kernels)                                   */
+    int32_t max_depth;          /* R = max_interaction_depth                                 */
+    int32_t share_var;          /* share_var_across_orders (oak_kernel.py:212-221)           */
+    int32_t n_order_var;        /* R+1 if share_var else 1                                   */
+    const double*  order_var;   /* [n_order_var] kernel.variances                            */
+    const int32_t* dim_type;    /* [D] OAK_DIM_*                                             */
+    const int32_t* active_col;  /* [D] column of X the sub-kernel reads (active_dims)        */
+    const double*  lengthscale; /* [D] base_kernel.lengthscales (RBF dims)                   */
+    const double*  base_var;    /* [D] base_kernel.variance / kernel.variance                */
+    const int32_t* measure;     /* [D] OAK_MEAS_* (RBF dims)                                 */
+    const double*  meas_p0;     /* [D] gaussian mu | uniform a | binary p0                   */
+    const double*  meas_p1;     /* [D] gaussian var | uniform b                              */
+    const int32_t* meas_k;      /* [D] #locations | #mixture comps | #categories             */
+    const int32_t* meas_off;    /* [D] offset (in doubles) of this dim's block in meas_data  */
+    const double*  meas_data;   /* empirical: loc[K],w[K]; mog: mu[K],var[K],w[K];
+                                   categorical: row-major C*C table B WITHOUT the variance
+                                   factor (A - Ap Ap^T / p^T A p, ortho_categorical_kernel.py:34-42)
+                                   followed by the C-vector p                                */
+    int32_t meas_data_len;
+} oak_kernel_desc;
+
+typedef struct oak_ctx oak_ctx;
+
+/* ---- runtime ------------------------------------------------------------------------------ */
+const char* oak_last_error(void);
+const char* oak_version(void);
+int oak_device_count(int* count);
+int oak_ctx_create(int device, oak_ctx** out);
+int oak_ctx_destroy(oak_ctx* ctx);
+int oak_sync(oak_ctx* ctx);
+/* wall time (ms) of the last named phase measured with hipEvents on the ctx stream:
+   name in {"gram","syrk","tail","featurize","total","bwd_gemm","bwd_gram"}; count = launches */
+int oak_last_timing(oak_ctx* ctx, const char* name, double* ms, int32_t* count);
+int oak_device_mem_info(oak_ctx* ctx, double* free_bytes, double* total_bytes);
+
+/* ---- Gram (replaces OAKKernel.K / K_diag, oak/oak_kernel.py:251-278, and through it
+ *      OrthogonalRBFKernel.K / K_diag ortho_rbf_kernel.py:157-177, OrthogonalBinary.K :40-59,
+ *      OrthogonalCategorical.K :55-74, compute_additive_terms oak_kernel.py:223-249) ---------- */
+/* out[n1 x n2] = K(X1, X2);  X2 == NULL means X2 = X1.  ldx = row stride of X1/X2 in doubles. */
+int oak_gram(oak_ctx* ctx, const oak_kernel_desc* desc,
+             const double* X1, int64_t n1, const double* X2, int64_t n2, int32_t ldx,
+             double* out);
+/* out[n] = K_diag(X) */
+int oak_gram_diag(oak_ctx* ctx, const oak_kernel_desc* desc,
+                  const double* X, int64_t n, int32_t ldx, double* out);
+/* KernelComponenent.K (oak_kernel.py:300-320): sigma2_{|S|} * prod_{d in S} k_d; subset = indices
+   into the D sub-kernels; apply_order_var mirrors share_var_across_orders of the component. */
+int oak_gram_component(oak_ctx* ctx, const oak_kernel_desc* desc,
+                       const int32_t* subset, int32_t subset_len, int32_t apply_order_var,
+                       const double* X1, int64_t n1, const double* X2, int64_t n2, int32_t ldx,
+                       double* out);
+int oak_gram_component_diag(oak_ctx* ctx, const oak_kernel_desc* desc,
+                            const int32_t* subset, int32_t subset_len, int32_t apply_order_var,
+                            const double* X, int64_t n, int32_t ldx, double* out);
+
+/* ---- SGPR (replaces gpflow.models.SGPR as constructed at oak/model_utils.py:149-157:
+ *      elbo / predict_f / the alpha of oak/utils.py:180-198) --------------------------------- */
+/* Upload training data (X [N x ldx], Y [N], single output column) and inducing inputs Z [M x ldx].
+   Data stay resident in HBM until replaced. */
+int oak_sgpr_set_data(oak_ctx* ctx, const double* X, const double* Y, int64_t N, int32_t ldx);
+int oak_sgpr_set_inducing(oak_ctx* ctx, const double* Z, int64_t M, int32_t ldx);
+/* Row budget of the N x M Kuf panel kept in HBM per pass (0 = library default). */
+int oak_sgpr_set_panel_rows(oak_ctx* ctx, int64_t rows);
+/* Sufficient statistics of the local rows, left on the device in the packed layout
+   [Phi (M*M) | psi (M) | kappa | yy | n_rows], Phi = Kuf Kuf^T, psi = Kuf y,
+   kappa = sum K_diag(X), yy = y^T y. */
+int oak_sgpr_local_stats(oak_ctx* ctx, const oak_kernel_desc* desc, double jitter);
+/* Solve route.  1 = "phi": accumulate Phi = Kuf Kuf^T (M^2 N flops) and whiten the M x M result in the
+   tail; deviation from GPflow's op order grows like cond(Kuu)*eps.  2 = "whitened": apply L^-1 to each
+   Kuf column first, exactly GPflow's A = L^-1 Kuf (oak/utils.py:189), 2x the flops; the packed Phi slot
+   then holds W = L^-1 Phi L^-T.  0 = auto (whitened while N*M <= 2^24). All ranks must agree. */
+int oak_sgpr_set_route(oak_ctx* ctx, int32_t route);
+int oak_sgpr_stats_whitened(oak_ctx* ctx, int32_t* flag);
+int64_t oak_sgpr_stats_len(oak_ctx* ctx);                    /* M*M + M + 3 */
+int oak_sgpr_get_stats(oak_ctx* ctx, double* packed_out);    /* D2H copy of the packed buffer */
+int oak_sgpr_set_stats(oak_ctx* ctx, const double* packed, int32_t whitened);  /* H2D (externally reduced stats) */
+/* Replicated O(M^3) tail on the packed stats: L=chol(Kuu+jitter I), AAT, LB, c, alpha, ELBO
+   (gpflow SGPR.elbo; op order of oak/utils.py:187-198).  terms_out (may be NULL) receives
+   [sum log diag LB, c^T c, tr(AAT), kappa, yy, n_rows, log det Kuu, 0]. */
+int oak_sgpr_tail(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, double jitter,
+                  double* elbo_out, double* terms_out);
+/* Convenience: local_stats + (all-reduce when a communicator is attached) + tail. */
+int oak_sgpr_elbo(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, double jitter,
+                  double* elbo_out);
+/* alpha [M] of oak/utils.py:197-198; valid after a successful tail/elbo call. */
+int oak_sgpr_alpha(oak_ctx* ctx, double* alpha_out);
+/* SGPR.predict_f(full_cov=False): mean[Ns], var[Ns]; valid after tail/elbo with the same desc. */
+int oak_sgpr_predict(oak_ctx* ctx, const oak_kernel_desc* desc,
+                     const double* Xs, int64_t Ns, int32_t ldx, double* mean, double* var);
+/* d ELBO / d (constrained) parameters, packed as
+   [lengthscale (D) | base_var (D) | order_var (n_order_var) | noise_var | dTable (meas_data_len,
+   only categorical table entries are filled)].  Requires a preceding tail/elbo call. */
+int64_t oak_grad_len(const oak_kernel_desc* desc);
+int oak_sgpr_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, double jitter,
+                       double* elbo_out, double* grad_out);
+
+/* ---- GPR (replaces gpflow.models.GPR constructed at oak/model_utils.py:159;
+ *      in-tree mirror oak/utils.py:206-211) -------------------------------------------------- */
+int oak_gpr_set_data(oak_ctx* ctx, const double* X, const double* Y, int64_t N, int32_t ldx);
+int oak_gpr_log_marginal(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, double* out);
+int oak_gpr_alpha(oak_ctx* ctx, double* alpha_out);         /* cholesky_solve(L, Y), utils.py:211 */
+int oak_gpr_predict(oak_ctx* ctx, const oak_kernel_desc* desc,
+                    const double* Xs, int64_t Ns, int32_t ldx, double* mean, double* var);
+int oak_gpr_log_marginal_grad(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var,
+                              double* out, double* grad_out);
+
+/* ---- Sobol (replaces compute_sobol_oak, oak/utils.py:338-435, with compute_L :221-240,
+ *      compute_L_binary_kernel :243-272, compute_L_categorical_kernel :275-309,
+ *      compute_L_empirical_measure :312-335) ------------------------------------------------- */
+/* Xc [n x ldx] = inducing inputs (sparse) or training inputs (full GP); alpha [n].
+   subsets: concatenated dim indices, subset_off [n_subsets+1].  use_order_var mirrors
+   share_var_across_orders (utils.py:376-382).  out[n_subsets] = alpha^T (prod_d L_d) alpha. */
+int oak_sobol(oak_ctx* ctx, const oak_kernel_desc* desc, const double* Xc, int64_t n, int32_t ldx,
+              const double* alpha, const int32_t* subsets, const int32_t* subset_off,
+              int32_t n_subsets, int32_t use_order_var, double delta, double mu, double* out);
+/* Per-term predictive means (get_prediction_component, oak/utils.py:491-530):
+   out[n_subsets x ns] = (sigma2_|S| prod_{d in S} k_d(Xs, Xc)) alpha */
+int oak_component_predict(oak_ctx* ctx, const oak_kernel_desc* desc, const double* Xs, int64_t ns,
+                          const double* Xc, int64_t n, int32_t ldx, const double* alpha,
+                          const int32_t* subsets, const int32_t* subset_off, int32_t n_subsets,
+                          int32_t use_order_var, double* out);
+
+/* ---- multi-GPU (new; the reference has no distributed code).  One process per GPU; the packed
+ *      statistics are summed with one RCCL all-reduce (reduce-scatter + all-gather) over xGMI. */
+int oak_comm_unique_id(char* id_out_128);                      /* ncclGetUniqueId on rank 0   */
+int oak_comm_init(oak_ctx* ctx, const char* id_128, int32_t nranks, int32_t rank);
+int oak_comm_destroy(oak_ctx* ctx);
+int oak_comm_allreduce_stats(oak_ctx* ctx);                    /* in-place sum of packed stats */
+int oak_comm_allreduce_host(oak_ctx* ctx, double* buf, int64_t n); /* small host vector (gradients) */
+
+/* ---- device-resident benchmarking hooks (inputs already in HBM) ---------------------------- */
+/* Explicit Kuf panel for the rows set with oak_sgpr_set_data, written to a device buffer and not
+   copied back: the "Gram GB/s" workload.  bytes_out = algorithmic bytes 8*(N*M + N*D + M*D). */
+int oak_bench_gram_resident(oak_ctx* ctx, const oak_kernel_desc* desc, double* bytes_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OAK_HIP_H */

@@ -1,0 +1,344 @@
+// Fused OAK Gram kernel: constrained base kernels (RBF / binary / categorical) + elementary symmetric
+// polynomial combination, one pass, nothing but the final K tile leaves registers.
+//
+// Replaces OAKKernel.K / K_diag (oak/oak_kernel.py:251-278): the reference materialises D per-dimension
+// N x M matrices (:252-254), R+1 power sums and R Newton-Girard terms (:236-249).  Here each lane owns an
+// RT x CPT block of (row, column) pairs and runs the e_r recurrence  e_r += k_d * e_{r-1}  (r = R..1) over d in
+// registers -- algebraically the same elementary symmetric polynomials, D*R FMAs per pair and no pow().
+//
+// Roofline: fp64-VALU bound (one software exp2 per pair per dimension: ~17 DP ops), not HBM bound.
+// fp64 MFMA shares the DP pipe with fp64 VALU on gfx950 (measured, tools/ubench), so there is nothing to
+// overlap with; the kernel is written to issue the minimum number of DP instructions per pair.
+#include "oak_internal.h"
+
+namespace oak {
+
+// 2^t for t <= 0 (clamped at -1100): round-to-nearest split t = k + r, |r| <= 1/2, degree-13 Taylor in r*ln2,
+// then ldexp.  1.13 ulp max error measured against long-double exp2l (tools/ubench/fp64_overlap.hip).
+__device__ __forceinline__ double exp2_neg_poly(double t) {
+    // coefficients c_i = ln(2)^i / i!
+    constexpr double c1 = 6.931471805599453094e-01, c2 = 2.402265069591007123e-01, c3 = 5.550410866482157995e-02,
+                     c4 = 9.618129107628477162e-03, c5 = 1.333355814642844342e-03, c6 = 1.540353039338160995e-04,
+                     c7 = 1.525273380405984028e-05, c8 = 1.321548679014430949e-06, c9 = 1.017808600923969973e-07,
+                     c10 = 7.054911620801123329e-09, c11 = 4.445538271870811498e-10, c12 = 2.567843599348820514e-11,
+                     c13 = 1.369148885390412888e-12;
+    t = __builtin_fmax(t, -1100.0);
+    const double kd = __builtin_rint(t);
+    const double r = t - kd;
+    double p = c13;
+    p = __builtin_fma(p, r, c12);
+    p = __builtin_fma(p, r, c11);
+    p = __builtin_fma(p, r, c10);
+    p = __builtin_fma(p, r, c9);
+    p = __builtin_fma(p, r, c8);
+    p = __builtin_fma(p, r, c7);
+    p = __builtin_fma(p, r, c6);
+    p = __builtin_fma(p, r, c5);
+    p = __builtin_fma(p, r, c4);
+    p = __builtin_fma(p, r, c3);
+    p = __builtin_fma(p, r, c2);
+    p = __builtin_fma(p, r, c1);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_ldexp(p, (int)kd);
+}
+
+// One base-kernel value k_d(a, b).
+__device__ __forceinline__ double base_k_rbf(double xa, double ca, double xb, double cb, double log2bv) {
+    const double u = xa - xb;
+    const double t = __builtin_fma(-u, u, log2bv);
+    const double E = exp2_neg_poly(t);
+    return __builtin_fma(-ca, cb, E);
+}
+
+template <int R>
+__device__ __forceinline__ void esp_update(double (&e)[R > 0 ? R : 1], double k) {
+    if constexpr (R > 0) {
+#pragma unroll
+        for (int q = R - 1; q >= 1; --q) e[q] = __builtin_fma(k, e[q - 1], e[q]);
+        e[0] += k;
+    }
+}
+
+template <int R>
+__device__ __forceinline__ double esp_combine(const double (&e)[R > 0 ? R : 1], const DevDesc& dd) {
+    double K = dd.w[0];
+    if constexpr (R > 0) {
+#pragma unroll
+        for (int q = 0; q < R; ++q) K = __builtin_fma(dd.w[q + 1], e[q], K);
+    }
+    return K;
+}
+
+// Tile geometry: 256 threads = 4 waves.  Lane tx (0..63) owns CPT columns, wave ty owns RT rows per row-step.
+//   CPT == 4: columns jb + 2*tx + {0,1} and jb + 128 + 2*tx + {0,1}   (two 16-byte stores per row)
+//   CPT == 2: columns jb + 2*tx + {0,1}
+// The B-side (column) features of all D dims stay in LDS for the whole workgroup; A-side (row) features are
+// restaged per row-step.  Dynamic LDS = (D*TJ*2 + D*4*RT*2 + 4*RT) doubles.
+template <int R, int RT, int CPT>
+__global__ void __launch_bounds__(256)
+gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* __restrict__ Axs,
+            const double* __restrict__ Acn, int64_t a_ld, int64_t a0, int64_t na, const double* __restrict__ Bxs,
+            const double* __restrict__ Bcn, int64_t b_ld, int64_t nb, double* __restrict__ out, int64_t ldo,
+            int rows_per_wg, const double* __restrict__ yA, double* __restrict__ psi_part, int64_t zero_pad_to) {
+    constexpr int TJ = 64 * CPT;
+    constexpr int RS = 4 * RT;   // rows per row-step
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int D = dd.D;
+    double* Bx = smem;                 // [D][TJ]
+    double* Bc = Bx + D * TJ;          // [D][TJ]
+    double* Ax = Bc + D * TJ;          // [D][RS]
+    double* Ac = Ax + D * RS;          // [D][RS]
+    double* Ay = Ac + D * RS;          // [RS]
+    const int tid = threadIdx.x;
+    const int tx = tid & 63;
+    const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t jb = (int64_t)blockIdx.x * TJ;
+    const int64_t ib = (int64_t)blockIdx.y * rows_per_wg;      // relative to a0
+    const int64_t iend = (ib + rows_per_wg < na) ? ib + rows_per_wg : na;
+
+    // stage B-side features (coalesced over columns); Feat arrays are padded so reads past nb are safe zeros
+    for (int idx = tid; idx < D * TJ; idx += 256) {
+        const int d = idx / TJ, j = idx - d * TJ;
+        const int64_t gj = jb + j;
+        const bool ok = gj < nb;
+        Bx[idx] = ok ? Bxs[(int64_t)d * b_ld + gj] : 0.0;
+        Bc[idx] = ok ? Bcn[(int64_t)d * b_ld + gj] : 0.0;
+    }
+    double psi[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) psi[c] = 0.0;
+
+    for (int64_t i0 = ib; i0 < iend; i0 += RS) {
+        __syncthreads();   // previous step's readers done (and B-side staged on first pass)
+        for (int idx = tid; idx < D * RS; idx += 256) {
+            const int d = idx / RS, r = idx - d * RS;
+            const int64_t gi = i0 + r;
+            const bool ok = gi < iend;
+            Ax[idx] = ok ? Axs[(int64_t)d * a_ld + a0 + gi] : 0.0;
+            Ac[idx] = ok ? Acn[(int64_t)d * a_ld + a0 + gi] : 0.0;
+        }
+        if (yA != nullptr && tid < RS) Ay[tid] = (i0 + tid < iend) ? yA[a0 + i0 + tid] : 0.0;
+        __syncthreads();
+
+        double e[RT][CPT][R > 0 ? R : 1];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+#pragma unroll
+                for (int q = 0; q < (R > 0 ? R : 1); ++q) e[r][c][q] = 0.0;
+
+        if constexpr (R > 0) {
+            for (int d = 0; d < D; ++d) {
+                double xb[CPT], cb[CPT], xa[RT], ca[RT];
+#pragma unroll
+                for (int c2 = 0; c2 < CPT / 2; ++c2) {
+                    const double2 vx = *reinterpret_cast<const double2*>(&Bx[d * TJ + c2 * 128 + 2 * tx]);
+                    const double2 vc = *reinterpret_cast<const double2*>(&Bc[d * TJ + c2 * 128 + 2 * tx]);
+                    xb[2 * c2] = vx.x; xb[2 * c2 + 1] = vx.y;
+                    cb[2 * c2] = vc.x; cb[2 * c2 + 1] = vc.y;
+                }
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    xa[r] = Ax[d * RS + ty * RT + r];
+                    ca[r] = Ac[d * RS + ty * RT + r];
+                }
+                if (dd.type[d] == OAK_DIM_RBF) {
+                    const double l2 = dd.log2bv[d];
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+#pragma unroll
+                        for (int c = 0; c < CPT; ++c) {
+                            const double k = base_k_rbf(xa[r], ca[r], xb[c], cb[c], l2);
+                            esp_update<R>(e[r][c], k);
+                        }
+                } else {
+                    const int C = dd.ncat[d];
+                    const double* tab = tables + dd.tab_off[d];
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+#pragma unroll
+                        for (int c = 0; c < CPT; ++c) {
+                            const double k = tab[(int)xa[r] * C + (int)xb[c]];
+                            esp_update<R>(e[r][c], k);
+                        }
+                }
+            }
+        }
+        // epilogue: combine orders, optional psi accumulation, store
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int64_t gi = i0 + ty * RT + r;
+            double kv[CPT];
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) kv[c] = esp_combine<R>(e[r][c], dd);
+            if (yA != nullptr) {
+                const double yv = Ay[ty * RT + r];
+#pragma unroll
+                for (int c = 0; c < CPT; ++c) psi[c] = __builtin_fma(kv[c], yv, psi[c]);
+            }
+            if (gi < iend && out != nullptr) {
+                double* orow = out + gi * ldo;   // output rows are relative to the chunk start a0
+#pragma unroll
+                for (int c2 = 0; c2 < CPT / 2; ++c2) {
+                    const int64_t gj = jb + c2 * 128 + 2 * tx;
+                    const bool al = ((ldo & 1) == 0);
+                    if (gj + 1 < nb && al) {
+                        *reinterpret_cast<double2*>(orow + gj) = make_double2(kv[2 * c2], kv[2 * c2 + 1]);
+                    } else {
+                        if (gj < nb) orow[gj] = kv[2 * c2];
+                        else if (gj < zero_pad_to) orow[gj] = 0.0;
+                        if (gj + 1 < nb) orow[gj + 1] = kv[2 * c2 + 1];
+                        else if (gj + 1 < zero_pad_to) orow[gj + 1] = 0.0;
+                    }
+                }
+            }
+        }
+    }
+    if (yA != nullptr) {
+        // reduce the 4 waves' psi partials through LDS (fixed order -> deterministic), one row of partials per WG row-block
+        __syncthreads();
+        double* red = smem;   // reuse: [4][TJ]
+#pragma unroll
+        for (int c2 = 0; c2 < CPT / 2; ++c2) {
+            red[ty * TJ + c2 * 128 + 2 * tx] = psi[2 * c2];
+            red[ty * TJ + c2 * 128 + 2 * tx + 1] = psi[2 * c2 + 1];
+        }
+        __syncthreads();
+        for (int j = tid; j < TJ; j += 256) {
+            const int64_t gj = jb + j;
+            if (gj < nb) psi_part[(int64_t)blockIdx.y * nb + gj] = ((red[j] + red[TJ + j]) + red[2 * TJ + j]) + red[3 * TJ + j];
+        }
+    }
+}
+
+// column sums of a [rows x cols] row-major matrix in fixed order, accumulated onto out
+__global__ void __launch_bounds__(256) colsum_accum_kernel(const double* __restrict__ part, int64_t rows, int64_t cols,
+                                                           double* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= cols) return;
+    double s = 0.0;
+    for (int64_t r = 0; r < rows; ++r) s += part[r * cols + j];
+    out[j] += s;
+}
+
+template <int R>
+__global__ void __launch_bounds__(256) gram_diag_kernel(const DevDesc dd, const double* __restrict__ tables,
+                                                        const double* __restrict__ Axs, const double* __restrict__ Acn,
+                                                        int64_t a_ld, int64_t n, double* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double e[R > 0 ? R : 1];
+#pragma unroll
+    for (int q = 0; q < (R > 0 ? R : 1); ++q) e[q] = 0.0;
+    if constexpr (R > 0) {
+        for (int d = 0; d < dd.D; ++d) {
+            const double x = Axs[(int64_t)d * a_ld + i];
+            double k;
+            if (dd.type[d] == OAK_DIM_RBF) {
+                const double c = Acn[(int64_t)d * a_ld + i];
+                k = __builtin_fma(-c, c, dd.bv[d]);     // base K_diag = variance; minus c(x)^2/var_s (ortho_rbf_kernel.py:174-177)
+            } else {
+                const int C = dd.ncat[d];
+                k = tables[dd.tab_off[d] + C * C + (int)x];
+            }
+            esp_update<R>(e, k);
+        }
+    }
+    out[i] = esp_combine<R>(e, dd);
+}
+
+template <int R, int RT, int CPT>
+static int launch_gram_t(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int64_t na, const Feat& B,
+                         double* d_out, int64_t ldo, const double* d_yA, double* d_psi, int64_t zero_pad_to) {
+    constexpr int TJ = 64 * CPT;
+    constexpr int RS = 4 * RT;
+    const int D = pk.dd.D;
+    size_t lds = sizeof(double) * ((size_t)D * TJ * 2 + (size_t)D * RS * 2 + RS);
+    const size_t lds_red = sizeof(double) * 4 * TJ;
+    if (lds < lds_red) lds = lds_red;
+    if (lds > 160 * 1024) { set_error("gram: LDS request %zu exceeds 160 KiB (D=%d)", lds, D); return OAK_E_ARG; }
+    const int64_t nb = B.n;
+    const int64_t ncb = (nb + TJ - 1) / TJ;
+    // rows per workgroup: enough row-blocks to fill the chip (~8 WGs per CU), at least one row-step
+    int64_t target_wg = (int64_t)ctx->num_cu * 8;
+    int64_t nrb = (target_wg + ncb - 1) / ncb;
+    if (nrb < 1) nrb = 1;
+    int64_t rows = (na + nrb - 1) / nrb;
+    rows = ((rows + RS - 1) / RS) * RS;
+    if (rows < RS) rows = RS;
+    if (rows > 4096) rows = 4096;
+    nrb = (na + rows - 1) / rows;
+    if (nrb > 65535) { rows = ((na + 65534) / 65535 + RS - 1) / RS * RS; nrb = (na + rows - 1) / rows; }
+    double* d_part = nullptr;
+    if (d_yA != nullptr) OAK_CHECK(get_buf_t(ctx, "psi_part", (size_t)(nrb * nb), &d_part));
+    auto kern = gram_kernel<R, RT, CPT>;
+    if (lds > 64 * 1024) OAK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    dim3 grid((unsigned)ncb, (unsigned)nrb);
+    kern<<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, A.xs, A.cn, A.ld, a0, na, B.xs, B.cn, B.ld, nb, d_out, ldo,
+                                          (int)rows, d_yA, d_part, zero_pad_to);
+    OAK_HIP_CHECK(hipGetLastError());
+    if (d_yA != nullptr) {
+        colsum_accum_kernel<<<(unsigned)((nb + 255) / 256), 256, 0, ctx->stream>>>(d_part, nrb, nb, d_psi);
+        OAK_HIP_CHECK(hipGetLastError());
+    }
+    return OAK_OK;
+}
+
+template <int R>
+static int launch_gram_r(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int64_t na, const Feat& B,
+                         double* d_out, int64_t ldo, const double* d_yA, double* d_psi, int64_t zero_pad_to) {
+    const int D = pk.dd.D;
+    // register blocking: 16 pairs/lane for R<=2, 8 for R<=4, 4 above; halve the column tile when D*TJ*16 B > 64 KiB
+    if constexpr (R <= 2) {
+        if (D <= 16) return launch_gram_t<R, 4, 4>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+        return launch_gram_t<R, 4, 2>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+    } else if constexpr (R <= 4) {
+        if (D <= 16) return launch_gram_t<R, 2, 4>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+        return launch_gram_t<R, 2, 2>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+    } else {
+        if (D <= 16) return launch_gram_t<R, 1, 4>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+        return launch_gram_t<R, 1, 2>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+    }
+}
+
+int gram(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int64_t na, const Feat& B, double* d_out,
+         int64_t ldo, const double* d_yA, double* d_psi, int64_t zero_pad_to) {
+    if (na <= 0 || B.n <= 0) return OAK_OK;
+    switch (pk.dd.R) {
+        case 0: return launch_gram_r<0>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+        case 1: return launch_gram_r<1>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+        case 2: return launch_gram_r<2>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+        case 3: return launch_gram_r<3>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+        case 4: return launch_gram_r<4>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+        case 5: return launch_gram_r<5>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+        case 6: return launch_gram_r<6>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+        case 7: return launch_gram_r<7>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+        case 8: return launch_gram_r<8>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+    }
+    set_error("gram: unsupported depth %d", pk.dd.R);
+    return OAK_E_ARG;
+}
+
+int gram_diag(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, double* d_out, double* d_sum_accum) {
+    const int64_t n = A.n;
+    if (n <= 0) return OAK_OK;
+    const unsigned g = (unsigned)((n + 255) / 256);
+#define OAK_DIAG_CASE(RR) case RR: gram_diag_kernel<RR><<<g, 256, 0, ctx->stream>>>(pk.dd, pk.d_tables, A.xs, A.cn, A.ld, n, d_out); break;
+    switch (pk.dd.R) {
+        OAK_DIAG_CASE(0) OAK_DIAG_CASE(1) OAK_DIAG_CASE(2) OAK_DIAG_CASE(3) OAK_DIAG_CASE(4)
+        OAK_DIAG_CASE(5) OAK_DIAG_CASE(6) OAK_DIAG_CASE(7) OAK_DIAG_CASE(8)
+        default: set_error("gram_diag: unsupported depth %d", pk.dd.R); return OAK_E_ARG;
+    }
+#undef OAK_DIAG_CASE
+    OAK_HIP_CHECK(hipGetLastError());
+    if (d_sum_accum != nullptr) {
+        double* d_s = nullptr;
+        OAK_CHECK(get_buf_t(ctx, "diag_sum_tmp", 1, &d_s));
+        OAK_CHECK(reduce_sum(ctx, d_out, n, d_s, 0, 1));
+        OAK_CHECK(axpy(ctx, 1.0, d_s, d_sum_accum, 1));
+    }
+    return OAK_OK;
+}
+
+}  // namespace oak

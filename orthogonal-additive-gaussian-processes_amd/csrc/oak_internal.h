@@ -1,0 +1,170 @@
+// Internal declarations shared by the HIP translation units of liboak_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <map>
+#include "oak_hip.h"
+
+namespace oak {
+
+// ---- error plumbing -------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+#define OAK_HIP_CHECK(expr)                                                                    \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            oak::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,    \
+                           __LINE__);                                                          \
+            return OAK_E_HIP;                                                                  \
+        }                                                                                      \
+    } while (0)
+#define OAK_CHECK(expr)                                                                        \
+    do {                                                                                       \
+        int _s = (expr);                                                                       \
+        if (_s != OAK_OK) return _s;                                                           \
+    } while (0)
+#define OAK_REQUIRE(cond, ...)                                                                 \
+    do {                                                                                       \
+        if (!(cond)) {                                                                         \
+            oak::set_error(__VA_ARGS__);                                                       \
+            return OAK_E_ARG;                                                                  \
+        }                                                                                      \
+    } while (0)
+
+// ---- device-side kernel description (passed by value as a kernel argument) -------------------
+struct DevDesc {
+    int D;                         // number of sub-kernels
+    int R;                         // max interaction depth
+    double w[OAK_MAX_DEPTH + 1];   // weight of e_r in K: share_var ? sigma2_r : (r==0 ? sigma2_0 : 1)
+    unsigned char type[OAK_MAX_DIMS];
+    short col[OAK_MAX_DIMS];       // active column
+    int ncat[OAK_MAX_DIMS];        // categories (2 for binary)
+    int tab_off[OAK_MAX_DIMS];     // offset into the device table buffer: C*C table (variance applied) then C diag
+    double scale[OAK_MAX_DIMS];    // sqrt(log2(e)/2)/lengthscale     (RBF)
+    double log2bv[OAK_MAX_DIMS];   // log2(base variance)             (RBF)
+    double bv[OAK_MAX_DIMS];       // base variance
+};
+
+// measure parameters used only by the featurize kernels
+struct DevMeasure {
+    unsigned char kind[OAK_MAX_DIMS];
+    int k[OAK_MAX_DIMS];
+    int off[OAK_MAX_DIMS];         // offset into device meas buffer
+    double p0[OAK_MAX_DIMS], p1[OAK_MAX_DIMS];
+    double ls[OAK_MAX_DIMS];
+    double inv_sqrt_v[OAK_MAX_DIMS];   // 1/sqrt(var_s)   (0 for unconstrained)
+};
+
+// Featurised point set, struct-of-arrays, dimension-major: xs[d*ld + i], cn[d*ld + i]
+//   RBF dim:      xs = x * scale_d ;  cn = cov_X_s(x)/sqrt(var_s)
+//   discrete dim: xs = category index (as double) ; cn = 0
+struct Feat {
+    double* xs = nullptr;
+    double* cn = nullptr;
+    int64_t n = 0;
+    int64_t ld = 0;
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct Timing { double ms = 0; int count = 0; };
+
+struct PreparedKernel {
+    DevDesc dd;
+    DevMeasure dm;
+    std::vector<double> tables;      // host copy of the discrete tables
+    double* d_tables = nullptr;      // device (ctx scratch "tables")
+    double* d_meas = nullptr;        // device (ctx scratch "meas")
+    // host-side derivative helpers (per RBF dim): d inv_v / d lengthscale etc. are recomputed in grad code
+};
+
+}  // namespace oak
+
+struct oak_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::map<std::string, oak::DevBuf> bufs;     // named, grow-only device scratch
+    std::map<std::string, oak::Timing> timings;
+    // SGPR state
+    int64_t N = 0, M = 0;
+    int32_t ldx = 0;
+    int64_t panel_rows = 0;
+    bool have_data = false, have_Z = false, have_stats = false, have_post = false, stats_whitened = false;
+    int route = 0;   // 0 auto, 1 phi, 2 whitened
+    double noise_var = 0, jitter = 0;
+    // GPR state
+    int64_t gN = 0; int32_t gldx = 0; bool g_have_data = false, g_have_post = false; double g_noise = 0;
+    // communicator (RCCL, dlopen'ed)
+    void* comm = nullptr; int nranks = 1, rank = 0;
+    int num_cu = 256;
+};
+
+namespace oak {
+
+// scratch management ---------------------------------------------------------------------------
+int get_buf(oak_ctx* ctx, const char* name, size_t bytes, void** out);   // grow-only
+template <typename T> inline int get_buf_t(oak_ctx* ctx, const char* name, size_t count, T** out) {
+    void* p = nullptr; int s = get_buf(ctx, name, count * sizeof(T), &p); *out = (T*)p; return s;
+}
+void* peek_buf(oak_ctx* ctx, const char* name);
+
+struct PhaseTimer {   // hipEvent timing of a phase on the ctx stream (accumulates into ctx->timings)
+    oak_ctx* ctx; const char* name; hipEvent_t a, b; bool active;
+    PhaseTimer(oak_ctx* c, const char* n);
+    void stop();
+};
+void reset_timings(oak_ctx* ctx);
+
+// kernel description ----------------------------------------------------------------------------
+int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk);
+// component (single subset) description derived from a full one
+int prepare_component(oak_ctx* ctx, const oak_kernel_desc* desc, const int32_t* subset, int32_t len,
+                      int32_t apply_order_var, PreparedKernel* pk);
+
+// featurize -------------------------------------------------------------------------------------
+int featurize(oak_ctx* ctx, const PreparedKernel& pk, const double* dX, int64_t n, int32_t ldx,
+              const char* bufname, Feat* out);
+
+// gram ------------------------------------------------------------------------------------------
+// out[i*ldo + j] = K(A_i, B_j).  If yA != nullptr also accumulates psi[j] += sum_i K(i,j) y_i into d_psi
+// (d_psi must be zero-initialised by the caller or accumulate onto existing contents).
+// zero_pad_to: columns [B.n, zero_pad_to) of each row are written as 0 (panel padding for syrk).
+int gram(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int64_t na, const Feat& B,
+         double* d_out, int64_t ldo, const double* d_yA, double* d_psi, int64_t zero_pad_to);
+int gram_diag(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, double* d_out, double* d_sum_accum);
+
+// dense linear algebra on the device (fp64) -------------------------------------------------------
+int syrk_panel(oak_ctx* ctx, const double* d_panel, int64_t ldp, int64_t nrows, int64_t M, double* d_part,
+               int nsplit, bool accumulate);
+int syrk_plan_splits(oak_ctx* ctx, int64_t M);
+int syrk_reduce(oak_ctx* ctx, const double* d_part, int nsplit, int64_t M, double* d_phi /*[M*M]*/, bool accumulate);
+int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda);   // in place; strict upper zeroed
+// rows-trsm: each of the nrhs rows of BT (row stride ldb) is a right-hand side; solves L x = b (trans=0)
+// or L^T x = b (trans=1) in place.
+int trsm_rows(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, double* dBT, int64_t nrhs, int64_t ldb, int trans);
+int transpose(oak_ctx* ctx, const double* dA, int64_t rows, int64_t cols, int64_t lda, double* dB, int64_t ldb);
+int add_diag(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, double v);
+int scale_add_eye(oak_ctx* ctx, const double* dW, int64_t n, double s, double* dB);   // B = I + s*W
+int reduce_sum(oak_ctx* ctx, const double* d_x, int64_t n, double* d_out /*1*/, int mode /*0 sum,1 sumsq,2 sumlog*/, int64_t stride);
+int dot(oak_ctx* ctx, const double* d_x, const double* d_y, int64_t n, double* d_out);
+int gemv_rows(oak_ctx* ctx, const double* dA, int64_t rows, int64_t cols, int64_t lda, const double* d_x, double* d_y); // y = A x
+int row_sumsq(oak_ctx* ctx, const double* dA, int64_t rows, int64_t cols, int64_t lda, double* d_out);                  // out_i = sum_j A_ij^2
+int copy_d2d(oak_ctx* ctx, void* dst, const void* src, size_t bytes);
+int fill_zero(oak_ctx* ctx, void* dst, size_t bytes);
+int axpy(oak_ctx* ctx, double a, const double* x, double* y, int64_t n);  // y += a x
+int scale_vec(oak_ctx* ctx, double a, double* x, int64_t n);
+int gemm_nn(oak_ctx* ctx, const double* dA, const double* dB, double* dC, int64_t m, int64_t n, int64_t k,
+            int64_t lda, int64_t ldb, int64_t ldc, double alpha, double beta);   // C = alpha A B + beta C (row-major)
+
+// collectives --------------------------------------------------------------------------------------
+int comm_allreduce_dev(oak_ctx* ctx, double* d_buf, int64_t n);
+
+}  // namespace oak

@@ -1,0 +1,393 @@
+// Runtime: context, scratch buffers, error reporting, kernel-description preparation, featurize.
+#include "oak_internal.h"
+#include <cstdarg>
+#include <cmath>
+
+namespace oak {
+
+static thread_local char g_err[1024] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int get_buf(oak_ctx* ctx, const char* name, size_t bytes, void** out) {
+    DevBuf& b = ctx->bufs[name];
+    if (bytes == 0) bytes = 8;
+    if (b.bytes < bytes) {
+        if (b.p) {
+            OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            OAK_HIP_CHECK(hipFree(b.p));
+            b.p = nullptr; b.bytes = 0;
+        }
+        size_t want = (bytes + 255) & ~(size_t)255;
+        hipError_t e = hipMalloc(&b.p, want);
+        if (e != hipSuccess) {
+            b.p = nullptr;
+            set_error("hipMalloc(%zu bytes) for '%s' failed: %s", want, name, hipGetErrorString(e));
+            return OAK_E_HIP;
+        }
+        b.bytes = want;
+    }
+    *out = b.p;
+    return OAK_OK;
+}
+
+void* peek_buf(oak_ctx* ctx, const char* name) {
+    auto it = ctx->bufs.find(name);
+    return it == ctx->bufs.end() ? nullptr : it->second.p;
+}
+
+PhaseTimer::PhaseTimer(oak_ctx* c, const char* n) : ctx(c), name(n), a(nullptr), b(nullptr), active(false) {
+    if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) {
+        hipEventRecord(a, ctx->stream);
+        active = true;
+    }
+}
+struct PendingEvt { std::string name; hipEvent_t a, b; };
+static thread_local std::vector<PendingEvt> g_pending;
+void PhaseTimer::stop() {
+    if (!active) return;
+    hipEventRecord(b, ctx->stream);
+    g_pending.push_back({name, a, b});
+    active = false;
+}
+static void flush_timings(oak_ctx* ctx) {
+    for (auto& p : g_pending) {
+        float ms = 0;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            Timing& t = ctx->timings[p.name];
+            t.ms += ms; t.count += 1;
+        }
+        hipEventDestroy(p.a); hipEventDestroy(p.b);
+    }
+    g_pending.clear();
+}
+void reset_timings(oak_ctx* ctx) { flush_timings(ctx); ctx->timings.clear(); }
+
+int copy_d2d(oak_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    OAK_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return OAK_OK;
+}
+int fill_zero(oak_ctx* ctx, void* dst, size_t bytes) {
+    OAK_HIP_CHECK(hipMemsetAsync(dst, 0, bytes, ctx->stream));
+    return OAK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// featurize kernels
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) featurize_kernel(DevDesc dd, DevMeasure dm, const double* __restrict__ meas,
+                                                        const double* __restrict__ X, int64_t n, int ldx, int64_t ld,
+                                                        double* __restrict__ xs, double* __restrict__ cn) {
+    const int d = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ld) return;
+    double vx = 0.0, vc = 0.0;
+    if (i < n) {
+        const double x = X[i * ldx + dd.col[d]];
+        if (dd.type[d] == OAK_DIM_RBF) {
+            vx = x * dd.scale[d];
+            const double l = dm.ls[d], bv = dd.bv[d];
+            double c = 0.0;
+            switch (dm.kind[d]) {
+                case OAK_MEAS_GAUSSIAN: {   // oak/ortho_rbf_kernel.py:82-92
+                    const double mu = dm.p0[d], var = dm.p1[d];
+                    const double s = l * l + var;
+                    c = bv * l / sqrt(s) * exp(-0.5 * (x - mu) * (x - mu) / s);
+                } break;
+                case OAK_MEAS_UNIFORM: {    // oak/ortho_rbf_kernel.py:49-63
+                    const double a = dm.p0[d], b = dm.p1[d];
+                    const double r2l = 1.0 / (1.4142135623730951 * l);
+                    c = bv * l / (b - a) * 1.2533141373155001 * (erf((b - x) * r2l) - erf((a - x) * r2l));
+                } break;
+                case OAK_MEAS_EMPIRICAL: {  // oak/ortho_rbf_kernel.py:101-107
+                    const int K = dm.k[d];
+                    const double* loc = meas + dm.off[d];
+                    const double* w = loc + K;
+                    const double il2 = 0.5 / (l * l);
+                    double acc = 0.0;
+                    for (int k = 0; k < K; ++k) { const double u = x - loc[k]; acc += w[k] * exp(-u * u * il2); }
+                    c = bv * acc;
+                } break;
+                case OAK_MEAS_MOG: {        // oak/ortho_rbf_kernel.py:124-136
+                    const int K = dm.k[d];
+                    const double* mu = meas + dm.off[d];
+                    const double* var = mu + K;
+                    const double* w = var + K;
+                    double acc = 0.0;
+                    for (int k = 0; k < K; ++k) {
+                        const double s = l * l + var[k];
+                        const double u = x - mu[k];
+                        acc += w[k] * exp(-0.5 * u * u / s) / sqrt(s);
+                    }
+                    c = bv * l * acc;
+                } break;
+                default: c = 0.0;
+            }
+            vc = c * dm.inv_sqrt_v[d];
+        } else {
+            // tf.cast(float64 -> int32) truncates toward zero (ortho_binary_kernel.py:47); clamp keeps lookups in range
+            double t = trunc(x);
+            const double hi = (double)(dd.ncat[d] - 1);
+            t = t < 0.0 ? 0.0 : (t > hi ? hi : t);
+            vx = t; vc = 0.0;
+        }
+    }
+    xs[(int64_t)d * ld + i] = vx;
+    cn[(int64_t)d * ld + i] = vc;
+}
+
+// tmp[k] = w_k * sum_l w_l * bv * exp(-(loc_k-loc_l)^2 / (2 l^2))   (var_s of the empirical measure, :109-120)
+__global__ void empirical_var_kernel(const double* __restrict__ loc, const double* __restrict__ w, int K, double l,
+                                     double bv, double* __restrict__ tmp) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const double il2 = 0.5 / (l * l);
+    double acc = 0.0;
+    for (int j = 0; j < K; ++j) { const double u = loc[k] - loc[j]; acc += w[j] * exp(-u * u * il2); }
+    tmp[k] = w[k] * bv * acc;
+}
+
+static double host_var_s(int kind, double l, double bv, double p0, double p1, const double* data, int K) {
+    switch (kind) {
+        case OAK_MEAS_GAUSSIAN: return bv * l / std::sqrt(l * l + 2.0 * p1);       // :94-97
+        case OAK_MEAS_UNIFORM: {                                                   // :65-78
+            const double a = p0, b = p1;
+            const double y = (b - a) / std::sqrt(2.0) / l;
+            return 2.0 / ((b - a) * (b - a)) * bv * l * l *
+                   (std::sqrt(M_PI) * y * std::erf(y) + std::exp(-y * y) - 1.0);
+        }
+        case OAK_MEAS_MOG: {                                                       // :138-152
+            const double *mu = data, *var = data + K, *w = data + 2 * K;
+            double acc = 0.0;
+            for (int i = 0; i < K; ++i)
+                for (int j = 0; j < K; ++j) {
+                    const double s = l * l + var[i] + var[j];
+                    const double dm = mu[i] - mu[j];
+                    acc += w[i] * w[j] * bv * l / std::sqrt(s) * std::exp(-0.5 * dm * dm / s);
+                }
+            return acc;
+        }
+        default: return 0.0;
+    }
+}
+
+int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk) {
+    OAK_REQUIRE(desc != nullptr, "kernel description is NULL");
+    const int D = desc->num_dims, R = desc->max_depth;
+    OAK_REQUIRE(D >= 1 && D <= OAK_MAX_DIMS, "num_dims=%d outside [1,%d]", D, OAK_MAX_DIMS);
+    OAK_REQUIRE(R >= 0 && R <= OAK_MAX_DEPTH, "max_interaction_depth=%d outside [0,%d]", R, OAK_MAX_DEPTH);
+    OAK_REQUIRE(desc->n_order_var == (desc->share_var ? R + 1 : 1), "n_order_var=%d inconsistent", desc->n_order_var);
+    DevDesc& dd = pk->dd;
+    DevMeasure& dm = pk->dm;
+    memset(&dd, 0, sizeof(dd));
+    memset(&dm, 0, sizeof(dm));
+    dd.D = D; dd.R = R;
+    for (int r = 0; r <= R; ++r) dd.w[r] = desc->share_var ? desc->order_var[r] : (r == 0 ? desc->order_var[0] : 1.0);
+    pk->tables.clear();
+    // upload measure data first (needed by the empirical variance kernel)
+    double* d_meas = nullptr;
+    const int mlen = desc->meas_data_len > 0 ? desc->meas_data_len : 0;
+    OAK_CHECK(get_buf_t(ctx, "meas", (size_t)mlen + 1, &d_meas));
+    if (mlen > 0)
+        OAK_HIP_CHECK(hipMemcpyAsync(d_meas, desc->meas_data, sizeof(double) * mlen, hipMemcpyHostToDevice, ctx->stream));
+    pk->d_meas = d_meas;
+    for (int d = 0; d < D; ++d) {
+        const int t = desc->dim_type[d];
+        dd.type[d] = (unsigned char)t;
+        OAK_REQUIRE(desc->active_col[d] >= 0 && desc->active_col[d] < 32768, "active_col[%d] invalid", d);
+        dd.col[d] = (short)desc->active_col[d];
+        const double bv = desc->base_var[d];
+        dd.bv[d] = bv;
+        if (t == OAK_DIM_RBF) {
+            const double l = desc->lengthscale[d];
+            OAK_REQUIRE(l > 0.0 && bv > 0.0, "dim %d: lengthscale and variance must be positive", d);
+            dd.scale[d] = std::sqrt(0.5 * 1.4426950408889634074) / l;   // (x s - z s)^2 = (x-z)^2 log2(e) / (2 l^2)
+            dd.log2bv[d] = std::log2(bv);
+            dd.ncat[d] = 0; dd.tab_off[d] = 0;
+            const int kind = desc->measure[d];
+            dm.kind[d] = (unsigned char)kind;
+            dm.ls[d] = l;
+            dm.p0[d] = desc->meas_p0 ? desc->meas_p0[d] : 0.0;
+            dm.p1[d] = desc->meas_p1 ? desc->meas_p1[d] : 0.0;
+            dm.k[d] = desc->meas_k ? desc->meas_k[d] : 0;
+            dm.off[d] = desc->meas_off ? desc->meas_off[d] : 0;
+            double v = 0.0;
+            if (kind == OAK_MEAS_NONE) {
+                dm.inv_sqrt_v[d] = 0.0;
+            } else {
+                if (kind == OAK_MEAS_EMPIRICAL) {
+                    const int K = dm.k[d];
+                    OAK_REQUIRE(K >= 1 && dm.off[d] + 2 * K <= mlen, "dim %d: empirical measure data out of range", d);
+                    double* d_tmp = nullptr; double* d_s = nullptr;
+                    OAK_CHECK(get_buf_t(ctx, "empvar_tmp", (size_t)K, &d_tmp));
+                    OAK_CHECK(get_buf_t(ctx, "empvar_s", 1, &d_s));
+                    empirical_var_kernel<<<(K + 255) / 256, 256, 0, ctx->stream>>>(d_meas + dm.off[d], d_meas + dm.off[d] + K, K, l, bv, d_tmp);
+                    OAK_CHECK(reduce_sum(ctx, d_tmp, K, d_s, 0, 1));
+                    OAK_HIP_CHECK(hipMemcpyAsync(&v, d_s, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                } else {
+                    if (kind == OAK_MEAS_MOG)
+                        OAK_REQUIRE(dm.k[d] >= 1 && dm.off[d] + 3 * dm.k[d] <= mlen, "dim %d: MOG measure data out of range", d);
+                    OAK_REQUIRE(kind == OAK_MEAS_GAUSSIAN || kind == OAK_MEAS_UNIFORM || kind == OAK_MEAS_MOG, "dim %d: unknown measure %d", d, kind);
+                    v = host_var_s(kind, l, bv, dm.p0[d], dm.p1[d], desc->meas_data ? desc->meas_data + dm.off[d] : nullptr, dm.k[d]);
+                }
+                OAK_REQUIRE(v > 0.0 && std::isfinite(v), "dim %d: measure variance var_s=%g is not positive", d, v);
+                dm.inv_sqrt_v[d] = 1.0 / std::sqrt(v);
+            }
+        } else if (t == OAK_DIM_BINARY) {     // oak/ortho_binary_kernel.py:29-38
+            const double p0 = desc->meas_p0[d], p1 = 1.0 - p0;
+            dd.ncat[d] = 2;
+            dd.tab_off[d] = (int)pk->tables.size();
+            const double tab[6] = {p1 * p1 * bv, -p0 * p1 * bv, -p0 * p1 * bv, p0 * p0 * bv, p1 * p1 * bv, p0 * p0 * bv};
+            pk->tables.insert(pk->tables.end(), tab, tab + 6);
+        } else if (t == OAK_DIM_CATEGORICAL) {   // oak/ortho_categorical_kernel.py:34-53 (table built by the host mirror)
+            const int C = desc->meas_k[d];
+            const int off = desc->meas_off[d];
+            OAK_REQUIRE(C >= 1 && C <= 4096 && off >= 0 && off + C * C + C <= mlen, "dim %d: categorical table out of range", d);
+            dd.ncat[d] = C;
+            dd.tab_off[d] = (int)pk->tables.size();
+            for (int i = 0; i < C * C; ++i) pk->tables.push_back(desc->meas_data[off + i] * bv);
+            for (int i = 0; i < C; ++i) pk->tables.push_back(desc->meas_data[off + i * C + i] * bv);
+            dm.k[d] = C; dm.off[d] = off;
+        } else {
+            set_error("dim %d: unknown dim_type %d", d, t);
+            return OAK_E_ARG;
+        }
+    }
+    double* d_tab = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "tables", pk->tables.size() + 1, &d_tab));
+    if (!pk->tables.empty())
+        OAK_HIP_CHECK(hipMemcpyAsync(d_tab, pk->tables.data(), sizeof(double) * pk->tables.size(), hipMemcpyHostToDevice, ctx->stream));
+    pk->d_tables = d_tab;
+    // the host vector `tables` must outlive the async copy: synchronise (tiny copy, once per evaluation)
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return OAK_OK;
+}
+
+int prepare_component(oak_ctx* ctx, const oak_kernel_desc* desc, const int32_t* subset, int32_t len,
+                      int32_t apply_order_var, PreparedKernel* pk) {
+    OAK_CHECK(prepare_kernel(ctx, desc, pk));
+    OAK_REQUIRE(len >= 0 && len <= desc->num_dims, "subset length %d invalid", len);
+    // Build a description whose D sub-kernels are the subset and whose only non-zero ESP weight is e_len:
+    //   K_S = sigma2_{|S|} * prod_{d in S} k_d = w_len * e_len(k_S)   (oak/oak_kernel.py:300-320)
+    PreparedKernel full = *pk;
+    DevDesc& dd = pk->dd; DevMeasure& dm = pk->dm;
+    OAK_REQUIRE(len <= OAK_MAX_DEPTH, "component order %d exceeds OAK_MAX_DEPTH", len);
+    double wv = 1.0;
+    if (len == 0) wv = desc->order_var[0];
+    else if (apply_order_var) {
+        OAK_REQUIRE(desc->share_var && len <= desc->max_depth, "component order %d has no order variance", len);
+        wv = desc->order_var[len];
+    }
+    for (int r = 0; r <= OAK_MAX_DEPTH; ++r) dd.w[r] = 0.0;
+    dd.w[len] = wv;
+    dd.R = len;
+    if (len == 0) { dd.D = 1; return OAK_OK; }   // constant term: R = 0 -> K = w0 regardless of dims
+    dd.D = len;
+    for (int q = 0; q < len; ++q) {
+        const int s = subset[q];
+        OAK_REQUIRE(s >= 0 && s < desc->num_dims, "subset entry %d out of range", s);
+        dd.type[q] = full.dd.type[s]; dd.col[q] = full.dd.col[s]; dd.ncat[q] = full.dd.ncat[s];
+        dd.tab_off[q] = full.dd.tab_off[s]; dd.scale[q] = full.dd.scale[s]; dd.log2bv[q] = full.dd.log2bv[s];
+        dd.bv[q] = full.dd.bv[s];
+        dm.kind[q] = full.dm.kind[s]; dm.k[q] = full.dm.k[s]; dm.off[q] = full.dm.off[s]; dm.p0[q] = full.dm.p0[s];
+        dm.p1[q] = full.dm.p1[s]; dm.ls[q] = full.dm.ls[s]; dm.inv_sqrt_v[q] = full.dm.inv_sqrt_v[s];
+    }
+    return OAK_OK;
+}
+
+int featurize(oak_ctx* ctx, const PreparedKernel& pk, const double* dX, int64_t n, int32_t ldx, const char* bufname, Feat* out) {
+    const int D = pk.dd.D;
+    const int64_t ld = ((n + 63) / 64) * 64 + 64;   // padded so tile loads never run past the array
+    double* base = nullptr;
+    OAK_CHECK(get_buf_t(ctx, bufname, (size_t)(2 * D * ld), &base));
+    out->xs = base; out->cn = base + (size_t)D * ld; out->n = n; out->ld = ld;
+    dim3 grid((unsigned)((ld + 255) / 256), (unsigned)D);
+    featurize_kernel<<<grid, 256, 0, ctx->stream>>>(pk.dd, pk.dm, pk.d_meas, dX, n, ldx, ld, out->xs, out->cn);
+    OAK_HIP_CHECK(hipGetLastError());
+    return OAK_OK;
+}
+
+}  // namespace oak
+
+// ---------------------------------------------------------------------------------------------
+// C ABI: runtime
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* oak_last_error(void) { return oak::g_err; }
+const char* oak_version(void) { return "oak_hip 0.1.0 (gfx950)"; }
+
+int oak_device_count(int* count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; oak::set_error("hipGetDeviceCount: %s", hipGetErrorString(e)); return OAK_E_HIP; }
+    *count = n;
+    return OAK_OK;
+}
+
+int oak_ctx_create(int device, oak_ctx** out) {
+    if (!out) { oak::set_error("out is NULL"); return OAK_E_ARG; }
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        oak::set_error("no HIP device available (%s): the OAK HIP path has no CPU fallback", e == hipSuccess ? "count=0" : hipGetErrorString(e));
+        return OAK_E_HIP;
+    }
+    if (device < 0 || device >= n) { oak::set_error("device %d out of range [0,%d)", device, n); return OAK_E_ARG; }
+    OAK_HIP_CHECK(hipSetDevice(device));
+    oak_ctx* ctx = new oak_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+    if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; oak::set_error("hipStreamCreate failed"); return OAK_E_HIP; }
+    *out = ctx;
+    return OAK_OK;
+}
+
+int oak_ctx_destroy(oak_ctx* ctx) {
+    if (!ctx) return OAK_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    oak::reset_timings(ctx);
+    oak_comm_destroy(ctx);
+    for (auto& kv : ctx->bufs) if (kv.second.p) hipFree(kv.second.p);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return OAK_OK;
+}
+
+int oak_sync(oak_ctx* ctx) {
+    if (!ctx) { oak::set_error("ctx is NULL"); return OAK_E_ARG; }
+    OAK_HIP_CHECK(hipSetDevice(ctx->device));
+    OAK_HIP_CHECK(hipDeviceSynchronize());
+    return OAK_OK;
+}
+
+int oak_last_timing(oak_ctx* ctx, const char* name, double* ms, int32_t* count) {
+    if (!ctx || !name) { oak::set_error("bad argument"); return OAK_E_ARG; }
+    oak::flush_timings(ctx);
+    auto it = ctx->timings.find(name);
+    if (it == ctx->timings.end()) { if (ms) *ms = 0; if (count) *count = 0; return OAK_OK; }
+    if (ms) *ms = it->second.ms;
+    if (count) *count = it->second.count;
+    return OAK_OK;
+}
+
+int oak_device_mem_info(oak_ctx* ctx, double* free_bytes, double* total_bytes) {
+    if (!ctx) { oak::set_error("ctx is NULL"); return OAK_E_ARG; }
+    size_t f = 0, t = 0;
+    OAK_HIP_CHECK(hipSetDevice(ctx->device));
+    OAK_HIP_CHECK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = (double)f;
+    if (total_bytes) *total_bytes = (double)t;
+    return OAK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,536 @@
+// Host-side orchestration of the Gram / SGPR / GPR paths and their C ABI entry points.
+#include "oak_internal.h"
+#include <cmath>
+#include <cstdlib>
+
+namespace oak {
+
+static inline int64_t pad128(int64_t m) { return ((m + 127) / 128) * 128; }
+
+struct HostUpload {   // host -> device copy into a named scratch buffer
+    static int run(oak_ctx* ctx, const char* name, const double* h, size_t count, double** d) {
+        OAK_CHECK(get_buf_t(ctx, name, count, d));
+        if (count) OAK_HIP_CHECK(hipMemcpyAsync(*d, h, sizeof(double) * count, hipMemcpyHostToDevice, ctx->stream));
+        return OAK_OK;
+    }
+};
+
+__global__ void predict_var_kernel(const double* __restrict__ kdiag, const double* __restrict__ s2, const double* __restrict__ s1,
+                                   double* __restrict__ var, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) var[i] = kdiag[i] + (s2 ? s2[i] : 0.0) - s1[i];
+}
+
+static int guard(oak_ctx* ctx) {
+    if (!ctx) { set_error("ctx is NULL"); return OAK_E_ARG; }
+    OAK_HIP_CHECK(hipSetDevice(ctx->device));
+    return OAK_OK;
+}
+
+// K(X1, X2) -> host, chunked over rows so the device buffer stays bounded.
+static int gram_to_host(oak_ctx* ctx, const PreparedKernel& pk, const double* X1, int64_t n1, const double* X2, int64_t n2,
+                        int32_t ldx, double* out) {
+    double *dX1 = nullptr, *dX2 = nullptr;
+    OAK_CHECK(HostUpload::run(ctx, "gX1", X1, (size_t)n1 * ldx, &dX1));
+    Feat FA, FB;
+    OAK_CHECK(featurize(ctx, pk, dX1, n1, ldx, "gF1", &FA));
+    if (X2 != nullptr) {
+        OAK_CHECK(HostUpload::run(ctx, "gX2", X2, (size_t)n2 * ldx, &dX2));
+        OAK_CHECK(featurize(ctx, pk, dX2, n2, ldx, "gF2", &FB));
+    } else { FB = FA; n2 = n1; }
+    int64_t chunk = (int64_t)((size_t)1 << 30) / (n2 > 0 ? n2 : 1);   // <= 8 GiB per chunk
+    if (chunk < 16) chunk = 16;
+    if (chunk > n1) chunk = n1;
+    double* dK = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "gK", (size_t)chunk * n2, &dK));
+    for (int64_t a0 = 0; a0 < n1; a0 += chunk) {
+        const int64_t na = (a0 + chunk <= n1) ? chunk : n1 - a0;
+        OAK_CHECK(gram(ctx, pk, FA, a0, na, FB, dK, n2, nullptr, nullptr, 0));
+        OAK_HIP_CHECK(hipMemcpyAsync(out + a0 * n2, dK, sizeof(double) * (size_t)na * n2, hipMemcpyDeviceToHost, ctx->stream));
+        OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return OAK_OK;
+}
+
+static int gram_diag_to_host(oak_ctx* ctx, const PreparedKernel& pk, const double* X, int64_t n, int32_t ldx, double* out) {
+    double* dX = nullptr;
+    OAK_CHECK(HostUpload::run(ctx, "gX1", X, (size_t)n * ldx, &dX));
+    Feat FA;
+    OAK_CHECK(featurize(ctx, pk, dX, n, ldx, "gF1", &FA));
+    double* dD = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "gD", (size_t)n, &dD));
+    OAK_CHECK(gram_diag(ctx, pk, FA, dD, nullptr));
+    OAK_HIP_CHECK(hipMemcpyAsync(out, dD, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return OAK_OK;
+}
+
+// packed statistics buffer accessors
+struct Stats { double *phi, *psi, *kappa, *yy, *nrows; int64_t len; };
+static int stats_view(oak_ctx* ctx, Stats* s) {
+    const int64_t M = ctx->M;
+    double* base = nullptr;
+    s->len = M * M + M + 3;
+    OAK_CHECK(get_buf_t(ctx, "stats", (size_t)s->len, &base));
+    s->phi = base; s->psi = base + M * M; s->kappa = s->psi + M; s->yy = s->kappa + 1; s->nrows = s->yy + 1;
+    return OAK_OK;
+}
+
+int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
+    OAK_REQUIRE(ctx->have_data && ctx->have_Z, "SGPR: set_data and set_inducing must be called first");
+    const int64_t N = ctx->N, M = ctx->M, Mp = pad128(M);
+    double* dX = (double*)peek_buf(ctx, "X");
+    double* dY = (double*)peek_buf(ctx, "Y");
+    double* dZ = (double*)peek_buf(ctx, "Z");
+    Stats st;
+    OAK_CHECK(stats_view(ctx, &st));
+    OAK_CHECK(fill_zero(ctx, st.phi, sizeof(double) * (size_t)st.len));
+    Feat FX, FZ;
+    {
+        PhaseTimer t(ctx, "featurize");
+        OAK_CHECK(featurize(ctx, pk, dZ, M, ctx->ldx, "featZ", &FZ));
+        OAK_CHECK(featurize(ctx, pk, dX, N, ctx->ldx, "featX", &FX));
+        t.stop();
+    }
+    int64_t rows = ctx->panel_rows > 0 ? ctx->panel_rows : (int64_t)(((size_t)16 << 30) / (sizeof(double) * (size_t)Mp));
+    if (rows > N) rows = N;
+    if (rows < 16) rows = 16;
+    double* dPanel = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "panel", (size_t)rows * Mp, &dPanel));
+    const int nsplit = syrk_plan_splits(ctx, M);
+    double* dPart = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "syrk_part", (size_t)nsplit * Mp * Mp, &dPart));
+    // Route: "phi" accumulates Phi = Kuf Kuf^T and whitens the M x M result in the tail (M^2 N flops; error grows with
+    // cond(Kuu)); "whitened" applies L^-1 to every panel row first -- exactly GPflow's A = L^-1 Kuf (oak/utils.py:189),
+    // 2x the flops, error independent of forming Phi.  Auto: whitened while the extra TRSM is cheap.
+    const bool whiten = ctx->route == 2 || (ctx->route == 0 && N * M <= ((int64_t)1 << 24));
+    double* dLw = nullptr;
+    if (whiten) {
+        OAK_CHECK(get_buf_t(ctx, "L", (size_t)M * M, &dLw));
+        OAK_CHECK(gram(ctx, pk, FZ, 0, M, FZ, dLw, M, nullptr, nullptr, 0));
+        OAK_CHECK(add_diag(ctx, dLw, M, M, jitter));
+        OAK_CHECK(potrf_lower(ctx, dLw, M, M));
+    }
+    int chunk_idx = 0;
+    for (int64_t a0 = 0; a0 < N; a0 += rows, ++chunk_idx) {
+        const int64_t na = (a0 + rows <= N) ? rows : N - a0;
+        {
+            PhaseTimer t(ctx, "gram");
+            OAK_CHECK(gram(ctx, pk, FX, a0, na, FZ, dPanel, Mp, dY, st.psi, Mp));
+            t.stop();
+        }
+        if (whiten) {
+            PhaseTimer t(ctx, "trsm");
+            OAK_CHECK(trsm_rows(ctx, dLw, M, M, dPanel, na, Mp, 0));     // row n <- L^-1 K(Z, x_n)
+            t.stop();
+        }
+        {
+            PhaseTimer t(ctx, "syrk");
+            OAK_CHECK(syrk_panel(ctx, dPanel, Mp, na, M, dPart, nsplit, chunk_idx > 0));
+            t.stop();
+        }
+    }
+    {
+        PhaseTimer t(ctx, "reduce");
+        OAK_CHECK(syrk_reduce(ctx, dPart, nsplit, M, st.phi, false));
+        double* dDiag = nullptr;
+        OAK_CHECK(get_buf_t(ctx, "kdiag", (size_t)N, &dDiag));
+        OAK_CHECK(gram_diag(ctx, pk, FX, dDiag, st.kappa));
+        OAK_CHECK(reduce_sum(ctx, dY, N, st.yy, 1, 1));
+        const double nn = (double)N;
+        OAK_HIP_CHECK(hipMemcpyAsync(st.nrows, &nn, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // nn is a stack variable
+        t.stop();
+    }
+    ctx->have_stats = true;
+    ctx->stats_whitened = whiten;
+    ctx->have_post = false;
+    return OAK_OK;
+}
+
+int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out) {
+    OAK_REQUIRE(ctx->have_stats, "SGPR tail: no sufficient statistics (call local_stats / set_stats first)");
+    OAK_REQUIRE(noise_var > 0.0, "noise variance must be positive");
+    PhaseTimer t(ctx, "tail");
+    const int64_t M = ctx->M;
+    Stats st;
+    OAK_CHECK(stats_view(ctx, &st));
+    double* dZ = (double*)peek_buf(ctx, "Z");
+    Feat FZ;
+    OAK_CHECK(featurize(ctx, pk, dZ, M, ctx->ldx, "featZ", &FZ));
+    double *dL, *dT1, *dT2, *dLB, *dv1, *dc, *dalpha, *dscal;
+    OAK_CHECK(get_buf_t(ctx, "L", (size_t)M * M, &dL));
+    OAK_CHECK(get_buf_t(ctx, "T1", (size_t)M * M, &dT1));
+    OAK_CHECK(get_buf_t(ctx, "T2", (size_t)M * M, &dT2));
+    OAK_CHECK(get_buf_t(ctx, "LB", (size_t)M * M, &dLB));
+    OAK_CHECK(get_buf_t(ctx, "v1", (size_t)M, &dv1));
+    OAK_CHECK(get_buf_t(ctx, "c", (size_t)M, &dc));
+    OAK_CHECK(get_buf_t(ctx, "alpha", (size_t)M, &dalpha));
+    OAK_CHECK(get_buf_t(ctx, "scal", 8, &dscal));
+    // Kuu + jitter I -> L   (oak/utils.py:185,188)
+    OAK_CHECK(gram(ctx, pk, FZ, 0, M, FZ, dL, M, nullptr, nullptr, 0));
+    OAK_CHECK(add_diag(ctx, dL, M, M, jitter));
+    OAK_CHECK(potrf_lower(ctx, dL, M, M));
+    // W = L^-1 Phi L^-T  (= sigma^2 * A A^T, utils.py:189-190 without materialising A)
+    if (ctx->stats_whitened) {
+        OAK_CHECK(copy_d2d(ctx, dT2, st.phi, sizeof(double) * (size_t)M * M));   // statistics already hold W
+    } else {
+        OAK_CHECK(copy_d2d(ctx, dT1, st.phi, sizeof(double) * (size_t)M * M));
+        OAK_CHECK(trsm_rows(ctx, dL, M, M, dT1, M, M, 0));      // rows of T1 = L^-1 Phi[:, r]  -> T1 = (L^-1 Phi)^T
+        OAK_CHECK(transpose(ctx, dT1, M, M, M, dT2, M));        // T2 = L^-1 Phi
+        OAK_CHECK(trsm_rows(ctx, dL, M, M, dT2, M, M, 0));      // rows of T2 = L^-1 (L^-1 Phi)^T[:, r] -> T2 = W^T = W
+    }
+    // B = I + W / sigma^2 ; LB = chol(B)   (utils.py:190-193)
+    OAK_CHECK(scale_add_eye(ctx, dT2, M, 1.0 / noise_var, dLB));
+    OAK_CHECK(potrf_lower(ctx, dLB, M, M));
+    // c = LB^-1 L^-1 psi / sigma^2   (utils.py:194-195: Aerr = L^-1 psi / sigma, c = LB^-1 Aerr / sigma)
+    OAK_CHECK(copy_d2d(ctx, dv1, st.psi, sizeof(double) * (size_t)M));
+    OAK_CHECK(trsm_rows(ctx, dL, M, M, dv1, 1, M, 0));
+    OAK_CHECK(copy_d2d(ctx, dc, dv1, sizeof(double) * (size_t)M));
+    OAK_CHECK(trsm_rows(ctx, dLB, M, M, dc, 1, M, 0));
+    OAK_CHECK(scale_vec(ctx, 1.0 / noise_var, dc, M));
+    // alpha = L^-T LB^-T c   (utils.py:197-198)
+    OAK_CHECK(copy_d2d(ctx, dalpha, dc, sizeof(double) * (size_t)M));
+    OAK_CHECK(trsm_rows(ctx, dLB, M, M, dalpha, 1, M, 1));
+    OAK_CHECK(trsm_rows(ctx, dL, M, M, dalpha, 1, M, 1));
+    // scalars
+    OAK_CHECK(reduce_sum(ctx, dLB, M, dscal + 0, 2, M + 1));    // sum log diag LB
+    OAK_CHECK(reduce_sum(ctx, dc, M, dscal + 1, 1, 1));         // c^T c
+    OAK_CHECK(reduce_sum(ctx, dT2, M, dscal + 2, 0, M + 1));    // tr W
+    OAK_CHECK(copy_d2d(ctx, dscal + 3, st.kappa, sizeof(double) * 3));   // kappa, yy, nrows
+    OAK_CHECK(reduce_sum(ctx, dL, M, dscal + 6, 2, M + 1));     // sum log diag L
+    double h[8] = {0};
+    OAK_HIP_CHECK(hipMemcpyAsync(h, dscal, sizeof(double) * 7, hipMemcpyDeviceToHost, ctx->stream));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    t.stop();
+    const double sumlogLB = h[0], cTc = h[1], trAAT = h[2] / noise_var, kappa = h[3], yy = h[4], nrows = h[5];
+    // gpflow SGPR.elbo, P = 1
+    double bound = -0.5 * nrows * std::log(2.0 * M_PI);
+    bound += -sumlogLB;
+    bound -= 0.5 * nrows * std::log(noise_var);
+    bound += -0.5 * yy / noise_var;
+    bound += 0.5 * cTc;
+    bound += -0.5 * kappa / noise_var;
+    bound += 0.5 * trAAT;
+    if (elbo_out) *elbo_out = bound;
+    if (terms_out) {
+        terms_out[0] = sumlogLB; terms_out[1] = cTc; terms_out[2] = trAAT; terms_out[3] = kappa;
+        terms_out[4] = yy; terms_out[5] = nrows; terms_out[6] = 2.0 * h[6]; terms_out[7] = 0.0;
+    }
+    ctx->noise_var = noise_var; ctx->jitter = jitter;
+    ctx->have_post = true;
+    return OAK_OK;
+}
+
+}  // namespace oak
+
+using namespace oak;
+
+extern "C" {
+
+int oak_gram(oak_ctx* ctx, const oak_kernel_desc* desc, const double* X1, int64_t n1, const double* X2, int64_t n2,
+             int32_t ldx, double* out) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(X1 && out && n1 >= 0 && ldx >= 1, "oak_gram: bad arguments");
+    if (n1 == 0 || (X2 && n2 == 0)) return OAK_OK;
+    PreparedKernel pk;
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    return gram_to_host(ctx, pk, X1, n1, X2, n2, ldx, out);
+}
+
+int oak_gram_diag(oak_ctx* ctx, const oak_kernel_desc* desc, const double* X, int64_t n, int32_t ldx, double* out) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(X && out && n >= 0 && ldx >= 1, "oak_gram_diag: bad arguments");
+    if (n == 0) return OAK_OK;
+    PreparedKernel pk;
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    return gram_diag_to_host(ctx, pk, X, n, ldx, out);
+}
+
+int oak_gram_component(oak_ctx* ctx, const oak_kernel_desc* desc, const int32_t* subset, int32_t subset_len,
+                       int32_t apply_order_var, const double* X1, int64_t n1, const double* X2, int64_t n2, int32_t ldx,
+                       double* out) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(X1 && out && n1 >= 0 && ldx >= 1, "oak_gram_component: bad arguments");
+    if (n1 == 0 || (X2 && n2 == 0)) return OAK_OK;
+    PreparedKernel pk;
+    OAK_CHECK(prepare_component(ctx, desc, subset, subset_len, apply_order_var, &pk));
+    return gram_to_host(ctx, pk, X1, n1, X2, n2, ldx, out);
+}
+
+int oak_gram_component_diag(oak_ctx* ctx, const oak_kernel_desc* desc, const int32_t* subset, int32_t subset_len,
+                            int32_t apply_order_var, const double* X, int64_t n, int32_t ldx, double* out) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(X && out && n >= 0 && ldx >= 1, "oak_gram_component_diag: bad arguments");
+    if (n == 0) return OAK_OK;
+    PreparedKernel pk;
+    OAK_CHECK(prepare_component(ctx, desc, subset, subset_len, apply_order_var, &pk));
+    return gram_diag_to_host(ctx, pk, X, n, ldx, out);
+}
+
+// ---- SGPR ---------------------------------------------------------------------------------------
+int oak_sgpr_set_data(oak_ctx* ctx, const double* X, const double* Y, int64_t N, int32_t ldx) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(X && Y && N >= 1 && ldx >= 1, "oak_sgpr_set_data: bad arguments");
+    if (ctx->have_Z && ctx->ldx != ldx) ctx->have_Z = false;   // a new column count invalidates the old inducing inputs
+    double *dX, *dY;
+    OAK_CHECK(HostUpload::run(ctx, "X", X, (size_t)N * ldx, &dX));
+    OAK_CHECK(HostUpload::run(ctx, "Y", Y, (size_t)N, &dY));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->N = N; ctx->ldx = ldx; ctx->have_data = true; ctx->have_stats = false; ctx->have_post = false;
+    return OAK_OK;
+}
+
+int oak_sgpr_set_inducing(oak_ctx* ctx, const double* Z, int64_t M, int32_t ldx) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(Z && M >= 1 && ldx >= 1, "oak_sgpr_set_inducing: bad arguments");
+    if (ctx->have_data && ctx->ldx != ldx) ctx->have_data = false;   // likewise for the training data
+    OAK_REQUIRE(M <= 16384, "M=%lld inducing points exceeds the supported 16384", (long long)M);
+    double* dZ;
+    OAK_CHECK(HostUpload::run(ctx, "Z", Z, (size_t)M * ldx, &dZ));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->M = M; ctx->ldx = ldx; ctx->have_Z = true; ctx->have_stats = false; ctx->have_post = false;
+    return OAK_OK;
+}
+
+int oak_sgpr_set_panel_rows(oak_ctx* ctx, int64_t rows) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(rows >= 0, "panel rows must be >= 0");
+    ctx->panel_rows = rows;
+    return OAK_OK;
+}
+
+int oak_sgpr_local_stats(oak_ctx* ctx, const oak_kernel_desc* desc, double jitter) {
+    OAK_CHECK(guard(ctx));
+    PreparedKernel pk;
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    return sgpr_local_stats(ctx, pk, jitter);
+}
+
+int oak_sgpr_set_route(oak_ctx* ctx, int32_t route) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(route >= 0 && route <= 2, "route must be 0 (auto), 1 (phi) or 2 (whitened)");
+    ctx->route = route;
+    return OAK_OK;
+}
+
+int oak_sgpr_stats_whitened(oak_ctx* ctx, int32_t* flag) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(ctx->have_stats && flag, "no statistics available");
+    *flag = ctx->stats_whitened ? 1 : 0;
+    return OAK_OK;
+}
+
+int64_t oak_sgpr_stats_len(oak_ctx* ctx) { return ctx ? ctx->M * ctx->M + ctx->M + 3 : 0; }
+
+int oak_sgpr_get_stats(oak_ctx* ctx, double* packed_out) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(ctx->have_stats && packed_out, "no statistics available");
+    Stats st;
+    OAK_CHECK(stats_view(ctx, &st));
+    OAK_HIP_CHECK(hipMemcpyAsync(packed_out, st.phi, sizeof(double) * (size_t)st.len, hipMemcpyDeviceToHost, ctx->stream));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return OAK_OK;
+}
+
+int oak_sgpr_set_stats(oak_ctx* ctx, const double* packed, int32_t whitened) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(ctx->have_Z && packed, "set_inducing must precede set_stats");
+    Stats st;
+    OAK_CHECK(stats_view(ctx, &st));
+    OAK_HIP_CHECK(hipMemcpyAsync(st.phi, packed, sizeof(double) * (size_t)st.len, hipMemcpyHostToDevice, ctx->stream));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->have_stats = true; ctx->stats_whitened = whitened != 0; ctx->have_post = false;
+    return OAK_OK;
+}
+
+int oak_sgpr_tail(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, double jitter, double* elbo_out, double* terms_out) {
+    OAK_CHECK(guard(ctx));
+    PreparedKernel pk;
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    return sgpr_tail(ctx, pk, noise_var, jitter, elbo_out, terms_out);
+}
+
+int oak_sgpr_elbo(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, double jitter, double* elbo_out) {
+    OAK_CHECK(guard(ctx));
+    PreparedKernel pk;
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    PhaseTimer t(ctx, "total");
+    OAK_CHECK(sgpr_local_stats(ctx, pk, jitter));
+    if (ctx->comm != nullptr) OAK_CHECK(oak_comm_allreduce_stats(ctx));
+    OAK_CHECK(sgpr_tail(ctx, pk, noise_var, jitter, elbo_out, nullptr));
+    t.stop();
+    return OAK_OK;
+}
+
+int oak_sgpr_alpha(oak_ctx* ctx, double* alpha_out) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(alpha_out, "alpha_out is NULL");
+    if (!ctx->have_post) { set_error("SGPR posterior not available: call oak_sgpr_elbo/oak_sgpr_tail first"); return OAK_E_STATE; }
+    OAK_HIP_CHECK(hipMemcpyAsync(alpha_out, peek_buf(ctx, "alpha"), sizeof(double) * (size_t)ctx->M, hipMemcpyDeviceToHost, ctx->stream));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return OAK_OK;
+}
+
+int oak_sgpr_predict(oak_ctx* ctx, const oak_kernel_desc* desc, const double* Xs, int64_t Ns, int32_t ldx, double* mean, double* var) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(Xs && mean && var && Ns >= 0 && ldx == ctx->ldx, "oak_sgpr_predict: bad arguments");
+    if (!ctx->have_post) { set_error("SGPR posterior not available: call oak_sgpr_elbo/oak_sgpr_tail first"); return OAK_E_STATE; }
+    if (Ns == 0) return OAK_OK;
+    PreparedKernel pk;
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    const int64_t M = ctx->M;
+    double* dL = (double*)peek_buf(ctx, "L");
+    double* dLB = (double*)peek_buf(ctx, "LB");
+    double* dc = (double*)peek_buf(ctx, "c");
+    Feat FZ, FS;
+    OAK_CHECK(featurize(ctx, pk, (double*)peek_buf(ctx, "Z"), M, ctx->ldx, "featZ", &FZ));
+    int64_t chunk = (int64_t)(((size_t)1 << 29) / (size_t)M);    // <= 4 GiB of Ksu per pass
+    if (chunk > Ns) chunk = Ns;
+    if (chunk < 8) chunk = 8;
+    double *dXs, *dK, *ds1, *ds2, *dkd, *dmean, *dvar;
+    OAK_CHECK(get_buf_t(ctx, "pXs", (size_t)chunk * ldx, &dXs));
+    OAK_CHECK(get_buf_t(ctx, "pK", (size_t)chunk * M, &dK));
+    OAK_CHECK(get_buf_t(ctx, "ps1", (size_t)chunk, &ds1));
+    OAK_CHECK(get_buf_t(ctx, "ps2", (size_t)chunk, &ds2));
+    OAK_CHECK(get_buf_t(ctx, "pkd", (size_t)chunk, &dkd));
+    OAK_CHECK(get_buf_t(ctx, "pmean", (size_t)chunk, &dmean));
+    OAK_CHECK(get_buf_t(ctx, "pvar", (size_t)chunk, &dvar));
+    for (int64_t a0 = 0; a0 < Ns; a0 += chunk) {
+        const int64_t na = (a0 + chunk <= Ns) ? chunk : Ns - a0;
+        OAK_HIP_CHECK(hipMemcpyAsync(dXs, Xs + a0 * ldx, sizeof(double) * (size_t)na * ldx, hipMemcpyHostToDevice, ctx->stream));
+        OAK_CHECK(featurize(ctx, pk, dXs, na, ldx, "featS", &FS));
+        OAK_CHECK(gram(ctx, pk, FS, 0, na, FZ, dK, M, nullptr, nullptr, 0));       // rows = K(x*, Z) = Kus^T
+        OAK_CHECK(gram_diag(ctx, pk, FS, dkd, nullptr));
+        OAK_CHECK(trsm_rows(ctx, dL, M, M, dK, na, M, 0));                         // tmp1 = L^-1 Kus
+        OAK_CHECK(row_sumsq(ctx, dK, na, M, M, ds1));
+        OAK_CHECK(trsm_rows(ctx, dLB, M, M, dK, na, M, 0));                        // tmp2 = LB^-1 tmp1
+        OAK_CHECK(row_sumsq(ctx, dK, na, M, M, ds2));
+        OAK_CHECK(gemv_rows(ctx, dK, na, M, M, dc, dmean));                        // mean = tmp2^T c
+        predict_var_kernel<<<(unsigned)((na + 255) / 256), 256, 0, ctx->stream>>>(dkd, ds2, ds1, dvar, na);
+        OAK_HIP_CHECK(hipGetLastError());
+        OAK_HIP_CHECK(hipMemcpyAsync(mean + a0, dmean, sizeof(double) * (size_t)na, hipMemcpyDeviceToHost, ctx->stream));
+        OAK_HIP_CHECK(hipMemcpyAsync(var + a0, dvar, sizeof(double) * (size_t)na, hipMemcpyDeviceToHost, ctx->stream));
+        OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return OAK_OK;
+}
+
+// ---- GPR ----------------------------------------------------------------------------------------
+int oak_gpr_set_data(oak_ctx* ctx, const double* X, const double* Y, int64_t N, int32_t ldx) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(X && Y && N >= 1 && ldx >= 1, "oak_gpr_set_data: bad arguments");
+    OAK_REQUIRE(N <= 16384, "full GP with N=%lld rows exceeds the supported 16384 (use the sparse model)", (long long)N);
+    double *dX, *dY;
+    OAK_CHECK(HostUpload::run(ctx, "gprX", X, (size_t)N * ldx, &dX));
+    OAK_CHECK(HostUpload::run(ctx, "gprY", Y, (size_t)N, &dY));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->gN = N; ctx->gldx = ldx; ctx->g_have_data = true; ctx->g_have_post = false;
+    return OAK_OK;
+}
+
+int oak_gpr_log_marginal(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, double* out) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(ctx->g_have_data, "GPR: set_data must be called first");
+    OAK_REQUIRE(noise_var > 0.0, "noise variance must be positive");
+    PreparedKernel pk;
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    const int64_t N = ctx->gN;
+    Feat FX;
+    OAK_CHECK(featurize(ctx, pk, (double*)peek_buf(ctx, "gprX"), N, ctx->gldx, "gprF", &FX));
+    double *dL, *da, *dalpha, *dscal;
+    OAK_CHECK(get_buf_t(ctx, "gprL", (size_t)N * N, &dL));
+    OAK_CHECK(get_buf_t(ctx, "gpra", (size_t)N, &da));
+    OAK_CHECK(get_buf_t(ctx, "gpralpha", (size_t)N, &dalpha));
+    OAK_CHECK(get_buf_t(ctx, "scal", 8, &dscal));
+    OAK_CHECK(gram(ctx, pk, FX, 0, N, FX, dL, N, nullptr, nullptr, 0));     // K(X)          (oak/utils.py:208)
+    OAK_CHECK(add_diag(ctx, dL, N, N, noise_var));                          // + sigma^2 I   (:209)
+    OAK_CHECK(potrf_lower(ctx, dL, N, N));                                  // L             (:210)
+    OAK_CHECK(copy_d2d(ctx, da, peek_buf(ctx, "gprY"), sizeof(double) * (size_t)N));
+    OAK_CHECK(trsm_rows(ctx, dL, N, N, da, 1, N, 0));                       // a = L^-1 y
+    OAK_CHECK(copy_d2d(ctx, dalpha, da, sizeof(double) * (size_t)N));
+    OAK_CHECK(trsm_rows(ctx, dL, N, N, dalpha, 1, N, 1));                   // alpha = L^-T a (:211)
+    OAK_CHECK(reduce_sum(ctx, da, N, dscal + 0, 1, 1));
+    OAK_CHECK(reduce_sum(ctx, dL, N, dscal + 1, 2, N + 1));
+    double h[2];
+    OAK_HIP_CHECK(hipMemcpyAsync(h, dscal, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (out) *out = -0.5 * h[0] - h[1] - 0.5 * (double)N * std::log(2.0 * M_PI);
+    ctx->g_have_post = true; ctx->g_noise = noise_var;
+    return OAK_OK;
+}
+
+int oak_gpr_alpha(oak_ctx* ctx, double* alpha_out) {
+    OAK_CHECK(guard(ctx));
+    if (!ctx->g_have_post) { set_error("GPR posterior not available: call oak_gpr_log_marginal first"); return OAK_E_STATE; }
+    OAK_HIP_CHECK(hipMemcpyAsync(alpha_out, peek_buf(ctx, "gpralpha"), sizeof(double) * (size_t)ctx->gN, hipMemcpyDeviceToHost, ctx->stream));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return OAK_OK;
+}
+
+int oak_gpr_predict(oak_ctx* ctx, const oak_kernel_desc* desc, const double* Xs, int64_t Ns, int32_t ldx, double* mean, double* var) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(Xs && mean && var && Ns >= 0 && ldx == ctx->gldx, "oak_gpr_predict: bad arguments");
+    if (!ctx->g_have_post) { set_error("GPR posterior not available: call oak_gpr_log_marginal first"); return OAK_E_STATE; }
+    if (Ns == 0) return OAK_OK;
+    PreparedKernel pk;
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    const int64_t N = ctx->gN;
+    double* dL = (double*)peek_buf(ctx, "gprL");
+    double* dalpha = (double*)peek_buf(ctx, "gpralpha");
+    Feat FX, FS;
+    OAK_CHECK(featurize(ctx, pk, (double*)peek_buf(ctx, "gprX"), N, ctx->gldx, "gprF", &FX));
+    int64_t chunk = (int64_t)(((size_t)1 << 28) / (size_t)N);
+    if (chunk > Ns) chunk = Ns;
+    if (chunk < 8) chunk = 8;
+    double *dXs, *dK, *ds1, *dkd, *dmean, *dvar;
+    OAK_CHECK(get_buf_t(ctx, "pXs", (size_t)chunk * ldx, &dXs));
+    OAK_CHECK(get_buf_t(ctx, "pK", (size_t)chunk * N, &dK));
+    OAK_CHECK(get_buf_t(ctx, "ps1", (size_t)chunk, &ds1));
+    OAK_CHECK(get_buf_t(ctx, "pkd", (size_t)chunk, &dkd));
+    OAK_CHECK(get_buf_t(ctx, "pmean", (size_t)chunk, &dmean));
+    OAK_CHECK(get_buf_t(ctx, "pvar", (size_t)chunk, &dvar));
+    for (int64_t a0 = 0; a0 < Ns; a0 += chunk) {
+        const int64_t na = (a0 + chunk <= Ns) ? chunk : Ns - a0;
+        OAK_HIP_CHECK(hipMemcpyAsync(dXs, Xs + a0 * ldx, sizeof(double) * (size_t)na * ldx, hipMemcpyHostToDevice, ctx->stream));
+        OAK_CHECK(featurize(ctx, pk, dXs, na, ldx, "featS", &FS));
+        OAK_CHECK(gram(ctx, pk, FS, 0, na, FX, dK, N, nullptr, nullptr, 0));     // rows = K(x*, X)
+        OAK_CHECK(gram_diag(ctx, pk, FS, dkd, nullptr));
+        OAK_CHECK(gemv_rows(ctx, dK, na, N, N, dalpha, dmean));                  // mean = K(x*,X) alpha
+        OAK_CHECK(trsm_rows(ctx, dL, N, N, dK, na, N, 0));                       // A = L^-1 K(X,x*)
+        OAK_CHECK(row_sumsq(ctx, dK, na, N, N, ds1));
+        predict_var_kernel<<<(unsigned)((na + 255) / 256), 256, 0, ctx->stream>>>(dkd, nullptr, ds1, dvar, na);
+        OAK_HIP_CHECK(hipGetLastError());
+        OAK_HIP_CHECK(hipMemcpyAsync(mean + a0, dmean, sizeof(double) * (size_t)na, hipMemcpyDeviceToHost, ctx->stream));
+        OAK_HIP_CHECK(hipMemcpyAsync(var + a0, dvar, sizeof(double) * (size_t)na, hipMemcpyDeviceToHost, ctx->stream));
+        OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return OAK_OK;
+}
+
+// ---- device-resident benchmarking hook ------------------------------------------------------------
+int oak_bench_gram_resident(oak_ctx* ctx, const oak_kernel_desc* desc, double* bytes_out) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(ctx->have_data && ctx->have_Z, "set_data and set_inducing must be called first");
+    PreparedKernel pk;
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    const int64_t N = ctx->N, M = ctx->M, Mp = pad128(M);
+    Feat FX, FZ;
+    OAK_CHECK(featurize(ctx, pk, (double*)peek_buf(ctx, "Z"), M, ctx->ldx, "featZ", &FZ));
+    OAK_CHECK(featurize(ctx, pk, (double*)peek_buf(ctx, "X"), N, ctx->ldx, "featX", &FX));
+    int64_t rows = ctx->panel_rows > 0 ? ctx->panel_rows : (int64_t)(((size_t)16 << 30) / (sizeof(double) * (size_t)Mp));
+    if (rows > N) rows = N;
+    if (rows < 16) rows = 16;
+    double* dPanel = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "panel", (size_t)rows * Mp, &dPanel));
+    for (int64_t a0 = 0; a0 < N; a0 += rows) {
+        const int64_t na = (a0 + rows <= N) ? rows : N - a0;
+        PhaseTimer t(ctx, "gram");
+        OAK_CHECK(gram(ctx, pk, FX, a0, na, FZ, dPanel, Mp, nullptr, nullptr, Mp));
+        t.stop();
+    }
+    if (bytes_out) *bytes_out = 8.0 * ((double)N * M + (double)N * pk.dd.D + (double)M * pk.dd.D);
+    return OAK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,521 @@
+"""ctypes binding of ``liboak_hip.so`` (C ABI declared in ``include/oak_hip.h``).
+
+This is the only module that touches the native library.  There is no CPU
+fallback anywhere in the package: if the shared object is missing, or no HIP
+device is usable, the first compute call raises :class:`OakHipError`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from pathlib import Path
+from typing import Optional, Sequence
+
+import numpy as np
+
+OAK_OK, OAK_E_ARG, OAK_E_HIP, OAK_E_NOTPD, OAK_E_NCCL, OAK_E_STATE = 0, -1, -2, -3, -4, -5
+DIM_RBF, DIM_BINARY, DIM_CATEGORICAL = 0, 1, 2
+MEAS_NONE, MEAS_GAUSSIAN, MEAS_UNIFORM, MEAS_EMPIRICAL, MEAS_MOG = 0, 1, 2, 3, 4
+MAX_DIMS, MAX_DEPTH = 64, 8
+
+_PKG_ROOT = Path(__file__).resolve().parent.parent
+LIB_PATH = Path(os.environ.get("OAK_HIP_LIB", _PKG_ROOT / "lib" / "liboak_hip.so"))
+
+
+class OakHipError(RuntimeError):
+    """Raised when the native HIP library is missing or reports a runtime failure."""
+
+    def __init__(self, message: str, status: int = OAK_E_HIP):
+        super().__init__(message)
+        self.status = status
+
+
+class NotPositiveDefiniteError(OakHipError, ArithmeticError):
+    """Cholesky met a non-positive pivot (the reference surfaces tf.errors.InvalidArgumentError)."""
+
+
+class KernelDescStruct(C.Structure):
+    _fields_ = [
+        ("num_dims", C.c_int32), ("max_depth", C.c_int32), ("share_var", C.c_int32), ("n_order_var", C.c_int32),
+        ("order_var", C.POINTER(C.c_double)), ("dim_type", C.POINTER(C.c_int32)),
+        ("active_col", C.POINTER(C.c_int32)), ("lengthscale", C.POINTER(C.c_double)),
+        ("base_var", C.POINTER(C.c_double)), ("measure", C.POINTER(C.c_int32)),
+        ("meas_p0", C.POINTER(C.c_double)), ("meas_p1", C.POINTER(C.c_double)),
+        ("meas_k", C.POINTER(C.c_int32)), ("meas_off", C.POINTER(C.c_int32)),
+        ("meas_data", C.POINTER(C.c_double)), ("meas_data_len", C.c_int32),
+    ]
+
+
+_D = C.POINTER(C.c_double)
+_I = C.POINTER(C.c_int32)
+_CTX = C.c_void_p
+_DESC = C.POINTER(KernelDescStruct)
+
+# name -> (restype, argtypes); every symbol include/oak_hip.h declares
+SIGNATURES = {
+    "oak_last_error": (C.c_char_p, []),
+    "oak_version": (C.c_char_p, []),
+    "oak_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "oak_ctx_create": (C.c_int, [C.c_int, C.POINTER(_CTX)]),
+    "oak_ctx_destroy": (C.c_int, [_CTX]),
+    "oak_sync": (C.c_int, [_CTX]),
+    "oak_last_timing": (C.c_int, [_CTX, C.c_char_p, _D, _I]),
+    "oak_device_mem_info": (C.c_int, [_CTX, _D, _D]),
+    "oak_gram": (C.c_int, [_CTX, _DESC, _D, C.c_int64, _D, C.c_int64, C.c_int32, _D]),
+    "oak_gram_diag": (C.c_int, [_CTX, _DESC, _D, C.c_int64, C.c_int32, _D]),
+    "oak_gram_component": (C.c_int, [_CTX, _DESC, _I, C.c_int32, C.c_int32, _D, C.c_int64, _D, C.c_int64, C.c_int32, _D]),
+    "oak_gram_component_diag": (C.c_int, [_CTX, _DESC, _I, C.c_int32, C.c_int32, _D, C.c_int64, C.c_int32, _D]),
+    "oak_sgpr_set_data": (C.c_int, [_CTX, _D, _D, C.c_int64, C.c_int32]),
+    "oak_sgpr_set_inducing": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32]),
+    "oak_sgpr_set_panel_rows": (C.c_int, [_CTX, C.c_int64]),
+    "oak_sgpr_local_stats": (C.c_int, [_CTX, _DESC, C.c_double]),
+    "oak_sgpr_set_route": (C.c_int, [_CTX, C.c_int32]),
+    "oak_sgpr_stats_whitened": (C.c_int, [_CTX, _I]),
+    "oak_sgpr_stats_len": (C.c_int64, [_CTX]),
+    "oak_sgpr_get_stats": (C.c_int, [_CTX, _D]),
+    "oak_sgpr_set_stats": (C.c_int, [_CTX, _D, C.c_int32]),
+    "oak_sgpr_tail": (C.c_int, [_CTX, _DESC, C.c_double, C.c_double, _D, _D]),
+    "oak_sgpr_elbo": (C.c_int, [_CTX, _DESC, C.c_double, C.c_double, _D]),
+    "oak_sgpr_alpha": (C.c_int, [_CTX, _D]),
+    "oak_sgpr_predict": (C.c_int, [_CTX, _DESC, _D, C.c_int64, C.c_int32, _D, _D]),
+    "oak_grad_len": (C.c_int64, [_DESC]),
+    "oak_sgpr_elbo_grad": (C.c_int, [_CTX, _DESC, C.c_double, C.c_double, _D, _D]),
+    "oak_gpr_set_data": (C.c_int, [_CTX, _D, _D, C.c_int64, C.c_int32]),
+    "oak_gpr_log_marginal": (C.c_int, [_CTX, _DESC, C.c_double, _D]),
+    "oak_gpr_alpha": (C.c_int, [_CTX, _D]),
+    "oak_gpr_predict": (C.c_int, [_CTX, _DESC, _D, C.c_int64, C.c_int32, _D, _D]),
+    "oak_gpr_log_marginal_grad": (C.c_int, [_CTX, _DESC, C.c_double, _D, _D]),
+    "oak_sobol": (C.c_int, [_CTX, _DESC, _D, C.c_int64, C.c_int32, _D, _I, _I, C.c_int32, C.c_int32, C.c_double, C.c_double, _D]),
+    "oak_component_predict": (C.c_int, [_CTX, _DESC, _D, C.c_int64, _D, C.c_int64, C.c_int32, _D, _I, _I, C.c_int32, C.c_int32, _D]),
+    "oak_comm_unique_id": (C.c_int, [C.c_char_p]),
+    "oak_comm_init": (C.c_int, [_CTX, C.c_char_p, C.c_int32, C.c_int32]),
+    "oak_comm_destroy": (C.c_int, [_CTX]),
+    "oak_comm_allreduce_stats": (C.c_int, [_CTX]),
+    "oak_comm_allreduce_host": (C.c_int, [_CTX, _D, C.c_int64]),
+    "oak_bench_gram_resident": (C.c_int, [_CTX, _DESC, _D]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen the in-tree shared object; raise OakHipError when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise OakHipError(
+            f"native library {LIB_PATH} not found: build it with "
+            f"`make -C {_PKG_ROOT / 'csrc'}` (or `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "The OAK HIP path has no CPU fallback.")
+    lib = C.CDLL(str(LIB_PATH))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(status: int):
+    if status == OAK_OK:
+        return
+    msg = load_library().oak_last_error().decode("utf-8", "replace")
+    if status == OAK_E_NOTPD:
+        raise NotPositiveDefiniteError(msg, status)
+    if status == OAK_E_ARG:
+        raise ValueError(msg)
+    raise OakHipError(msg, status)
+
+
+def _f64(a, ndim=None) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if ndim is not None and a.ndim != ndim:
+        raise ValueError(f"expected a {ndim}-D array, got shape {a.shape}")
+    return a
+
+
+def _dp(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(_D)
+
+
+def _ip(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(_I)
+
+
+class KernelDesc:
+    """Owns the numpy arrays behind an ``oak_kernel_desc`` POD.
+
+    ``spec`` schema (plain data, also used by the test oracle):
+        {"dims": [...], "order_variances": [...], "max_interaction_depth": R, "share_var_across_orders": bool}
+    dim entries: {"type": "rbf", "lengthscale", "variance", "measure": None | ("gaussian", mu, var) |
+    ("uniform", a, b) | ("empirical", loc, w) | ("mog", means, vars, w), "active_dim": col (optional)},
+    {"type": "binary", "p0", "variance"}, {"type": "categorical", "p", "W", "kappa", "variance"}.
+    """
+
+    def __init__(self, spec: dict):
+        dims = spec["dims"]
+        D = len(dims)
+        R = int(spec["max_interaction_depth"])
+        if not (1 <= D <= MAX_DIMS):
+            raise ValueError(f"number of sub-kernels {D} outside [1, {MAX_DIMS}]")
+        if not (0 <= R <= MAX_DEPTH):
+            raise ValueError(f"max_interaction_depth {R} outside [0, {MAX_DEPTH}] supported by the fused HIP kernels")
+        share = bool(spec.get("share_var_across_orders", True))
+        ov = _f64(np.asarray(spec["order_variances"], dtype=np.float64).reshape(-1))
+        if ov.size != (R + 1 if share else 1):
+            raise ValueError("order_variances has the wrong length")
+        self.order_var = ov
+        self.dim_type = np.zeros(D, np.int32)
+        self.active_col = np.zeros(D, np.int32)
+        self.lengthscale = np.ones(D, np.float64)
+        self.base_var = np.ones(D, np.float64)
+        self.measure = np.zeros(D, np.int32)
+        self.meas_p0 = np.zeros(D, np.float64)
+        self.meas_p1 = np.zeros(D, np.float64)
+        self.meas_k = np.zeros(D, np.int32)
+        self.meas_off = np.zeros(D, np.int32)
+        data = []
+        off = 0
+        self.cat_blocks = {}   # dim -> (offset, C) of the categorical table inside meas_data
+        for d, dim in enumerate(dims):
+            self.active_col[d] = int(dim.get("active_dim", d))
+            self.base_var[d] = float(np.asarray(dim.get("variance", 1.0)).reshape(-1)[0])
+            t = dim["type"]
+            if t == "rbf":
+                self.dim_type[d] = DIM_RBF
+                self.lengthscale[d] = float(np.asarray(dim["lengthscale"]).reshape(-1)[0])
+                m = dim.get("measure")
+                if m is None:
+                    self.measure[d] = MEAS_NONE
+                elif m[0] == "gaussian":
+                    self.measure[d] = MEAS_GAUSSIAN
+                    self.meas_p0[d], self.meas_p1[d] = float(m[1]), float(m[2])
+                elif m[0] == "uniform":
+                    self.measure[d] = MEAS_UNIFORM
+                    self.meas_p0[d], self.meas_p1[d] = float(m[1]), float(m[2])
+                elif m[0] == "empirical":
+                    loc = _f64(np.asarray(m[1], dtype=np.float64).reshape(-1))
+                    w = _f64(np.asarray(m[2], dtype=np.float64).reshape(-1))
+                    if loc.size != w.size:
+                        raise ValueError("empirical measure: locations and weights differ in length")
+                    self.measure[d] = MEAS_EMPIRICAL
+                    self.meas_k[d], self.meas_off[d] = loc.size, off
+                    data += [loc, w]
+                    off += 2 * loc.size
+                elif m[0] == "mog":
+                    mu, var, w = (_f64(np.asarray(x, dtype=np.float64).reshape(-1)) for x in m[1:4])
+                    if not (mu.size == var.size == w.size):
+                        raise ValueError("MOG measure: means, variances and weights differ in length")
+                    self.measure[d] = MEAS_MOG
+                    self.meas_k[d], self.meas_off[d] = mu.size, off
+                    data += [mu, var, w]
+                    off += 3 * mu.size
+                else:
+                    raise NotImplementedError(f"unknown measure {m[0]!r}")
+            elif t == "binary":
+                self.dim_type[d] = DIM_BINARY
+                self.meas_p0[d] = float(dim["p0"])
+                self.meas_k[d] = 2
+            elif t == "categorical":
+                self.dim_type[d] = DIM_CATEGORICAL
+                B, p = categorical_table_unit(dim["W"], dim["kappa"], dim["p"])
+                Cn = B.shape[0]
+                self.meas_k[d], self.meas_off[d] = Cn, off
+                self.cat_blocks[d] = (off, Cn)
+                data += [B.reshape(-1), p.reshape(-1)]
+                off += Cn * Cn + Cn
+            else:
+                raise NotImplementedError(f"unknown sub-kernel type {t!r}")
+        self.meas_data = _f64(np.concatenate(data)) if data else np.zeros(1, np.float64)
+        self.meas_len = off
+        s = KernelDescStruct()
+        s.num_dims, s.max_depth, s.share_var, s.n_order_var = D, R, int(share), int(ov.size)
+        s.order_var = _dp(self.order_var)
+        s.dim_type = _ip(self.dim_type)
+        s.active_col = _ip(self.active_col)
+        s.lengthscale = _dp(self.lengthscale)
+        s.base_var = _dp(self.base_var)
+        s.measure = _ip(self.measure)
+        s.meas_p0 = _dp(self.meas_p0)
+        s.meas_p1 = _dp(self.meas_p1)
+        s.meas_k = _ip(self.meas_k)
+        s.meas_off = _ip(self.meas_off)
+        s.meas_data = _dp(self.meas_data)
+        s.meas_data_len = int(off)
+        self.struct = s
+        self.D, self.R, self.share = D, R, share
+        self.min_cols = int(self.active_col.max()) + 1
+
+    @property
+    def ref(self):
+        return C.byref(self.struct)
+
+
+def categorical_table_unit(W, kappa, p):
+    """Unit-variance coregion table B = A - (Ap)(Ap)^T / (p^T A p), A = W W^T + diag(kappa)
+    (oak/ortho_categorical_kernel.py:34-42) -- O(C^2) parameter preparation done on the host."""
+    W = np.asarray(W, dtype=np.float64)
+    kappa = np.asarray(kappa, dtype=np.float64).reshape(-1)
+    p = np.asarray(p, dtype=np.float64).reshape(-1, 1)
+    A = W @ W.T + np.diag(kappa)
+    Ap = A @ p
+    B = A - (Ap @ Ap.T) / float(p.T @ Ap)
+    return np.ascontiguousarray(B), np.ascontiguousarray(p)
+
+
+class HipContext:
+    """One device context (HIP stream + device scratch); mirrors ``oak_ctx``."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        h = _CTX()
+        _check(self._lib.oak_ctx_create(int(device), C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.oak_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- helpers ------------------------------------------------------------------------------
+    @staticmethod
+    def _check_cols(desc: KernelDesc, X: np.ndarray):
+        if X.ndim != 2 or X.shape[1] < desc.min_cols:
+            raise ValueError(f"input has shape {X.shape}; the kernel reads column {desc.min_cols - 1}")
+
+    def sync(self):
+        _check(self._lib.oak_sync(self._h))
+
+    def timing(self, name: str):
+        ms, cnt = C.c_double(), C.c_int32()
+        _check(self._lib.oak_last_timing(self._h, name.encode(), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    def mem_info(self):
+        f, t = C.c_double(), C.c_double()
+        _check(self._lib.oak_device_mem_info(self._h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
+    # -- Gram ---------------------------------------------------------------------------------
+    def gram(self, desc: KernelDesc, X, X2=None) -> np.ndarray:
+        X = _f64(X, 2)
+        self._check_cols(desc, X)
+        if X2 is None:
+            out = np.empty((X.shape[0], X.shape[0]))
+            if out.size:
+                _check(self._lib.oak_gram(self._h, desc.ref, _dp(X), X.shape[0], None, 0, X.shape[1], _dp(out)))
+            return out
+        X2 = _f64(X2, 2)
+        if X2.shape[1] != X.shape[1]:
+            raise ValueError("X and X2 differ in their number of columns")
+        out = np.empty((X.shape[0], X2.shape[0]))
+        if out.size:
+            _check(self._lib.oak_gram(self._h, desc.ref, _dp(X), X.shape[0], _dp(X2), X2.shape[0], X.shape[1], _dp(out)))
+        return out
+
+    def gram_diag(self, desc: KernelDesc, X) -> np.ndarray:
+        X = _f64(X, 2)
+        self._check_cols(desc, X)
+        out = np.empty(X.shape[0])
+        if out.size:
+            _check(self._lib.oak_gram_diag(self._h, desc.ref, _dp(X), X.shape[0], X.shape[1], _dp(out)))
+        return out
+
+    def gram_component(self, desc: KernelDesc, subset: Sequence[int], apply_order_var: bool, X, X2=None) -> np.ndarray:
+        X = _f64(X, 2)
+        self._check_cols(desc, X)
+        sub = np.ascontiguousarray(subset, dtype=np.int32)
+        n2 = X.shape[0]
+        X2p = None
+        if X2 is not None:
+            X2 = _f64(X2, 2)
+            n2, X2p = X2.shape[0], _dp(X2)
+        out = np.empty((X.shape[0], n2))
+        if out.size:
+            _check(self._lib.oak_gram_component(self._h, desc.ref, _ip(sub), sub.size, int(apply_order_var), _dp(X),
+                                                X.shape[0], X2p, 0 if X2 is None else n2, X.shape[1], _dp(out)))
+        return out
+
+    def gram_component_diag(self, desc: KernelDesc, subset: Sequence[int], apply_order_var: bool, X) -> np.ndarray:
+        X = _f64(X, 2)
+        self._check_cols(desc, X)
+        sub = np.ascontiguousarray(subset, dtype=np.int32)
+        out = np.empty(X.shape[0])
+        if out.size:
+            _check(self._lib.oak_gram_component_diag(self._h, desc.ref, _ip(sub), sub.size, int(apply_order_var), _dp(X),
+                                                     X.shape[0], X.shape[1], _dp(out)))
+        return out
+
+    # -- SGPR ---------------------------------------------------------------------------------
+    def sgpr_set_data(self, X, Y):
+        X, Y = _f64(X, 2), _f64(np.asarray(Y).reshape(-1))
+        if Y.shape[0] != X.shape[0]:
+            raise ValueError("X and Y differ in their number of rows")
+        _check(self._lib.oak_sgpr_set_data(self._h, _dp(X), _dp(Y), X.shape[0], X.shape[1]))
+
+    def sgpr_set_inducing(self, Z):
+        Z = _f64(Z, 2)
+        _check(self._lib.oak_sgpr_set_inducing(self._h, _dp(Z), Z.shape[0], Z.shape[1]))
+
+    def sgpr_set_panel_rows(self, rows: int):
+        _check(self._lib.oak_sgpr_set_panel_rows(self._h, int(rows)))
+
+    ROUTES = {"auto": 0, "phi": 1, "whitened": 2}
+
+    def sgpr_set_route(self, route):
+        _check(self._lib.oak_sgpr_set_route(self._h, self.ROUTES.get(route, route)))
+
+    def sgpr_stats_whitened(self) -> bool:
+        f = C.c_int32()
+        _check(self._lib.oak_sgpr_stats_whitened(self._h, C.byref(f)))
+        return bool(f.value)
+
+    def sgpr_local_stats(self, desc: KernelDesc, jitter: float = 1e-6):
+        _check(self._lib.oak_sgpr_local_stats(self._h, desc.ref, float(jitter)))
+
+    def sgpr_get_stats(self) -> np.ndarray:
+        out = np.empty(self._lib.oak_sgpr_stats_len(self._h))
+        _check(self._lib.oak_sgpr_get_stats(self._h, _dp(out)))
+        return out
+
+    def sgpr_set_stats(self, packed, whitened: bool = False):
+        packed = _f64(packed, 1)
+        if packed.size != self._lib.oak_sgpr_stats_len(self._h):
+            raise ValueError("packed statistics have the wrong length")
+        _check(self._lib.oak_sgpr_set_stats(self._h, _dp(packed), int(whitened)))
+
+    def sgpr_tail(self, desc: KernelDesc, noise_var: float, jitter: float = 1e-6):
+        e = C.c_double()
+        terms = np.zeros(8)
+        _check(self._lib.oak_sgpr_tail(self._h, desc.ref, float(noise_var), float(jitter), C.byref(e), _dp(terms)))
+        return e.value, terms
+
+    def sgpr_elbo(self, desc: KernelDesc, noise_var: float, jitter: float = 1e-6) -> float:
+        e = C.c_double()
+        _check(self._lib.oak_sgpr_elbo(self._h, desc.ref, float(noise_var), float(jitter), C.byref(e)))
+        return e.value
+
+    def sgpr_alpha(self, M: int) -> np.ndarray:
+        out = np.empty(M)
+        _check(self._lib.oak_sgpr_alpha(self._h, _dp(out)))
+        return out
+
+    def sgpr_predict(self, desc: KernelDesc, Xs):
+        Xs = _f64(Xs, 2)
+        mean, var = np.empty(Xs.shape[0]), np.empty(Xs.shape[0])
+        _check(self._lib.oak_sgpr_predict(self._h, desc.ref, _dp(Xs), Xs.shape[0], Xs.shape[1], _dp(mean), _dp(var)))
+        return mean, var
+
+    def grad_len(self, desc: KernelDesc) -> int:
+        return int(self._lib.oak_grad_len(desc.ref))
+
+    def sgpr_elbo_grad(self, desc: KernelDesc, noise_var: float, jitter: float = 1e-6):
+        e = C.c_double()
+        g = np.zeros(self.grad_len(desc))
+        _check(self._lib.oak_sgpr_elbo_grad(self._h, desc.ref, float(noise_var), float(jitter), C.byref(e), _dp(g)))
+        return e.value, g
+
+    # -- GPR ----------------------------------------------------------------------------------
+    def gpr_set_data(self, X, Y):
+        X, Y = _f64(X, 2), _f64(np.asarray(Y).reshape(-1))
+        if Y.shape[0] != X.shape[0]:
+            raise ValueError("X and Y differ in their number of rows")
+        _check(self._lib.oak_gpr_set_data(self._h, _dp(X), _dp(Y), X.shape[0], X.shape[1]))
+
+    def gpr_log_marginal(self, desc: KernelDesc, noise_var: float) -> float:
+        e = C.c_double()
+        _check(self._lib.oak_gpr_log_marginal(self._h, desc.ref, float(noise_var), C.byref(e)))
+        return e.value
+
+    def gpr_log_marginal_grad(self, desc: KernelDesc, noise_var: float):
+        e = C.c_double()
+        g = np.zeros(self.grad_len(desc))
+        _check(self._lib.oak_gpr_log_marginal_grad(self._h, desc.ref, float(noise_var), C.byref(e), _dp(g)))
+        return e.value, g
+
+    def gpr_alpha(self, N: int) -> np.ndarray:
+        out = np.empty(N)
+        _check(self._lib.oak_gpr_alpha(self._h, _dp(out)))
+        return out
+
+    def gpr_predict(self, desc: KernelDesc, Xs):
+        Xs = _f64(Xs, 2)
+        mean, var = np.empty(Xs.shape[0]), np.empty(Xs.shape[0])
+        _check(self._lib.oak_gpr_predict(self._h, desc.ref, _dp(Xs), Xs.shape[0], Xs.shape[1], _dp(mean), _dp(var)))
+        return mean, var
+
+    # -- Sobol / components -------------------------------------------------------------------
+    @staticmethod
+    def _pack_subsets(subsets):
+        off = np.zeros(len(subsets) + 1, np.int32)
+        flat = []
+        for i, s in enumerate(subsets):
+            flat += [int(v) for v in s]
+            off[i + 1] = len(flat)
+        return np.ascontiguousarray(flat if flat else [0], dtype=np.int32), off
+
+    def sobol(self, desc: KernelDesc, Xc, alpha, subsets, use_order_var=True, delta=1.0, mu=0.0) -> np.ndarray:
+        Xc, alpha = _f64(Xc, 2), _f64(np.asarray(alpha).reshape(-1))
+        flat, off = self._pack_subsets(subsets)
+        out = np.zeros(len(subsets))
+        _check(self._lib.oak_sobol(self._h, desc.ref, _dp(Xc), Xc.shape[0], Xc.shape[1], _dp(alpha), _ip(flat), _ip(off),
+                                   len(subsets), int(use_order_var), float(delta), float(mu), _dp(out)))
+        return out
+
+    def component_predict(self, desc: KernelDesc, Xs, Xc, alpha, subsets, use_order_var=True) -> np.ndarray:
+        Xs, Xc, alpha = _f64(Xs, 2), _f64(Xc, 2), _f64(np.asarray(alpha).reshape(-1))
+        flat, off = self._pack_subsets(subsets)
+        out = np.zeros((len(subsets), Xs.shape[0]))
+        _check(self._lib.oak_component_predict(self._h, desc.ref, _dp(Xs), Xs.shape[0], _dp(Xc), Xc.shape[0], Xs.shape[1],
+                                               _dp(alpha), _ip(flat), _ip(off), len(subsets), int(use_order_var), _dp(out)))
+        return out
+
+    # -- multi-GPU ----------------------------------------------------------------------------
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _check(load_library().oak_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, nranks: int, rank: int):
+        _check(self._lib.oak_comm_init(self._h, unique_id, int(nranks), int(rank)))
+
+    def comm_allreduce_stats(self):
+        _check(self._lib.oak_comm_allreduce_stats(self._h))
+
+    def comm_allreduce_host(self, buf: np.ndarray):
+        buf = _f64(buf, 1)
+        _check(self._lib.oak_comm_allreduce_host(self._h, _dp(buf), buf.size))
+        return buf
+
+    # -- benchmarking -------------------------------------------------------------------------
+    def bench_gram_resident(self, desc: KernelDesc) -> float:
+        b = C.c_double()
+        _check(self._lib.oak_bench_gram_resident(self._h, desc.ref, C.byref(b)))
+        return b.value
+
+
+_default_ctx: Optional[HipContext] = None
+
+
+def default_context() -> HipContext:
+    """Process-wide context on device ``OAK_HIP_DEVICE`` (default: LOCAL_RANK or 0)."""
+    global _default_ctx
+    if _default_ctx is None:
+        dev = int(os.environ.get("OAK_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        _default_ctx = HipContext(dev)
+    return _default_ctx
+
+
+def device_count() -> int:
+    n = C.c_int()
+    st = load_library().oak_device_count(C.byref(n))
+    return n.value if st == OAK_OK else 0

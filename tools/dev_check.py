@@ -1,0 +1,71 @@
+"""Developer smoke script: HIP path vs oracle at small sizes + timing at the headline size."""
+import sys, time, os
+from pathlib import Path
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT / "orthogonal-additive-gaussian-processes_amd"))
+sys.path.insert(0, str(ROOT))
+import numpy as np
+from oak import _capi
+from oracle import oak_oracle as o
+
+ctx = _capi.HipContext(0)
+rng = np.random.default_rng(0)
+
+def relerr(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+# 1. mixed kernel gram
+X = rng.standard_normal((300, 5)); X[:, 3] = rng.integers(0, 2, 300); X[:, 4] = rng.integers(0, 4, 300)
+Z = X[:37].copy()
+W = rng.uniform(size=(4, 2))
+for R in range(0, 6):
+    spec = o.make_spec(5, R, p0=[None, None, None, 0.4, None], p=[None, None, None, None, np.array([.1, .2, .3, .4])],
+                       lengthscales=[0.7, 1.3, 2.0, 1, 1], order_variances=list(0.5 + rng.uniform(size=R + 1)),
+                       cat_W=[None] * 4 + [W], cat_kappa=[None] * 4 + [np.array([1., 2., .5, 1.5])])
+    spec["dims"][1]["measure"] = ("uniform", -3.0, 3.5)
+    spec["dims"][2]["measure"] = ("mog", np.array([-1., 1.]), np.array([.5, 2.]), np.array([.3, .7]))
+    d = _capi.KernelDesc(spec)
+    K = ctx.gram(d, X, Z); Kr = o.oak_K(spec, X, Z)
+    Kd = ctx.gram_diag(d, X); Kdr = o.oak_K_diag(spec, X)
+    Ks = ctx.gram(d, X)
+    print(f"R={R} gram relerr {relerr(K, Kr):.2e} diag {relerr(Kd, Kdr):.2e} sym {relerr(Ks, o.oak_K(spec, X)):.2e}")
+
+# 2. SGPR
+for (N, D, M, R) in [(1000, 3, 50, 2), (5000, 8, 200, 2), (4099, 6, 131, 3)]:
+    X, y, Z = o.synthetic_problem(N, D, M)
+    spec = o.make_spec(D, R, lengthscales=list(0.8 + rng.uniform(size=D)), order_variances=list(0.5 + rng.uniform(size=R + 1)))
+    d = _capi.KernelDesc(spec)
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z)
+    er = o.sgpr_elbo(spec, X, y, Z, 0.01)
+    ctx.sgpr_set_route("phi"); e1 = ctx.sgpr_elbo(d, 0.01)
+    print(f"   phi-route rel {abs(e1-er)/abs(er):.2e}  cond(Kuu) {np.linalg.cond(o.oak_K(spec, Z)+1e-6*np.eye(M)):.2e}")
+    ctx.sgpr_set_route("whitened")
+    t = time.time(); e = ctx.sgpr_elbo(d, 0.01); t1 = time.time() - t
+    a = ctx.sgpr_alpha(M); ar = o.sgpr_alpha(spec, X, y, Z, 0.01)[:, 0]
+    m, v = ctx.sgpr_predict(d, X[:500]); mr, vr = o.sgpr_predict_f(spec, X, y, Z, 0.01, X[:500])
+    st = ctx.sgpr_get_stats()
+    kuf = o.oak_K(spec, Z, X)
+    ctx.sgpr_set_route("phi"); ctx.sgpr_local_stats(d); st = ctx.sgpr_get_stats()
+    print(f"N={N} D={D} M={M} R={R}: elbo {e:.10f} ref {er:.10f} rel {abs(e-er)/abs(er):.2e} | alpha {relerr(a, ar):.2e} | mean {relerr(m, mr[:,0]):.2e} var abs {np.abs(v-vr[:,0]).max():.2e} | Phi {relerr(st[:M*M].reshape(M,M), kuf@kuf.T):.2e} psi {relerr(st[M*M:M*M+M], (kuf@y)[:,0]):.2e} ({t1*1e3:.1f} ms)")
+
+# 3. GPR
+X, y, _ = o.synthetic_problem(700, 4, 10)
+spec = o.make_spec(4, 2)
+d = _capi.KernelDesc(spec)
+ctx.gpr_set_data(X, y)
+l = ctx.gpr_log_marginal(d, 0.01); lr = o.gpr_log_marginal_likelihood(spec, X, y, 0.01)
+m, v = ctx.gpr_predict(d, X[:100] + 0.1); mr, vr = o.gpr_predict_f(spec, X, y, 0.01, X[:100] + 0.1)
+print(f"GPR logml {l:.8f} ref {lr:.8f} rel {abs(l-lr)/abs(lr):.2e} mean {relerr(m, mr[:,0]):.2e} var {np.abs(v-vr[:,0]).max():.2e}")
+
+# 4. headline timing
+if len(sys.argv) > 1 and sys.argv[1] == "big":
+    N, D, M, R = 1 << 20, 16, 1024, 2
+    X, y, Z = o.synthetic_problem(N, D, M)
+    spec = o.make_spec(D, R)
+    d = _capi.KernelDesc(spec)
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("phi")
+    for it in range(3):
+        t = time.time(); e = ctx.sgpr_elbo(d, 0.01); ctx.sync(); dt = time.time() - t
+        print(f"headline elbo {e:.6f} wall {dt*1e3:.1f} ms")
+    for nm in ["featurize", "gram", "trsm", "syrk", "reduce", "tail", "total"]:
+        print(nm, ctx.timing(nm))
