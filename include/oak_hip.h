@@ -86,6 +86,7 @@ int oak_sync(oak_ctx* ctx);
 /* wall time (ms) of the last named phase measured with hipEvents on the ctx stream:
    name in {"gram","syrk","tail","featurize","total","bwd_gemm","bwd_gram"}; count = launches */
 int oak_last_timing(oak_ctx* ctx, const char* name, double* ms, int32_t* count);
+int oak_reset_timings(oak_ctx* ctx);
 int oak_device_mem_info(oak_ctx* ctx, double* free_bytes, double* total_bytes);
 
 /* ---- Gram (replaces OAKKernel.K / K_diag, oak/oak_kernel.py:251-278, and through it
@@ -168,6 +169,16 @@ int oak_gpr_log_marginal_grad(oak_ctx* ctx, const oak_kernel_desc* desc, double 
 int oak_sobol(oak_ctx* ctx, const oak_kernel_desc* desc, const double* Xc, int64_t n, int32_t ldx,
               const double* alpha, const int32_t* subsets, const int32_t* subset_off,
               int32_t n_subsets, int32_t use_order_var, double delta, double mu, double* out);
+/* One per-dimension integral matrix L_d(v) [n x n] as the reference's compute_L* helpers return it
+   (v = the helper's `variance` argument; delta is used as a standard deviation, utils.py:116-165). */
+int oak_sobol_L(oak_ctx* ctx, const oak_kernel_desc* desc, int32_t dim, double v, double delta, double mu,
+                const double* Xc, int64_t n, int32_t ldx, double* out);
+/* cov_X_s(X) [n] and var_s of RBF sub-kernel `dim` (oak/ortho_rbf_kernel.py:47-152); either output may be NULL. */
+int oak_cov_x_s(oak_ctx* ctx, const oak_kernel_desc* desc, int32_t dim, const double* X, int64_t n, int32_t ldx,
+                double* c_out, double* var_s_out);
+/* [e_0 .. e_R] of D stacked length-n arrays (OAKKernel.compute_additive_terms, oak/oak_kernel.py:223-249):
+   mats [D x n] -> out [(R+1) x n]. */
+int oak_additive_terms(oak_ctx* ctx, const double* mats, int32_t D, int64_t n, int32_t R, double* out);
 /* Per-term predictive means (get_prediction_component, oak/utils.py:491-530):
    out[n_subsets x ns] = (sigma2_|S| prod_{d in S} k_d(Xs, Xc)) alpha */
 int oak_component_predict(oak_ctx* ctx, const oak_kernel_desc* desc, const double* Xs, int64_t ns,

@@ -1,0 +1,133 @@
+// Multi-GPU exchange: one RCCL reduce-scatter + all-gather (= all-reduce) of the packed SGPR statistics over xGMI.
+// The reference has no distributed code; every N-dependent term of the ELBO is a sum over rows, so
+// each rank reduces its own row shard to [Phi | psi | kappa | yy | n] and only that M^2+M+3 vector is exchanged.
+// librccl.so is dlopen'ed on first use so single-GPU runs carry no RCCL dependency.
+#include "oak_internal.h"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+
+namespace oak {
+
+struct Rccl {
+    void* h = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclReduceScatter) ReduceScatter = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+};
+static Rccl g_rccl;
+
+static int load_rccl() {
+    if (g_rccl.h) return OAK_OK;
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void* h = nullptr;
+    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) { set_error("cannot dlopen librccl.so: %s", dlerror()); return OAK_E_NCCL; }
+#define OAK_SYM(field, sym)                                                                  \
+    g_rccl.field = (decltype(g_rccl.field))dlsym(h, sym);                                    \
+    if (!g_rccl.field) { set_error("librccl.so lacks symbol %s", sym); return OAK_E_NCCL; }
+    OAK_SYM(GetUniqueId, "ncclGetUniqueId")
+    OAK_SYM(CommInitRank, "ncclCommInitRank")
+    OAK_SYM(CommDestroy, "ncclCommDestroy")
+    OAK_SYM(ReduceScatter, "ncclReduceScatter")
+    OAK_SYM(AllGather, "ncclAllGather")
+    OAK_SYM(AllReduce, "ncclAllReduce")
+    OAK_SYM(GetErrorString, "ncclGetErrorString")
+#undef OAK_SYM
+    g_rccl.h = h;
+    return OAK_OK;
+}
+
+#define OAK_NCCL_CHECK(expr)                                                                  \
+    do {                                                                                      \
+        ncclResult_t _r = (expr);                                                             \
+        if (_r != ncclSuccess) {                                                              \
+            set_error("%s failed: %s", #expr, g_rccl.GetErrorString(_r));                     \
+            return OAK_E_NCCL;                                                                \
+        }                                                                                     \
+    } while (0)
+
+// In-place sum over ranks of d_buf[0..n): reduce-scatter of equal slices, then all-gather.  The scratch tail that
+// pads n up to a multiple of nranks lives in a separate zeroed staging buffer so d_buf need not be over-allocated.
+int comm_allreduce_dev(oak_ctx* ctx, double* d_buf, int64_t n) {
+    if (ctx->comm == nullptr || ctx->nranks <= 1) return OAK_OK;
+    OAK_CHECK(load_rccl());
+    const int64_t P = ctx->nranks;
+    const int64_t slice = (n + P - 1) / P;
+    double* d_stage = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "comm_stage", (size_t)(slice * P), &d_stage));
+    OAK_CHECK(fill_zero(ctx, d_stage + n, sizeof(double) * (size_t)(slice * P - n)));
+    OAK_CHECK(copy_d2d(ctx, d_stage, d_buf, sizeof(double) * (size_t)n));
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    OAK_NCCL_CHECK(g_rccl.ReduceScatter(d_stage, d_stage + ctx->rank * slice, (size_t)slice, ncclFloat64, ncclSum, comm, ctx->stream));
+    OAK_NCCL_CHECK(g_rccl.AllGather(d_stage + ctx->rank * slice, d_stage, (size_t)slice, ncclFloat64, comm, ctx->stream));
+    OAK_CHECK(copy_d2d(ctx, d_buf, d_stage, sizeof(double) * (size_t)n));
+    return OAK_OK;
+}
+
+}  // namespace oak
+
+using namespace oak;
+
+extern "C" {
+
+int oak_comm_unique_id(char* id_out_128) {
+    if (!id_out_128) { set_error("id_out is NULL"); return OAK_E_ARG; }
+    OAK_CHECK(load_rccl());
+    ncclUniqueId id;
+    OAK_NCCL_CHECK(g_rccl.GetUniqueId(&id));
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    memcpy(id_out_128, &id, 128);
+    return OAK_OK;
+}
+
+int oak_comm_init(oak_ctx* ctx, const char* id_128, int32_t nranks, int32_t rank) {
+    if (!ctx || !id_128) { set_error("bad argument"); return OAK_E_ARG; }
+    OAK_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "rank %d / nranks %d invalid", rank, nranks);
+    OAK_HIP_CHECK(hipSetDevice(ctx->device));
+    OAK_CHECK(load_rccl());
+    if (ctx->comm) oak_comm_destroy(ctx);
+    ncclUniqueId id;
+    memcpy(&id, id_128, 128);
+    ncclComm_t comm = nullptr;
+    OAK_NCCL_CHECK(g_rccl.CommInitRank(&comm, nranks, id, rank));
+    ctx->comm = (void*)comm; ctx->nranks = nranks; ctx->rank = rank;
+    return OAK_OK;
+}
+
+int oak_comm_destroy(oak_ctx* ctx) {
+    if (!ctx || !ctx->comm) return OAK_OK;
+    if (g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)ctx->comm);
+    ctx->comm = nullptr; ctx->nranks = 1; ctx->rank = 0;
+    return OAK_OK;
+}
+
+int oak_comm_allreduce_stats(oak_ctx* ctx) {
+    if (!ctx) { set_error("ctx is NULL"); return OAK_E_ARG; }
+    OAK_HIP_CHECK(hipSetDevice(ctx->device));
+    OAK_REQUIRE(ctx->have_stats, "no local statistics to reduce");
+    if (ctx->comm == nullptr || ctx->nranks <= 1) return OAK_OK;
+    double* d_stats = (double*)peek_buf(ctx, "stats");
+    PhaseTimer t(ctx, "allreduce");
+    OAK_CHECK(comm_allreduce_dev(ctx, d_stats, ctx->M * ctx->M + ctx->M + 3));
+    t.stop();
+    return OAK_OK;
+}
+
+int oak_comm_allreduce_host(oak_ctx* ctx, double* buf, int64_t n) {
+    if (!ctx || !buf || n < 0) { set_error("bad argument"); return OAK_E_ARG; }
+    OAK_HIP_CHECK(hipSetDevice(ctx->device));
+    if (ctx->comm == nullptr || ctx->nranks <= 1 || n == 0) return OAK_OK;
+    double* d = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "comm_host", (size_t)n, &d));
+    OAK_HIP_CHECK(hipMemcpyAsync(d, buf, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    OAK_CHECK(comm_allreduce_dev(ctx, d, n));
+    OAK_HIP_CHECK(hipMemcpyAsync(buf, d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return OAK_OK;
+}
+
+}  // extern "C"

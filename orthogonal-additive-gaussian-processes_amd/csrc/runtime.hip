@@ -380,6 +380,12 @@ int oak_last_timing(oak_ctx* ctx, const char* name, double* ms, int32_t* count) 
     return OAK_OK;
 }
 
+int oak_reset_timings(oak_ctx* ctx) {
+    if (!ctx) { oak::set_error("ctx is NULL"); return OAK_E_ARG; }
+    oak::reset_timings(ctx);
+    return OAK_OK;
+}
+
 int oak_device_mem_info(oak_ctx* ctx, double* free_bytes, double* total_bytes) {
     if (!ctx) { oak::set_error("ctx is NULL"); return OAK_E_ARG; }
     size_t f = 0, t = 0;

@@ -60,6 +60,7 @@ SIGNATURES = {
     "oak_ctx_destroy": (C.c_int, [_CTX]),
     "oak_sync": (C.c_int, [_CTX]),
     "oak_last_timing": (C.c_int, [_CTX, C.c_char_p, _D, _I]),
+    "oak_reset_timings": (C.c_int, [_CTX]),
     "oak_device_mem_info": (C.c_int, [_CTX, _D, _D]),
     "oak_gram": (C.c_int, [_CTX, _DESC, _D, C.c_int64, _D, C.c_int64, C.c_int32, _D]),
     "oak_gram_diag": (C.c_int, [_CTX, _DESC, _D, C.c_int64, C.c_int32, _D]),
@@ -86,6 +87,9 @@ SIGNATURES = {
     "oak_gpr_predict": (C.c_int, [_CTX, _DESC, _D, C.c_int64, C.c_int32, _D, _D]),
     "oak_gpr_log_marginal_grad": (C.c_int, [_CTX, _DESC, C.c_double, _D, _D]),
     "oak_sobol": (C.c_int, [_CTX, _DESC, _D, C.c_int64, C.c_int32, _D, _I, _I, C.c_int32, C.c_int32, C.c_double, C.c_double, _D]),
+    "oak_sobol_L": (C.c_int, [_CTX, _DESC, C.c_int32, C.c_double, C.c_double, C.c_double, _D, C.c_int64, C.c_int32, _D]),
+    "oak_cov_x_s": (C.c_int, [_CTX, _DESC, C.c_int32, _D, C.c_int64, C.c_int32, _D, _D]),
+    "oak_additive_terms": (C.c_int, [_CTX, _D, C.c_int32, C.c_int64, C.c_int32, _D]),
     "oak_component_predict": (C.c_int, [_CTX, _DESC, _D, C.c_int64, _D, C.c_int64, C.c_int32, _D, _I, _I, C.c_int32, C.c_int32, _D]),
     "oak_comm_unique_id": (C.c_int, [C.c_char_p]),
     "oak_comm_init": (C.c_int, [_CTX, C.c_char_p, C.c_int32, C.c_int32]),
@@ -260,7 +264,7 @@ def categorical_table_unit(W, kappa, p):
     p = np.asarray(p, dtype=np.float64).reshape(-1, 1)
     A = W @ W.T + np.diag(kappa)
     Ap = A @ p
-    B = A - (Ap @ Ap.T) / float(p.T @ Ap)
+    B = A - (Ap @ Ap.T) / float((p.T @ Ap)[0, 0])
     return np.ascontiguousarray(B), np.ascontiguousarray(p)
 
 
@@ -298,6 +302,9 @@ class HipContext:
         ms, cnt = C.c_double(), C.c_int32()
         _check(self._lib.oak_last_timing(self._h, name.encode(), C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
+
+    def reset_timings(self):
+        _check(self._lib.oak_reset_timings(self._h))
 
     def mem_info(self):
         f, t = C.c_double(), C.c_double()
@@ -468,6 +475,26 @@ class HipContext:
         out = np.zeros(len(subsets))
         _check(self._lib.oak_sobol(self._h, desc.ref, _dp(Xc), Xc.shape[0], Xc.shape[1], _dp(alpha), _ip(flat), _ip(off),
                                    len(subsets), int(use_order_var), float(delta), float(mu), _dp(out)))
+        return out
+
+    def sobol_L(self, desc: KernelDesc, dim: int, v: float, delta: float, mu: float, Xc) -> np.ndarray:
+        Xc = _f64(Xc, 2)
+        out = np.empty((Xc.shape[0], Xc.shape[0]))
+        _check(self._lib.oak_sobol_L(self._h, desc.ref, int(dim), float(v), float(delta), float(mu), _dp(Xc), Xc.shape[0],
+                                     Xc.shape[1], _dp(out)))
+        return out
+
+    def measure_cov(self, desc: KernelDesc, dim: int, X):
+        X = _f64(X, 2)
+        c = np.empty(X.shape[0])
+        v = C.c_double()
+        _check(self._lib.oak_cov_x_s(self._h, desc.ref, int(dim), _dp(X), X.shape[0], X.shape[1], _dp(c), C.byref(v)))
+        return c, v.value
+
+    def additive_terms(self, mats, R: int) -> np.ndarray:
+        mats = _f64(mats, 2)
+        out = np.empty((R + 1, mats.shape[1]))
+        _check(self._lib.oak_additive_terms(self._h, _dp(mats), mats.shape[0], mats.shape[1], int(R), _dp(out)))
         return out
 
     def component_predict(self, desc: KernelDesc, Xs, Xc, alpha, subsets, use_order_var=True) -> np.ndarray:

@@ -1,0 +1,90 @@
+"""Row-sharded SGPR across the GPUs of one node (new; the reference is single-process).
+
+Every N-dependent quantity of the collapsed bound is a sum over rows, so rank g reduces its contiguous block
+``X[lo:hi]`` to the packed statistics ``[Phi | psi | kappa | yy | n]`` (M^2 + M + 3 doubles) on its own GPU and the
+only exchange is one sum-all-reduce of that vector -- RCCL reduce-scatter + all-gather over xGMI inside
+``liboak_hip`` (``oak_comm_allreduce_stats``).  The O(M^3) tail is then replicated.  This module holds the
+process-level plumbing: shard arithmetic, the packed layout, the communicator bootstrap (unique id broadcast over
+the torch.distributed control plane) and a reducer interface so the exchange can be exercised on CPU with gloo.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import numpy as np
+
+
+def shard_bounds(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous block [lo, hi) of rank `rank`; blocks differ by at most one row and tile [0, n_rows)."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside [0, {world})")
+    return (n_rows * rank) // world, (n_rows * (rank + 1)) // world
+
+
+def stats_len(M: int) -> int:
+    return M * M + M + 3
+
+
+def pack_stats(Phi: np.ndarray, psi: np.ndarray, kappa: float, yy: float, n_rows: float) -> np.ndarray:
+    M = Phi.shape[0]
+    out = np.empty(stats_len(M))
+    out[:M * M] = np.asarray(Phi, dtype=np.float64).reshape(-1)
+    out[M * M:M * M + M] = np.asarray(psi, dtype=np.float64).reshape(-1)
+    out[M * M + M:] = (kappa, yy, n_rows)
+    return out
+
+
+def unpack_stats(packed: np.ndarray, M: int):
+    packed = np.asarray(packed, dtype=np.float64)
+    if packed.size != stats_len(M):
+        raise ValueError("packed statistics have the wrong length")
+    return (packed[:M * M].reshape(M, M), packed[M * M:M * M + M].copy(), float(packed[M * M + M]),
+            float(packed[M * M + M + 1]), float(packed[M * M + M + 2]))
+
+
+def torch_allreduce(packed: np.ndarray) -> np.ndarray:
+    """Sum over the default torch.distributed group (gloo on CPU) -- the test/CPU stand-in for the RCCL exchange."""
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(np.ascontiguousarray(packed, dtype=np.float64))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.numpy()
+
+
+def choose_route(n_total: int, M: int) -> str:
+    """All ranks must agree on the solve route; decide it from GLOBAL sizes (same rule as the library's auto)."""
+    return "whitened" if n_total * M <= (1 << 24) else "phi"
+
+
+class ShardedSGPR:
+    """One rank's view of a row-sharded SGPR.
+
+    ``ctx`` is this rank's :class:`oak._capi.HipContext`.  With ``reducer=None`` the packed statistics are summed on
+    the device by RCCL (``init_rccl`` must have been called); passing a callable (e.g. :func:`torch_allreduce`) routes
+    the exchange through the host instead, which is how the N>1 logic is tested without GPUs' xGMI links.
+    """
+
+    def __init__(self, ctx, X_local, y_local, Z, n_total: int, reducer: Optional[Callable[[np.ndarray], np.ndarray]] = None,
+                 route: Optional[str] = None):
+        self.ctx, self.reducer = ctx, reducer
+        self.M = int(np.asarray(Z).shape[0])
+        self.n_total = int(n_total)
+        ctx.sgpr_set_data(X_local, y_local)
+        ctx.sgpr_set_inducing(Z)
+        ctx.sgpr_set_route(route or choose_route(self.n_total, self.M))
+
+    @staticmethod
+    def init_rccl(ctx, rank: int, world: int, broadcast: Callable[[Optional[bytes]], bytes]):
+        """Bootstrap the RCCL communicator: rank 0 draws the unique id, `broadcast` ships it to everyone."""
+        uid = broadcast(ctx.comm_unique_id() if rank == 0 else None)
+        ctx.comm_init(uid, world, rank)
+
+    def elbo(self, desc, noise_var: float, jitter: float = 1e-6) -> float:
+        if self.reducer is None:
+            return self.ctx.sgpr_elbo(desc, noise_var, jitter)       # local stats + RCCL all-reduce + tail
+        self.ctx.sgpr_local_stats(desc, jitter)
+        whitened = self.ctx.sgpr_stats_whitened()
+        total = self.reducer(self.ctx.sgpr_get_stats())
+        self.ctx.sgpr_set_stats(total, whitened)
+        e, _ = self.ctx.sgpr_tail(desc, noise_var, jitter)
+        return e

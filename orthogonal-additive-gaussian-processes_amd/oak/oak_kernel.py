@@ -1,0 +1,240 @@
+"""Composite orthogonal additive kernel: host mirror of oak/oak_kernel.py:24-364.
+
+The class keeps the reference's constructor, attributes (``kernels``, ``variances``) and methods
+(``K``, ``K_diag``, ``compute_additive_terms``) so model/utility code written against the reference keeps
+working; evaluation is delegated to the fused HIP Gram kernel, which never materialises the D per-dimension
+matrices nor the Newton-Girard intermediates.
+"""
+from __future__ import annotations
+
+import itertools
+from typing import List, Optional, Tuple, Type
+
+import numpy as np
+
+from . import _capi
+from . import gpflow_lite as gpflow
+from .gpflow_lite import Parameter, TensorLike, _as_value
+from .input_measures import EmpiricalMeasure, GaussianMeasure, MOGMeasure
+from .ortho_binary_kernel import OrthogonalBinary
+from .ortho_categorical_kernel import OrthogonalCategorical
+from .ortho_rbf_kernel import OrthogonalRBFKernel
+
+
+def bounded_param(low: float, high: float, param: float) -> Parameter:
+    """Parameter constrained to (low, high) by a scaled sigmoid (oak/oak_kernel.py:24-33)."""
+    return Parameter(param, transform=gpflow.Sigmoid(low, high))
+
+
+def _first_col(k) -> int:
+    dims = k.active_dims
+    if isinstance(dims, slice):
+        return 0
+    return int(np.asarray(dims).reshape(-1)[0])
+
+
+def _sub_kernel_spec(k, col: int) -> dict:
+    if isinstance(k, (OrthogonalRBFKernel, OrthogonalBinary, OrthogonalCategorical)):
+        return k.dim_spec(col)
+    if isinstance(k, gpflow.RBF):   # unconstrained additive model, oak_kernel.py:199-210
+        return dict(type="rbf", lengthscale=float(np.asarray(_as_value(k.lengthscales)).reshape(-1)[0]),
+                    variance=float(np.asarray(_as_value(k.variance)).reshape(-1)[0]), measure=None, active_dim=col)
+    raise NotImplementedError(f"no HIP description for sub-kernel {type(k).__name__}")
+
+
+def kernel_to_spec(kernel) -> dict:
+    """Plain-data description (see _capi.KernelDesc) of an OAKKernel or of a single constrained sub-kernel."""
+    if isinstance(kernel, OAKKernel):
+        dims = [_sub_kernel_spec(k, _first_col(k)) for k in kernel.kernels]
+        return dict(dims=dims, order_variances=[float(np.asarray(_as_value(v)).reshape(-1)[0]) for v in kernel.variances],
+                    max_interaction_depth=int(kernel.max_interaction_depth),
+                    share_var_across_orders=bool(kernel.share_var_across_orders))
+    if isinstance(kernel, (OrthogonalRBFKernel, OrthogonalBinary, OrthogonalCategorical, gpflow.RBF)):
+        if isinstance(kernel, gpflow.RBF) and not isinstance(kernel.active_dims, slice) and len(kernel.active_dims) != 1:
+            raise NotImplementedError("multi-column stand-alone RBF inside a model is not on the OAK path")
+        return dict(dims=[_sub_kernel_spec(kernel, _first_col(kernel))], order_variances=[0.0, 1.0],
+                    max_interaction_depth=1, share_var_across_orders=True)
+    raise NotImplementedError(f"kernel {type(kernel).__name__} is not supported by the HIP path")
+
+
+class OAKKernel(gpflow.Kernel):
+    """Orthogonal additive kernel (oak/oak_kernel.py:36-278); arguments as in the reference (:59-73)."""
+
+    def __init__(
+        self,
+        base_kernels: List[Type[gpflow.Kernel]],
+        num_dims: int,
+        max_interaction_depth: int,
+        active_dims: Optional[List[List[int]]] = None,
+        constrain_orthogonal: bool = False,
+        p0: Optional[List[float]] = None,
+        p: Optional[List[float]] = None,
+        lengthscale_bounds: Optional[List[float]] = None,
+        empirical_locations: Optional[List[float]] = None,
+        empirical_weights: Optional[List[float]] = None,
+        gmm_measures: Optional[List[MOGMeasure]] = None,
+        share_var_across_orders: Optional[bool] = True,
+    ):
+        super().__init__(active_dims=range(num_dims))
+        if active_dims is None:
+            active_dims = [[d] for d in range(num_dims)]
+        flat = [d for group in active_dims for d in group]
+        assert max(flat) <= num_dims, "Active dims exceeding num dims."                    # :79 (sic: <=)
+        assert len(flat) == len(np.unique(flat)), "Active dims contains duplicates."       # :80-82
+        n_sub = len(active_dims)
+        self.base_kernels, self.max_interaction_depth = base_kernels, max_interaction_depth
+        self.share_var_across_orders = share_var_across_orders
+        p0 = [None] * n_sub if p0 is None else p0
+        p = [None] * n_sub if p is None else p
+        one = np.ones(1)   # constant (non-trainable) unit variance, as tf.ones(1) in :164-166,179,187,209
+        self.kernels = []
+        if constrain_orthogonal:
+            if empirical_locations is None:
+                assert empirical_weights is None, "Cannot have weights without locations"
+                empirical_locations, empirical_weights = [None] * n_sub, [None] * n_sub
+            elif empirical_weights is not None:
+                n_loc = [None if empirical_locations[d] is None else len(empirical_locations[d]) for d in range(n_sub)]
+                n_w = [None if empirical_weights[d] is None else len(empirical_weights[d]) for d in range(n_sub)]
+                assert n_loc == n_w, f"Shape of empirical measure locations {n_loc} do not match weights {n_w}"
+            gmm_measures = [None] * n_sub if gmm_measures is None else gmm_measures
+            delta2 = 1   # variance of the Gaussian input measure, hard-coded in the reference (:84)
+            for d in range(n_sub):
+                if empirical_locations[d] is not None and gmm_measures[d] is not None:
+                    raise ValueError(f"Both empirical and GMM measure defined for input {d}")      # :132-138
+                if p0[d] is None and p[d] is None:
+                    if empirical_locations[d] is not None:
+                        meas = EmpiricalMeasure(empirical_locations[d], empirical_weights[d])
+                        k = OrthogonalRBFKernel(base_kernels[d](), meas, active_dims=active_dims[d])
+                    elif gmm_measures[d] is not None:
+                        k = OrthogonalRBFKernel(base_kernels[d](), measure=gmm_measures[d], active_dims=active_dims[d])
+                    else:
+                        k = OrthogonalRBFKernel(base_kernels[d](), GaussianMeasure(0, delta2), active_dims=active_dims[d])
+                        if share_var_across_orders:
+                            k.base_kernel.variance = one
+                    if lengthscale_bounds is not None:
+                        k.base_kernel.lengthscales = bounded_param(lengthscale_bounds[0], lengthscale_bounds[1], 1)
+                elif p[d] is not None:
+                    assert base_kernels[d] is None
+                    k = OrthogonalCategorical(p=p[d], active_dims=active_dims[d])
+                    if share_var_across_orders:
+                        k.variance = one
+                else:
+                    assert base_kernels[d] is None
+                    k = OrthogonalBinary(p0=p0[d], active_dims=active_dims[d])
+                    if share_var_across_orders:
+                        k.variance = one
+                self.kernels.append(k)
+        else:   # unconstrained kernel with the additive structure (:191-210)
+            assert empirical_locations is None, "Cannot have empirical locations without orthogonal constraint"
+            assert empirical_weights is None, "Cannot have empirical weights without orthogonal constraint"
+            for d in range(n_sub):
+                if p0[d] is None:
+                    k = base_kernels[d](active_dims=active_dims[d])
+                else:
+                    assert base_kernels[d] is None
+                    k = OrthogonalBinary(p0=p0[d], active_dims=active_dims[d])
+                if share_var_across_orders:
+                    k.variance = one
+                self.kernels.append(k)
+        n_var = max_interaction_depth + 1 if share_var_across_orders else 1       # :212-221
+        self.variances = [Parameter(1.0, transform=gpflow.positive()) for _ in range(n_var)]
+
+    # -- evaluation ------------------------------------------------------------------------------------
+    def _desc(self) -> _capi.KernelDesc:
+        return _capi.KernelDesc(kernel_to_spec(self))
+
+    def compute_additive_terms(self, kernel_matrices):
+        """[e_0 .. e_R] of the given same-shaped arrays (oak/oak_kernel.py:223-249), on the device."""
+        mats = [np.asarray(m, dtype=np.float64) for m in kernel_matrices]
+        shape = mats[0].shape
+        stacked = np.ascontiguousarray(np.stack([m.reshape(-1) for m in mats]))
+        out = _capi.default_context().additive_terms(stacked, int(self.max_interaction_depth))
+        return [TensorLike(o.reshape(shape)) for o in out]
+
+    def K(self, X, X2=None):
+        return TensorLike(_capi.default_context().gram(self._desc(), X, X2))          # :251-265
+
+    def K_diag(self, X):
+        return TensorLike(_capi.default_context().gram_diag(self._desc(), X))          # :267-278
+
+
+class KernelComponenent(gpflow.Kernel):
+    """One additive term sigma2_|S| * prod_{d in S} k_d (oak/oak_kernel.py:281-335; the reference's spelling)."""
+
+    def __init__(self, oak_kernel: OAKKernel, iComponent_list: List[int], share_var_across_orders: Optional[bool] = True):
+        super().__init__(active_dims=oak_kernel.active_dims)
+        self.oak_kernel = oak_kernel
+        self.iComponent_list = iComponent_list
+        self.share_var_across_orders = share_var_across_orders
+        self.kernels = [k for i, k in enumerate(oak_kernel.kernels) if i in iComponent_list]
+
+    def _subset(self):
+        return sorted(int(i) for i in self.iComponent_list)
+
+    def K(self, X, X2=None):
+        ctx = _capi.default_context()
+        return TensorLike(ctx.gram_component(self.oak_kernel._desc(), self._subset(), bool(self.share_var_across_orders), X, X2))
+
+    def K_diag(self, X):
+        ctx = _capi.default_context()
+        return TensorLike(ctx.gram_component_diag(self.oak_kernel._desc(), self._subset(), bool(self.share_var_across_orders), X))
+
+
+def get_list_representation(kernel: OAKKernel, num_dims: int, share_var_across_orders: Optional[bool] = True
+                            ) -> Tuple[List[List[int]], List[KernelComponenent]]:
+    """All interaction subsets up to the kernel's depth, constant term first (oak/oak_kernel.py:338-364).
+    As in the reference (:362) non-constant components ignore ``share_var_across_orders``."""
+    assert isinstance(kernel, OAKKernel)
+    selected_dims: List[List[int]] = [[]]
+    kernel_list = [KernelComponenent(kernel, [], share_var_across_orders=share_var_across_orders)]
+    for order in range(1, kernel.max_interaction_depth + 1):
+        for combo in itertools.combinations(np.arange(num_dims), order):
+            selected_dims.append(list(combo))
+            kernel_list.append(KernelComponenent(kernel, list(combo)))
+    return selected_dims, kernel_list
+
+
+# --------------------------------------------------------------------------------------------------------
+# gradient scatter: packed d objective / d (constrained parameter) from the HIP backward pass -> Parameter objects
+# layout of gvec: [lengthscale (D) | base_var (D) | order_var (n_order_var) | noise_var | dTable (meas_data_len)]
+# --------------------------------------------------------------------------------------------------------
+def scatter_gradient(kernel, likelihood, desc: _capi.KernelDesc, gvec: np.ndarray, variables):
+    D = desc.D
+    g_ls, g_bv = gvec[:D], gvec[D:2 * D]
+    n_ov = desc.order_var.size
+    g_ov = gvec[2 * D:2 * D + n_ov]
+    g_noise = gvec[2 * D + n_ov]
+    g_tab = gvec[2 * D + n_ov + 1:]
+    lookup = {id(likelihood.variance): g_noise}
+    subs = kernel.kernels if isinstance(kernel, OAKKernel) else [kernel]
+    if isinstance(kernel, OAKKernel):
+        for r, v in enumerate(kernel.variances):
+            lookup[id(v)] = g_ov[r]
+    for d, k in enumerate(subs):
+        base = getattr(k, "base_kernel", k)
+        if hasattr(base, "lengthscales") and isinstance(base.lengthscales, Parameter):
+            lookup[id(base.lengthscales)] = g_ls[d]
+        var = getattr(base, "variance", None)
+        if isinstance(var, Parameter):
+            lookup[id(var)] = g_bv[d]
+        if isinstance(k, OrthogonalCategorical):
+            off, C = desc.cat_blocks[d]
+            GB = g_tab[off:off + C * C].reshape(C, C)      # d obj / d B (unit-variance table)
+            gW, gk = _categorical_chain(k.W.numpy(), k.kappa.numpy(), np.asarray(k.p, dtype=np.float64).reshape(-1, 1), GB)
+            lookup[id(k.W)] = gW
+            lookup[id(k.kappa)] = gk
+    return [lookup.get(id(p)) for p in variables]
+
+
+def _categorical_chain(W, kappa, p, GB):
+    """Back-propagate d/dB through B = A - (Ap)(Ap)^T / (p^T A p), A = W W^T + diag(kappa)."""
+    A = W @ W.T + np.diag(kappa)
+    u = A @ p
+    s = float((p.T @ u)[0, 0])
+    Gs = 0.5 * (GB + GB.T)
+    # dB = dA - (dA p u^T + u p^T dA)/s + u u^T (p^T dA p)/s^2
+    GA = GB - (GB @ u @ p.T + p @ (u.T @ GB)) / s + p @ p.T * float((u.T @ GB @ u)[0, 0]) / (s * s)
+    del Gs
+    gW = (GA + GA.T) @ W
+    gk = np.diag(GA).copy()
+    return gW, gk

@@ -1,0 +1,159 @@
+"""Sobol indices, sufficient statistics and per-component predictions: host mirror of oak/utils.py:116-574.
+
+``compute_sobol_oak`` and ``get_prediction_component`` run on the device (``oak_sobol`` / ``oak_component_predict``):
+per-dimension L_d matrices are generated once and shared by every subset instead of being rebuilt per term.
+The closed forms f1..f4 are kept as NumPy helpers because the reference's tests call them directly.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import _capi
+from . import gpflow_lite as gpflow
+from .gpflow_lite import TensorLike
+from .input_measures import EmpiricalMeasure, MOGMeasure
+from .oak_kernel import KernelComponenent, OAKKernel, get_list_representation, kernel_to_spec
+from .ortho_binary_kernel import OrthogonalBinary
+from .ortho_categorical_kernel import OrthogonalCategorical
+from .ortho_rbf_kernel import OrthogonalRBFKernel
+
+
+# ---- closed-form Gaussian-measure integrals, eq. (44)-(47) of the paper (oak/utils.py:116-165) -------------
+def f1(x, y, sigma, lengthscales, delta, mu):
+    l2, d2 = lengthscales ** 2, delta ** 2
+    return (sigma ** 4 * lengthscales / np.sqrt(l2 + 2 * d2) * np.exp(-((x - y) ** 2) / (4 * l2))
+            * np.exp(-((mu - (x + y) / 2) ** 2) / (2 * d2 + l2)))
+
+
+def f2(x, y, sigma, lengthscales, delta, mu):
+    l2, d2 = lengthscales ** 2, delta ** 2
+    M = 1 / l2 + 1 / (l2 + d2)
+    m = (mu / (l2 + d2) + x / l2) / M
+    C = x ** 2 / l2 + mu ** 2 / (l2 + d2) - m ** 2 * M
+    return (sigma ** 4 * lengthscales * np.sqrt((l2 + 2 * d2) / (d2 * M + 1)) * np.exp(-C / 2) / (l2 + d2)
+            * np.exp(-((y - mu) ** 2) / (2 * (l2 + d2))) * np.exp(-((m - mu) ** 2) / (2 * (1 / M + d2))))
+
+
+def f3(x, y, sigma, lengthscales, delta, mu):
+    return f2(y, x, sigma, lengthscales, delta, mu)
+
+
+def f4(x, y, sigma, lengthscales, delta, mu):
+    l2, d2 = lengthscales ** 2, delta ** 2
+    return (sigma ** 4 * l2 * (l2 + 2 * d2) * np.sqrt((l2 + d2) / (l2 + 3 * d2)) / ((l2 + d2) ** 2)
+            * np.exp(-((x - mu) ** 2 + (y - mu) ** 2) / (2 * (l2 + d2))))
+
+
+# ---- per-dimension L matrices (oak/utils.py:221-335), evaluated on the device --------------------------------
+def _one_dim_desc(dim_spec):
+    return _capi.KernelDesc(dict(dims=[dim_spec], order_variances=[0.0, 1.0], max_interaction_depth=1,
+                                 share_var_across_orders=True))
+
+
+def compute_L(X, lengthscale: float, variance: float, dim: int, delta: float, mu: float) -> np.ndarray:
+    X = np.asarray(X, dtype=np.float64)
+    d = dict(type="rbf", lengthscale=float(lengthscale), variance=1.0, measure=("gaussian", 0.0, 1.0), active_dim=int(dim))
+    return _capi.default_context().sobol_L(_one_dim_desc(d), 0, float(variance), float(delta), float(mu), X)
+
+
+def compute_L_binary_kernel(X, p0: float, variance: float, dim: int) -> np.ndarray:
+    assert 0 <= p0 <= 1
+    X = np.asarray(X, dtype=np.float64)
+    d = dict(type="binary", p0=float(p0), variance=1.0, active_dim=int(dim))
+    return _capi.default_context().sobol_L(_one_dim_desc(d), 0, float(variance), 1.0, 0.0, X)
+
+
+def compute_L_categorical_kernel(X, W, kappa, p, variance: float, dim: int) -> np.ndarray:
+    p = np.asarray(p, dtype=np.float64).reshape(-1, 1)
+    assert np.abs(p.sum() - 1) < 1e-6
+    X = np.asarray(X, dtype=np.float64)
+    d = dict(type="categorical", p=p, W=np.asarray(W, dtype=np.float64), kappa=np.asarray(kappa, dtype=np.float64),
+             variance=1.0, active_dim=int(dim))
+    return _capi.default_context().sobol_L(_one_dim_desc(d), 0, float(variance), 1.0, 0.0, X)
+
+
+def compute_L_empirical_measure(x, w, kernel: OrthogonalRBFKernel, z) -> np.ndarray:
+    """L = Kxu^T diag(w) Kxu with Kxu = kernel.K(x, z) (oak/utils.py:312-335)."""
+    z = np.asarray(z, dtype=np.float64).reshape(-1, 1)
+    d = kernel.dim_spec(0)
+    d["measure"] = ("empirical", np.asarray(x, dtype=np.float64).reshape(-1, 1), np.asarray(w, dtype=np.float64).reshape(-1, 1))
+    return _capi.default_context().sobol_L(_one_dim_desc(d), 0, 1.0, 1.0, 0.0, z)
+
+
+# ---- sufficient statistics (oak/utils.py:168-218) ------------------------------------------------------------
+def get_model_sufficient_statistics(m, get_L=True):
+    """alpha such that the predictive mean is K(x*, Xc) alpha.  The "effective L" (get_L=True) is only consumed by
+    plotting_utils, which is out of scope for this build."""
+    if get_L:
+        raise NotImplementedError("get_L=True (effective Cholesky factor) is only used by plotting_utils; call with get_L=False")
+    if isinstance(m, (gpflow.SGPR, gpflow.GPR)):
+        return m.alpha()
+    raise NotImplementedError
+
+
+def _sobol_inputs(model):
+    assert isinstance(model.kernel, OAKKernel), "only work for OAK kernel"
+    num_dims = model.data[0].shape[1]
+    selected, kernel_list = get_list_representation(model.kernel, num_dims=num_dims)
+    return num_dims, selected[1:], kernel_list
+
+
+def compute_sobol_oak(model, delta: float, mu: float, share_var_across_orders: Optional[bool] = True
+                      ) -> Tuple[List[List[int]], List[float]]:
+    """Sobol index alpha^T (prod_{d in S} L_d) alpha of every non-constant term (oak/utils.py:338-435)."""
+    num_dims, subsets, _ = _sobol_inputs(model)
+    for k in model.kernel.kernels:   # same support matrix as the reference (:386-427)
+        if isinstance(k, OrthogonalRBFKernel):
+            if isinstance(k.measure, MOGMeasure):
+                raise NotImplementedError
+        elif not isinstance(k, (OrthogonalBinary, OrthogonalCategorical)):
+            raise NotImplementedError
+    Xc = model.inducing_variable.Z.numpy() if isinstance(model, gpflow.SGPR) else model.data[0]
+    alpha = get_model_sufficient_statistics(model, get_L=False)
+    desc = _capi.KernelDesc(kernel_to_spec(model.kernel))
+    sobol = _capi.default_context().sobol(desc, Xc, np.asarray(alpha).reshape(-1), subsets,
+                                          use_order_var=bool(share_var_across_orders), delta=delta, mu=mu)
+    assert len(subsets) == len(sobol)
+    return subsets, [float(s) for s in sobol]
+
+
+def get_prediction_component(m, alpha, X: np.ndarray = None, share_var_across_orders: Optional[bool] = True) -> list:
+    """Predictive mean of every additive term (oak/utils.py:491-530)."""
+    if X is None:
+        X = m.data[0]
+    X = np.asarray(X, dtype=np.float64)
+    subsets = get_list_representation(m.kernel, num_dims=X.shape[1])[0][1:]
+    Xc = m.data[0] if isinstance(m, gpflow.GPR) else m.inducing_variable.Z.numpy()
+    desc = _capi.KernelDesc(kernel_to_spec(m.kernel))
+    out = _capi.default_context().component_predict(desc, X, Xc, np.asarray(alpha).reshape(-1), subsets,
+                                                    use_order_var=bool(share_var_across_orders))
+    return [TensorLike(row) for row in out]
+
+
+# ---- inducing-point initialisation (oak/utils.py:533-574): scikit-learn on the host, as in the reference ----------
+def initialize_kmeans_with_binary(X, binary_index: list, continuous_index: Optional[list] = None, n_clusters: Optional[int] = 200):
+    from sklearn.cluster import KMeans
+    X = np.asarray(X)
+    Z = np.zeros([n_clusters, X.shape[1]])
+    for index in binary_index:
+        km = KMeans(n_clusters=n_clusters, random_state=0).fit(X[:, index][:, None])
+        Z[:, index] = km.cluster_centers_.astype(int)[:, 0]
+    if continuous_index is not None:
+        km = KMeans(n_clusters=n_clusters, random_state=0).fit(X[:, continuous_index])
+        Z[:, continuous_index] = km.cluster_centers_
+    return Z
+
+
+def initialize_kmeans_with_categorical(X, binary_index: list, categorical_index: list, continuous_index: list,
+                                       n_clusters: Optional[int] = 200):
+    from sklearn.cluster import KMeans
+    X = np.asarray(X)
+    Z = np.zeros([n_clusters, X.shape[1]])
+    for index in binary_index + categorical_index:
+        km = KMeans(n_clusters=n_clusters, random_state=0).fit(X[:, index][:, None])
+        Z[:, index] = km.cluster_centers_.astype(int)[:, 0]
+    km = KMeans(n_clusters=n_clusters, random_state=0).fit(X[:, continuous_index])
+    Z[:, continuous_index] = km.cluster_centers_
+    return Z

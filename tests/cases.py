@@ -1,0 +1,73 @@
+"""Seeded problem builders shared by the golden-vector generator and the parity tests."""
+import sys
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (str(ROOT / "orthogonal-additive-gaussian-processes_amd"), str(ROOT)):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+from oracle import oak_oracle as o  # noqa: E402
+
+
+def case_A():
+    """BASELINE synthetic inputs, all-continuous Gaussian-measure OAK of order 2 (the benchmark's kernel family)."""
+    X, y, Z = o.synthetic_problem(384, 5, 48)
+    spec = o.make_spec(5, 2, lengthscales=[0.9, 1.1, 0.7, 1.6, 1.25], order_variances=[0.8, 1.4, 0.6])
+    return spec, X, y, Z, 0.02
+
+
+def case_B():
+    """Every sub-kernel type and input measure in one kernel, order 3."""
+    rng = np.random.default_rng(7)
+    N, M = 160, 24
+    X = rng.standard_normal((N, 6))
+    X[:, 3] = rng.integers(0, 2, N)
+    X[:, 4] = rng.integers(0, 4, N)
+    X[:, 5] = rng.uniform(-2, 2, N)
+    y = (np.sin(X[:, 0]) + X[:, 1] * X[:, 3] + 0.3 * X[:, 4] + 0.1 * rng.standard_normal(N)).reshape(-1, 1)
+    y = (y - y.mean()) / y.std()
+    Z = X[:M].copy()
+    W = rng.uniform(size=(4, 2))
+    spec = o.make_spec(6, 3, p0=[None, None, None, 0.45, None, None], p=[None] * 4 + [np.array([.2, .3, .1, .4])] + [None],
+                       lengthscales=[0.8, 1.4, 2.1, 1, 1, 0.6], order_variances=[0.6, 1.3, 0.7, 0.4],
+                       cat_W=[None] * 4 + [W, None], cat_kappa=[None] * 4 + [np.array([1.0, 0.7, 1.4, 0.9]), None])
+    spec["dims"][1]["measure"] = ("uniform", -3.2, 3.4)
+    spec["dims"][2]["measure"] = ("mog", np.array([-1.0, 0.8]), np.array([0.6, 1.7]), np.array([0.35, 0.65]))
+    loc = np.unique(np.round(X[:, 5], 1)).reshape(-1, 1)
+    spec["dims"][5]["measure"] = ("empirical", loc, np.full((len(loc), 1), 1.0 / len(loc)))
+    return spec, X, y, Z, 0.05
+
+
+def random_spec(rng, D, R, kinds=("gaussian",), share=True):
+    """Random-parameter OAK spec over D columns; kinds cycles through sub-kernel/measure types."""
+    dims = []
+    for d in range(D):
+        kind = kinds[d % len(kinds)]
+        if kind == "binary":
+            dims.append(dict(type="binary", p0=float(rng.uniform(0.2, 0.8)), variance=1.0 if share else float(rng.uniform(0.5, 2))))
+        elif kind == "categorical":
+            C = 3 + d % 3
+            p = rng.uniform(0.5, 1.5, C); p /= p.sum()
+            dims.append(dict(type="categorical", p=p.reshape(-1, 1), W=rng.uniform(size=(C, 2)), kappa=rng.uniform(0.5, 1.5, C),
+                             variance=1.0 if share else float(rng.uniform(0.5, 2))))
+        else:
+            meas = {"gaussian": ("gaussian", 0.0, 1.0), "none": None,
+                    "uniform": ("uniform", -3.0, 3.0),
+                    "mog": ("mog", np.array([-0.7, 0.9]), np.array([0.8, 1.3]), np.array([0.4, 0.6])),
+                    "gauss2": ("gaussian", 0.3, 2.0)}[kind]
+            dims.append(dict(type="rbf", lengthscale=float(rng.uniform(0.5, 2.5)), variance=1.0 if share else float(rng.uniform(0.5, 2)), measure=meas))
+    ov = list(rng.uniform(0.3, 1.5, R + 1 if share else 1))
+    return dict(dims=dims, order_variances=ov, max_interaction_depth=R, share_var_across_orders=share)
+
+
+def random_inputs(rng, spec, n):
+    D = len(spec["dims"])
+    X = rng.standard_normal((n, D))
+    for d, dim in enumerate(spec["dims"]):
+        if dim["type"] == "binary":
+            X[:, d] = rng.integers(0, 2, n)
+        elif dim["type"] == "categorical":
+            X[:, d] = rng.integers(0, len(dim["p"]), n)
+    return X

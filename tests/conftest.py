@@ -1,0 +1,38 @@
+"""Shared pytest configuration.
+
+* ``gpu`` marker: tests that need a real MI355X (run with ``-m gpu``); everything else runs on CPU.
+* The CPU suite never touches a GPU: it checks the oracle against the reference's own test properties and the
+  committed golden vectors, the host-side logic, and that the C-ABI library loads and exports every declared symbol.
+"""
+import json
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+for p in (str(ROOT / "orthogonal-additive-gaussian-processes_amd"), str(ROOT)):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a HIP device (MI355X); deselected by -m 'not gpu'")
+
+
+@pytest.fixture
+def concrete_normalised_10_rows_data():
+    """10 rows x 7 columns of normalised UCI-concrete inputs + targets: the data fixture of the reference's
+    tests/conftest.py:11-41, stored as data in tests/golden/concrete_10rows.json."""
+    d = json.loads((GOLDEN / "concrete_10rows.json").read_text())
+    return np.array(d["X"]), np.array(d["y"])
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """Session-wide HIP context; the test FAILS (not skips) if the native library or the device is missing."""
+    from oak import _capi
+    return _capi.HipContext(0)

@@ -1,0 +1,164 @@
+"""GPU parity: the fused HIP Gram kernel (through the C ABI) against the CPU oracle.  Tolerance: elementwise
+|K_hip - K_oracle| <= 1e-12 * max|K_oracle| (fp64)."""
+import numpy as np
+import pytest
+
+import cases
+from conftest import GOLDEN
+from oak import _capi
+from oracle import oak_oracle as o
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-12
+
+
+def close(a, b, tol=TOL):
+    scale = max(np.abs(b).max(), 1e-300)
+    err = np.abs(np.asarray(a) - np.asarray(b)).max() / scale
+    assert err <= tol, f"max scaled error {err:.3e} > {tol:.1e}"
+
+
+@pytest.mark.parametrize("R", range(0, 9))
+@pytest.mark.parametrize("kinds", [("gaussian",), ("gaussian", "uniform", "mog", "none", "gauss2"),
+                                   ("gaussian", "binary", "categorical")])
+def test_gram_all_orders_and_kernel_types(hip, R, kinds):
+    rng = np.random.default_rng(100 + R)
+    D = 9
+    spec = cases.random_spec(rng, D, R, kinds)
+    X, X2 = cases.random_inputs(rng, spec, 203), cases.random_inputs(rng, spec, 77)
+    d = _capi.KernelDesc(spec)
+    close(hip.gram(d, X, X2), o.oak_K(spec, X, X2))
+    close(hip.gram(d, X), o.oak_K(spec, X))
+    close(hip.gram_diag(d, X), o.oak_K_diag(spec, X))
+
+
+@pytest.mark.parametrize("D", [1, 16, 17, 33, 64])
+def test_gram_wide_inputs(hip, D):
+    """D > 16 switches the column tile (LDS budget); D = 64 is the documented maximum."""
+    rng = np.random.default_rng(D)
+    spec = cases.random_spec(rng, D, min(2, D), ("gaussian", "gaussian", "binary"))
+    X, X2 = cases.random_inputs(rng, spec, 150), cases.random_inputs(rng, spec, 300)
+    d = _capi.KernelDesc(spec)
+    close(hip.gram(d, X, X2), o.oak_K(spec, X, X2))
+
+
+@pytest.mark.parametrize("n1,n2", [(1, 1), (1, 513), (513, 1), (16, 255), (17, 257), (1000, 3), (3, 1000)])
+def test_gram_ragged_shapes(hip, n1, n2):
+    rng = np.random.default_rng(n1 * 1000 + n2)
+    spec = cases.random_spec(rng, 4, 2)
+    X, X2 = rng.standard_normal((n1, 4)), rng.standard_normal((n2, 4))
+    d = _capi.KernelDesc(spec)
+    K = hip.gram(d, X, X2)
+    assert K.shape == (n1, n2)
+    close(K, o.oak_K(spec, X, X2))
+
+
+def test_empty_inputs(hip):
+    spec = cases.random_spec(np.random.default_rng(0), 3, 2)
+    d = _capi.KernelDesc(spec)
+    assert hip.gram(d, np.zeros((0, 3)), np.zeros((5, 3))).shape == (0, 5)
+    assert hip.gram(d, np.zeros((5, 3)), np.zeros((0, 3))).shape == (5, 0)
+    assert hip.gram_diag(d, np.zeros((0, 3))).shape == (0,)
+
+
+def test_not_shared_variances(hip):
+    """share_var_across_orders=False: sigma2_0 e_0 + e_1 + ... + e_R with trainable base variances (oak_kernel.py:261-265)."""
+    rng = np.random.default_rng(3)
+    spec = cases.random_spec(rng, 5, 3, ("gaussian", "binary"), share=False)
+    X, X2 = cases.random_inputs(rng, spec, 90), cases.random_inputs(rng, spec, 40)
+    d = _capi.KernelDesc(spec)
+    close(hip.gram(d, X, X2), o.oak_K(spec, X, X2))
+    close(hip.gram_diag(d, X), o.oak_K_diag(spec, X))
+
+
+def test_active_columns_and_extra_columns(hip):
+    """Sub-kernels may read any column (active_dims); unused columns are ignored."""
+    rng = np.random.default_rng(4)
+    spec = cases.random_spec(rng, 3, 2)
+    for d_, col in zip(spec["dims"], (4, 0, 2)):
+        d_["active_dim"] = col
+    X, X2 = rng.standard_normal((50, 6)), rng.standard_normal((20, 6))
+    close(hip.gram(_capi.KernelDesc(spec), X, X2), o.oak_K(spec, X, X2))
+
+
+def test_discrete_inputs_truncate_like_tf_cast(hip):
+    """tf.cast(float64 -> int32) truncates (ortho_binary_kernel.py:47): 1.9 -> category 1."""
+    rng = np.random.default_rng(5)
+    spec = cases.random_spec(rng, 2, 2, ("binary", "categorical"))
+    X = cases.random_inputs(rng, spec, 60) + 0.45
+    close(hip.gram(_capi.KernelDesc(spec), X), o.oak_K(spec, X))
+
+
+def test_components_sum_to_kernel(hip):
+    """KernelComponenent terms through oak_gram_component (tests/test_oak_kernel.py:32-144)."""
+    rng = np.random.default_rng(6)
+    spec = cases.random_spec(rng, 4, 3, ("gaussian", "binary", "uniform", "categorical"))
+    X, X2 = cases.random_inputs(rng, spec, 45), cases.random_inputs(rng, spec, 31)
+    d = _capi.KernelDesc(spec)
+    total, total_diag = np.zeros((45, 31)), np.zeros(45)
+    for S in o.list_representation(4, 3):
+        KS = hip.gram_component(d, S, True, X, X2)
+        close(KS, o.component_K(spec, S, X, X2))
+        total += KS
+        total_diag += hip.gram_component_diag(d, S, True, X)
+    close(total, o.oak_K(spec, X, X2), 1e-11)
+    close(total_diag, o.oak_K_diag(spec, X), 1e-11)
+
+
+def test_small_and_large_lengthscales_against_mpmath(hip):
+    """The reference's |x|^2+|z|^2-2xz distance loses digits for tiny lengthscales; the HIP kernel uses (x-z)^2.
+    Both are checked against 50-digit arithmetic: HIP within 1e-13, and never worse than the oracle."""
+    import mpmath as mp
+    mp.mp.dps = 50
+    rng = np.random.default_rng(7)
+    for l in (0.02, 0.3, 30.0):
+        spec = o.make_spec(1, 1, lengthscales=[l], order_variances=[0.0, 1.0])
+        X, Z = rng.standard_normal((6, 1)) * 2, rng.standard_normal((5, 1)) * 2
+        K = hip.gram(_capi.KernelDesc(spec), X, Z)
+        Ko = o.oak_K(spec, X, Z)
+        lm = mp.mpf(l)
+        c = lambda t: lm / mp.sqrt(lm ** 2 + 1) * mp.exp(-t ** 2 / (2 * (lm ** 2 + 1)))
+        v = lm / mp.sqrt(lm ** 2 + 2)
+        truth = np.array([[float(mp.exp(-(mp.mpf(float(x)) - mp.mpf(float(z))) ** 2 / (2 * lm ** 2)) - c(mp.mpf(float(x))) * c(mp.mpf(float(z))) / v)
+                           for z in Z[:, 0]] for x in X[:, 0]])
+        e_hip, e_or = np.abs(K - truth).max(), np.abs(Ko - truth).max()
+        assert e_hip <= 1e-13 and e_hip <= max(e_or, 1e-15) * 4
+
+
+def test_golden_vectors(hip):
+    g = np.load(GOLDEN / "oracle_vectors.npz")
+    for name, rows in (("A", 64), ("B", 50)):
+        spec, X, y, Z, noise = getattr(cases, f"case_{name}")()
+        d = _capi.KernelDesc(spec)
+        close(hip.gram(d, X[:rows], Z), g[f"{name}_K"])
+        close(hip.gram_diag(d, X), g[f"{name}_Kdiag"])
+
+
+def test_additive_terms_and_measure_helpers(hip):
+    """compute_additive_terms (oak_kernel.py:223-249) and cov_X_s / var_s (ortho_rbf_kernel.py:47-152) entry points."""
+    rng = np.random.default_rng(8)
+    mats = rng.standard_normal((4, 10))
+    for R in (0, 2, 4):
+        out = hip.additive_terms(mats, R)
+        ref = o.compute_additive_terms([m for m in mats], R)
+        for a, b in zip(out, ref):
+            np.testing.assert_allclose(a, b, rtol=1e-12, atol=1e-13)
+    spec, *_ = cases.case_B()
+    X = rng.standard_normal((30, 6))
+    d = _capi.KernelDesc(spec)
+    for dim in (0, 1, 2, 5):
+        c, v = hip.measure_cov(d, dim, X)
+        np.testing.assert_allclose(c, o.cov_X_s(X[:, dim:dim + 1], spec["dims"][dim])[:, 0], rtol=1e-12)
+        np.testing.assert_allclose(v, o.var_s(spec["dims"][dim]), rtol=1e-12)
+
+
+def test_bad_arguments_raise(hip):
+    spec = cases.random_spec(np.random.default_rng(0), 3, 2)
+    d = _capi.KernelDesc(spec)
+    with pytest.raises(ValueError):
+        hip.gram(d, np.zeros((4, 2)))            # kernel reads column 2
+    with pytest.raises(ValueError):
+        hip.gram(d, np.zeros((4, 3)), np.zeros((4, 4)))
+    bad = dict(spec, dims=[dict(spec["dims"][0], lengthscale=-1.0)] + spec["dims"][1:])
+    with pytest.raises(ValueError):
+        hip.gram(_capi.KernelDesc(bad), np.zeros((4, 3)))

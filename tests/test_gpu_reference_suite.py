@@ -1,0 +1,314 @@
+"""The reference's own test-suite for this path, run against the drop-in mirror package (same class names,
+arguments and error behaviour), with every number produced by the HIP library.  Each test names the reference test
+it follows; `gpflow` here is the minimal stand-in `oak.gpflow_lite`."""
+import numpy as np
+import pytest
+
+from oak import gpflow_lite as gpflow
+from oak.input_measures import EmpiricalMeasure, GaussianMeasure, MOGMeasure, UniformMeasure
+from oak.model_utils import create_model_oak, load_model, oak_model, save_model
+from oak.oak_kernel import KernelComponenent, OAKKernel, get_list_representation
+from oak.ortho_binary_kernel import OrthogonalBinary
+from oak.ortho_categorical_kernel import OrthogonalCategorical
+from oak.ortho_rbf_kernel import OrthogonalRBFKernel
+from oak.utils import (compute_L_binary_kernel, compute_L_empirical_measure, compute_sobol_oak, f1, f2, f4,
+                       get_model_sufficient_statistics, get_prediction_component, initialize_kmeans_with_binary)
+
+pytestmark = pytest.mark.gpu
+
+
+def _kernels_1d():
+    return [
+        OAKKernel([gpflow.kernels.RBF], num_dims=1, max_interaction_depth=1),
+        OAKKernel([gpflow.kernels.RBF], num_dims=1, max_interaction_depth=1, constrain_orthogonal=True),
+        OrthogonalBinary(),
+        OrthogonalRBFKernel(gpflow.kernels.RBF(), GaussianMeasure(0, 1)),
+        OrthogonalRBFKernel(gpflow.kernels.RBF(), UniformMeasure(0, 1)),
+        OrthogonalRBFKernel(gpflow.kernels.RBF(), EmpiricalMeasure(np.array([[0.1], [0.5], [0.5]]))),
+        OrthogonalRBFKernel(gpflow.kernels.RBF(), MOGMeasure(np.array([3.0, 2.0]), np.array([3.0, 10.0]), np.array([0.6, 0.4]))),
+    ]
+
+
+@pytest.mark.parametrize("idx", range(7))
+def test_kernel_1d(idx):
+    """tests/test_kernel_properties.py:27-66."""
+    kernel = _kernels_1d()[idx]
+    X = np.array([[0.1], [0.5], [0.5]])
+    np.testing.assert_allclose(np.diag(kernel.K(X, X)), kernel.K_diag(X), err_msg="diagonal calculation is not correct")
+    np.testing.assert_allclose(kernel.K(X, X), kernel(X, X), err_msg="k and k.K not the same")
+
+
+@pytest.mark.parametrize("num_dims", [3, 4])
+def test_newton_girard(num_dims):
+    """tests/test_kernel_properties.py:69-86."""
+    from functools import reduce
+    from itertools import combinations
+    k = OAKKernel([gpflow.kernels.RBF for _ in range(num_dims)], num_dims=num_dims, max_interaction_depth=num_dims)
+    xx = [np.random.randn(2, 2) for _ in range(num_dims)]
+    result = k.compute_additive_terms(xx)
+    hard = [np.ones((2, 2))] + [reduce(np.add, map(lambda x: np.prod(x, axis=0), combinations(xx, i))) for i in range(1, num_dims)]
+    for r1, r2 in zip(result, hard):
+        np.testing.assert_allclose(r1, r2, rtol=1e-7, atol=1e-12)
+
+
+@pytest.mark.parametrize("active_dims", [[0], [1]])
+@pytest.mark.parametrize("midx", range(5))
+def test_orthogonal_rbf_kernel_2d_with_active_dims(active_dims, midx):
+    """tests/test_kernel_properties.py:89-116."""
+    measure = [GaussianMeasure(0, 1), UniformMeasure(0, 1), EmpiricalMeasure(np.array([[0.1], [0.5]])),
+               MOGMeasure(np.array([3.0, 2.0]), np.array([3.0, 10.0]), np.array([0.6, 0.4])),
+               MOGMeasure(np.array([3, 2], dtype=int), np.array([3, 10], dtype=int), np.array([0.6, 0.4]))][midx]
+    k = OrthogonalRBFKernel(gpflow.kernels.RBF(lengthscales=10), measure, active_dims=active_dims)
+    X = np.array([[0.1, 0.2], [0.5, 0.5], [0.5, 0.7]])
+    np.testing.assert_allclose(np.diag(k.K(X[:, active_dims], X[:, active_dims])), k.K_diag(X[:, active_dims]))
+    np.testing.assert_allclose(k.K(X[:, active_dims]), k(X, X))
+
+
+def test_MOGMeasure_equivalence_to_GaussianMeasure():
+    """tests/test_orthogonality.py:152-165."""
+    k_gmm = OrthogonalRBFKernel(gpflow.kernels.RBF(lengthscales=10.0), MOGMeasure(np.array([3.0, 3.0]), np.array([5.0, 5.0]), np.array([0.2, 0.8])))
+    k_gaussian = OrthogonalRBFKernel(gpflow.kernels.RBF(lengthscales=10.0), GaussianMeasure(3, 5))
+    xx = np.array([[-2], [2.0], [3.0]])
+    np.testing.assert_allclose(k_gaussian.K(xx), k_gmm.K(xx))
+
+
+def test_cov_and_var_against_monte_carlo():
+    """tests/test_orthogonality.py:27-75 (2 decimals)."""
+    rng = np.random.default_rng(0)
+    for meas, sampler in ((GaussianMeasure(0, 1), lambda n: rng.normal(size=n)), (UniformMeasure(0, 1), lambda n: rng.uniform(size=n))):
+        k = OrthogonalRBFKernel(gpflow.kernels.RBF(lengthscales=10), meas)
+        s = sampler(10000)[:, None]
+        np.testing.assert_almost_equal(abs(k.cov_X_s(np.zeros((1, 1)))[0, 0] - np.mean(k.base_kernel.K(np.zeros((1, 1)), s))), 0.0, decimal=2)
+        np.testing.assert_almost_equal(abs(k.var_s() - np.mean(k.cov_X_s(s))), 0.0, decimal=2)
+
+
+def test_OrthogonalCategorical_zero_mean():
+    """tests/test_categorical_kernel.py:13-23."""
+    np.random.seed(44)
+    p = np.ones((2, 1)) / 2
+    k = OrthogonalCategorical(p, rank=2, active_dims=[0])
+    xx = np.reshape(np.random.choice(2, 300, p=p[:, 0]), (-1, 1)).astype(float)
+    K = np.asarray(k.K(xx))
+    f = np.random.multivariate_normal(np.zeros(300), K + 1e-10 * np.eye(300), size=500)
+    assert np.abs(f.mean()) < 5e-2
+    np.testing.assert_allclose(np.asarray(k.K(np.array([[0.0], [1.0]]))) @ p, 0.0, atol=1e-14)
+
+
+@pytest.mark.parametrize("data", [[[0.0], [1.0], [2.0]], [[0.0, 1.0], [1.0, 1.0], [2.0, 2.0]]])
+@pytest.mark.parametrize("num_inducings", [0, 2])
+@pytest.mark.parametrize("lengthscale_bounds", [[1e-6, 2], None])
+def test_oak(data, num_inducings, lengthscale_bounds):
+    """tests/test_oak_kernel.py:14-29."""
+    X = np.array(data)
+    y = np.array(data)[:, 0].reshape(-1, 1)
+    Z = X[:num_inducings, :] if num_inducings > 0 else None
+    model = create_model_oak((X, y), inducing_pts=Z, lengthscale_bounds=lengthscale_bounds)
+    assert not np.isnan(model.maximum_log_likelihood_objective())
+
+
+def test_kernel_components(concrete_normalised_10_rows_data):
+    """tests/test_oak_kernel.py:32-117."""
+    X, y = concrete_normalised_10_rows_data
+    x1 = X[:, 1][:, None]
+    k = OAKKernel([gpflow.kernels.RBF], num_dims=1, max_interaction_depth=0, constrain_orthogonal=True)
+    k.variances[0].assign(0.3)
+    np.testing.assert_allclose(k(x1), KernelComponenent(k, [])(x1), err_msg="0 order")
+    k = OAKKernel([gpflow.kernels.RBF], num_dims=1, max_interaction_depth=1, constrain_orthogonal=True)
+    k.variances[0].assign(0.3)
+    k.variances[1].assign(3.3)
+    np.testing.assert_allclose(k(x1), KernelComponenent(k, [])(x1) + KernelComponenent(k, [0])(x1), err_msg="1 order 1-D")
+    x2 = X[:, :2]
+    k = OAKKernel([gpflow.kernels.RBF] * 2, num_dims=2, max_interaction_depth=2, constrain_orthogonal=True)
+    for i, v in enumerate((1.3, 3.3, 4.3)):
+        k.variances[i].assign(v)
+    parts = [KernelComponenent(k, S) for S in ([], [0], [1], [0, 1])]
+    np.testing.assert_allclose(k(x2), sum(np.asarray(c(x2)) for c in parts), err_msg="2 order 2-D")
+    np.testing.assert_allclose(k.K_diag(x2), sum(np.asarray(c.K_diag(x2)) for c in parts), err_msg="2 order 2-D K_diag")
+
+
+@pytest.mark.parametrize("num_dims", (2, 5, 7))
+def test_get_list_representation_two_dimensional(num_dims, concrete_normalised_10_rows_data):
+    """tests/test_oak_kernel.py:120-144."""
+    X, y = concrete_normalised_10_rows_data
+    k = OAKKernel([gpflow.kernels.RBF] * 2, num_dims=2, max_interaction_depth=2, constrain_orthogonal=True)
+    selected_dims, kernel_list = get_list_representation(k, num_dims=2)
+    if num_dims == 2:
+        assert selected_dims == [[], [0], [1], [0, 1]]
+    assert len(kernel_list) == len(selected_dims)
+    np.testing.assert_allclose(k.K_diag(X), np.diag(k(X)))
+    np.testing.assert_allclose(k.K_diag(X), np.sum([np.asarray(l.K_diag(X)) for l in kernel_list], axis=0))
+    np.testing.assert_allclose(k(X), np.sum([np.asarray(l(X)) for l in kernel_list], axis=0))
+
+
+@pytest.mark.parametrize("use_sparsity_prior", [True, False])
+@pytest.mark.parametrize("initialise_inducing_points", [True, False])
+@pytest.mark.parametrize("sparse", [True, False])
+@pytest.mark.parametrize("clip", [True, False])
+def test_oak_model(use_sparsity_prior, initialise_inducing_points, sparse, clip):
+    """tests/test_oak_model.py:15-58."""
+    np.random.seed(44)
+    N = 100
+    X = np.random.normal(0, 1, (N, 3))
+    y = X[:, 0] ** 2 + X[:, 1] + X[:, 1] * X[:, 2] + np.random.normal(0, 0.01, (N,))
+    idx = np.random.permutation(N)
+    tr, te = idx[:80], idx[80:]
+    oak = oak_model(num_inducing=50, max_interaction_depth=2, use_sparsity_prior=use_sparsity_prior, sparse=sparse)
+    oak.fit(X[tr], y[tr, None], initialise_inducing_points=initialise_inducing_points, optimise=False)
+    y_pred = oak.predict(X[te], clip=clip)
+    assert np.mean((y_pred - y[te]) ** 2) < np.mean((y[te].mean() - y[te]) ** 2)
+    assert np.isfinite(oak.get_loglik(X[te], y[te, None], clip=clip))
+
+
+@pytest.mark.parametrize("interaction_depth", [1, 2])
+@pytest.mark.parametrize("use_sparsity_prior", [True, False])
+def test_oak_model_with_binary_and_categorical_data(interaction_depth, use_sparsity_prior):
+    """tests/test_oak_model.py:61-88."""
+    np.random.seed(44)
+    N = 20
+    X = np.vstack([np.random.choice([0, 1], size=N, p=[0.8, 0.2]), np.random.choice([0, 1, 2, 3], size=N, p=[0.2, 0.2, 0.3, 0.3]),
+                   np.random.randn(N)]).T.astype(float)
+    Y = (np.sin(X[:, 2]) + np.random.normal(0, 0.01, (N,))).reshape(-1, 1)
+    oak = oak_model(binary_feature=[0], categorical_feature=[1], max_interaction_depth=interaction_depth, use_sparsity_prior=use_sparsity_prior)
+    oak.fit(X, Y, optimise=False)
+    assert not np.isnan(oak.m.log_marginal_likelihood())
+
+
+@pytest.fixture
+def binary_5D_data():
+    np.random.seed(42)
+    return np.random.randint(0, 2, 15).reshape(3, 5).astype(float), np.random.randn(3, 1)
+
+
+@pytest.mark.parametrize("binary_feature, categorical_feature, gmm_measure, empirical_measure",
+                         [[[0], [1], [0, 0, 2, 3, 0], [4]], [[0], [1], None, [2, 3]], [[0, 1], [2], [0, 0, 0, 2, 0], [4]], [[0, 1], [2], None, [3, 4]]])
+def test_oak_model_creation(binary_5D_data, binary_feature, categorical_feature, gmm_measure, empirical_measure):
+    """tests/test_oak_model.py:101-126, 182-205."""
+    X, Y = binary_5D_data
+    oak = oak_model(num_inducing=3, binary_feature=binary_feature, categorical_feature=categorical_feature, gmm_measure=gmm_measure,
+                    empirical_measure=empirical_measure)
+    oak.fit(X, Y, optimise=False)
+    assert np.isfinite(oak.m.maximum_log_likelihood_objective())
+
+
+@pytest.mark.parametrize("binary_feature, categorical_feature, gmm_measure, empirical_measure",
+                         [[[0, 1], [1], [0] * 5, [3]], [[0], [1], None, [0]], [[0], [1], None, [1]], [[0], [1], [2, 0, 0, 0, 0], [2, 4]]])
+def test_oak_illegal_model_creation_overlapping_indices(binary_5D_data, binary_feature, categorical_feature, gmm_measure, empirical_measure):
+    """tests/test_oak_model.py:208-238."""
+    X, Y = binary_5D_data
+    oak = oak_model(binary_feature=binary_feature, categorical_feature=categorical_feature, gmm_measure=gmm_measure, empirical_measure=empirical_measure)
+    with pytest.raises(ValueError):
+        oak.fit(X, Y, optimise=False)
+
+
+@pytest.mark.parametrize("binary_feature, categorical_feature", [[[0], [1]], [[0], [1, 3]]])
+def test_oak_sobol_supported(binary_5D_data, binary_feature, categorical_feature):
+    """tests/test_oak_model.py:129-155."""
+    X, Y = binary_5D_data
+    cont = list(set(np.arange(5)) - set(binary_feature + categorical_feature))
+    X[:, cont] = X[:, cont] + np.random.normal(0, 1, (X.shape[0], len(cont)))
+    oak = oak_model(binary_feature=binary_feature, categorical_feature=categorical_feature)
+    oak.fit(X, Y, optimise=False)
+    assert np.all(oak.get_sobol() >= 0)
+
+
+def test_oak_sobol_not_supported(binary_5D_data):
+    """tests/test_oak_model.py:158-174."""
+    X, Y = binary_5D_data
+    X = X + np.random.normal(0, 1, X.shape)
+    oak = oak_model(gmm_measure=[0, 0, 3, 0, 0])
+    oak.fit(X, Y, optimise=False)
+    with pytest.raises(NotImplementedError):
+        oak.get_sobol()
+
+
+@pytest.mark.parametrize("share_var_across_orders", [True, False])
+def test_get_prediction_component(share_var_across_orders):
+    """tests/test_utils.py:42-75: the per-term predictions add up to predict_f."""
+    np.random.seed(44)
+    N = 2000
+    X = np.random.normal(0, 1, (N, 3))
+    y = (X[:, 0] ** 2 + X[:, 1] + X[:, 1] * X[:, 2] + np.random.normal(0, 0.01, (N,))).reshape(-1, 1)
+    oak = oak_model(num_inducing=50, max_interaction_depth=2, share_var_across_orders=share_var_across_orders)
+    oak.fit(X, y, optimise=False)
+    oak.m.kernel.variances[0].assign(1e-16)
+    oak.alpha = get_model_sufficient_statistics(oak.m, get_L=False)
+    comps = get_prediction_component(oak.m, oak.alpha, oak._transform_x(X), share_var_across_orders=share_var_across_orders)
+    out = np.sum([c.numpy() for c in comps], axis=0)
+    np.testing.assert_allclose(out, oak.m.predict_f(oak._transform_x(X))[0].numpy()[:, 0], rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.parametrize("is_sgpr", (False, True))
+@pytest.mark.parametrize("share_var_across_orders", [True, False])
+def test_compute_sobol(is_sgpr, share_var_across_orders):
+    """tests/test_sobol_oak_kernel.py:31-126 (OAK branch): Sobol indices of x0^2 + 2 x1 + x0 x1 are [2, 4, 1]."""
+    from sklearn.cluster import KMeans
+    np.random.seed(0)
+    X = np.random.normal(0, 1, (500, 2))
+    Y = np.reshape(X[:, 0] ** 2 + X[:, 1] * 2 + X[:, 0] * X[:, 1], (-1, 1))
+    Z = KMeans(n_clusters=300, random_state=0, n_init=2).fit(X).cluster_centers_ if is_sgpr else None
+    model = create_model_oak((X, Y), inducing_pts=Z, optimise=False, zfixed=False, lengthscale_bounds=[1e-6, 100],
+                             share_var_across_orders=share_var_across_orders)
+    if share_var_across_orders:
+        for i, v in enumerate((0.76, 96.935, 128.27)):
+            model.kernel.variances[i].assign(v)
+    else:
+        model.kernel.variances[0].assign(0.01)
+        model.kernel.kernels[0].base_kernel.variance.assign(1)
+        model.kernel.kernels[1].base_kernel.variance.assign(1)
+    model.kernel.kernels[0].base_kernel.lengthscales.assign(2.91)
+    model.kernel.kernels[1].base_kernel.lengthscales.assign(9.20)
+    idx, sobol = compute_sobol_oak(model, 1, 0, share_var_across_orders=share_var_across_orders)
+    assert idx == [[0], [1], [0, 1]]
+    if share_var_across_orders:
+        np.testing.assert_array_almost_equal(sobol, np.array([2.0, 4.0, 1.0]), decimal=1)
+    else:
+        assert np.all(np.array(sobol) > 0)
+
+
+@pytest.mark.parametrize("p", (0.0, 0.77, 1.0))
+def test_compute_L_binary_kernel(p):
+    """tests/test_sobol.py:186-208."""
+    X = np.reshape(np.random.binomial(1, p, 1000), (-1, 1)).astype(float)
+    L = compute_L_binary_kernel(X, p, 1, 0)
+    K = OrthogonalBinary(p0=p, active_dims=[0])
+    x0, x1 = np.zeros((1, 1)), np.ones((1, 1))
+    L1 = np.matmul(K(X, x0), K(x0, X)) * p + np.matmul(K(X, x1), K(x1, X)) * (1 - p)
+    assert np.max(np.abs(L - L1)) < 1e-15
+
+
+def test_sobol_empirical_measure():
+    """tests/test_sobol_oak_kernel.py:129-155."""
+    x = np.random.normal(0, 1, (10, 1))
+    y = x ** 2 + np.cos(x) + np.random.normal(0, 0.1, (10, 1))
+    kernel = OrthogonalRBFKernel(gpflow.kernels.RBF(), EmpiricalMeasure(x, np.ones(x.shape) / 10), active_dims=[0])
+    m = gpflow.models.GPR((x, y), kernel=kernel)
+    var_samples = np.var(m.predict_f(x)[0].numpy())
+    alpha = get_model_sufficient_statistics(m, get_L=False)
+    L = compute_L_empirical_measure(m.kernel.measure.location, m.kernel.measure.weights, m.kernel, x)
+    np.testing.assert_array_almost_equal(var_samples, float((alpha.T @ L @ alpha)[0, 0]), decimal=5)
+
+
+def test_save_and_load_model(tmp_path):
+    """oak/model_utils.py:44-87: npz with the positional list of trainable parameter values."""
+    X = np.random.default_rng(0).standard_normal((30, 2))
+    y = X[:, :1] ** 2
+    m1 = create_model_oak((X, y), lengthscale_bounds=[1e-3, 1e3])
+    m1.kernel.kernels[0].base_kernel.lengthscales.assign(2.5)
+    m1.kernel.variances[1].assign(0.37)
+    save_model(m1, tmp_path / "sub" / "model.npz")
+    m2 = create_model_oak((X, y), lengthscale_bounds=[1e-3, 1e3])
+    load_model(m2, tmp_path / "sub" / "model.npz")
+    for a, b in zip(m1.trainable_parameters, m2.trainable_parameters):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=1e-12)
+    np.testing.assert_allclose(m1.maximum_log_likelihood_objective(), m2.maximum_log_likelihood_objective(), rtol=1e-12)
+
+
+def test_initialize_kmeans_with_binary():
+    """tests/test_utils.py:18-39."""
+    np.random.seed(44)
+    X = np.zeros((100, 3))
+    X[:, 0] = np.random.binomial(1, 0.33, 100)
+    X[:, 2] = np.random.binomial(1, 0.33, 100)
+    X[:, 1] = np.random.normal(0, 4, 100)
+    Z = initialize_kmeans_with_binary(X, [0, 2], [1], 50)
+    assert Z.shape == (50, 3) and isinstance(Z, np.ndarray)

@@ -1,0 +1,160 @@
+"""GPU parity of the SGPR / GPR solve path through the C ABI.  Tolerances (fp64): ELBO <= 1e-10 relative (whitened
+route always; phi route on problems with cond(Kuu) <= 1e5, cond stated in each test), predictive mean/var <= 1e-9."""
+import numpy as np
+import pytest
+
+import cases
+from conftest import GOLDEN
+from oak import _capi
+from oracle import c_oracle, oak_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return abs(a - b) / abs(b)
+
+
+def setup(hip, X, y, Z, route):
+    hip.sgpr_set_data(X, y)
+    hip.sgpr_set_inducing(Z)
+    hip.sgpr_set_route(route)
+    hip.sgpr_set_panel_rows(0)
+
+
+@pytest.mark.parametrize("route", ["phi", "whitened"])
+@pytest.mark.parametrize("N,D,M,R", [(5000, 8, 200, 2), (4099, 6, 131, 3), (2048, 16, 128, 2), (777, 5, 129, 4), (300, 3, 300, 1)])
+def test_elbo_alpha_predict_match_oracle(hip, route, N, D, M, R):
+    rng = np.random.default_rng(N + M)
+    X, y, Z = o.synthetic_problem(N, D, M, seed=N)
+    spec = o.make_spec(D, R, lengthscales=list(rng.uniform(0.9, 1.8, D)), order_variances=list(rng.uniform(0.5, 1.5, R + 1)))
+    cond = np.linalg.cond(o.oak_K(spec, Z) + 1e-6 * np.eye(M))
+    d = _capi.KernelDesc(spec)
+    setup(hip, X, y, Z, route)
+    e = hip.sgpr_elbo(d, 0.01)
+    er = o.sgpr_elbo(spec, X, y, Z, 0.01)
+    tol = 1e-10 if (route == "whitened" or cond < 1e5) else 1e-16 * cond * 100
+    assert rel(e, er) <= tol, f"route={route} cond={cond:.2e} rel={rel(e, er):.2e}"
+    Xs = rng.standard_normal((257, D))
+    m, v = hip.sgpr_predict(d, Xs)
+    mr, vr = o.sgpr_predict_f(spec, X, y, Z, 0.01, Xs)
+    ptol = 1e-9 if (route == "whitened" or cond < 1e5) else max(1e-9, 1e-16 * cond * 100)
+    assert np.abs(m - mr[:, 0]).max() <= ptol * max(1.0, np.abs(mr).max())
+    assert np.abs(v - vr[:, 0]).max() <= ptol * max(1.0, np.abs(vr).max())
+    a = hip.sgpr_alpha(M)
+    np.testing.assert_allclose(o.oak_K(spec, Xs, Z) @ a, mr[:, 0], rtol=1e-6, atol=ptol * 10)
+
+
+def test_whitened_route_on_an_ill_conditioned_problem(hip):
+    """cond(Kuu) ~ 1e6: the whitened (GPflow A-route) solve stays at 1e-10, the phi route degrades like cond*eps."""
+    X, y, Z = o.synthetic_problem(1000, 3, 50)
+    rng = np.random.default_rng(0)
+    spec = o.make_spec(3, 2, lengthscales=list(0.8 + rng.uniform(size=3)), order_variances=list(0.5 + rng.uniform(size=3)))
+    d = _capi.KernelDesc(spec)
+    er = o.sgpr_elbo(spec, X, y, Z, 0.01)
+    setup(hip, X, y, Z, "whitened")
+    assert rel(hip.sgpr_elbo(d, 0.01), er) <= 1e-10
+    setup(hip, X, y, Z, "phi")
+    assert rel(hip.sgpr_elbo(d, 0.01), er) <= 1e-7
+
+
+def test_sufficient_statistics(hip):
+    X, y, Z = o.synthetic_problem(3001, 7, 200)
+    spec = o.make_spec(7, 2)
+    d = _capi.KernelDesc(spec)
+    setup(hip, X, y, Z, "phi")
+    hip.sgpr_local_stats(d)
+    st = hip.sgpr_get_stats()
+    M = 200
+    kuf = o.oak_K(spec, Z, X)
+    Phi = st[:M * M].reshape(M, M)
+    np.testing.assert_allclose(Phi, kuf @ kuf.T, rtol=1e-12, atol=1e-9)
+    np.testing.assert_array_equal(Phi, Phi.T)                      # exactly symmetric by construction
+    np.testing.assert_allclose(st[M * M:M * M + M], (kuf @ y)[:, 0], rtol=1e-11, atol=1e-10)
+    np.testing.assert_allclose(st[M * M + M], o.oak_K_diag(spec, X).sum(), rtol=1e-13)
+    np.testing.assert_allclose(st[M * M + M + 1], float((y ** 2).sum()), rtol=1e-13)
+    assert st[M * M + M + 2] == 3001
+
+
+def test_panel_chunking_and_determinism(hip):
+    """Row panels of any size give the same statistics to rounding; repeated evaluation is bitwise identical."""
+    X, y, Z = o.synthetic_problem(6000, 5, 150)
+    spec = o.make_spec(5, 2)
+    d = _capi.KernelDesc(spec)
+    setup(hip, X, y, Z, "phi")
+    e_full = hip.sgpr_elbo(d, 0.01)
+    assert hip.sgpr_elbo(d, 0.01) == e_full
+    for rows in (16, 1000, 4096):
+        hip.sgpr_set_panel_rows(rows)
+        assert rel(hip.sgpr_elbo(d, 0.01), e_full) <= 1e-12
+    hip.sgpr_set_panel_rows(0)
+
+
+def test_stats_are_additive_over_row_shards(hip):
+    """The multi-GPU contract: statistics of disjoint row blocks add up to the statistics of their union."""
+    X, y, Z = o.synthetic_problem(5000, 6, 140)
+    spec = o.make_spec(6, 2)
+    d = _capi.KernelDesc(spec)
+    setup(hip, X, y, Z, "phi")
+    hip.sgpr_local_stats(d)
+    full = hip.sgpr_get_stats()
+    acc = np.zeros_like(full)
+    for lo, hi in ((0, 1777), (1777, 4000), (4000, 5000)):
+        hip.sgpr_set_data(X[lo:hi], y[lo:hi])
+        hip.sgpr_local_stats(d)
+        acc += hip.sgpr_get_stats()
+    np.testing.assert_allclose(acc, full, rtol=1e-12, atol=1e-9)
+    hip.sgpr_set_stats(acc, False)
+    e, terms = hip.sgpr_tail(d, 0.01)
+    assert rel(e, o.sgpr_elbo(spec, X, y, Z, 0.01)) <= 1e-10 and terms[5] == 5000
+
+
+def test_mixed_kernel_golden_vectors(hip):
+    g = np.load(GOLDEN / "oracle_vectors.npz")
+    for name, start in (("A", 300), ("B", 100)):
+        spec, X, y, Z, noise = getattr(cases, f"case_{name}")()
+        d = _capi.KernelDesc(spec)
+        setup(hip, X, y, Z, "whitened")
+        assert rel(hip.sgpr_elbo(d, noise), float(g[f"{name}_elbo"])) <= 1e-10
+        m, v = hip.sgpr_predict(d, X[start:])
+        assert np.abs(m - g[f"{name}_mean"][:, 0]).max() <= 1e-9 and np.abs(v - g[f"{name}_var"][:, 0]).max() <= 1e-9
+        np.testing.assert_allclose(hip.sgpr_alpha(len(Z)), g[f"{name}_alpha"][:, 0], rtol=1e-5, atol=1e-7)
+
+
+def test_c2_scale_against_the_multicore_oracle(hip):
+    """BASELINE config 2 (N=65536, D=8, M=512, order 2) against the chunked C/BLAS oracle; cond(Kuu) ~ 9e4."""
+    X, y, Z = o.synthetic_problem(65536, 8, 512)
+    spec = o.make_spec(8, 2)
+    d = _capi.KernelDesc(spec)
+    er = c_oracle.sgpr_elbo_chunked(spec, X, y, Z, 0.01, chunk=8192)
+    for route in ("phi", "whitened"):
+        setup(hip, X, y, Z, route)
+        assert rel(hip.sgpr_elbo(d, 0.01), er) <= 1e-10, route
+
+
+def test_non_positive_definite_and_state_errors(hip):
+    X, y, Z = o.synthetic_problem(200, 2, 20)
+    spec = o.make_spec(2, 2)
+    d = _capi.KernelDesc(spec)
+    Zdup = np.vstack([Z[:10], Z[:10]])          # duplicated inducing inputs, no jitter -> singular Kuu
+    setup(hip, X, y, Zdup, "phi")
+    with pytest.raises(_capi.NotPositiveDefiniteError):
+        hip.sgpr_elbo(d, 0.01, jitter=0.0)
+    with pytest.raises(_capi.OakHipError):
+        hip.sgpr_predict(d, X[:5])              # no posterior after the failed factorisation
+    with pytest.raises(ValueError):
+        hip.sgpr_elbo(d, -1.0)
+
+
+def test_gpr_matches_oracle(hip):
+    for N, D, R in ((700, 4, 2), (1030, 8, 2), (65, 3, 3)):
+        X, y, _ = o.synthetic_problem(N, D, 4, seed=N)
+        spec = o.make_spec(D, R)
+        d = _capi.KernelDesc(spec)
+        hip.gpr_set_data(X, y)
+        assert rel(hip.gpr_log_marginal(d, 0.01), o.gpr_log_marginal_likelihood(spec, X, y, 0.01)) <= 1e-11
+        Xs = X[:90] + 0.1
+        m, v = hip.gpr_predict(d, Xs)
+        mr, vr = o.gpr_predict_f(spec, X, y, 0.01, Xs)
+        assert np.abs(m - mr[:, 0]).max() <= 1e-9 and np.abs(v - vr[:, 0]).max() <= 1e-9
+        np.testing.assert_allclose(hip.gpr_alpha(N), o.gpr_alpha(spec, X, y, 0.01)[:, 0], rtol=1e-6, atol=1e-6)

@@ -1,0 +1,174 @@
+"""Host-side logic of the mirror package that needs no device: transforms, parameter containers, kernel description
+packing, constructor semantics and error conventions of the reference interface."""
+import itertools
+
+import numpy as np
+import pytest
+
+import cases
+from oak import _capi
+from oak import gpflow_lite as gpflow
+from oak.input_measures import EmpiricalMeasure, GaussianMeasure, MOGMeasure, UniformMeasure
+from oak.model_utils import _calculate_features, estimate_one_dim_gmm
+from oak.normalising_flow import Normalizer
+from oak.oak_kernel import OAKKernel, KernelComponenent, _categorical_chain, bounded_param, get_list_representation, kernel_to_spec
+from oak.ortho_binary_kernel import OrthogonalBinary
+from oak.ortho_categorical_kernel import OrthogonalCategorical
+from oak.ortho_rbf_kernel import OrthogonalRBFKernel
+from oracle import oak_oracle as o
+
+
+@pytest.mark.parametrize("tr", [gpflow.Softplus(), gpflow.Softplus(1e-6), gpflow.Sigmoid(1e-3, 1e3), gpflow.Sigmoid(1e-6, 2)])
+def test_transform_roundtrip_and_derivative(tr):
+    u = np.linspace(-6, 6, 25)
+    x = tr.forward(u)
+    np.testing.assert_allclose(tr.inverse(x), u, rtol=1e-9, atol=1e-9)
+    h = 1e-6
+    np.testing.assert_allclose(tr.dforward(u), (tr.forward(u + h) - tr.forward(u - h)) / (2 * h), rtol=1e-6, atol=1e-9)
+
+
+def test_transforms_match_oracle_restatement():
+    u = np.linspace(-4, 4, 9)
+    np.testing.assert_allclose(gpflow.Softplus().forward(u), o.softplus(u))
+    np.testing.assert_allclose(gpflow.Sigmoid(1e-3, 1e3).forward(u), o.sigmoid_bounded(u, 1e-3, 1e3))
+
+
+def test_parameter_assign_numpy_and_prior():
+    p = gpflow.Parameter(1.0, transform=gpflow.positive())
+    p.assign(0.3)
+    assert abs(float(p.numpy()) - 0.3) < 1e-15
+    p.prior = gpflow.Gamma(1.0, 0.2)
+    np.testing.assert_allclose(p.log_prior_density(), o.gamma_log_prob(0.3), rtol=1e-14)
+    b = bounded_param(1e-3, 1e3, 1)
+    assert abs(float(b.numpy()) - 1.0) < 1e-12
+    with pytest.raises(ValueError):
+        gpflow.Parameter(-1.0, transform=gpflow.positive())
+
+
+def test_oak_kernel_constructor_semantics():
+    k = OAKKernel([gpflow.RBF] * 3, num_dims=3, max_interaction_depth=2, constrain_orthogonal=True, lengthscale_bounds=[1e-3, 1e3])
+    assert len(k.kernels) == 3 and len(k.variances) == 3
+    assert all(isinstance(s, OrthogonalRBFKernel) and isinstance(s.measure, GaussianMeasure) for s in k.kernels)
+    # shared variances: base variances are constants, not trainable parameters (oak_kernel.py:163-166)
+    assert not isinstance(k.kernels[0].base_kernel.variance, gpflow.Parameter)
+    assert isinstance(k.kernels[0].base_kernel.lengthscales.transform, gpflow.Sigmoid)
+    names = [n for n, _ in k.named_parameters()]
+    assert sum("lengthscales" in n for n in names) == 3 and sum(n.startswith("variances") for n in names) == 3
+    k2 = OAKKernel([gpflow.RBF] * 2, num_dims=2, max_interaction_depth=2, constrain_orthogonal=True, share_var_across_orders=False)
+    assert len(k2.variances) == 1 and isinstance(k2.kernels[0].base_kernel.variance, gpflow.Parameter)
+    spec = kernel_to_spec(k)
+    assert spec["max_interaction_depth"] == 2 and [d["measure"][0] for d in spec["dims"]] == ["gaussian"] * 3
+    desc = _capi.KernelDesc(spec)
+    assert desc.D == 3 and desc.R == 2 and list(desc.active_col) == [0, 1, 2]
+
+
+def test_oak_kernel_mixed_types_and_errors():
+    p = np.array([0.2, 0.3, 0.5]).reshape(-1, 1)
+    k = OAKKernel([gpflow.RBF, None, None], num_dims=3, max_interaction_depth=2, constrain_orthogonal=True,
+                  p0=[None, 0.4, None], p=[None, None, p])
+    assert isinstance(k.kernels[1], OrthogonalBinary) and isinstance(k.kernels[2], OrthogonalCategorical)
+    spec = kernel_to_spec(k)
+    assert [d["type"] for d in spec["dims"]] == ["rbf", "binary", "categorical"]
+    with pytest.raises(ValueError):   # both empirical and GMM measure on one input (oak_kernel.py:132-138)
+        OAKKernel([gpflow.RBF], num_dims=1, max_interaction_depth=1, constrain_orthogonal=True,
+                  empirical_locations=[np.zeros((2, 1))], empirical_weights=[np.full((2, 1), .5)],
+                  gmm_measures=[MOGMeasure(np.zeros(1), np.ones(1), np.ones(1))])
+    with pytest.raises(AssertionError):   # duplicate active dims (oak_kernel.py:80-82)
+        OAKKernel([gpflow.RBF] * 2, num_dims=2, max_interaction_depth=1, active_dims=[[0], [0]])
+    with pytest.raises(AssertionError):   # empirical locations without the orthogonal constraint (:192-197)
+        OAKKernel([gpflow.RBF], num_dims=1, max_interaction_depth=1, empirical_locations=[np.zeros((2, 1))])
+    with pytest.raises(NotImplementedError):
+        OrthogonalRBFKernel(OrthogonalBinary(), GaussianMeasure(0, 1))
+    with pytest.raises(NotImplementedError):
+        OrthogonalRBFKernel(gpflow.RBF(), object())
+
+
+def test_measures_validate():
+    with pytest.raises(AssertionError):
+        EmpiricalMeasure(np.zeros((3, 1)), np.ones((3, 1)))
+    with pytest.raises(AssertionError):
+        MOGMeasure(np.zeros(2), np.ones(2), np.array([0.5, 0.6]))
+    with pytest.raises(ValueError):
+        MOGMeasure(np.zeros((2, 1)), np.ones(2), np.array([0.5, 0.5]))
+    m = MOGMeasure(np.array([3, 2], dtype=int), np.array([3, 10], dtype=int), np.array([0.6, 0.4]))
+    assert m.means.dtype == float and m.variances.dtype == float
+    assert EmpiricalMeasure(np.zeros((4, 1))).weights.shape == (4, 1)
+    assert UniformMeasure(0, 1).as_tuple() == ("uniform", 0.0, 1.0)
+
+
+def test_list_representation_matches_reference_order():
+    k = OAKKernel([gpflow.RBF] * 4, num_dims=4, max_interaction_depth=3, constrain_orthogonal=True)
+    sel, comps = get_list_representation(k, num_dims=4)
+    expect = [[]] + [list(c) for r in (1, 2, 3) for c in itertools.combinations(range(4), r)]
+    assert sel == expect == o.list_representation(4, 3)
+    assert all(isinstance(c, KernelComponenent) for c in comps) and len(comps) == len(sel)
+    k2 = OAKKernel([gpflow.RBF] * 2, num_dims=2, max_interaction_depth=2, constrain_orthogonal=True)
+    assert get_list_representation(k2, num_dims=2)[0] == [[], [0], [1], [0, 1]]
+
+
+def test_kernel_desc_packs_every_measure():
+    spec, *_ = cases.case_B()
+    d = _capi.KernelDesc(spec)
+    assert list(d.dim_type) == [0, 0, 0, 1, 2, 0]
+    assert list(d.measure[[0, 1, 2, 5]]) == [_capi.MEAS_GAUSSIAN, _capi.MEAS_UNIFORM, _capi.MEAS_MOG, _capi.MEAS_EMPIRICAL]
+    off, C = d.cat_blocks[4]
+    B = d.meas_data[off:off + C * C].reshape(C, C)
+    np.testing.assert_allclose(B, o.categorical_table({**spec["dims"][4], "variance": 1.0}), rtol=1e-14)
+    with pytest.raises(ValueError):
+        _capi.KernelDesc(dict(dims=spec["dims"], order_variances=[1.0], max_interaction_depth=3, share_var_across_orders=True))
+    with pytest.raises(ValueError):
+        _capi.KernelDesc(dict(dims=spec["dims"][:1], order_variances=[1.0] * 10, max_interaction_depth=9, share_var_across_orders=True))
+
+
+def test_categorical_chain_rule_matches_finite_differences():
+    rng = np.random.default_rng(0)
+    C = 4
+    W, kappa = rng.uniform(size=(C, 2)), rng.uniform(0.5, 1.5, C)
+    p = rng.uniform(0.5, 1.5, C); p = (p / p.sum()).reshape(-1, 1)
+    G = rng.standard_normal((C, C))
+    f = lambda W_, k_: float(np.sum(G * _capi.categorical_table_unit(W_, k_, p)[0]))
+    gW, gk = _categorical_chain(W, kappa, p, G)
+    h = 1e-6
+    for idx in np.ndindex(W.shape):
+        Wp, Wm = W.copy(), W.copy(); Wp[idx] += h; Wm[idx] -= h
+        np.testing.assert_allclose(gW[idx], (f(Wp, kappa) - f(Wm, kappa)) / (2 * h), rtol=1e-5, atol=1e-7)
+    for i in range(C):
+        kp, km = kappa.copy(), kappa.copy(); kp[i] += h; km[i] -= h
+        np.testing.assert_allclose(gk[i], (f(W, kp) - f(W, km)) / (2 * h), rtol=1e-5, atol=1e-7)
+
+
+def test_calculate_features_and_errors():
+    rng = np.random.default_rng(1)
+    X = np.stack([rng.integers(0, 2, 30), rng.integers(0, 3, 30), rng.standard_normal(30)], axis=1).astype(float)
+    cont, binary, cat, p0, p = _calculate_features(X, categorical_feature=[1], binary_feature=[0])
+    assert (cont, binary, cat) == ([2], [0], [1])
+    np.testing.assert_allclose(p0[0], 1 - X[:, 0].mean())
+    np.testing.assert_allclose(p[1].sum(), 1.0)
+    assert _calculate_features(X, None, None)[3] is None
+    with pytest.raises(ValueError):
+        _calculate_features(X, categorical_feature=[0], binary_feature=[0])
+
+
+def test_gmm_fit():
+    """tests/test_orthogonality.py:168-171."""
+    measure = estimate_one_dim_gmm(K=2, X=np.array([1.0, 1, 1, 10, 10, 10]))
+    np.testing.assert_almost_equal(np.sort(measure.means), np.array([1.0, 10.0]))
+
+
+def test_normalising_flow():
+    """tests/test_normalising_flow.py:17-41 (NumPy flow, L-BFGS-B on the KL objective)."""
+    rng = np.random.default_rng(44)
+    x = rng.normal(2, 0.5, size=(100, 1))
+    n = Normalizer(x, log=False)
+    before = n.KL_objective()
+    gpflow.Scipy().minimize(n.KL_objective, n.trainable_variables)
+    y = np.asarray(n.bijector(x))
+    np.testing.assert_almost_equal(0, y.mean(), decimal=2)
+    np.testing.assert_almost_equal(1, y.std(), decimal=2)
+    assert n.kstest()[1] > 0.05 and n.KL_objective() < before
+    np.testing.assert_allclose(n.bijector.inverse(y), x, rtol=1e-9)
+    nl = Normalizer(np.exp(x[:, 0]), log=True)
+    h = 1e-6
+    xs = np.exp(x[:5, 0])
+    np.testing.assert_allclose(nl.bijector.forward_log_det_jacobian(xs),
+                               np.log((np.asarray(nl.bijector(xs + h)) - np.asarray(nl.bijector(xs - h))) / (2 * h)), rtol=1e-6)
