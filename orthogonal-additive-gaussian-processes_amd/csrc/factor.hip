@@ -1,0 +1,359 @@
+// Cholesky, triangular solves and a general fp64 MFMA GEMM: the O(M^3) "tail" of the SGPR objective
+// (replaces tf.linalg.cholesky / triangular_solve / matmul at oak/utils.py:187-198).
+//
+// The tail is latency-bound at M <= 2048, so the design goal is few, wide launches:
+//   * gemm_mfma  : C = beta*C + alpha*A*op(B), 64x64 tiles, v_mfma_f64_16x16x4, LDS pitches chosen conflict-free.
+//   * potrf_lower: right-looking, NB = 32.  The 32x32 diagonal block is factored by ONE wave with its rows in
+//                  registers (v_readlane broadcasts, no barriers); panel rows are solved one per lane.
+//   * trsm_rows  : NB = 128 blocked: small in-LDS leaf solves + MFMA GEMM updates.
+#include "oak_internal.h"
+
+namespace oak {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+// ---------------------------------------------------------------------------------------------
+// general GEMM (row-major):  BT = 1: C[m x n] = beta*C + alpha * A[m x k] * B[n x k]^T
+//                            BT = 0: C[m x n] = beta*C + alpha * A[m x k] * B[k x n]
+// lower_only: skip 64x64 tiles strictly above the diagonal (symmetric rank-k updates).
+// ---------------------------------------------------------------------------------------------
+constexpr int GM_T = 64, GM_K = 16, GM_PA = GM_K + 2, GM_PB = GM_T + 16;
+
+template <int BT>
+__global__ void __launch_bounds__(256) gemm_mfma_kernel(const double* __restrict__ A, const double* __restrict__ B,
+                                                        double* __restrict__ C, int64_t m, int64_t n, int64_t k, int64_t lda,
+                                                        int64_t ldb, int64_t ldc, double alpha, double beta, int lower_only) {
+    __shared__ __attribute__((aligned(16))) double As[GM_T * GM_PA];
+    __shared__ __attribute__((aligned(16))) double Bs[(BT ? GM_T * GM_PA : GM_K * GM_PB)];
+    if (lower_only && blockIdx.x > blockIdx.y) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int64_t r0 = (int64_t)blockIdx.y * GM_T, c0 = (int64_t)blockIdx.x * GM_T;
+    const int fi = lane & 15, fk = lane >> 4;
+    double4_t acc[2][2];
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) acc[g][h] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    // staging coordinates
+    const int ar = tid >> 2, ak = (tid & 3) * 4;             // A (and B when BT): row 0..63, k offset 0,4,8,12
+    const int bk = tid >> 4, bn = (tid & 15) * 4;            // B when !BT: k row 0..15, n offset 0..60
+    const int64_t arow = (r0 + ar < m) ? r0 + ar : m - 1;
+    const int64_t brow = BT ? ((c0 + ar < n) ? c0 + ar : n - 1) : 0;
+    for (int64_t k0 = 0; k0 < k; k0 += GM_K) {
+        double va[4], vb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t kk = k0 + ak + q;
+            const int64_t kc = kk < k ? kk : k - 1;
+            const double x = A[arow * lda + kc];
+            va[q] = (kk < k && r0 + ar < m) ? x : 0.0;
+            if (BT) {
+                const double y = B[brow * ldb + kc];
+                vb[q] = (kk < k && c0 + ar < n) ? y : 0.0;
+            } else {
+                const int64_t kr = k0 + bk, nc = c0 + bn + q;
+                const double y = B[(kr < k ? kr : k - 1) * ldb + (nc < n ? nc : n - 1)];
+                vb[q] = (kr < k && nc < n) ? y : 0.0;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            As[ar * GM_PA + ak + q] = va[q];
+            if (BT) Bs[ar * GM_PA + ak + q] = vb[q];
+            else Bs[bk * GM_PB + bn + q] = vb[q];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < GM_K / 4; ++ks) {
+            double a[2], b[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) a[g] = As[(wr * 32 + 16 * g + fi) * GM_PA + 4 * ks + fk];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                b[h] = BT ? Bs[(wc * 32 + 16 * h + fi) * GM_PA + 4 * ks + fk] : Bs[(4 * ks + fk) * GM_PB + wc * 32 + 16 * h + fi];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) acc[g][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g], b[h], acc[g][h], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t row = r0 + wr * 32 + 16 * g + 4 * reg + fk, col = c0 + wc * 32 + 16 * h + fi;
+                if (row < m && col < n) {
+                    double* q = C + row * ldc + col;
+                    const double v = alpha * acc[g][h][reg];
+                    *q = (beta == 0.0) ? v : __builtin_fma(beta, *q, v);
+                }
+            }
+}
+
+static int gemm_launch(oak_ctx* ctx, int bt, const double* dA, const double* dB, double* dC, int64_t m, int64_t n, int64_t k,
+                       int64_t lda, int64_t ldb, int64_t ldc, double alpha, double beta, int lower_only) {
+    if (m <= 0 || n <= 0) return OAK_OK;
+    dim3 grid((unsigned)((n + GM_T - 1) / GM_T), (unsigned)((m + GM_T - 1) / GM_T));
+    if (bt) gemm_mfma_kernel<1><<<grid, 256, 0, ctx->stream>>>(dA, dB, dC, m, n, k, lda, ldb, ldc, alpha, beta, lower_only);
+    else    gemm_mfma_kernel<0><<<grid, 256, 0, ctx->stream>>>(dA, dB, dC, m, n, k, lda, ldb, ldc, alpha, beta, lower_only);
+    OAK_HIP_CHECK(hipGetLastError());
+    return OAK_OK;
+}
+int gemm_nn(oak_ctx* ctx, const double* dA, const double* dB, double* dC, int64_t m, int64_t n, int64_t k, int64_t lda,
+            int64_t ldb, int64_t ldc, double alpha, double beta) {
+    return gemm_launch(ctx, 0, dA, dB, dC, m, n, k, lda, ldb, ldc, alpha, beta, 0);
+}
+int gemm_nt(oak_ctx* ctx, const double* dA, const double* dB, double* dC, int64_t m, int64_t n, int64_t k, int64_t lda,
+            int64_t ldb, int64_t ldc, double alpha, double beta, int lower_only) {
+    return gemm_launch(ctx, 1, dA, dB, dC, m, n, k, lda, ldb, ldc, alpha, beta, lower_only);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cholesky (lower), right-looking, NB = 32
+// ---------------------------------------------------------------------------------------------
+constexpr int PO_NB = 32;
+
+// One wave factors the 32x32 block held in LDS (row i in lane i's registers); lanes >= 32 idle.
+__device__ __forceinline__ void potf2_32_wave(double* Dg /*[32][33]*/, int lane, int64_t j0, int* info) {
+    const int i = lane & 31;
+    double a[PO_NB];
+#pragma unroll
+    for (int c = 0; c < PO_NB; ++c) a[c] = Dg[i * (PO_NB + 1) + c];
+    bool bad = false;
+    int bad_at = 0;
+#pragma unroll
+    for (int k = 0; k < PO_NB; ++k) {
+        const double akk = readlane_f64(a[k], k);
+        if (!(akk > 0.0) && !bad) { bad = true; bad_at = k; }
+        const double s = sqrt(akk);
+        const double lik = (i == k) ? s : a[k] / s;
+        if (i >= k) a[k] = lik;
+#pragma unroll
+        for (int j = k + 1; j < PO_NB; ++j) {
+            const double ljk = readlane_f64(a[k], j);
+            if (i >= j) a[j] = __builtin_fma(-a[k], ljk, a[j]);
+        }
+    }
+    if (lane < PO_NB) {
+#pragma unroll
+        for (int c = 0; c < PO_NB; ++c) Dg[i * (PO_NB + 1) + c] = (c <= i) ? a[c] : 0.0;
+    }
+    if (bad && lane == 0 && info != nullptr) atomicMin(info, (int)(j0 + bad_at + 1));
+}
+
+__global__ void __launch_bounds__(256) potrf_panel_kernel(double* __restrict__ A, int64_t n, int64_t lda, int64_t j0, int* __restrict__ info) {
+    __shared__ double Dg[PO_NB * (PO_NB + 1)];
+    const int tid = threadIdx.x;
+    const int nb = (n - j0 < PO_NB) ? (int)(n - j0) : PO_NB;
+    {
+        // 1024 entries, 4 per thread, clamped addresses (no divergent loads); identity padding beyond nb
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + 256 * q;
+            const int i = idx >> 5, j = idx & 31;
+            const int ic = i < nb ? i : nb - 1, jc = j < nb ? j : nb - 1;
+            const double x = A[(j0 + ic) * lda + j0 + jc];
+            v[q] = (i < nb && j < nb) ? ((j <= i) ? x : 0.0) : ((i == j) ? 1.0 : 0.0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int idx = tid + 256 * q; Dg[(idx >> 5) * (PO_NB + 1) + (idx & 31)] = v[q]; }
+    }
+    __syncthreads();
+    if (tid < 64) potf2_32_wave(Dg, tid, j0, blockIdx.x == 0 ? info : nullptr);
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int idx = tid; idx < nb * nb; idx += 256) {
+            const int i = idx / nb, j = idx - i * nb;
+            A[(j0 + i) * lda + j0 + j] = Dg[i * (PO_NB + 1) + j];
+        }
+    }
+    // rows below the diagonal block: X * L_jj^T = A_panel, one row per lane
+    const int64_t row = j0 + nb + (int64_t)blockIdx.x * 256 + tid;
+    if (row < n && nb == PO_NB) {
+        double x[PO_NB];
+        double* ap = A + row * lda + j0;
+#pragma unroll
+        for (int c = 0; c < PO_NB; ++c) x[c] = ap[c];
+#pragma unroll
+        for (int c = 0; c < PO_NB; ++c) {
+            double s = x[c];
+#pragma unroll
+            for (int p = 0; p < c; ++p) s = __builtin_fma(-x[p], Dg[c * (PO_NB + 1) + p], s);
+            x[c] = s / Dg[c * (PO_NB + 1) + c];
+        }
+#pragma unroll
+        for (int c = 0; c < PO_NB; ++c) ap[c] = x[c];
+    }
+}
+
+__global__ void zero_upper_kernel(double* __restrict__ A, int64_t n, int64_t lda) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (j < n && j > i) A[i * lda + j] = 0.0;
+}
+
+int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda) {
+    int* d_info = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "potrf_info", 1, &d_info));
+    const int big = 0x7fffffff;
+    OAK_HIP_CHECK(hipMemcpyAsync(d_info, &big, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    for (int64_t j0 = 0; j0 < n; j0 += PO_NB) {
+        const int64_t below = n - j0 - PO_NB;
+        const unsigned gp = below > 0 ? (unsigned)((below + 255) / 256) : 1u;
+        potrf_panel_kernel<<<gp, 256, 0, ctx->stream>>>(dA, n, lda, j0, d_info);
+        if (below > 0) {
+            // trailing update A22 -= L21 L21^T (lower tiles only): MFMA GEMM, K = 32
+            const double* L21 = dA + (j0 + PO_NB) * lda + j0;
+            double* A22 = dA + (j0 + PO_NB) * lda + (j0 + PO_NB);
+            OAK_CHECK(gemm_nt(ctx, L21, L21, A22, below, below, PO_NB, lda, lda, lda, -1.0, 1.0, 1));
+        }
+    }
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
+    zero_upper_kernel<<<grid, 256, 0, ctx->stream>>>(dA, n, lda);
+    OAK_HIP_CHECK(hipGetLastError());
+    int info = 0;
+    OAK_HIP_CHECK(hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (info != big) {
+        set_error("Cholesky decomposition was not successful: leading minor of order %d is not positive definite (n=%lld)", info, (long long)n);
+        return OAK_E_NOTPD;
+    }
+    return OAK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// rows-TRSM leaf: n <= 256.  Each right-hand side is a contiguous row of BT; a group of 32 lanes owns one rhs.
+// ---------------------------------------------------------------------------------------------
+template <int TRANS>
+__global__ void __launch_bounds__(256) trsm_leaf_kernel(const double* __restrict__ L, int64_t n, int64_t ldl,
+                                                        double* __restrict__ BT, int64_t nrhs, int64_t ldb, int nblk, int rb) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* Lt = sm;                       // [32][33]
+    double* xs = sm + 32 * 33;             // [rb][nblk*32]
+    const int tid = threadIdx.x;           // 256 threads always; groups >= rb only help staging
+    const int rr = tid >> 5, i = tid & 31;
+    const bool worker = rr < rb;
+    const int64_t npad = (int64_t)nblk * 32;
+    const int64_t rhs = (int64_t)blockIdx.x * rb + rr;
+    const bool valid = worker && rhs < nrhs;
+    double* xr = xs + (int64_t)(worker ? rr : 0) * npad;
+    if (worker)
+        for (int64_t c = i; c < npad; c += 32) xr[c] = (valid && c < n) ? BT[rhs * ldb + c] : 0.0;
+    auto load_block = [&](int rbk, int cbk) {   // Lt[a][b] = L[rbk*32+a][cbk*32+b]; identity padding past n
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + 256 * q;
+            const int a = idx >> 5, b = idx & 31;
+            const int64_t gr = (int64_t)rbk * 32 + a, gc = (int64_t)cbk * 32 + b;
+            const double x = L[(gr < n ? gr : n - 1) * ldl + (gc < n ? gc : n - 1)];
+            v[q] = (gr < n && gc < n) ? ((gc <= gr) ? x : 0.0) : ((gr == gc) ? 1.0 : 0.0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int idx = tid + 256 * q; Lt[(idx >> 5) * 33 + (idx & 31)] = v[q]; }
+    };
+    if (TRANS == 0) {
+        for (int jb = 0; jb < nblk; ++jb) {
+            __syncthreads();
+            double s = xr[jb * 32 + i];
+            for (int kb = 0; kb < jb; ++kb) {
+                __syncthreads();
+                load_block(jb, kb);
+                __syncthreads();
+                const double* xk = xr + kb * 32;
+#pragma unroll
+                for (int k2 = 0; k2 < 32; ++k2) s = __builtin_fma(-Lt[i * 33 + k2], xk[k2], s);
+            }
+            __syncthreads();
+            load_block(jb, jb);
+            __syncthreads();
+            double x = 0.0;
+#pragma unroll
+            for (int p = 0; p < 32; ++p) {
+                const double xp = __shfl(s, p, 32) / Lt[p * 33 + p];
+                if (i == p) x = xp;
+                if (i > p) s = __builtin_fma(-Lt[i * 33 + p], xp, s);
+            }
+            if (worker) xr[jb * 32 + i] = x;
+        }
+    } else {
+        for (int jb = nblk - 1; jb >= 0; --jb) {
+            __syncthreads();
+            double s = xr[jb * 32 + i];
+            for (int kb = nblk - 1; kb > jb; --kb) {
+                __syncthreads();
+                load_block(kb, jb);
+                __syncthreads();
+                const double* xk = xr + kb * 32;
+#pragma unroll
+                for (int k2 = 0; k2 < 32; ++k2) s = __builtin_fma(-Lt[k2 * 33 + i], xk[k2], s);
+            }
+            __syncthreads();
+            load_block(jb, jb);
+            __syncthreads();
+            double x = 0.0;
+#pragma unroll
+            for (int p = 31; p >= 0; --p) {
+                const double xp = __shfl(s, p, 32) / Lt[p * 33 + p];
+                if (i == p) x = xp;
+                if (i < p) s = __builtin_fma(-Lt[p * 33 + i], xp, s);
+            }
+            if (worker) xr[jb * 32 + i] = x;
+        }
+    }
+    __syncthreads();
+    if (valid)
+        for (int64_t c = i; c < n; c += 32) BT[rhs * ldb + c] = xr[c];
+}
+
+static int trsm_leaf(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, double* dBT, int64_t nrhs, int64_t ldb, int trans) {
+    const int nblk = (int)((n + 31) / 32);
+    int rb = 8;
+    while (rb > 1 && rb / 2 >= nrhs) rb >>= 1;
+    const size_t lds = sizeof(double) * ((size_t)rb * nblk * 32 + 32 * 33);
+    const unsigned grid = (unsigned)((nrhs + rb - 1) / rb);
+    if (trans) trsm_leaf_kernel<1><<<grid, 256, lds, ctx->stream>>>(dL, n, ldl, dBT, nrhs, ldb, nblk, rb);
+    else       trsm_leaf_kernel<0><<<grid, 256, lds, ctx->stream>>>(dL, n, ldl, dBT, nrhs, ldb, nblk, rb);
+    OAK_HIP_CHECK(hipGetLastError());
+    return OAK_OK;
+}
+
+// Blocked rows-TRSM: every row b of BT is replaced by the solution of L x = b (trans = 0) or L^T x = b (trans = 1).
+int trsm_rows(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, double* dBT, int64_t nrhs, int64_t ldb, int trans) {
+    if (n <= 0 || nrhs <= 0) return OAK_OK;
+    constexpr int64_t NB = 128;
+    if (n <= 2 * NB) return trsm_leaf(ctx, dL, n, ldl, dBT, nrhs, ldb, trans);
+    if (!trans) {
+        for (int64_t j0 = 0; j0 < n; j0 += NB) {
+            const int64_t nbj = (n - j0 < NB) ? n - j0 : NB;
+            OAK_CHECK(trsm_leaf(ctx, dL + j0 * ldl + j0, nbj, ldl, dBT + j0, nrhs, ldb, 0));
+            const int64_t rest = n - j0 - nbj;
+            if (rest > 0)   // B[:, rest] -= X_j L[rest, j]^T
+                OAK_CHECK(gemm_nt(ctx, dBT + j0, dL + (j0 + nbj) * ldl + j0, dBT + j0 + nbj, nrhs, rest, nbj, ldb, ldl, ldb, -1.0, 1.0, 0));
+        }
+    } else {
+        const int64_t last = ((n - 1) / NB) * NB;
+        for (int64_t j0 = last; j0 >= 0; j0 -= NB) {
+            const int64_t nbj = (n - j0 < NB) ? n - j0 : NB;
+            OAK_CHECK(trsm_leaf(ctx, dL + j0 * ldl + j0, nbj, ldl, dBT + j0, nrhs, ldb, 1));
+            if (j0 > 0)     // B[:, 0:j0] -= X_j L[j, 0:j0]
+                OAK_CHECK(gemm_nn(ctx, dBT + j0, dL + j0 * ldl, dBT, nrhs, j0, nbj, ldb, ldl, ldb, -1.0, 1.0));
+        }
+    }
+    return OAK_OK;
+}
+
+}  // namespace oak

@@ -13,42 +13,66 @@
 
 namespace oak {
 
-// 2^t for t <= 0 (clamped at -1100): round-to-nearest split t = k + r, |r| <= 1/2, degree-13 Taylor in r*ln2,
-// then ldexp.  1.13 ulp max error measured against long-double exp2l (tools/ubench/fp64_overlap.hip).
-__device__ __forceinline__ double exp2_neg_poly(double t) {
-    // coefficients c_i = ln(2)^i / i!
+// 2^t for t <= 0, for CPT independent arguments at once (interleaved so the DP pipe always has independent work):
+//   a = t + 1.5*2^46 rounds t to a multiple of 1/64 (round-to-nearest); its low mantissa bits hold k = 64*rint-part, so
+//   j = k & 63 indexes a 64-entry table of 2^(j/64) (LDS), e = k >> 6 is added straight into the exponent field, and
+//   r = t - k/64, |r| <= 1/128, needs only a degree-5 polynomial: 2^t = 2^e * T[j] * (1 + r*(c1 + ... + r*c5)).
+// Max error 1.6 ulp against 50-digit arithmetic (tests/test_gpu_gram.py::test_exp2_accuracy); t is clamped at -1020 so the
+// exponent arithmetic cannot wrap (values below 2^-1020 are far under the 1e-12 parity tolerance of any Gram entry).
+__constant__ double c_exp2_table[64] = {
+    1.0, 1.01088928605170046, 1.0218971486541166782, 1.0330248790212284225,
+    1.0442737824274138403, 1.0556451783605571588, 1.0671404006768236182, 1.0787607977571197937,
+    1.0905077326652576592, 1.1023825833078409436, 1.1143867425958925363, 1.1265216186082418998,
+    1.1387886347566916537, 1.1511892299529827058, 1.1637248587775775138, 1.1763969916502812763,
+    1.1892071150027210667, 1.2021567314527031421, 1.2152473599804688781, 1.2284805361068700057,
+    1.2418578120734840486, 1.2553807570246910896, 1.2690509571917332226, 1.2828700160787782807,
+    1.2968395546510096659, 1.3109612115247643419, 1.3252366431597412946, 1.3396675240533030054,
+    1.3542555469368927283, 1.3690024229745906119, 1.3839098819638319549, 1.3989796725383111402,
+    1.4142135623730950488, 1.4296133383919700112, 1.44518080697704662, 1.4609177941806469887,
+    1.4768261459394993114, 1.4929077282912648492, 1.5091644275934227398, 1.5255981507445383069,
+    1.5422108254079408236, 1.559004400237836967, 1.5759808451078864865, 1.5931421513422668979,
+    1.6104903319492543082, 1.6280274218573477668, 1.6457554781539648445, 1.663676580326736435,
+    1.6817928305074290861, 1.7001063537185234695, 1.7186192981224779156, 1.737333835273706249,
+    1.7562521603732994831, 1.7753764925265212526, 1.7947090750031071864, 1.8142521755003987562,
+    1.8340080864093424635, 1.8539791250833855684, 1.8741676341102999013, 1.8945759815869656413,
+    1.9152065613971472939, 1.9360617934922944506, 1.957144124175400269, 1.9784560263879509683,
+};
+
+template <int NV>
+__device__ __forceinline__ void exp2_neg_vec(const double (&t_in)[NV], double (&out)[NV], const double* __restrict__ tab) {
     constexpr double c1 = 6.931471805599453094e-01, c2 = 2.402265069591007123e-01, c3 = 5.550410866482157995e-02,
-                     c4 = 9.618129107628477162e-03, c5 = 1.333355814642844342e-03, c6 = 1.540353039338160995e-04,
-                     c7 = 1.525273380405984028e-05, c8 = 1.321548679014430949e-06, c9 = 1.017808600923969973e-07,
-                     c10 = 7.054911620801123329e-09, c11 = 4.445538271870811498e-10, c12 = 2.567843599348820514e-11,
-                     c13 = 1.369148885390412888e-12;
-    t = __builtin_fmax(t, -1100.0);
-    const double kd = __builtin_rint(t);
-    const double r = t - kd;
-    double p = c13;
-    p = __builtin_fma(p, r, c12);
-    p = __builtin_fma(p, r, c11);
-    p = __builtin_fma(p, r, c10);
-    p = __builtin_fma(p, r, c9);
-    p = __builtin_fma(p, r, c8);
-    p = __builtin_fma(p, r, c7);
-    p = __builtin_fma(p, r, c6);
-    p = __builtin_fma(p, r, c5);
-    p = __builtin_fma(p, r, c4);
-    p = __builtin_fma(p, r, c3);
-    p = __builtin_fma(p, r, c2);
-    p = __builtin_fma(p, r, c1);
-    p = __builtin_fma(p, r, 1.0);
-    return __builtin_ldexp(p, (int)kd);
+                     c4 = 9.618129107628477162e-03, c5 = 1.333355814642844342e-03;
+    constexpr double MAGIC = 105553116266496.0;   // 1.5 * 2^46: ulp = 2^-6
+    double t[NV], a[NV], r[NV], p[NV], tv[NV];
+    int ki[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) t[v] = __builtin_fmax(t_in[v], -1020.0);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) a[v] = t[v] + MAGIC;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) ki[v] = __double2loint(a[v]);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) tv[v] = tab[ki[v] & 63];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) r[v] = t[v] - (a[v] - MAGIC);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(c5, r[v], c4);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(p[v], r[v], c3);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(p[v], r[v], c2);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(p[v], r[v], c1);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(p[v], r[v], 1.0);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        // scale the table value by 2^e through its exponent field (T[j] in [1,2), e >= -1020: always a normal number)
+        const int hi = __double2hiint(tv[v]) + (ki[v] >> 6) * 1048576;
+        out[v] = __hiloint2double(hi, __double2loint(tv[v])) * p[v];
+    }
 }
 
-// One base-kernel value k_d(a, b).
-__device__ __forceinline__ double base_k_rbf(double xa, double ca, double xb, double cb, double log2bv) {
-    const double u = xa - xb;
-    const double t = __builtin_fma(-u, u, log2bv);
-    const double E = exp2_neg_poly(t);
-    return __builtin_fma(-ca, cb, E);
-}
 
 template <int R>
 __device__ __forceinline__ void esp_update(double (&e)[R > 0 ? R : 1], double k) {
@@ -89,6 +113,7 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
     double* Ax = Bc + D * TJ;          // [D][RS]
     double* Ac = Ax + D * RS;          // [D][RS]
     double* Ay = Ac + D * RS;          // [RS]
+    double* Tab = Ay + RS;             // [64]  2^(j/64)
     const int tid = threadIdx.x;
     const int tx = tid & 63;
     const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -104,6 +129,7 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
         Bx[idx] = ok ? Bxs[(int64_t)d * b_ld + gj] : 0.0;
         Bc[idx] = ok ? Bcn[(int64_t)d * b_ld + gj] : 0.0;
     }
+    if (tid < 64) Tab[tid] = c_exp2_table[tid];
     double psi[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) psi[c] = 0.0;
@@ -146,12 +172,17 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
                 if (dd.type[d] == OAK_DIM_RBF) {
                     const double l2 = dd.log2bv[d];
 #pragma unroll
-                    for (int r = 0; r < RT; ++r)
+                    for (int r = 0; r < RT; ++r) {
+                        double t[CPT], E[CPT];
 #pragma unroll
                         for (int c = 0; c < CPT; ++c) {
-                            const double k = base_k_rbf(xa[r], ca[r], xb[c], cb[c], l2);
-                            esp_update<R>(e[r][c], k);
+                            const double u = xa[r] - xb[c];
+                            t[c] = __builtin_fma(-u, u, l2);
                         }
+                        exp2_neg_vec<CPT>(t, E, Tab);
+#pragma unroll
+                        for (int c = 0; c < CPT; ++c) esp_update<R>(e[r][c], __builtin_fma(-ca[r], cb[c], E[c]));
+                    }
                 } else {
                     const int C = dd.ncat[d];
                     const double* tab = tables + dd.tab_off[d];
@@ -254,7 +285,7 @@ static int launch_gram_t(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, 
     constexpr int TJ = 64 * CPT;
     constexpr int RS = 4 * RT;
     const int D = pk.dd.D;
-    size_t lds = sizeof(double) * ((size_t)D * TJ * 2 + (size_t)D * RS * 2 + RS);
+    size_t lds = sizeof(double) * ((size_t)D * TJ * 2 + (size_t)D * RS * 2 + RS + 64);
     const size_t lds_red = sizeof(double) * 4 * TJ;
     if (lds < lds_red) lds = lds_red;
     if (lds > 160 * 1024) { set_error("gram: LDS request %zu exceeds 160 KiB (D=%d)", lds, D); return OAK_E_ARG; }

@@ -97,7 +97,7 @@ struct oak_ctx {
     int64_t N = 0, M = 0;
     int32_t ldx = 0;
     int64_t panel_rows = 0;
-    bool have_data = false, have_Z = false, have_stats = false, have_post = false, stats_whitened = false;
+    bool have_data = false, have_Z = false, have_stats = false, have_post = false, stats_whitened = false, have_alpha = false;
     int route = 0;   // 0 auto, 1 phi, 2 whitened
     double noise_var = 0, jitter = 0;
     // GPR state
@@ -163,6 +163,8 @@ int axpy(oak_ctx* ctx, double a, const double* x, double* y, int64_t n);  // y +
 int scale_vec(oak_ctx* ctx, double a, double* x, int64_t n);
 int gemm_nn(oak_ctx* ctx, const double* dA, const double* dB, double* dC, int64_t m, int64_t n, int64_t k,
             int64_t lda, int64_t ldb, int64_t ldc, double alpha, double beta);   // C = alpha A B + beta C (row-major)
+int gemm_nt(oak_ctx* ctx, const double* dA, const double* dB, double* dC, int64_t m, int64_t n, int64_t k,
+            int64_t lda, int64_t ldb, int64_t ldc, double alpha, double beta, int lower_only);   // C = alpha A B^T + beta C
 
 // collectives --------------------------------------------------------------------------------------
 int comm_allreduce_dev(oak_ctx* ctx, double* d_buf, int64_t n);

@@ -158,14 +158,13 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     double* dZ = (double*)peek_buf(ctx, "Z");
     Feat FZ;
     OAK_CHECK(featurize(ctx, pk, dZ, M, ctx->ldx, "featZ", &FZ));
-    double *dL, *dT1, *dT2, *dLB, *dv1, *dc, *dalpha, *dscal;
+    double *dL, *dT1, *dT2, *dLB, *dv1, *dc, *dscal;
     OAK_CHECK(get_buf_t(ctx, "L", (size_t)M * M, &dL));
-    OAK_CHECK(get_buf_t(ctx, "T1", (size_t)M * M, &dT1));
+    OAK_CHECK(get_buf_t(ctx, "T1", (size_t)(M + 1) * M, &dT1));
     OAK_CHECK(get_buf_t(ctx, "T2", (size_t)M * M, &dT2));
     OAK_CHECK(get_buf_t(ctx, "LB", (size_t)M * M, &dLB));
     OAK_CHECK(get_buf_t(ctx, "v1", (size_t)M, &dv1));
     OAK_CHECK(get_buf_t(ctx, "c", (size_t)M, &dc));
-    OAK_CHECK(get_buf_t(ctx, "alpha", (size_t)M, &dalpha));
     OAK_CHECK(get_buf_t(ctx, "scal", 8, &dscal));
     // Kuu + jitter I -> L   (oak/utils.py:185,188)
     OAK_CHECK(gram(ctx, pk, FZ, 0, M, FZ, dL, M, nullptr, nullptr, 0));
@@ -174,9 +173,13 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     // W = L^-1 Phi L^-T  (= sigma^2 * A A^T, utils.py:189-190 without materialising A)
     if (ctx->stats_whitened) {
         OAK_CHECK(copy_d2d(ctx, dT2, st.phi, sizeof(double) * (size_t)M * M));   // statistics already hold W
+        OAK_CHECK(copy_d2d(ctx, dv1, st.psi, sizeof(double) * (size_t)M));
+        OAK_CHECK(trsm_rows(ctx, dL, M, M, dv1, 1, M, 0));
     } else {
-        OAK_CHECK(copy_d2d(ctx, dT1, st.phi, sizeof(double) * (size_t)M * M));
-        OAK_CHECK(trsm_rows(ctx, dL, M, M, dT1, M, M, 0));      // rows of T1 = L^-1 Phi[:, r]  -> T1 = (L^-1 Phi)^T
+        // rows 0..M-1 of T1 = Phi (symmetric), row M = psi: one blocked solve gives (L^-1 Phi)^T and L^-1 psi together
+        OAK_CHECK(copy_d2d(ctx, dT1, st.phi, sizeof(double) * (size_t)(M * M + M)));
+        OAK_CHECK(trsm_rows(ctx, dL, M, M, dT1, M + 1, M, 0));
+        OAK_CHECK(copy_d2d(ctx, dv1, dT1 + M * M, sizeof(double) * (size_t)M));
         OAK_CHECK(transpose(ctx, dT1, M, M, M, dT2, M));        // T2 = L^-1 Phi
         OAK_CHECK(trsm_rows(ctx, dL, M, M, dT2, M, M, 0));      // rows of T2 = L^-1 (L^-1 Phi)^T[:, r] -> T2 = W^T = W
     }
@@ -184,15 +187,9 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     OAK_CHECK(scale_add_eye(ctx, dT2, M, 1.0 / noise_var, dLB));
     OAK_CHECK(potrf_lower(ctx, dLB, M, M));
     // c = LB^-1 L^-1 psi / sigma^2   (utils.py:194-195: Aerr = L^-1 psi / sigma, c = LB^-1 Aerr / sigma)
-    OAK_CHECK(copy_d2d(ctx, dv1, st.psi, sizeof(double) * (size_t)M));
-    OAK_CHECK(trsm_rows(ctx, dL, M, M, dv1, 1, M, 0));
     OAK_CHECK(copy_d2d(ctx, dc, dv1, sizeof(double) * (size_t)M));
     OAK_CHECK(trsm_rows(ctx, dLB, M, M, dc, 1, M, 0));
     OAK_CHECK(scale_vec(ctx, 1.0 / noise_var, dc, M));
-    // alpha = L^-T LB^-T c   (utils.py:197-198)
-    OAK_CHECK(copy_d2d(ctx, dalpha, dc, sizeof(double) * (size_t)M));
-    OAK_CHECK(trsm_rows(ctx, dLB, M, M, dalpha, 1, M, 1));
-    OAK_CHECK(trsm_rows(ctx, dL, M, M, dalpha, 1, M, 1));
     // scalars
     OAK_CHECK(reduce_sum(ctx, dLB, M, dscal + 0, 2, M + 1));    // sum log diag LB
     OAK_CHECK(reduce_sum(ctx, dc, M, dscal + 1, 1, 1));         // c^T c
@@ -219,6 +216,20 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     }
     ctx->noise_var = noise_var; ctx->jitter = jitter;
     ctx->have_post = true;
+    ctx->have_alpha = false;
+    return OAK_OK;
+}
+
+// alpha = L^-T LB^-T c (oak/utils.py:197-198); computed on first request, not on every objective evaluation
+int sgpr_ensure_alpha(oak_ctx* ctx) {
+    if (ctx->have_alpha) return OAK_OK;
+    const int64_t M = ctx->M;
+    double* dalpha = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "alpha", (size_t)M, &dalpha));
+    OAK_CHECK(copy_d2d(ctx, dalpha, peek_buf(ctx, "c"), sizeof(double) * (size_t)M));
+    OAK_CHECK(trsm_rows(ctx, (double*)peek_buf(ctx, "LB"), M, M, dalpha, 1, M, 1));
+    OAK_CHECK(trsm_rows(ctx, (double*)peek_buf(ctx, "L"), M, M, dalpha, 1, M, 1));
+    ctx->have_alpha = true;
     return OAK_OK;
 }
 
@@ -367,6 +378,7 @@ int oak_sgpr_alpha(oak_ctx* ctx, double* alpha_out) {
     OAK_CHECK(guard(ctx));
     OAK_REQUIRE(alpha_out, "alpha_out is NULL");
     if (!ctx->have_post) { set_error("SGPR posterior not available: call oak_sgpr_elbo/oak_sgpr_tail first"); return OAK_E_STATE; }
+    OAK_CHECK(sgpr_ensure_alpha(ctx));
     OAK_HIP_CHECK(hipMemcpyAsync(alpha_out, peek_buf(ctx, "alpha"), sizeof(double) * (size_t)ctx->M, hipMemcpyDeviceToHost, ctx->stream));
     OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return OAK_OK;

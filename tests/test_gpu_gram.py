@@ -162,3 +162,26 @@ def test_bad_arguments_raise(hip):
     bad = dict(spec, dims=[dict(spec["dims"][0], lengthscale=-1.0)] + spec["dims"][1:])
     with pytest.raises(ValueError):
         hip.gram(_capi.KernelDesc(bad), np.zeros((4, 3)))
+
+
+def test_exp2_accuracy(hip):
+    """The hand-written table+polynomial exp2 inside the Gram kernel against 50-digit arithmetic: an unconstrained 1-D RBF
+    is exactly exp(-(x-z)^2 / (2 l^2)).  Forming the exponent t = -(x s)^2 in fp64 carries ~3 eps relative error, which
+    any exp amplifies to ~2|t| ulp; the bound below is 4 ulp for the exp2 itself plus that conditioning term."""
+    import mpmath as mp
+    mp.mp.dps = 50
+    rng = np.random.default_rng(9)
+    spec = dict(dims=[dict(type="rbf", lengthscale=1.0, variance=1.0, measure=None)], order_variances=[0.0, 1.0],
+                max_interaction_depth=1, share_var_across_orders=True)
+    x = np.concatenate([rng.uniform(-6, 6, 300), 10.0 ** rng.uniform(-6, 1.5, 200), [0.0, 1e-300, 38.0]]).reshape(-1, 1)
+    z = np.zeros((1, 1))
+    K = hip.gram(_capi.KernelDesc(spec), x, z)[:, 0]
+    truth = np.array([float(mp.exp(-mp.mpf(float(v)) ** 2 / 2)) for v in x[:, 0]])
+    ok = truth > 1e-290
+    ulp = np.abs(K[ok] - truth[ok]) / (np.spacing(truth[ok]))
+    bound = 4.0 + 3.0 * np.abs(np.log2(truth[ok]))
+    assert np.all(ulp <= bound), (ulp / bound).max()
+    near = truth[ok] > 0.01                       # |t| < 7: the exp2 error dominates
+    assert ulp[near].max() <= 24.0, ulp[near].max()
+    assert K[-3] == 1.0 and K[-2] == 1.0
+    assert np.all(K[~ok] < 1e-289)

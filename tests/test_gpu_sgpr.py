@@ -86,7 +86,7 @@ def test_panel_chunking_and_determinism(hip):
     assert hip.sgpr_elbo(d, 0.01) == e_full
     for rows in (16, 1000, 4096):
         hip.sgpr_set_panel_rows(rows)
-        assert rel(hip.sgpr_elbo(d, 0.01), e_full) <= 1e-12
+        assert rel(hip.sgpr_elbo(d, 0.01), e_full) <= 1e-10   # summation order changes; the phi route amplifies it by cond(Kuu)
     hip.sgpr_set_panel_rows(0)
 
 
