@@ -1,0 +1,630 @@
+// Analytic gradient of the SGPR bound / GPR log-marginal w.r.t. the (constrained) kernel and noise parameters.
+// The reference obtains these from TensorFlow reverse-mode autodiff through SGPR.elbo (oak/model_utils.py:168-173);
+// here they are closed-form adjoints:
+//   F(Kuu, Phi, psi, kappa, s2) -> G_uu = dF/dKuu, H/(2 s2) = dF/dPhi, a/s2 = dF/dpsi, -1/(2 s2) = dF/dkappa, dF/ds2,
+//   Gfu = dF/dKfu = Kfu H / s2 + y a^T / s2                                  (one N x M x M GEMM, fp64 MFMA)
+//   dF/dtheta = <Gfu, dKfu/dtheta> + <G_uu, dKuu/dtheta> - 1/(2 s2) sum_n dKdiag_n/dtheta   (fused pair kernels below)
+// The pair kernel recomputes each base-kernel value and contracts G with dK/dk_d * dk_d/dtheta, where
+// dK/dk_d = sum_r w_r e_{r-1}^{(-d)} uses leave-one-out elementary symmetric polynomials (e^{(-d)}_q = e_q - k_d e^{(-d)}_{q-1}).
+#include "oak_internal.h"
+#include <cmath>
+
+namespace oak {
+
+__constant__ double c_exp2_table_g[64] = {
+    1.0, 1.0108892860517004600, 1.0218971486541166782, 1.0330248790212284225,
+    1.0442737824274138403, 1.0556451783605571588, 1.0671404006768236182, 1.0787607977571197937,
+    1.0905077326652576592, 1.1023825833078409436, 1.1143867425958925363, 1.1265216186082418997,
+    1.1387886347566916537, 1.1511892299529827082, 1.1637248587775775138, 1.1763969916502812763,
+    1.1892071150027210667, 1.2021567314527031420, 1.2152473599804688781, 1.2284805361068700056,
+    1.2418578120734840486, 1.2553807570246910895, 1.2690509571917332225, 1.2828700160787782807,
+    1.2968395546510096659, 1.3109612115247643419, 1.3252366431597412946, 1.3396675240533030053,
+    1.3542555469368927283, 1.3690024229745906119, 1.3839098819638319549, 1.3989796725383111402,
+    1.4142135623730950488, 1.4296133383919700113, 1.4451808069770466200, 1.4609177941806469887,
+    1.4768261459394993114, 1.4929077282912648492, 1.5091644275934227398, 1.5255981507445383069,
+    1.5422108254079408236, 1.5590044002378369670, 1.5759808451078864865, 1.5931421513422668980,
+    1.6104903319492543082, 1.6280274218573478129, 1.6457554781539648445, 1.6636765803267364350,
+    1.6817928305074290861, 1.7001063537185234695, 1.7186192981224779156, 1.7373338352737062489,
+    1.7562521603732994832, 1.7753764925265212526, 1.7947090750031071864, 1.8142521755003987562,
+    1.8340080864093424635, 1.8539791250833855684, 1.8741676341102999014, 1.8945759815869656413,
+    1.9152065613971472939, 1.9360617934922944505, 1.9571441241754002690, 1.9784560263879509682
+};
+
+// scalar variant of the Gram kernel's exp2 (same table + degree-5 polynomial)
+__device__ __forceinline__ double exp2_neg_tab(double t, const double* __restrict__ tab) {
+    constexpr double c1 = 6.931471805599453094e-01, c2 = 2.402265069591007123e-01, c3 = 5.550410866482157995e-02,
+                     c4 = 9.618129107628477162e-03, c5 = 1.333355814642844342e-03;
+    constexpr double MAGIC = 105553116266496.0;
+    t = __builtin_fmax(t, -1020.0);
+    const double a = t + MAGIC;
+    const int ki = __double2loint(a);
+    const double tv = tab[ki & 63];
+    const double r = t - (a - MAGIC);
+    double p = __builtin_fma(c5, r, c4);
+    p = __builtin_fma(p, r, c3);
+    p = __builtin_fma(p, r, c2);
+    p = __builtin_fma(p, r, c1);
+    p = __builtin_fma(p, r, 1.0);
+    const int hi = __double2hiint(tv) + (ki >> 6) * 1048576;
+    return __hiloint2double(hi, __double2loint(tv)) * p;
+}
+
+struct GradDesc {   // per-dim constants of the derivative formulas
+    double dE_scale[OAK_MAX_DIMS];   // 2 ln2 / lengthscale : dE/dl = E * (xs_a - xs_b)^2 * dE_scale
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// layout of one partial / output record: [gl (D) | gk (D) | gw (R+1) | gtab (tablen)]
+//   gl[d] = sum G dK/dk_d dk_d/dl_d ;  gk[d] = sum G dK/dk_d k_d  (-> d/d base_var_d after division by base_var_d)
+//   gw[r] = sum G e_r ; gtab[off + ia*C + ib] = sum G dK/dk_d  over pairs with categories (ia, ib)  (x base_var later)
+template <int R, int CPT>
+__global__ void __launch_bounds__(256)
+gram_bwd_kernel(const DevDesc dd, const GradDesc gd, const double* __restrict__ tables, int tablen,
+                const double* __restrict__ Axs, const double* __restrict__ Acn, const double* __restrict__ Adcn, int64_t a_ld,
+                int64_t a0, int64_t na, const double* __restrict__ Bxs, const double* __restrict__ Bcn,
+                const double* __restrict__ Bdcn, int64_t b_ld, int64_t nb, const double* __restrict__ G, int64_t ldg,
+                const double* __restrict__ yA, const double* __restrict__ avec, double g_scale, int rows_per_wg,
+                double* __restrict__ partial) {
+    constexpr int TJ = 64 * CPT;
+    constexpr int RT = 2, RS = 4 * RT;
+    constexpr int RR = R > 0 ? R : 1;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int D = dd.D;
+    double* Bx = smem;                  // [D][TJ]
+    double* Bc = Bx + D * TJ;
+    double* Bd = Bc + D * TJ;
+    double* Ax = Bd + D * TJ;           // [D][RS]
+    double* Ac = Ax + D * RS;
+    double* Ad = Ac + D * RS;
+    double* Ay = Ad + D * RS;           // [RS]
+    double* Av = Ay + RS;               // [TJ]  a_m / s2 slice (rank-1 term)
+    double* Tab = Av + TJ;              // [64]
+    double* accL = Tab + 64;            // [4][D]
+    double* accK = accL + 4 * D;        // [4][D]
+    double* accT = accK + 4 * D;        // [tablen]
+    const int tid = threadIdx.x, tx = tid & 63;
+    const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t jb = (int64_t)blockIdx.x * TJ;
+    const int64_t ib = (int64_t)blockIdx.y * rows_per_wg;
+    const int64_t iend = (ib + rows_per_wg < na) ? ib + rows_per_wg : na;
+    for (int idx = tid; idx < D * TJ; idx += 256) {
+        const int d = idx / TJ, j = idx - d * TJ;
+        const int64_t gj = jb + j;
+        const bool ok = gj < nb;
+        Bx[idx] = ok ? Bxs[(int64_t)d * b_ld + gj] : 0.0;
+        Bc[idx] = ok ? Bcn[(int64_t)d * b_ld + gj] : 0.0;
+        Bd[idx] = ok ? Bdcn[(int64_t)d * b_ld + gj] : 0.0;
+    }
+    for (int j = tid; j < TJ; j += 256) Av[j] = (avec != nullptr && jb + j < nb) ? avec[jb + j] : 0.0;
+    if (tid < 64) Tab[tid] = c_exp2_table_g[tid];
+    for (int idx = tid; idx < 8 * D; idx += 256) accL[idx] = 0.0;     // accL and accK are contiguous
+    for (int idx = tid; idx < tablen; idx += 256) accT[idx] = 0.0;
+    double gw[R + 1];
+#pragma unroll
+    for (int q = 0; q <= R; ++q) gw[q] = 0.0;
+    const int lane0 = (tx == 0);
+
+    for (int64_t i0 = ib; i0 < iend; i0 += RS) {
+        __syncthreads();
+        for (int idx = tid; idx < D * RS; idx += 256) {
+            const int d = idx / RS, r = idx - d * RS;
+            const int64_t gi = i0 + r;
+            const bool ok = gi < iend;
+            Ax[idx] = ok ? Axs[(int64_t)d * a_ld + a0 + gi] : 0.0;
+            Ac[idx] = ok ? Acn[(int64_t)d * a_ld + a0 + gi] : 0.0;
+            Ad[idx] = ok ? Adcn[(int64_t)d * a_ld + a0 + gi] : 0.0;
+        }
+        if (tid < RS) Ay[tid] = (yA != nullptr && i0 + tid < iend) ? yA[a0 + i0 + tid] : 0.0;
+        __syncthreads();
+        // adjoint of K for this lane's RT x CPT pairs
+        double g[RT][CPT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                const int64_t gi = i0 + ty * RT + r, gj = jb + CPT * tx + c;
+                double v = 0.0;
+                if (gi < iend && gj < nb) v = g_scale * G[gi * ldg + gj] + Ay[ty * RT + r] * Av[CPT * tx + c];
+                g[r][c] = v;
+            }
+        // pass 1: elementary symmetric polynomials
+        double e[RT][CPT][RR];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+#pragma unroll
+                for (int q = 0; q < RR; ++q) e[r][c][q] = 0.0;
+        if constexpr (R > 0) {
+            for (int d = 0; d < D; ++d) {
+                const bool rbf = dd.type[d] == OAK_DIM_RBF;
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int c = 0; c < CPT; ++c) {
+                        const double xa = Ax[d * RS + ty * RT + r], xb = Bx[d * TJ + CPT * tx + c];
+                        double k;
+                        if (rbf) {
+                            const double u = xa - xb;
+                            const double E = exp2_neg_tab(__builtin_fma(-u, u, dd.log2bv[d]), Tab);
+                            k = __builtin_fma(-Ac[d * RS + ty * RT + r], Bc[d * TJ + CPT * tx + c], E);
+                        } else {
+                            k = tables[dd.tab_off[d] + (int)xa * dd.ncat[d] + (int)xb];
+                        }
+#pragma unroll
+                        for (int q = R - 1; q >= 1; --q) e[r][c][q] = __builtin_fma(k, e[r][c][q - 1], e[r][c][q]);
+                        e[r][c][0] += k;
+                    }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                gw[0] += g[r][c];
+#pragma unroll
+                for (int q = 1; q <= R; ++q) gw[q] = __builtin_fma(g[r][c], e[r][c][q - 1], gw[q]);
+            }
+        // pass 2: leave-one-out coefficients and parameter contractions
+        if constexpr (R > 0) {
+            for (int d = 0; d < D; ++d) {
+                const bool rbf = dd.type[d] == OAK_DIM_RBF;
+                double cl = 0.0, ck = 0.0;
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int c = 0; c < CPT; ++c) {
+                        const double xa = Ax[d * RS + ty * RT + r], xb = Bx[d * TJ + CPT * tx + c];
+                        double k, dkl = 0.0;
+                        int tidx = 0;
+                        if (rbf) {
+                            const double u = xa - xb;
+                            const double u2 = u * u;
+                            const double E = exp2_neg_tab(dd.log2bv[d] - u2, Tab);
+                            const double ca = Ac[d * RS + ty * RT + r], cb = Bc[d * TJ + CPT * tx + c];
+                            k = __builtin_fma(-ca, cb, E);
+                            dkl = E * u2 * gd.dE_scale[d] - (Ad[d * RS + ty * RT + r] * cb + ca * Bd[d * TJ + CPT * tx + c]);
+                        } else {
+                            tidx = dd.tab_off[d] + (int)xa * dd.ncat[d] + (int)xb;
+                            k = tables[tidx];
+                        }
+                        double f = 1.0, coef = dd.w[1];
+#pragma unroll
+                        for (int q = 1; q < R; ++q) {
+                            f = __builtin_fma(-k, f, e[r][c][q - 1]);
+                            coef = __builtin_fma(dd.w[q + 1], f, coef);
+                        }
+                        const double gc = g[r][c] * coef;
+                        cl = __builtin_fma(gc, dkl, cl);
+                        ck = __builtin_fma(gc, k, ck);
+                        if (!rbf && dd.type[d] == OAK_DIM_CATEGORICAL && gc != 0.0) atomicAdd(&accT[tidx], gc);
+                    }
+                cl = wave_sum(cl);
+                ck = wave_sum(ck);
+                if (lane0) { accL[ty * D + d] += cl; accK[ty * D + d] += ck; }
+            }
+        }
+    }
+    // workgroup record
+#pragma unroll
+    for (int q = 0; q <= R; ++q) gw[q] = wave_sum(gw[q]);
+    __syncthreads();
+    double* red = Ax;   // reuse [4][R+1]
+    if (lane0) {
+#pragma unroll
+        for (int q = 0; q <= R; ++q) red[ty * (R + 1) + q] = gw[q];
+    }
+    __syncthreads();
+    const int64_t reclen = 2 * D + (R + 1) + tablen;
+    double* rec = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * reclen;
+    for (int idx = tid; idx < D; idx += 256) {
+        rec[idx] = ((accL[idx] + accL[D + idx]) + accL[2 * D + idx]) + accL[3 * D + idx];
+        rec[D + idx] = ((accK[idx] + accK[D + idx]) + accK[2 * D + idx]) + accK[3 * D + idx];
+    }
+    if (tid <= R) rec[2 * D + tid] = ((red[tid] + red[(R + 1) + tid]) + red[2 * (R + 1) + tid]) + red[3 * (R + 1) + tid];
+    for (int idx = tid; idx < tablen; idx += 256) rec[2 * D + (R + 1) + idx] = accT[idx];
+}
+
+// Diagonal term: sum_n gconst * dKdiag_n / dtheta, one point per lane.
+template <int R>
+__global__ void __launch_bounds__(256)
+diag_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen, const double* __restrict__ Axs,
+                const double* __restrict__ Acn, const double* __restrict__ Adcn, int64_t a_ld, int64_t n, double gconst,
+                int64_t rows_per_wg, double* __restrict__ partial) {
+    constexpr int RR = R > 0 ? R : 1;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int D = dd.D;
+    double* accL = smem;             // [4][D]
+    double* accK = accL + 4 * D;     // [4][D]
+    double* accT = accK + 4 * D;     // [tablen]
+    double* red = accT + tablen;     // [4][R+1]
+    const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
+    for (int idx = tid; idx < 8 * D + tablen; idx += 256) smem[idx] = 0.0;
+    __syncthreads();
+    double gw[R + 1];
+#pragma unroll
+    for (int q = 0; q <= R; ++q) gw[q] = 0.0;
+    const int64_t i_begin = (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t i_end = (i_begin + rows_per_wg < n) ? i_begin + rows_per_wg : n;
+    for (int64_t i0 = i_begin; i0 < i_end; i0 += 256) {
+        const int64_t i = i0 + tid;
+        const bool ok = i < i_end;
+        const double g = ok ? gconst : 0.0;
+        const int64_t ic = ok ? i : i_begin;
+        double e[RR];
+#pragma unroll
+        for (int q = 0; q < RR; ++q) e[q] = 0.0;
+        if constexpr (R > 0) {
+            for (int d = 0; d < D; ++d) {
+                double k;
+                if (dd.type[d] == OAK_DIM_RBF) { const double c = Acn[(int64_t)d * a_ld + ic]; k = __builtin_fma(-c, c, dd.bv[d]); }
+                else k = tables[dd.tab_off[d] + dd.ncat[d] * dd.ncat[d] + (int)Axs[(int64_t)d * a_ld + ic]];
+#pragma unroll
+                for (int q = R - 1; q >= 1; --q) e[q] = __builtin_fma(k, e[q - 1], e[q]);
+                e[0] += k;
+            }
+        }
+        gw[0] += g;
+#pragma unroll
+        for (int q = 1; q <= R; ++q) gw[q] = __builtin_fma(g, e[q - 1], gw[q]);
+        if constexpr (R > 0) {
+            for (int d = 0; d < D; ++d) {
+                double k, dkl = 0.0;
+                int tidx = 0;
+                const bool rbf = dd.type[d] == OAK_DIM_RBF;
+                if (rbf) {
+                    const double c = Acn[(int64_t)d * a_ld + ic];
+                    k = __builtin_fma(-c, c, dd.bv[d]);
+                    dkl = -2.0 * c * Adcn[(int64_t)d * a_ld + ic];
+                } else {
+                    const int C = dd.ncat[d];
+                    const int xi = (int)Axs[(int64_t)d * a_ld + ic];
+                    k = tables[dd.tab_off[d] + C * C + xi];
+                    tidx = dd.tab_off[d] + xi * C + xi;
+                }
+                double f = 1.0, coef = dd.w[1];
+#pragma unroll
+                for (int q = 1; q < R; ++q) { f = __builtin_fma(-k, f, e[q - 1]); coef = __builtin_fma(dd.w[q + 1], f, coef); }
+                const double gc = g * coef;
+                double cl = wave_sum(gc * dkl), ck = wave_sum(gc * k);
+                if (!rbf && dd.type[d] == OAK_DIM_CATEGORICAL && gc != 0.0) atomicAdd(&accT[tidx], gc);
+                if (tx == 0) { accL[ty * D + d] += cl; accK[ty * D + d] += ck; }
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q <= R; ++q) gw[q] = wave_sum(gw[q]);
+    if (tx == 0) {
+#pragma unroll
+        for (int q = 0; q <= R; ++q) red[ty * (R + 1) + q] = gw[q];
+    }
+    __syncthreads();
+    const int64_t reclen = 2 * D + (R + 1) + tablen;
+    double* rec = partial + (int64_t)blockIdx.x * reclen;
+    for (int idx = tid; idx < D; idx += 256) {
+        rec[idx] = ((accL[idx] + accL[D + idx]) + accL[2 * D + idx]) + accL[3 * D + idx];
+        rec[D + idx] = ((accK[idx] + accK[D + idx]) + accK[2 * D + idx]) + accK[3 * D + idx];
+    }
+    if (tid <= R) rec[2 * D + tid] = ((red[tid] + red[(R + 1) + tid]) + red[2 * (R + 1) + tid]) + red[3 * (R + 1) + tid];
+    for (int idx = tid; idx < tablen; idx += 256) rec[2 * D + (R + 1) + idx] = accT[idx];
+}
+
+// out[j] += sum_w partial[w][j]   (fixed order)
+__global__ void __launch_bounds__(256) reduce_records_kernel(const double* __restrict__ partial, int64_t nrec, int64_t reclen,
+                                                             double* __restrict__ out) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= reclen) return;
+    double s = 0.0;
+    for (int64_t w = 0; w < nrec; ++w) s += partial[w * reclen + j];
+    out[j] += s;
+}
+
+static GradDesc make_grad_desc(const PreparedKernel& pk) {
+    GradDesc gd;
+    for (int d = 0; d < OAK_MAX_DIMS; ++d) gd.dE_scale[d] = 0.0;
+    for (int d = 0; d < pk.dd.D; ++d)
+        if (pk.dd.type[d] == OAK_DIM_RBF) gd.dE_scale[d] = 2.0 * 0.6931471805599453094 / pk.dm.ls[d];
+    return gd;
+}
+
+static int64_t record_len(const PreparedKernel& pk) { return 2 * pk.dd.D + (pk.dd.R + 1) + (int64_t)pk.tables.size(); }
+
+// d_rec[reclen] += contraction of G (na x nb block, + optional rank-1 yA avec^T) with dK/dtheta over pairs (A rows a0.., B)
+int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int64_t na, const Feat& B, const double* d_G,
+             int64_t ldg, double g_scale, const double* d_yA, const double* d_avec, double* d_rec) {
+    if (na <= 0 || B.n <= 0) return OAK_OK;
+    OAK_REQUIRE(A.dcn != nullptr && B.dcn != nullptr, "gram_bwd: features were not prepared for the backward pass");
+    const int D = pk.dd.D, R = pk.dd.R;
+    const int tablen = (int)pk.tables.size();
+    OAK_REQUIRE(tablen <= 4096, "gradient: discrete tables too large (%d doubles)", tablen);
+    const int cpt = (D <= 40) ? 2 : 1;
+    const int TJ = 64 * cpt, RS = 8;
+    const size_t lds = sizeof(double) * ((size_t)3 * D * TJ + (size_t)3 * D * RS + RS + TJ + 64 + 8 * D + tablen + 64);
+    OAK_REQUIRE(lds <= 160 * 1024, "gram_bwd: LDS request %zu exceeds 160 KiB", lds);
+    const int64_t nb = B.n;
+    const int64_t ncb = (nb + TJ - 1) / TJ;
+    int64_t nrb = ((int64_t)ctx->num_cu * 8 + ncb - 1) / ncb;
+    int64_t rows = (na + nrb - 1) / nrb;
+    rows = ((rows + RS - 1) / RS) * RS;
+    if (rows < RS) rows = RS;
+    if (rows > 4096) rows = 4096;
+    nrb = (na + rows - 1) / rows;
+    if (nrb > 65535) { rows = (((na + 65534) / 65535 + RS - 1) / RS) * RS; nrb = (na + rows - 1) / rows; }
+    const int64_t reclen = record_len(pk);
+    double* d_part = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "bwd_part", (size_t)(nrb * ncb * reclen), &d_part));
+    const GradDesc gd = make_grad_desc(pk);
+    dim3 grid((unsigned)ncb, (unsigned)nrb);
+#define OAK_BWD_LAUNCH(RR, CP)                                                                                                   \
+    {                                                                                                                            \
+        auto kern = gram_bwd_kernel<RR, CP>;                                                                                     \
+        if (lds > 64 * 1024) OAK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        kern<<<grid, 256, lds, ctx->stream>>>(pk.dd, gd, pk.d_tables, tablen, A.xs, A.cn, A.dcn, A.ld, a0, na, B.xs, B.cn, B.dcn,  \
+                                              B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part);                     \
+    }
+#define OAK_BWD_CASE(RR) case RR: if (cpt == 2) OAK_BWD_LAUNCH(RR, 2) else OAK_BWD_LAUNCH(RR, 1) break;
+    switch (R) {
+        OAK_BWD_CASE(0) OAK_BWD_CASE(1) OAK_BWD_CASE(2) OAK_BWD_CASE(3) OAK_BWD_CASE(4)
+        OAK_BWD_CASE(5) OAK_BWD_CASE(6) OAK_BWD_CASE(7) OAK_BWD_CASE(8)
+        default: set_error("gram_bwd: unsupported depth %d", R); return OAK_E_ARG;
+    }
+#undef OAK_BWD_CASE
+#undef OAK_BWD_LAUNCH
+    OAK_HIP_CHECK(hipGetLastError());
+    reduce_records_kernel<<<(unsigned)((reclen + 255) / 256), 256, 0, ctx->stream>>>(d_part, nrb * ncb, reclen, d_rec);
+    OAK_HIP_CHECK(hipGetLastError());
+    return OAK_OK;
+}
+
+int diag_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, double gconst, double* d_rec) {
+    if (A.n <= 0) return OAK_OK;
+    const int D = pk.dd.D, R = pk.dd.R;
+    const int tablen = (int)pk.tables.size();
+    const int64_t reclen = record_len(pk);
+    int64_t nwg = (A.n + 4095) / 4096;
+    if (nwg > 2048) nwg = 2048;
+    int64_t rows = (A.n + nwg - 1) / nwg;
+    rows = ((rows + 255) / 256) * 256;
+    nwg = (A.n + rows - 1) / rows;
+    double* d_part = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "bwd_part_diag", (size_t)(nwg * reclen), &d_part));
+    const size_t lds = sizeof(double) * ((size_t)8 * D + tablen + 4 * (R + 1) + 8);
+#define OAK_DB_CASE(RR) case RR: diag_bwd_kernel<RR><<<(unsigned)nwg, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen, A.xs, A.cn, A.dcn, A.ld, A.n, gconst, rows, d_part); break;
+    switch (R) {
+        OAK_DB_CASE(0) OAK_DB_CASE(1) OAK_DB_CASE(2) OAK_DB_CASE(3) OAK_DB_CASE(4)
+        OAK_DB_CASE(5) OAK_DB_CASE(6) OAK_DB_CASE(7) OAK_DB_CASE(8)
+        default: set_error("diag_bwd: unsupported depth %d", R); return OAK_E_ARG;
+    }
+#undef OAK_DB_CASE
+    OAK_HIP_CHECK(hipGetLastError());
+    reduce_records_kernel<<<(unsigned)((reclen + 255) / 256), 256, 0, ctx->stream>>>(d_part, nwg, reclen, d_rec);
+    OAK_HIP_CHECK(hipGetLastError());
+    return OAK_OK;
+}
+
+// ---- small M x M helpers ---------------------------------------------------------------------------------
+__global__ void set_identity_kernel(double* __restrict__ A, int64_t n) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (j < n) A[i * n + j] = (i == j) ? 1.0 : 0.0;
+}
+// H = Kinv - Sinv - a a^T ;  Guu = 0.5 H - 0.5 KWK / s2
+__global__ void combine_h_kernel(const double* __restrict__ Kinv, const double* __restrict__ Sinv, const double* __restrict__ a,
+                                 const double* __restrict__ KWK, double s2, int64_t n, double* __restrict__ H, double* __restrict__ Guu) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (j >= n) return;
+    const double h = Kinv[i * n + j] - Sinv[i * n + j] - a[i] * a[j];
+    H[i * n + j] = h;
+    Guu[i * n + j] = 0.5 * h - 0.5 * KWK[i * n + j] / s2;
+}
+// GPR: G = 0.5 (alpha alpha^T - Kinv)
+__global__ void combine_gpr_kernel(const double* __restrict__ Kinv, const double* __restrict__ a, int64_t n, double* __restrict__ G) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (j < n) G[i * n + j] = 0.5 * (a[i] * a[j] - Kinv[i * n + j]);
+}
+
+int set_identity(oak_ctx* ctx, double* dA, int64_t n) {
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
+    set_identity_kernel<<<grid, 256, 0, ctx->stream>>>(dA, n);
+    OAK_HIP_CHECK(hipGetLastError());
+    return OAK_OK;
+}
+
+// scatter a device record [gl | gk | gw | gtab] into the public gradient layout
+// [lengthscale (D) | base_var (D) | order_var (n_order_var) | noise | dTable (meas_data_len)]
+static void scatter_record(const oak_kernel_desc* desc, const PreparedKernel& pk, const std::vector<double>& rec, double dnoise,
+                           double* grad_out) {
+    const int D = desc->num_dims, R = desc->max_depth;
+    const int64_t glen = 2 * D + desc->n_order_var + 1 + desc->meas_data_len;
+    for (int64_t i = 0; i < glen; ++i) grad_out[i] = 0.0;
+    for (int d = 0; d < D; ++d) {
+        if (desc->dim_type[d] == OAK_DIM_RBF) grad_out[d] = rec[d];
+        grad_out[D + d] = rec[D + d] / desc->base_var[d];        // k_d is linear in its base variance
+    }
+    if (desc->share_var) for (int r = 0; r <= R; ++r) grad_out[2 * D + r] = rec[2 * D + r];
+    else grad_out[2 * D] = rec[2 * D];
+    grad_out[2 * D + desc->n_order_var] = dnoise;
+    double* gt = grad_out + 2 * D + desc->n_order_var + 1;
+    for (int d = 0; d < D; ++d) {
+        if (desc->dim_type[d] != OAK_DIM_CATEGORICAL) continue;
+        const int C = desc->meas_k[d];
+        const int toff = pk.dd.tab_off[d];
+        for (int i = 0; i < C * C; ++i) gt[desc->meas_off[d] + i] = rec[2 * D + (R + 1) + toff + i] * desc->base_var[d];
+    }
+}
+
+}  // namespace oak
+
+using namespace oak;
+
+extern "C" {
+
+int64_t oak_grad_len(const oak_kernel_desc* desc) {
+    return desc ? 2 * (int64_t)desc->num_dims + desc->n_order_var + 1 + desc->meas_data_len : 0;
+}
+
+int oak_sgpr_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, double jitter, double* elbo_out, double* grad_out) {
+    if (!ctx) { set_error("ctx is NULL"); return OAK_E_ARG; }
+    OAK_HIP_CHECK(hipSetDevice(ctx->device));
+    OAK_REQUIRE(grad_out != nullptr, "grad_out is NULL");
+    OAK_REQUIRE(ctx->have_data && ctx->have_Z, "SGPR: set_data and set_inducing must be called first");
+    PreparedKernel pk;
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    PhaseTimer ttot(ctx, "total");
+    // ---- forward ------------------------------------------------------------------------------------------
+    OAK_CHECK(sgpr_local_stats(ctx, pk, jitter));
+    if (ctx->comm != nullptr) OAK_CHECK(oak_comm_allreduce_stats(ctx));
+    double elbo = 0.0, terms[8];
+    OAK_CHECK(sgpr_tail(ctx, pk, noise_var, jitter, &elbo, terms));
+    OAK_CHECK(sgpr_ensure_alpha(ctx));
+    const int64_t N = ctx->N, M = ctx->M, Mp = ((M + 127) / 128) * 128;
+    const double s2 = noise_var;
+    double* dL = (double*)peek_buf(ctx, "L");
+    double* dLB = (double*)peek_buf(ctx, "LB");
+    double* dW = (double*)peek_buf(ctx, "T2");
+    double* da = (double*)peek_buf(ctx, "alpha");
+    double* dY = (double*)peek_buf(ctx, "Y");
+    // ---- M x M adjoints -----------------------------------------------------------------------------------
+    double *dLinvT, *dPT, *dKinv, *dSinv, *dTmp, *dKWK, *dH, *dGuu, *dKuu, *dsc, *dvec;
+    {
+        PhaseTimer t(ctx, "bwd_tail");
+        OAK_CHECK(get_buf_t(ctx, "g_LinvT", (size_t)M * M, &dLinvT));
+        OAK_CHECK(get_buf_t(ctx, "g_PT", (size_t)M * M, &dPT));
+        OAK_CHECK(get_buf_t(ctx, "g_Kinv", (size_t)M * M, &dKinv));
+        OAK_CHECK(get_buf_t(ctx, "g_Sinv", (size_t)M * M, &dSinv));
+        OAK_CHECK(get_buf_t(ctx, "g_Tmp", (size_t)M * M, &dTmp));
+        OAK_CHECK(get_buf_t(ctx, "g_KWK", (size_t)M * M, &dKWK));
+        OAK_CHECK(get_buf_t(ctx, "g_H", (size_t)M * M, &dH));
+        OAK_CHECK(get_buf_t(ctx, "g_Guu", (size_t)M * M, &dGuu));
+        OAK_CHECK(get_buf_t(ctx, "g_Kuu", (size_t)M * M, &dKuu));
+        OAK_CHECK(get_buf_t(ctx, "g_sc", 8, &dsc));
+        OAK_CHECK(get_buf_t(ctx, "g_vec", (size_t)M, &dvec));
+        OAK_CHECK(set_identity(ctx, dLinvT, M));
+        OAK_CHECK(trsm_rows(ctx, dL, M, M, dLinvT, M, M, 0));                       // rows = columns of L^-1
+        OAK_CHECK(copy_d2d(ctx, dPT, dLinvT, sizeof(double) * (size_t)M * M));
+        OAK_CHECK(trsm_rows(ctx, dLB, M, M, dPT, M, M, 0));                         // rows = columns of LB^-1 L^-1
+        OAK_CHECK(gemm_nt(ctx, dLinvT, dLinvT, dKinv, M, M, M, M, M, M, 1.0, 0.0, 0));     // Kuu^-1
+        OAK_CHECK(gemm_nt(ctx, dPT, dPT, dSinv, M, M, M, M, M, M, 1.0, 0.0, 0));           // Sigma^-1
+        OAK_CHECK(gemm_nn(ctx, dLinvT, dW, dTmp, M, M, M, M, M, M, 1.0, 0.0));             // L^-T W
+        OAK_CHECK(gemm_nt(ctx, dTmp, dLinvT, dKWK, M, M, M, M, M, M, 1.0, 0.0, 0));        // Kuu^-1 Phi Kuu^-1
+        dim3 grid((unsigned)((M + 255) / 256), (unsigned)M);
+        combine_h_kernel<<<grid, 256, 0, ctx->stream>>>(dKinv, dSinv, da, dKWK, s2, M, dH, dGuu);
+        OAK_HIP_CHECK(hipGetLastError());
+        // Kuu (+ jitter) = L L^T, for tr(Sigma^-1 Kuu) and a^T Kuu a
+        OAK_CHECK(gemm_nt(ctx, dL, dL, dKuu, M, M, M, M, M, M, 1.0, 0.0, 0));
+        OAK_CHECK(dot(ctx, dSinv, dKuu, M * M, dsc + 0));                            // tr(Sigma^-1 Kuu)
+        OAK_CHECK(gemv_rows(ctx, dKuu, M, M, M, da, dvec));
+        OAK_CHECK(dot(ctx, dvec, da, M, dsc + 1));                                   // a^T Kuu a
+        t.stop();
+    }
+    // psi^T a needs the raw psi: in the whitened route stats.psi is still raw (only Phi is replaced by W)
+    double* d_stats = (double*)peek_buf(ctx, "stats");
+    OAK_CHECK(dot(ctx, d_stats + M * M, da, M, dsc + 2));
+    double hs[3];
+    OAK_HIP_CHECK(hipMemcpyAsync(hs, dsc, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx->stream));
+    // ---- N-sized contractions ---------------------------------------------------------------------------------
+    const int64_t reclen = record_len(pk);
+    double* d_rec = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "g_rec", (size_t)reclen, &d_rec));
+    OAK_CHECK(fill_zero(ctx, d_rec, sizeof(double) * (size_t)reclen));
+    Feat FX, FZ;
+    OAK_CHECK(featurize(ctx, pk, (double*)peek_buf(ctx, "Z"), M, ctx->ldx, "featZg", &FZ, true));
+    OAK_CHECK(featurize(ctx, pk, (double*)peek_buf(ctx, "X"), N, ctx->ldx, "featXg", &FX, true));
+    // a / s2 as the rank-1 partner of y
+    double* d_as2 = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "g_as2", (size_t)M, &d_as2));
+    OAK_CHECK(copy_d2d(ctx, d_as2, da, sizeof(double) * (size_t)M));
+    OAK_CHECK(scale_vec(ctx, 1.0 / s2, d_as2, M));
+    int64_t rows = ctx->panel_rows > 0 ? ctx->panel_rows : (int64_t)(((size_t)16 << 30) / (sizeof(double) * (size_t)Mp));
+    if (rows > N) rows = N;
+    if (rows < 16) rows = 16;
+    double *dPanel = nullptr, *dG = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "panel", (size_t)rows * Mp, &dPanel));
+    OAK_CHECK(get_buf_t(ctx, "gpanel", (size_t)rows * Mp, &dG));
+    const bool reuse_panel = (rows >= N) && !ctx->stats_whitened;    // forward left the raw Kfu panel in place
+    for (int64_t a0 = 0; a0 < N; a0 += rows) {
+        const int64_t na = (a0 + rows <= N) ? rows : N - a0;
+        if (!reuse_panel) {
+            PhaseTimer t(ctx, "gram");
+            OAK_CHECK(gram(ctx, pk, FX, a0, na, FZ, dPanel, Mp, nullptr, nullptr, Mp));
+            t.stop();
+        }
+        {
+            PhaseTimer t(ctx, "bwd_gemm");      // Gfu = Kfu H   (scaled by 1/s2 inside the pair kernel)
+            OAK_CHECK(gemm_nt(ctx, dPanel, dH, dG, na, M, M, Mp, M, Mp, 1.0, 0.0, 0));
+            t.stop();
+        }
+        {
+            PhaseTimer t(ctx, "bwd_gram");
+            OAK_CHECK(gram_bwd(ctx, pk, FX, a0, na, FZ, dG, Mp, 1.0 / s2, dY, d_as2, d_rec));
+            t.stop();
+        }
+    }
+    {
+        PhaseTimer t(ctx, "bwd_small");
+        // <G_uu, dKuu> is replicated on every rank; each contributes 1/nranks so the all-reduce below restores it once
+        OAK_CHECK(gram_bwd(ctx, pk, FZ, 0, M, FZ, dGuu, M, 1.0 / (double)(ctx->comm ? ctx->nranks : 1), nullptr, nullptr, d_rec));
+        OAK_CHECK(diag_bwd(ctx, pk, FX, -0.5 / s2, d_rec));                                      // -1/(2 s2) sum dKdiag
+        t.stop();
+    }
+    if (ctx->comm != nullptr) OAK_CHECK(comm_allreduce_dev(ctx, d_rec, reclen));
+    std::vector<double> rec((size_t)reclen);
+    OAK_HIP_CHECK(hipMemcpyAsync(rec.data(), d_rec, sizeof(double) * (size_t)reclen, hipMemcpyDeviceToHost, ctx->stream));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ttot.stop();
+    const double n_tot = terms[5], kappa = terms[3], yy = terms[4], trW = terms[2] * s2;
+    const double trSK = hs[0], aKa = hs[1], psia = hs[2];
+    const double dnoise = -0.5 * n_tot / s2 + 0.5 * (yy + kappa) / (s2 * s2) - 0.5 * trW / (s2 * s2) - psia / (s2 * s2) +
+                          0.5 * ((double)M - trSK) / s2 + 0.5 * (psia - s2 * aKa) / (s2 * s2);
+    scatter_record(desc, pk, rec, dnoise, grad_out);
+    if (elbo_out) *elbo_out = elbo;
+    return OAK_OK;
+}
+
+int oak_gpr_log_marginal_grad(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, double* out, double* grad_out) {
+    if (!ctx) { set_error("ctx is NULL"); return OAK_E_ARG; }
+    OAK_HIP_CHECK(hipSetDevice(ctx->device));
+    OAK_REQUIRE(grad_out != nullptr, "grad_out is NULL");
+    double logml = 0.0;
+    OAK_CHECK(oak_gpr_log_marginal(ctx, desc, noise_var, &logml));
+    PreparedKernel pk;
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    const int64_t N = ctx->gN;
+    double* dL = (double*)peek_buf(ctx, "gprL");
+    double* dalpha = (double*)peek_buf(ctx, "gpralpha");
+    double *dLinvT, *dKinv, *dG, *dsc;
+    OAK_CHECK(get_buf_t(ctx, "g_LinvT", (size_t)N * N, &dLinvT));
+    OAK_CHECK(get_buf_t(ctx, "g_Kinv", (size_t)N * N, &dKinv));
+    OAK_CHECK(get_buf_t(ctx, "g_Guu", (size_t)N * N, &dG));
+    OAK_CHECK(get_buf_t(ctx, "g_sc", 8, &dsc));
+    OAK_CHECK(set_identity(ctx, dLinvT, N));
+    OAK_CHECK(trsm_rows(ctx, dL, N, N, dLinvT, N, N, 0));
+    OAK_CHECK(gemm_nt(ctx, dLinvT, dLinvT, dKinv, N, N, N, N, N, N, 1.0, 0.0, 0));        // (K + s2 I)^-1
+    dim3 grid((unsigned)((N + 255) / 256), (unsigned)N);
+    combine_gpr_kernel<<<grid, 256, 0, ctx->stream>>>(dKinv, dalpha, N, dG);              // dF/dK = 0.5 (alpha alpha^T - K^-1)
+    OAK_HIP_CHECK(hipGetLastError());
+    OAK_CHECK(reduce_sum(ctx, dG, N, dsc, 0, N + 1));                                     // dF/ds2 = tr(dF/dK)
+    const int64_t reclen = record_len(pk);
+    double* d_rec = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "g_rec", (size_t)reclen, &d_rec));
+    OAK_CHECK(fill_zero(ctx, d_rec, sizeof(double) * (size_t)reclen));
+    Feat FX;
+    OAK_CHECK(featurize(ctx, pk, (double*)peek_buf(ctx, "gprX"), N, ctx->gldx, "featXg", &FX, true));
+    OAK_CHECK(gram_bwd(ctx, pk, FX, 0, N, FX, dG, N, 1.0, nullptr, nullptr, d_rec));
+    std::vector<double> rec((size_t)reclen);
+    double dnoise = 0.0;
+    OAK_HIP_CHECK(hipMemcpyAsync(rec.data(), d_rec, sizeof(double) * (size_t)reclen, hipMemcpyDeviceToHost, ctx->stream));
+    OAK_HIP_CHECK(hipMemcpyAsync(&dnoise, dsc, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    scatter_record(desc, pk, rec, dnoise, grad_out);
+    if (out) *out = logml;
+    return OAK_OK;
+}
+
+}  // extern "C"

@@ -57,6 +57,7 @@ struct DevMeasure {
     double p0[OAK_MAX_DIMS], p1[OAK_MAX_DIMS];
     double ls[OAK_MAX_DIMS];
     double inv_sqrt_v[OAK_MAX_DIMS];   // 1/sqrt(var_s)   (0 for unconstrained)
+    double dlogv[OAK_MAX_DIMS];        // d log(var_s) / d lengthscale  (gradient path)
 };
 
 // Featurised point set, struct-of-arrays, dimension-major: xs[d*ld + i], cn[d*ld + i]
@@ -65,6 +66,7 @@ struct DevMeasure {
 struct Feat {
     double* xs = nullptr;
     double* cn = nullptr;
+    double* dcn = nullptr;     // d cn / d lengthscale_d (only when featurized for the backward pass)
     int64_t n = 0;
     int64_t ld = 0;
 };
@@ -131,7 +133,7 @@ int prepare_component(oak_ctx* ctx, const oak_kernel_desc* desc, const int32_t* 
 
 // featurize -------------------------------------------------------------------------------------
 int featurize(oak_ctx* ctx, const PreparedKernel& pk, const double* dX, int64_t n, int32_t ldx,
-              const char* bufname, Feat* out);
+              const char* bufname, Feat* out, bool with_grad = false);
 
 // gram ------------------------------------------------------------------------------------------
 // out[i*ldo + j] = K(A_i, B_j).  If yA != nullptr also accumulates psi[j] += sum_i K(i,j) y_i into d_psi
@@ -165,6 +167,11 @@ int gemm_nn(oak_ctx* ctx, const double* dA, const double* dB, double* dC, int64_
             int64_t lda, int64_t ldb, int64_t ldc, double alpha, double beta);   // C = alpha A B + beta C (row-major)
 int gemm_nt(oak_ctx* ctx, const double* dA, const double* dB, double* dC, int64_t m, int64_t n, int64_t k,
             int64_t lda, int64_t ldb, int64_t ldc, double alpha, double beta, int lower_only);   // C = alpha A B^T + beta C
+
+// SGPR pipeline pieces shared between translation units
+int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter);
+int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out);
+int sgpr_ensure_alpha(oak_ctx* ctx);
 
 // collectives --------------------------------------------------------------------------------------
 int comm_allreduce_dev(oak_ctx* ctx, double* d_buf, int64_t n);

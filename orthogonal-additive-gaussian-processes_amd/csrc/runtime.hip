@@ -82,53 +82,66 @@ int fill_zero(oak_ctx* ctx, void* dst, size_t bytes) {
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) featurize_kernel(DevDesc dd, DevMeasure dm, const double* __restrict__ meas,
                                                         const double* __restrict__ X, int64_t n, int ldx, int64_t ld,
-                                                        double* __restrict__ xs, double* __restrict__ cn) {
+                                                        double* __restrict__ xs, double* __restrict__ cn, double* __restrict__ dcn) {
     const int d = blockIdx.y;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ld) return;
-    double vx = 0.0, vc = 0.0;
+    double vx = 0.0, vc = 0.0, vd = 0.0;
     if (i < n) {
         const double x = X[i * ldx + dd.col[d]];
         if (dd.type[d] == OAK_DIM_RBF) {
             vx = x * dd.scale[d];
             const double l = dm.ls[d], bv = dd.bv[d];
-            double c = 0.0;
+            double c = 0.0, dc = 0.0;     // cov_X_s(x) and its lengthscale derivative
             switch (dm.kind[d]) {
                 case OAK_MEAS_GAUSSIAN: {   // oak/ortho_rbf_kernel.py:82-92
                     const double mu = dm.p0[d], var = dm.p1[d];
                     const double s = l * l + var;
-                    c = bv * l / sqrt(s) * exp(-0.5 * (x - mu) * (x - mu) / s);
+                    const double u2 = (x - mu) * (x - mu);
+                    c = bv * l / sqrt(s) * exp(-0.5 * u2 / s);
+                    dc = c * (1.0 / l - l / s + u2 * l / (s * s));
                 } break;
                 case OAK_MEAS_UNIFORM: {    // oak/ortho_rbf_kernel.py:49-63
                     const double a = dm.p0[d], b = dm.p1[d];
                     const double r2l = 1.0 / (1.4142135623730951 * l);
-                    c = bv * l / (b - a) * 1.2533141373155001 * (erf((b - x) * r2l) - erf((a - x) * r2l));
+                    const double zb = (b - x) * r2l, za = (a - x) * r2l;
+                    const double pre = bv * l / (b - a) * 1.2533141373155001;
+                    c = pre * (erf(zb) - erf(za));
+                    dc = c / l + pre * 1.1283791670955126 * (-zb * exp(-zb * zb) + za * exp(-za * za)) / l;
                 } break;
                 case OAK_MEAS_EMPIRICAL: {  // oak/ortho_rbf_kernel.py:101-107
                     const int K = dm.k[d];
                     const double* loc = meas + dm.off[d];
                     const double* w = loc + K;
                     const double il2 = 0.5 / (l * l);
-                    double acc = 0.0;
-                    for (int k = 0; k < K; ++k) { const double u = x - loc[k]; acc += w[k] * exp(-u * u * il2); }
+                    double acc = 0.0, dacc = 0.0;
+                    for (int k = 0; k < K; ++k) {
+                        const double u = x - loc[k];
+                        const double e = w[k] * exp(-u * u * il2);
+                        acc += e; dacc += e * u * u;
+                    }
                     c = bv * acc;
+                    dc = bv * dacc / (l * l * l);
                 } break;
                 case OAK_MEAS_MOG: {        // oak/ortho_rbf_kernel.py:124-136
                     const int K = dm.k[d];
                     const double* mu = meas + dm.off[d];
                     const double* var = mu + K;
                     const double* w = var + K;
-                    double acc = 0.0;
+                    double acc = 0.0, dacc = 0.0;
                     for (int k = 0; k < K; ++k) {
                         const double s = l * l + var[k];
                         const double u = x - mu[k];
-                        acc += w[k] * exp(-0.5 * u * u / s) / sqrt(s);
+                        const double e = w[k] * exp(-0.5 * u * u / s) / sqrt(s);
+                        acc += e; dacc += e * (-l / s + u * u * l / (s * s));
                     }
                     c = bv * l * acc;
+                    dc = c / l + bv * l * dacc;
                 } break;
-                default: c = 0.0;
+                default: c = 0.0; dc = 0.0;
             }
             vc = c * dm.inv_sqrt_v[d];
+            vd = (dc - 0.5 * c * dm.dlogv[d]) * dm.inv_sqrt_v[d];   // d/dl [ c / sqrt(v) ]
         } else {
             // tf.cast(float64 -> int32) truncates toward zero (ortho_binary_kernel.py:47); clamp keeps lookups in range
             double t = trunc(x);
@@ -139,40 +152,56 @@ __global__ void __launch_bounds__(256) featurize_kernel(DevDesc dd, DevMeasure d
     }
     xs[(int64_t)d * ld + i] = vx;
     cn[(int64_t)d * ld + i] = vc;
+    if (dcn != nullptr) dcn[(int64_t)d * ld + i] = vd;
 }
 
 // tmp[k] = w_k * sum_l w_l * bv * exp(-(loc_k-loc_l)^2 / (2 l^2))   (var_s of the empirical measure, :109-120)
 __global__ void empirical_var_kernel(const double* __restrict__ loc, const double* __restrict__ w, int K, double l,
-                                     double bv, double* __restrict__ tmp) {
+                                     double bv, double* __restrict__ tmp, double* __restrict__ dtmp) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     const double il2 = 0.5 / (l * l);
-    double acc = 0.0;
-    for (int j = 0; j < K; ++j) { const double u = loc[k] - loc[j]; acc += w[j] * exp(-u * u * il2); }
+    double acc = 0.0, dacc = 0.0;
+    for (int j = 0; j < K; ++j) {
+        const double u = loc[k] - loc[j];
+        const double e = w[j] * exp(-u * u * il2);
+        acc += e; dacc += e * u * u;
+    }
     tmp[k] = w[k] * bv * acc;
+    dtmp[k] = w[k] * bv * dacc / (l * l * l);   // d/dl
 }
 
-static double host_var_s(int kind, double l, double bv, double p0, double p1, const double* data, int K) {
+// var_s of the measure and its lengthscale derivative (*dv)
+static double host_var_s(int kind, double l, double bv, double p0, double p1, const double* data, int K, double* dv) {
     switch (kind) {
-        case OAK_MEAS_GAUSSIAN: return bv * l / std::sqrt(l * l + 2.0 * p1);       // :94-97
+        case OAK_MEAS_GAUSSIAN: {                                                  // :94-97
+            const double v = bv * l / std::sqrt(l * l + 2.0 * p1);
+            *dv = v * (1.0 / l - l / (l * l + 2.0 * p1));
+            return v;
+        }
         case OAK_MEAS_UNIFORM: {                                                   // :65-78
             const double a = p0, b = p1;
             const double y = (b - a) / std::sqrt(2.0) / l;
-            return 2.0 / ((b - a) * (b - a)) * bv * l * l *
-                   (std::sqrt(M_PI) * y * std::erf(y) + std::exp(-y * y) - 1.0);
+            const double pre = 2.0 / ((b - a) * (b - a)) * bv * l * l;
+            const double v = pre * (std::sqrt(M_PI) * y * std::erf(y) + std::exp(-y * y) - 1.0);
+            *dv = 2.0 * v / l + pre * std::sqrt(M_PI) * std::erf(y) * (-y / l);
+            return v;
         }
         case OAK_MEAS_MOG: {                                                       // :138-152
             const double *mu = data, *var = data + K, *w = data + 2 * K;
-            double acc = 0.0;
+            double acc = 0.0, dacc = 0.0;
             for (int i = 0; i < K; ++i)
                 for (int j = 0; j < K; ++j) {
                     const double s = l * l + var[i] + var[j];
                     const double dm = mu[i] - mu[j];
-                    acc += w[i] * w[j] * bv * l / std::sqrt(s) * std::exp(-0.5 * dm * dm / s);
+                    const double t = w[i] * w[j] * bv * l / std::sqrt(s) * std::exp(-0.5 * dm * dm / s);
+                    acc += t;
+                    dacc += t * (1.0 / l - l / s + dm * dm * l / (s * s));
                 }
+            *dv = dacc;
             return acc;
         }
-        default: return 0.0;
+        default: *dv = 0.0; return 0.0;
     }
 }
 
@@ -216,28 +245,33 @@ int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk
             dm.p1[d] = desc->meas_p1 ? desc->meas_p1[d] : 0.0;
             dm.k[d] = desc->meas_k ? desc->meas_k[d] : 0;
             dm.off[d] = desc->meas_off ? desc->meas_off[d] : 0;
-            double v = 0.0;
+            double v = 0.0, dv = 0.0;
             if (kind == OAK_MEAS_NONE) {
                 dm.inv_sqrt_v[d] = 0.0;
+                dm.dlogv[d] = 0.0;
             } else {
                 if (kind == OAK_MEAS_EMPIRICAL) {
                     const int K = dm.k[d];
                     OAK_REQUIRE(K >= 1 && dm.off[d] + 2 * K <= mlen, "dim %d: empirical measure data out of range", d);
                     double* d_tmp = nullptr; double* d_s = nullptr;
-                    OAK_CHECK(get_buf_t(ctx, "empvar_tmp", (size_t)K, &d_tmp));
-                    OAK_CHECK(get_buf_t(ctx, "empvar_s", 1, &d_s));
-                    empirical_var_kernel<<<(K + 255) / 256, 256, 0, ctx->stream>>>(d_meas + dm.off[d], d_meas + dm.off[d] + K, K, l, bv, d_tmp);
+                    OAK_CHECK(get_buf_t(ctx, "empvar_tmp", (size_t)2 * K, &d_tmp));
+                    OAK_CHECK(get_buf_t(ctx, "empvar_s", 2, &d_s));
+                    empirical_var_kernel<<<(K + 255) / 256, 256, 0, ctx->stream>>>(d_meas + dm.off[d], d_meas + dm.off[d] + K, K, l, bv, d_tmp, d_tmp + K);
                     OAK_CHECK(reduce_sum(ctx, d_tmp, K, d_s, 0, 1));
-                    OAK_HIP_CHECK(hipMemcpyAsync(&v, d_s, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+                    OAK_CHECK(reduce_sum(ctx, d_tmp + K, K, d_s + 1, 0, 1));
+                    double hv[2] = {0, 0};
+                    OAK_HIP_CHECK(hipMemcpyAsync(hv, d_s, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
                     OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+                    v = hv[0]; dv = hv[1];
                 } else {
                     if (kind == OAK_MEAS_MOG)
                         OAK_REQUIRE(dm.k[d] >= 1 && dm.off[d] + 3 * dm.k[d] <= mlen, "dim %d: MOG measure data out of range", d);
                     OAK_REQUIRE(kind == OAK_MEAS_GAUSSIAN || kind == OAK_MEAS_UNIFORM || kind == OAK_MEAS_MOG, "dim %d: unknown measure %d", d, kind);
-                    v = host_var_s(kind, l, bv, dm.p0[d], dm.p1[d], desc->meas_data ? desc->meas_data + dm.off[d] : nullptr, dm.k[d]);
+                    v = host_var_s(kind, l, bv, dm.p0[d], dm.p1[d], desc->meas_data ? desc->meas_data + dm.off[d] : nullptr, dm.k[d], &dv);
                 }
                 OAK_REQUIRE(v > 0.0 && std::isfinite(v), "dim %d: measure variance var_s=%g is not positive", d, v);
                 dm.inv_sqrt_v[d] = 1.0 / std::sqrt(v);
+                dm.dlogv[d] = dv / v;
             }
         } else if (t == OAK_DIM_BINARY) {     // oak/ortho_binary_kernel.py:29-38
             const double p0 = desc->meas_p0[d], p1 = 1.0 - p0;
@@ -296,19 +330,21 @@ int prepare_component(oak_ctx* ctx, const oak_kernel_desc* desc, const int32_t* 
         dd.tab_off[q] = full.dd.tab_off[s]; dd.scale[q] = full.dd.scale[s]; dd.log2bv[q] = full.dd.log2bv[s];
         dd.bv[q] = full.dd.bv[s];
         dm.kind[q] = full.dm.kind[s]; dm.k[q] = full.dm.k[s]; dm.off[q] = full.dm.off[s]; dm.p0[q] = full.dm.p0[s];
-        dm.p1[q] = full.dm.p1[s]; dm.ls[q] = full.dm.ls[s]; dm.inv_sqrt_v[q] = full.dm.inv_sqrt_v[s];
+        dm.p1[q] = full.dm.p1[s]; dm.ls[q] = full.dm.ls[s]; dm.inv_sqrt_v[q] = full.dm.inv_sqrt_v[s]; dm.dlogv[q] = full.dm.dlogv[s];
     }
     return OAK_OK;
 }
 
-int featurize(oak_ctx* ctx, const PreparedKernel& pk, const double* dX, int64_t n, int32_t ldx, const char* bufname, Feat* out) {
+int featurize(oak_ctx* ctx, const PreparedKernel& pk, const double* dX, int64_t n, int32_t ldx, const char* bufname, Feat* out,
+              bool with_grad) {
     const int D = pk.dd.D;
     const int64_t ld = ((n + 63) / 64) * 64 + 64;   // padded so tile loads never run past the array
     double* base = nullptr;
-    OAK_CHECK(get_buf_t(ctx, bufname, (size_t)(2 * D * ld), &base));
+    OAK_CHECK(get_buf_t(ctx, bufname, (size_t)((with_grad ? 3 : 2) * D * ld), &base));
     out->xs = base; out->cn = base + (size_t)D * ld; out->n = n; out->ld = ld;
+    out->dcn = with_grad ? base + (size_t)2 * D * ld : nullptr;
     dim3 grid((unsigned)((ld + 255) / 256), (unsigned)D);
-    featurize_kernel<<<grid, 256, 0, ctx->stream>>>(pk.dd, pk.dm, pk.d_meas, dX, n, ldx, ld, out->xs, out->cn);
+    featurize_kernel<<<grid, 256, 0, ctx->stream>>>(pk.dd, pk.dm, pk.d_meas, dX, n, ldx, ld, out->xs, out->cn, out->dcn);
     OAK_HIP_CHECK(hipGetLastError());
     return OAK_OK;
 }

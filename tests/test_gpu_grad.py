@@ -1,0 +1,179 @@
+"""GPU: analytic gradients of the SGPR bound / GPR log-marginal (HIP backward pass) against central finite
+differences of the CPU ORACLE objective (the reference obtains them by TF autodiff, oak/model_utils.py:168-173),
+and the reference's optimisation tests (tests/test_optimisation.py)."""
+import copy
+
+import numpy as np
+import pytest
+
+import cases
+from oak import _capi
+from oak import gpflow_lite as gpflow
+from oak.input_measures import GaussianMeasure
+from oak.model_utils import create_model_oak
+from oak.oak_kernel import _categorical_chain
+from oak.ortho_rbf_kernel import OrthogonalRBFKernel
+from oracle import oak_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def fd(fun, h=1e-5):
+    return (fun(h) - fun(-h)) / (2 * h)
+
+
+def check(g, ref, rtol=2e-5, atol=1e-6):
+    np.testing.assert_allclose(g, ref, rtol=rtol, atol=atol * max(1.0, abs(ref)))
+
+
+@pytest.mark.parametrize("route", ["phi", "whitened"])
+@pytest.mark.parametrize("R", [1, 2, 3])
+def test_sgpr_gradient_continuous(hip, route, R):
+    rng = np.random.default_rng(R)
+    D, N, M = 4, 300, 24
+    X, y, Z = o.synthetic_problem(N, D, M, seed=5)
+    spec = o.make_spec(D, R, lengthscales=list(rng.uniform(0.8, 1.6, D)), order_variances=list(rng.uniform(0.5, 1.5, R + 1)))
+    s2 = 0.07
+    hip.sgpr_set_data(X, y); hip.sgpr_set_inducing(Z); hip.sgpr_set_route(route)
+    e, g = hip.sgpr_elbo_grad(_capi.KernelDesc(spec), s2)
+    np.testing.assert_allclose(e, o.sgpr_elbo(spec, X, y, Z, s2), rtol=1e-10 if route == "whitened" else 1e-8)
+
+    def with_ls(d, h):
+        s = copy.deepcopy(spec); s["dims"][d]["lengthscale"] += h
+        return o.sgpr_elbo(s, X, y, Z, s2)
+
+    def with_ov(r, h):
+        s = copy.deepcopy(spec); s["order_variances"][r] += h
+        return o.sgpr_elbo(s, X, y, Z, s2)
+
+    for d in range(D):
+        check(g[d], fd(lambda h: with_ls(d, h)))
+    for r in range(R + 1):
+        check(g[2 * D + r], fd(lambda h: with_ov(r, h)))
+    check(g[2 * D + R + 1], fd(lambda h: o.sgpr_elbo(spec, X, y, Z, s2 + h), h=1e-6))
+
+
+def test_sgpr_gradient_all_kernel_types(hip):
+    """Every sub-kernel type / measure, base variances trainable (share_var_across_orders=False), categorical table."""
+    spec, X, y, Z, s2 = cases.case_B()
+    spec = copy.deepcopy(spec)
+    spec["share_var_across_orders"] = False
+    spec["order_variances"] = [0.6]
+    for i, dim in enumerate(spec["dims"]):
+        dim["variance"] = 0.7 + 0.15 * i
+    hip.sgpr_set_data(X, y); hip.sgpr_set_inducing(Z); hip.sgpr_set_route("whitened")
+    desc = _capi.KernelDesc(spec)
+    e, g = hip.sgpr_elbo_grad(desc, s2)
+    np.testing.assert_allclose(e, o.sgpr_elbo(spec, X, y, Z, s2), rtol=1e-10)
+    D = 6
+
+    def perturbed(path, h):
+        s = copy.deepcopy(spec)
+        if path[0] == "ls":
+            s["dims"][path[1]]["lengthscale"] += h
+        elif path[0] == "bv":
+            s["dims"][path[1]]["variance"] += h
+        elif path[0] == "ov":
+            s["order_variances"][0] += h
+        elif path[0] == "W":
+            s["dims"][4]["W"] = s["dims"][4]["W"].copy(); s["dims"][4]["W"][path[1]] += h
+        elif path[0] == "kappa":
+            s["dims"][4]["kappa"] = s["dims"][4]["kappa"].copy(); s["dims"][4]["kappa"][path[1]] += h
+        return o.sgpr_elbo(s, X, y, Z, s2)
+
+    for d in (0, 1, 2, 5):          # RBF dims: Gaussian, uniform, MOG, empirical measures
+        check(g[d], fd(lambda h: perturbed(("ls", d), h)), rtol=5e-5)
+    for d in range(D):
+        check(g[D + d], fd(lambda h: perturbed(("bv", d), h)), rtol=5e-5)
+    check(g[2 * D], fd(lambda h: perturbed(("ov",), h)))
+    check(g[2 * D + 1], fd(lambda h: o.sgpr_elbo(spec, X, y, Z, s2 + h), h=1e-6))     # layout: ls(6) | bv(6) | ov(1) | noise | table
+    off, C = desc.cat_blocks[4]
+    GB = g[2 * D + 2:][off:off + C * C].reshape(C, C)
+    gW, gk = _categorical_chain(spec["dims"][4]["W"], spec["dims"][4]["kappa"], spec["dims"][4]["p"], GB)
+    for idx in [(0, 0), (2, 1), (3, 0)]:
+        check(gW[idx], fd(lambda h: perturbed(("W", idx), h)), rtol=1e-4)
+    for i in range(C):
+        check(gk[i], fd(lambda h: perturbed(("kappa", i), h)), rtol=1e-4)
+
+
+def test_gpr_gradient(hip):
+    X, y, _ = o.synthetic_problem(150, 3, 4, seed=9)
+    spec = o.make_spec(3, 2, lengthscales=[0.9, 1.3, 1.1], order_variances=[0.7, 1.2, 0.9])
+    s2 = 0.05
+    hip.gpr_set_data(X, y)
+    v, g = hip.gpr_log_marginal_grad(_capi.KernelDesc(spec), s2)
+    np.testing.assert_allclose(v, o.gpr_log_marginal_likelihood(spec, X, y, s2), rtol=1e-11)
+    for d in range(3):
+        def f(h, d=d):
+            s = copy.deepcopy(spec); s["dims"][d]["lengthscale"] += h
+            return o.gpr_log_marginal_likelihood(s, X, y, s2)
+        check(g[d], fd(f))
+    for r in range(3):
+        def f(h, r=r):
+            s = copy.deepcopy(spec); s["order_variances"][r] += h
+            return o.gpr_log_marginal_likelihood(s, X, y, s2)
+        check(g[6 + r], fd(f))
+    check(g[9], fd(lambda h: o.gpr_log_marginal_likelihood(spec, X, y, s2 + h), h=1e-6))
+
+
+def test_model_loss_gradient_through_transforms_and_prior():
+    """d training_loss / d unconstrained variables (softplus / sigmoid transforms, Gamma prior) vs finite differences."""
+    rng = np.random.default_rng(1)
+    X = rng.standard_normal((120, 3)); X[:, 2] = rng.integers(0, 2, 120)
+    y = (np.sin(X[:, :1]) + X[:, 1:2] * X[:, 2:3]) + 0.1 * rng.standard_normal((120, 1))
+    model = create_model_oak((X, y), inducing_pts=X[:15].copy(), p0=[None, None, 0.5], lengthscale_bounds=[1e-3, 1e3])
+    variables = model.trainable_variables
+    loss, grads = model._training_loss_and_grad(variables)
+    np.testing.assert_allclose(loss, model.training_loss(), rtol=1e-12)
+    for p, g in zip(variables, grads):
+        u0 = p.unconstrained_variable.copy()
+        h = 1e-5
+        p._u = u0 + h; lp = model.training_loss()
+        p._u = u0 - h; lm = model.training_loss()
+        p._u = u0
+        np.testing.assert_allclose(float(np.asarray(g).reshape(-1)[0]), (lp - lm) / (2 * h), rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("num_inducings", [0, 2])
+def test_OrthogonalRBFKernel_optimisation(num_inducings):
+    """tests/test_optimisation.py:17-45."""
+    X = np.array([[0.0], [1.0], [2.0]]); y = X.copy()
+    Z = X[:num_inducings, :] if num_inducings > 0 else None
+    k = OrthogonalRBFKernel(gpflow.kernels.RBF(lengthscales=10), GaussianMeasure(0, 1))
+    model = gpflow.models.SGPR((X, y), kernel=k, inducing_variable=gpflow.InducingPoints(Z)) if Z is not None else gpflow.models.GPR((X, y), kernel=k)
+    if Z is not None:
+        gpflow.set_trainable(model.inducing_variable, False)
+    initial = model.maximum_log_likelihood_objective()
+    assert not np.isnan(initial)
+    gpflow.optimizers.Scipy().minimize(model.training_loss_closure(), model.trainable_variables, method="BFGS", compile=True,
+                                       options=dict(disp=False, maxiter=2))
+    assert initial < model.maximum_log_likelihood_objective()
+
+
+@pytest.mark.parametrize("num_inducings", [0, 2])
+def test_oak_optimisation(num_inducings):
+    """tests/test_optimisation.py:48-70."""
+    X = np.array([[0.0], [1.0], [2.0]]); y = X.copy()
+    Z = X[:num_inducings, :] if num_inducings > 0 else None
+    model = create_model_oak((X, y), inducing_pts=Z, optimise=False, zfixed=True)
+    initial = model.maximum_log_likelihood_objective()
+    assert not np.isnan(initial)
+    gpflow.optimizers.Scipy().minimize(model.training_loss_closure(), model.trainable_variables, method="BFGS", compile=True,
+                                       options=dict(disp=False, maxiter=2))
+    assert initial < model.maximum_log_likelihood_objective()
+
+
+def test_fit_with_bfgs_improves_the_objective():
+    """oak_model.fit(optimise=True): BFGS on the analytic gradient lowers the loss and predicts better than the initial model."""
+    from oak.model_utils import oak_model
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((400, 3))
+    y = (X[:, 0] ** 2 + X[:, 1] + X[:, 1] * X[:, 2] + 0.05 * rng.standard_normal(400)).reshape(-1, 1)
+    oak = oak_model(num_inducing=40, max_interaction_depth=2, sparse=True, use_normalising_flow=False)
+    oak.fit(X, y, optimise=False)
+    before = oak.m.training_loss()
+    res = gpflow.optimizers.Scipy().minimize(oak.m.training_loss_closure(), oak.m.trainable_variables, method="BFGS",
+                                             options=dict(maxiter=15))
+    assert oak.m.training_loss() < before - 1.0
+    pred = oak.predict(X[:50])
+    assert np.mean((pred - y[:50, 0]) ** 2) < 0.05 * np.var(y)
