@@ -102,6 +102,95 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(const double* __restrict
             }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Large NT GEMM for the adjoint panel  Gfu = Kfu H  (N x M x M, the dominant kernel of the backward pass):
+// 128x128 tiles, 4 waves of 64x64, K-chunks of 16 staged through LDS with a register prefetch one stage ahead
+// (branch-free, clamped loads -- see syrk_kernel), LDS pitch 18 doubles -> conflict-free ds_read_b64 fragments.
+// Workgroups that share a row block of A are mapped to the same XCD (b % 8) so the A tile is fetched into one L2.
+// Requirements: lda, ldb even and A, B 16-byte aligned (the caller falls back to the 64x64 kernel otherwise).
+// ---------------------------------------------------------------------------------------------
+constexpr int G2_T = 128, G2_K = 16, G2_P = G2_K + 2;
+constexpr int G2_LPR = G2_K / 2;            // lanes per row chunk (16 B each)
+constexpr int G2_RPL = 64 / G2_LPR;          // rows per wave-load
+constexpr int G2_NQ = G2_T / (4 * G2_RPL);   // loads per thread per matrix
+
+__global__ void __launch_bounds__(256, 2)
+gemm128_nt_kernel(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, int64_t m, int64_t n,
+                  int64_t k, int64_t lda, int64_t ldb, int64_t ldc, double alpha, double beta, int ntn) {
+    __shared__ __attribute__((aligned(16))) double As[G2_T * G2_P];
+    __shared__ __attribute__((aligned(16))) double Bs[G2_T * G2_P];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    // XCD-aware tile mapping: the ntn column tiles of one row block run on the same XCD
+    const int64_t grp_size = 8LL * ntn;
+    const int64_t grp = blockIdx.x / grp_size, within = blockIdx.x - grp * grp_size;
+    const int64_t rb = grp * 8 + (within & 7);
+    const int64_t cb = within >> 3;
+    const int64_t r0 = rb * G2_T, c0 = cb * G2_T;
+    if (r0 >= m) return;
+    const int fi = lane & 15, fk = lane >> 4;
+    double4_t acc[4][4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int h = 0; h < 4; ++h) acc[g][h] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const int lr = lane / G2_LPR, lc = (lane % G2_LPR) * 2;
+    double2 ra[G2_NQ], rbv[G2_NQ];
+    auto load_stage = [&](int64_t k0) {
+#pragma unroll
+        for (int q = 0; q < G2_NQ; ++q) {
+            const int row = (wave * G2_NQ + q) * G2_RPL + lr;
+            const int64_t ar = (r0 + row < m) ? r0 + row : m - 1;
+            const int64_t br = (c0 + row < n) ? c0 + row : n - 1;
+            const int64_t kc = (k0 + lc + 1 < k) ? k0 + lc : ((k >= 2) ? k - 2 : 0);
+            const double2 va = *reinterpret_cast<const double2*>(A + ar * lda + kc);
+            const double2 vb = *reinterpret_cast<const double2*>(B + br * ldb + kc);
+            const bool okk = k0 + lc + 1 < k;
+            const bool oka = okk && (r0 + row < m), okb = okk && (c0 + row < n);
+            ra[q] = make_double2(oka ? va.x : 0.0, oka ? va.y : 0.0);
+            rbv[q] = make_double2(okb ? vb.x : 0.0, okb ? vb.y : 0.0);
+        }
+    };
+    load_stage(0);
+    for (int64_t k0 = 0; k0 < k; k0 += G2_K) {
+#pragma unroll
+        for (int q = 0; q < G2_NQ; ++q) {
+            const int row = (wave * G2_NQ + q) * G2_RPL + lr;
+            *reinterpret_cast<double2*>(&As[row * G2_P + lc]) = ra[q];
+            *reinterpret_cast<double2*>(&Bs[row * G2_P + lc]) = rbv[q];
+        }
+        __syncthreads();
+        load_stage((k0 + G2_K < k) ? k0 + G2_K : 0);
+#pragma unroll
+        for (int ks = 0; ks < G2_K / 4; ++ks) {
+            double a[4], b[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) a[g] = As[(64 * wr + 16 * g + fi) * G2_P + 4 * ks + fk];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) b[h] = Bs[(64 * wc + 16 * h + fi) * G2_P + 4 * ks + fk];
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) acc[g][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g], b[h], acc[g][h], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int64_t row = r0 + 64 * wr + 16 * g + 4 * reg + fk, col = c0 + 64 * wc + 16 * h + fi;
+                if (row < m && col < n) {
+                    double* q = C + row * ldc + col;
+                    const double v = alpha * acc[g][h][reg];
+                    *q = (beta == 0.0) ? v : __builtin_fma(beta, *q, v);
+                }
+            }
+}
+
 static int gemm_launch(oak_ctx* ctx, int bt, const double* dA, const double* dB, double* dC, int64_t m, int64_t n, int64_t k,
                        int64_t lda, int64_t ldb, int64_t ldc, double alpha, double beta, int lower_only) {
     if (m <= 0 || n <= 0) return OAK_OK;
@@ -117,6 +206,15 @@ int gemm_nn(oak_ctx* ctx, const double* dA, const double* dB, double* dC, int64_
 }
 int gemm_nt(oak_ctx* ctx, const double* dA, const double* dB, double* dC, int64_t m, int64_t n, int64_t k, int64_t lda,
             int64_t ldb, int64_t ldc, double alpha, double beta, int lower_only) {
+    const bool aligned = ((lda | ldb) & 1) == 0 && (((uintptr_t)dA | (uintptr_t)dB) & 15) == 0 && k >= 2 && (k & 1) == 0;
+    if (!lower_only && aligned && m >= 2048 && n >= 128 && m > 0 && n > 0) {
+        const int ntn = (int)((n + G2_T - 1) / G2_T);
+        const int64_t nrb = (m + G2_T - 1) / G2_T;
+        const int64_t ngrp = (nrb + 7) / 8;
+        gemm128_nt_kernel<<<(unsigned)(ngrp * 8 * ntn), 256, 0, ctx->stream>>>(dA, dB, dC, m, n, k, lda, ldb, ldc, alpha, beta, ntn);
+        OAK_HIP_CHECK(hipGetLastError());
+        return OAK_OK;
+    }
     return gemm_launch(ctx, 1, dA, dB, dC, m, n, k, lda, ldb, ldc, alpha, beta, lower_only);
 }
 

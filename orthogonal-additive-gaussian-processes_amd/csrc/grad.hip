@@ -8,6 +8,7 @@
 // dK/dk_d = sum_r w_r e_{r-1}^{(-d)} uses leave-one-out elementary symmetric polynomials (e^{(-d)}_q = e_q - k_d e^{(-d)}_{q-1}).
 #include "oak_internal.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace oak {
 
@@ -187,7 +188,7 @@ gram_bwd_kernel(const DevDesc dd, const GradDesc gd, const double* __restrict__ 
                             const double E = exp2_neg_tab(dd.log2bv[d] - u2, Tab);
                             const double ca = Ac[d * RS + ty * RT + r], cb = Bc[d * TJ + CPT * tx + c];
                             k = __builtin_fma(-ca, cb, E);
-                            dkl = E * u2 * gd.dE_scale[d] - (Ad[d * RS + ty * RT + r] * cb + ca * Bd[d * TJ + CPT * tx + c]);
+                            dkl = E * u2 - (Ad[d * RS + ty * RT + r] * cb + ca * Bd[d * TJ + CPT * tx + c]);   // in units of 2 ln2 / l
                         } else {
                             tidx = dd.tab_off[d] + (int)xa * dd.ncat[d] + (int)xb;
                             k = tables[tidx];
@@ -226,6 +227,184 @@ gram_bwd_kernel(const DevDesc dd, const GradDesc gd, const double* __restrict__ 
         rec[D + idx] = ((accK[idx] + accK[D + idx]) + accK[2 * D + idx]) + accK[3 * D + idx];
     }
     if (tid <= R) rec[2 * D + tid] = ((red[tid] + red[(R + 1) + tid]) + red[2 * (R + 1) + tid]) + red[3 * (R + 1) + tid];
+    for (int idx = tid; idx < tablen; idx += 256) rec[2 * D + (R + 1) + idx] = accT[idx];
+}
+
+// 4 exp2 at once, interleaved (same algorithm as exp2_neg_tab / the Gram kernel's exp2_neg_vec)
+__device__ __forceinline__ void exp2_neg_tab4(const double (&t_in)[4], double (&out)[4], const double* __restrict__ tab) {
+    constexpr double c1 = 6.931471805599453094e-01, c2 = 2.402265069591007123e-01, c3 = 5.550410866482157995e-02,
+                     c4 = 9.618129107628477162e-03, c5 = 1.333355814642844342e-03;
+    constexpr double MAGIC = 105553116266496.0;
+    double t[4], a[4], r[4], p[4], tv[4];
+    int ki[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) t[v] = __builtin_fmax(t_in[v], -1020.0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) a[v] = t[v] + MAGIC;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) ki[v] = __double2loint(a[v]);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) tv[v] = tab[ki[v] & 63];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) r[v] = t[v] - (a[v] - MAGIC);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) p[v] = __builtin_fma(c5, r[v], c4);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) p[v] = __builtin_fma(p[v], r[v], c3);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) p[v] = __builtin_fma(p[v], r[v], c2);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) p[v] = __builtin_fma(p[v], r[v], c1);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) p[v] = __builtin_fma(p[v], r[v], 1.0);
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        const int hi = __double2hiint(tv[v]) + (ki[v] >> 6) * 1048576;
+        out[v] = __hiloint2double(hi, __double2loint(tv[v])) * p[v];
+    }
+}
+
+// Fast path (1 <= R <= 4, D <= DMAX <= 16): one exp2 per pair per dimension.  Each lane walks its pairs one at a time,
+// keeps k_d and dk_d/dl_d of all dimensions in registers (vectorised 4 dimensions at a time for ILP), and accumulates the
+// per-dimension contractions in registers across the whole row range; one workgroup reduction at the very end.
+template <int R, int DMAX, bool ALLRBF>
+__global__ void __launch_bounds__(256)
+gram_bwd_fast_kernel(const DevDesc dd, const GradDesc gd, const double* __restrict__ tables, int tablen,
+                     const double* __restrict__ Axs, const double* __restrict__ Acn, const double* __restrict__ Adcn, int64_t a_ld,
+                     int64_t a0, int64_t na, const double* __restrict__ Bxs, const double* __restrict__ Bcn,
+                     const double* __restrict__ Bdcn, int64_t b_ld, int64_t nb, const double* __restrict__ G, int64_t ldg,
+                     const double* __restrict__ yA, const double* __restrict__ avec, double g_scale, int rows_per_wg,
+                     double* __restrict__ partial) {
+    constexpr int CPT = 2, TJ = 64 * CPT, RT = 2, RS = 4 * RT;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int D = dd.D;
+    double* Bx = smem;                  // [DMAX][TJ]
+    double* Bc = Bx + DMAX * TJ;
+    double* Bd = Bc + DMAX * TJ;
+    double* Ax = Bd + DMAX * TJ;        // [DMAX][RS]
+    double* Ac = Ax + DMAX * RS;
+    double* Ad = Ac + DMAX * RS;
+    double* Ay = Ad + DMAX * RS;        // [RS]
+    double* Av = Ay + RS;               // [TJ]
+    double* Tab = Av + TJ;              // [64]
+    double* Cst = Tab + 64;             // [DMAX] log2(base variance) per dim
+    double* accT = Cst + DMAX;          // [tablen]
+    double* red = accT + tablen;        // [4][2*DMAX + R + 1]
+    const int tid = threadIdx.x, tx = tid & 63;
+    const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t jb = (int64_t)blockIdx.x * TJ;
+    const int64_t ib = (int64_t)blockIdx.y * rows_per_wg;
+    const int64_t iend = (ib + rows_per_wg < na) ? ib + rows_per_wg : na;
+    for (int idx = tid; idx < DMAX * TJ; idx += 256) {
+        const int d = idx / TJ, j = idx - d * TJ;
+        const int64_t gj = jb + j;
+        const bool ok = gj < nb && d < D;
+        Bx[idx] = ok ? Bxs[(int64_t)d * b_ld + gj] : 0.0;
+        Bc[idx] = ok ? Bcn[(int64_t)d * b_ld + gj] : 0.0;
+        Bd[idx] = ok ? Bdcn[(int64_t)d * b_ld + gj] : 0.0;
+    }
+    for (int j = tid; j < TJ; j += 256) Av[j] = (avec != nullptr && jb + j < nb) ? avec[jb + j] : 0.0;
+    if (tid < 64) Tab[tid] = c_exp2_table_g[tid];
+    if (tid < DMAX) Cst[tid] = (tid < D && dd.type[tid] == OAK_DIM_RBF) ? dd.log2bv[tid] : -1100.0;
+    for (int idx = tid; idx < tablen; idx += 256) accT[idx] = 0.0;
+    double gl[DMAX], gk[DMAX], gw[R + 1];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) { gl[d] = 0.0; gk[d] = 0.0; }
+#pragma unroll
+    for (int q = 0; q <= R; ++q) gw[q] = 0.0;
+
+    for (int64_t i0 = ib; i0 < iend; i0 += RS) {
+        __syncthreads();
+        for (int idx = tid; idx < DMAX * RS; idx += 256) {
+            const int d = idx / RS, r = idx - d * RS;
+            const int64_t gi = i0 + r;
+            const bool ok = gi < iend && d < D;
+            Ax[idx] = ok ? Axs[(int64_t)d * a_ld + a0 + gi] : 0.0;
+            Ac[idx] = ok ? Acn[(int64_t)d * a_ld + a0 + gi] : 0.0;
+            Ad[idx] = ok ? Adcn[(int64_t)d * a_ld + a0 + gi] : 0.0;
+        }
+        if (tid < RS) Ay[tid] = (yA != nullptr && i0 + tid < iend) ? yA[a0 + i0 + tid] : 0.0;
+        __syncthreads();
+#pragma unroll 1
+        for (int pr = 0; pr < RT * CPT; ++pr) {      // one pair at a time: only one set of k[], dk[] is live
+            {
+                const int r = pr >> 1, c = pr & 1;
+                const int row = ty * RT + r, col = CPT * tx + c;
+                const int64_t gi = i0 + row, gj = jb + col;
+                double g = 0.0;
+                if (gi < iend && gj < nb) g = g_scale * G[gi * ldg + gj] + Ay[row] * Av[col];
+                double k[DMAX], dk[DMAX];
+#pragma unroll
+                for (int d0 = 0; d0 < DMAX; d0 += 4) {
+                    double t[4], u2[4], E[4], ca[4], cb[4], xa4[4], xb4[4];
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int d = d0 + v;
+                        xa4[v] = Ax[d * RS + row]; xb4[v] = Bx[d * TJ + col];
+                        ca[v] = Ac[d * RS + row]; cb[v] = Bc[d * TJ + col];
+                        const double u = xa4[v] - xb4[v];
+                        u2[v] = u * u;
+                        t[v] = Cst[d] - u2[v];              // log2(base variance); -1100 for the padding dims d >= D
+                    }
+                    exp2_neg_tab4(t, E, Tab);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        const int d = d0 + v;
+                        double kv = __builtin_fma(-ca[v], cb[v], E[v]);
+                        double dv = __builtin_fma(E[v], u2[v], -__builtin_fma(Ad[d * RS + row], cb[v], ca[v] * Bd[d * TJ + col]));
+                        if constexpr (!ALLRBF) {
+                            if (d < D && dd.type[d] != OAK_DIM_RBF) { kv = tables[dd.tab_off[d] + (int)xa4[v] * dd.ncat[d] + (int)xb4[v]]; dv = 0.0; }
+                        }
+                        k[d] = kv; dk[d] = dv;
+                    }
+                }
+                double e[R];
+#pragma unroll
+                for (int q = 0; q < R; ++q) e[q] = 0.0;
+#pragma unroll
+                for (int d = 0; d < DMAX; ++d) {
+#pragma unroll
+                    for (int q = R - 1; q >= 1; --q) e[q] = __builtin_fma(k[d], e[q - 1], e[q]);
+                    e[0] += k[d];
+                }
+                gw[0] += g;
+#pragma unroll
+                for (int q = 1; q <= R; ++q) gw[q] = __builtin_fma(g, e[q - 1], gw[q]);
+#pragma unroll
+                for (int d = 0; d < DMAX; ++d) {
+                    double f = 1.0, coef = dd.w[1];
+#pragma unroll
+                    for (int q = 1; q < R; ++q) { f = __builtin_fma(-k[d], f, e[q - 1]); coef = __builtin_fma(dd.w[q + 1], f, coef); }
+                    const double gc = g * coef;
+                    gl[d] = __builtin_fma(gc, dk[d], gl[d]);
+                    gk[d] = __builtin_fma(gc, k[d], gk[d]);
+                    if constexpr (!ALLRBF) {
+                        if (d < D && dd.type[d] == OAK_DIM_CATEGORICAL && gc != 0.0)
+                            atomicAdd(&accT[dd.tab_off[d] + (int)Ax[d * RS + row] * dd.ncat[d] + (int)Bx[d * TJ + col]], gc);
+                    }
+                }
+            }
+        }
+    }
+    // workgroup reduction of the register accumulators
+    constexpr int NACC = 2 * DMAX + R + 1;
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) { gl[d] = wave_sum(gl[d]); gk[d] = wave_sum(gk[d]); }
+#pragma unroll
+    for (int q = 0; q <= R; ++q) gw[q] = wave_sum(gw[q]);
+    __syncthreads();
+    if (tx == 0) {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) { red[ty * NACC + d] = gl[d]; red[ty * NACC + DMAX + d] = gk[d]; }
+#pragma unroll
+        for (int q = 0; q <= R; ++q) red[ty * NACC + 2 * DMAX + q] = gw[q];
+    }
+    __syncthreads();
+    const int64_t reclen = 2 * D + (R + 1) + tablen;
+    double* rec = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * reclen;
+    auto sum4 = [&](int j) { return ((red[j] + red[NACC + j]) + red[2 * NACC + j]) + red[3 * NACC + j]; };
+    for (int d = tid; d < D; d += 256) { rec[d] = sum4(d); rec[D + d] = sum4(DMAX + d); }
+    if (tid <= R) rec[2 * D + tid] = sum4(2 * DMAX + tid);
     for (int idx = tid; idx < tablen; idx += 256) rec[2 * D + (R + 1) + idx] = accT[idx];
 }
 
@@ -341,9 +520,14 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     const int D = pk.dd.D, R = pk.dd.R;
     const int tablen = (int)pk.tables.size();
     OAK_REQUIRE(tablen <= 4096, "gradient: discrete tables too large (%d doubles)", tablen);
+    const bool fast = (R >= 1 && R <= 4 && D <= 16 && getenv("OAK_BWD_GENERIC") == nullptr);
+    bool allrbf = true;
+    for (int d = 0; d < D; ++d) allrbf = allrbf && pk.dd.type[d] == OAK_DIM_RBF;
+    const int dmax = D <= 8 ? 8 : 16;
     const int cpt = (D <= 40) ? 2 : 1;
     const int TJ = 64 * cpt, RS = 8;
-    const size_t lds = sizeof(double) * ((size_t)3 * D * TJ + (size_t)3 * D * RS + RS + TJ + 64 + 8 * D + tablen + 64);
+    const size_t lds = fast ? sizeof(double) * ((size_t)3 * dmax * TJ + (size_t)3 * dmax * RS + RS + TJ + 64 + dmax + tablen + 4 * (2 * dmax + R + 1) + 8)
+                            : sizeof(double) * ((size_t)3 * D * TJ + (size_t)3 * D * RS + RS + TJ + 64 + 8 * D + tablen + 64);
     OAK_REQUIRE(lds <= 160 * 1024, "gram_bwd: LDS request %zu exceeds 160 KiB", lds);
     const int64_t nb = B.n;
     const int64_t ncb = (nb + TJ - 1) / TJ;
@@ -366,7 +550,20 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
         kern<<<grid, 256, lds, ctx->stream>>>(pk.dd, gd, pk.d_tables, tablen, A.xs, A.cn, A.dcn, A.ld, a0, na, B.xs, B.cn, B.dcn,  \
                                               B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part);                     \
     }
+#define OAK_BWD_FAST(RR, DM)                                                                                                      \
+    if (allrbf) gram_bwd_fast_kernel<RR, DM, true><<<grid, 256, lds, ctx->stream>>>(pk.dd, gd, pk.d_tables, tablen, A.xs, A.cn, A.dcn, \
+                        A.ld, a0, na, B.xs, B.cn, B.dcn, B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part);             \
+    else gram_bwd_fast_kernel<RR, DM, false><<<grid, 256, lds, ctx->stream>>>(pk.dd, gd, pk.d_tables, tablen, A.xs, A.cn, A.dcn,   \
+                        A.ld, a0, na, B.xs, B.cn, B.dcn, B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part);
 #define OAK_BWD_CASE(RR) case RR: if (cpt == 2) OAK_BWD_LAUNCH(RR, 2) else OAK_BWD_LAUNCH(RR, 1) break;
+    if (fast) {
+        switch (R * 100 + dmax) {
+            case 108: OAK_BWD_FAST(1, 8) break;   case 116: OAK_BWD_FAST(1, 16) break;
+            case 208: OAK_BWD_FAST(2, 8) break;   case 216: OAK_BWD_FAST(2, 16) break;
+            case 308: OAK_BWD_FAST(3, 8) break;   case 316: OAK_BWD_FAST(3, 16) break;
+            case 408: OAK_BWD_FAST(4, 8) break;   case 416: OAK_BWD_FAST(4, 16) break;
+        }
+    } else
     switch (R) {
         OAK_BWD_CASE(0) OAK_BWD_CASE(1) OAK_BWD_CASE(2) OAK_BWD_CASE(3) OAK_BWD_CASE(4)
         OAK_BWD_CASE(5) OAK_BWD_CASE(6) OAK_BWD_CASE(7) OAK_BWD_CASE(8)
@@ -374,6 +571,7 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     }
 #undef OAK_BWD_CASE
 #undef OAK_BWD_LAUNCH
+#undef OAK_BWD_FAST
     OAK_HIP_CHECK(hipGetLastError());
     reduce_records_kernel<<<(unsigned)((reclen + 255) / 256), 256, 0, ctx->stream>>>(d_part, nrb * ncb, reclen, d_rec);
     OAK_HIP_CHECK(hipGetLastError());
@@ -444,7 +642,7 @@ static void scatter_record(const oak_kernel_desc* desc, const PreparedKernel& pk
     const int64_t glen = 2 * D + desc->n_order_var + 1 + desc->meas_data_len;
     for (int64_t i = 0; i < glen; ++i) grad_out[i] = 0.0;
     for (int d = 0; d < D; ++d) {
-        if (desc->dim_type[d] == OAK_DIM_RBF) grad_out[d] = rec[d];
+        if (desc->dim_type[d] == OAK_DIM_RBF) grad_out[d] = rec[d] * (1.3862943611198906 / desc->lengthscale[d]);   // kernels work in units of 2 ln2 / l
         grad_out[D + d] = rec[D + d] / desc->base_var[d];        // k_d is linear in its base variance
     }
     if (desc->share_var) for (int r = 0; r <= R; ++r) grad_out[2 * D + r] = rec[2 * D + r];

@@ -141,7 +141,8 @@ __global__ void __launch_bounds__(256) featurize_kernel(DevDesc dd, DevMeasure d
                 default: c = 0.0; dc = 0.0;
             }
             vc = c * dm.inv_sqrt_v[d];
-            vd = (dc - 0.5 * c * dm.dlogv[d]) * dm.inv_sqrt_v[d];   // d/dl [ c / sqrt(v) ]
+            // d/dl [ c / sqrt(v) ], pre-divided by 2 ln2 / l: the pair kernels form dk/dl in units of that factor (see grad.hip)
+            vd = (dc - 0.5 * c * dm.dlogv[d]) * dm.inv_sqrt_v[d] * (l / 1.3862943611198906);
         } else {
             // tf.cast(float64 -> int32) truncates toward zero (ortho_binary_kernel.py:47); clamp keeps lookups in range
             double t = trunc(x);

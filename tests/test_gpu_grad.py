@@ -53,6 +53,29 @@ def test_sgpr_gradient_continuous(hip, route, R):
     check(g[2 * D + R + 1], fd(lambda h: o.sgpr_elbo(spec, X, y, Z, s2 + h), h=1e-6))
 
 
+@pytest.mark.parametrize("D,R", [(12, 2), (16, 3), (20, 2), (9, 5)])
+def test_sgpr_gradient_kernel_variants(hip, D, R):
+    """D <= 8 / <= 16 take the register-resident fast backward kernel, larger D or R > 4 the generic two-pass kernel:
+    all must agree with finite differences of the oracle (a subset of parameters is probed)."""
+    rng = np.random.default_rng(D * 10 + R)
+    N, M = 260, 20
+    X, y, Z = o.synthetic_problem(N, D, M, seed=D)
+    spec = o.make_spec(D, R, lengthscales=list(rng.uniform(0.9, 1.8, D)), order_variances=list(rng.uniform(0.3, 0.9, R + 1)))
+    s2 = 0.1
+    hip.sgpr_set_data(X, y); hip.sgpr_set_inducing(Z); hip.sgpr_set_route("whitened")
+    e, g = hip.sgpr_elbo_grad(_capi.KernelDesc(spec), s2)
+    for d in (0, D // 2, D - 1):
+        def f(h, d=d):
+            s = copy.deepcopy(spec); s["dims"][d]["lengthscale"] += h
+            return o.sgpr_elbo(s, X, y, Z, s2)
+        check(g[d], fd(f), rtol=5e-5)
+    for r in (0, R):
+        def f(h, r=r):
+            s = copy.deepcopy(spec); s["order_variances"][r] += h
+            return o.sgpr_elbo(s, X, y, Z, s2)
+        check(g[2 * D + r], fd(f), rtol=5e-5)
+
+
 def test_sgpr_gradient_all_kernel_types(hip):
     """Every sub-kernel type / measure, base variances trainable (share_var_across_orders=False), categorical table."""
     spec, X, y, Z, s2 = cases.case_B()
