@@ -136,8 +136,34 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    timings = {k: ctx.timing(k) for k in ["featurize", "gram", "trsm", "syrk", "reduce", "allreduce", "tail", "total",
-                                          "bwd_gemm", "bwd_gram", "bwd_tail"]}
+    PHASES = ["featurize", "gram", "trsm", "syrk", "reduce", "allreduce", "tail", "total", "bwd_gemm", "bwd_gram", "bwd_tail",
+              "bwd_small"]
+    timings = {k: ctx.timing(k) for k in PHASES}
+
+    # ---- secondary measurement: forward + analytic gradient (what one BFGS iteration of the reference computes) ----
+    grad_info = None
+    if not args.grad:
+        def grad_step():
+            desc = _capi.KernelDesc(spec)
+            elbo, g = ctx.sgpr_elbo_grad(desc, noise, jitter)
+            return -(elbo + log_prior(spec["order_variances"]))
+        gsteps = max(2, min(args.steps, 5))
+        grad_step()
+        ctx.reset_timings()
+        barrier()
+        tg = time.perf_counter()
+        for _ in range(gsteps):
+            grad_step()
+        barrier()
+        dtg = time.perf_counter() - tg
+        if dist is not None:
+            import torch
+            t = torch.tensor([dtg], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dtg = float(t.item())
+        gt = {k: ctx.timing(k) for k in PHASES}
+        grad_info = {"steps_per_sec": gsteps / dtg, "ms_per_step": dtg / gsteps * 1e3, "steps": gsteps,
+                     "phase_ms_per_step": {k: v[0] / gsteps for k, v in gt.items() if v[1]}}
 
     # ---- explicit Gram GB/s (the second half of BASELINE's metric) -------------------------------------------
     ctx.reset_timings()
@@ -206,6 +232,7 @@ def main():
                           "note": "fp64 Gram generation is DP-VALU bound (software exp2), not HBM bound"},
         "roofline": roofline,
         "phase_ms_per_step": {k: (v[0] / args.steps) for k, v in timings.items() if v[1]},
+        "forward_plus_gradient": grad_info,
     }
 
     # ---- CPU baseline: oracle port on this box's host cores, bounded sample ------------------------------------

@@ -1,0 +1,50 @@
+"""GPU: the multi-GPU plumbing that can be exercised on a one-GPU box: RCCL is dlopen'ed, a 1-rank communicator is
+created, the reduce-scatter + all-gather exchange is the identity, and the host-reducer path of ShardedSGPR (the one the
+2-rank gloo CPU test drives with oracle statistics) reproduces the single-context ELBO from HIP statistics."""
+import numpy as np
+import pytest
+
+from oak import _capi
+from oak import distributed as D
+from oracle import oak_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def test_single_rank_rccl_exchange_is_identity():
+    ctx = _capi.HipContext(0)
+    X, y, Z = o.synthetic_problem(3000, 5, 100)
+    spec = o.make_spec(5, 2)
+    d = _capi.KernelDesc(spec)
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("phi")
+    e0 = ctx.sgpr_elbo(d, 0.01)
+    uid = _capi.HipContext.comm_unique_id()
+    assert len(uid) == 128
+    ctx.comm_init(uid, 1, 0)
+    assert ctx.sgpr_elbo(d, 0.01) == e0
+    e1, g1 = ctx.sgpr_elbo_grad(d, 0.01)
+    assert e1 == e0 and np.all(np.isfinite(g1))
+    v = np.arange(5.0)
+    np.testing.assert_array_equal(ctx.comm_allreduce_host(v.copy()), v)
+    ctx.close()
+
+
+def test_sharded_sgpr_host_reducer_matches_single_context():
+    """Two row shards evaluated one after the other on the same GPU, reduced on the host: the N>1 code path minus xGMI."""
+    X, y, Z = o.synthetic_problem(4001, 6, 120)
+    spec = o.make_spec(6, 2)
+    d = _capi.KernelDesc(spec)
+    ref = o.sgpr_elbo(spec, X, y, Z, 0.01)
+    world = 2
+    ctxs = [_capi.HipContext(0) for _ in range(world)]
+    packed = []
+    for r, c in enumerate(ctxs):
+        lo, hi = D.shard_bounds(len(X), r, world)
+        c.sgpr_set_data(X[lo:hi], y[lo:hi]); c.sgpr_set_inducing(Z); c.sgpr_set_route(D.choose_route(len(X), len(Z)))
+        c.sgpr_local_stats(d)
+        packed.append(c.sgpr_get_stats())
+    total = packed[0] + packed[1]
+    for r, c in enumerate(ctxs):
+        lo, hi = D.shard_bounds(len(X), r, world)
+        m = D.ShardedSGPR(c, X[lo:hi], y[lo:hi], Z, len(X), reducer=lambda p, t=total: t)
+        assert abs(m.elbo(d, 0.01) - ref) <= 1e-10 * abs(ref)
