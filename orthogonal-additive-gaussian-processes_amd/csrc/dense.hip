@@ -22,15 +22,28 @@ constexpr int SY_LD = SY_T + 16;   // LDS row stride (doubles): k-group rows lan
 template <int SY_KB>
 __global__ void __launch_bounds__(256, 2)
 syrk_kernel(const double* __restrict__ P, int64_t ldp, int64_t nrows, int ntile, int nsplit, int64_t rows_per_split,
-            double* __restrict__ part, int64_t Mp, int accumulate) {
+            double* __restrict__ part, int64_t Mp, int accumulate, int xcd_map) {
     __shared__ __attribute__((aligned(16))) double As[SY_KB * SY_LD];
     __shared__ __attribute__((aligned(16))) double Bs[SY_KB * SY_LD];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    const int pair = blockIdx.x / nsplit;
-    const int split = blockIdx.x - pair * nsplit;
+    // XCD-aware decode: workgroup b runs on XCD b % 8 (observed dispatch rule; affects speed only).  XCD x owns the row
+    // splits [x*s, (x+1)*s), s = nsplit/8, and walks them in order, all tile pairs of one split before the next: the
+    // ~64 resident workgroups of an XCD therefore stream the SAME panel rows at the same time and each row chunk is
+    // fetched into that XCD's L2 once instead of once per tile pair (9x at M = 1024).
+    int pair, split;
+    if (xcd_map) {
+        const int npairs = ntile * (ntile + 1) / 2;
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        const int sl = j / npairs;
+        pair = j - sl * npairs;
+        split = xcd * (nsplit >> 3) + sl;
+    } else {
+        pair = blockIdx.x / nsplit;
+        split = blockIdx.x - pair * nsplit;
+    }
     int bi = 0, rem = pair;
     while (rem >= ntile - bi) { rem -= ntile - bi; ++bi; }
     const int bj = bi + rem;
@@ -110,27 +123,65 @@ syrk_kernel(const double* __restrict__ P, int64_t ldp, int64_t nrows, int ntile,
             }
 }
 
+// Fixed-order sum of the split partials.  Only tiles of the upper block triangle were written; each thread sums one
+// element of such a tile over the splits (coalesced reads) and stores it to (i, j) and to its mirror (j, i).
 __global__ void __launch_bounds__(256) syrk_reduce_kernel(const double* __restrict__ part, int nsplit, int64_t M, int64_t Mp,
-                                                          double* __restrict__ phi, int accumulate) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t i = blockIdx.y;
-    if (j >= M) return;
-    const bool upper = (i / SY_T) <= (j / SY_T);
-    const int64_t src = upper ? (i * Mp + j) : (j * Mp + i);
-    double s = 0.0;
-    for (int sp = 0; sp < nsplit; ++sp) s += part[(int64_t)sp * Mp * Mp + src];
-    if (accumulate) phi[i * M + j] += s; else phi[i * M + j] = s;
+                                                          int ntile, double* __restrict__ phi, int accumulate) {
+    int bi = 0, rem = blockIdx.y;
+    while (rem >= ntile - bi) { rem -= ntile - bi; ++bi; }
+    const int bj = bi + rem;
+    const int e = blockIdx.x * 256 + threadIdx.x;          // element within the 128 x 128 tile
+    const int64_t i = (int64_t)bi * SY_T + (e >> 7), j = (int64_t)bj * SY_T + (e & 127);
+    if (i >= M || j >= M) return;
+    const int64_t src = i * Mp + j;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int sp = 0;
+    for (; sp + 4 <= nsplit; sp += 4) {                      // four independent chains, combined in a fixed order
+        s0 += part[(int64_t)(sp + 0) * Mp * Mp + src];
+        s1 += part[(int64_t)(sp + 1) * Mp * Mp + src];
+        s2 += part[(int64_t)(sp + 2) * Mp * Mp + src];
+        s3 += part[(int64_t)(sp + 3) * Mp * Mp + src];
+    }
+    for (; sp < nsplit; ++sp) s0 += part[(int64_t)sp * Mp * Mp + src];
+    const double s = (s0 + s1) + (s2 + s3);
+    if (accumulate) {
+        phi[i * M + j] += s;
+        if (bi != bj) phi[j * M + i] += s;
+    } else {
+        phi[i * M + j] = s;
+        if (bi != bj) phi[j * M + i] = s;
+    }
 }
 
-int syrk_plan_splits(oak_ctx* ctx, int64_t M) {
+static bool syrk_xcd_mapping() {
+    const char* e = getenv("OAK_SYRK_XCD");
+    return !(e && atoi(e) == 0);
+}
+
+// Number of row splits.  XCD mode: 8*s splits, s per XCD, chosen so that s*npairs workgroups fill the XCD's resident slots
+// in (nearly) whole rounds while every workgroup still streams >= 2048 rows.
+int syrk_plan_splits(oak_ctx* ctx, int64_t M, int64_t nrows) {
     const int ntile = (int)((M + SY_T - 1) / SY_T);
     const int npairs = ntile * (ntile + 1) / 2;
     int per_cu = 2;
     if (const char* e = getenv("OAK_SYRK_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 4) per_cu = v; }
-    int nsplit = (ctx->num_cu * per_cu) / npairs;
-    if (nsplit < 1) nsplit = 1;
-    if (nsplit > 256) nsplit = 256;
-    return nsplit;
+    if (!syrk_xcd_mapping()) {
+        int nsplit = (ctx->num_cu * per_cu) / npairs;
+        if (nsplit < 1) nsplit = 1;
+        if (nsplit > 256) nsplit = 256;
+        return nsplit;
+    }
+    const int slots = (ctx->num_cu / 8) * per_cu;
+    int best_s = 1;
+    double best_eff = 0.0;
+    for (int sp = 1; sp <= 16; ++sp) {
+        if (sp > 1 && nrows / (8 * sp) < 2048) break;
+        const int total = sp * npairs;
+        const int rounds = (total + slots - 1) / slots;
+        const double eff = (double)total / ((double)rounds * slots);
+        if (eff > best_eff + 0.005) { best_eff = eff; best_s = sp; }
+    }
+    return 8 * best_s;
 }
 
 int syrk_panel(oak_ctx* ctx, const double* d_panel, int64_t ldp, int64_t nrows, int64_t M, double* d_part, int nsplit, bool accumulate) {
@@ -144,9 +195,10 @@ int syrk_panel(oak_ctx* ctx, const double* d_panel, int64_t ldp, int64_t nrows, 
     rps = ((rps + kb - 1) / kb) * kb;
     if (rps < kb) rps = kb;
     const unsigned grid = (unsigned)(npairs * nsplit);
-    if (kb == 8) syrk_kernel<8><<<grid, 256, 0, ctx->stream>>>(d_panel, ldp, nrows, ntile, nsplit, rps, d_part, Mp, accumulate ? 1 : 0);
-    else if (kb == 32) syrk_kernel<32><<<grid, 256, 0, ctx->stream>>>(d_panel, ldp, nrows, ntile, nsplit, rps, d_part, Mp, accumulate ? 1 : 0);
-    else syrk_kernel<16><<<grid, 256, 0, ctx->stream>>>(d_panel, ldp, nrows, ntile, nsplit, rps, d_part, Mp, accumulate ? 1 : 0);
+    const int xm = (syrk_xcd_mapping() && (nsplit % 8) == 0) ? 1 : 0;
+    if (kb == 8) syrk_kernel<8><<<grid, 256, 0, ctx->stream>>>(d_panel, ldp, nrows, ntile, nsplit, rps, d_part, Mp, accumulate ? 1 : 0, xm);
+    else if (kb == 32) syrk_kernel<32><<<grid, 256, 0, ctx->stream>>>(d_panel, ldp, nrows, ntile, nsplit, rps, d_part, Mp, accumulate ? 1 : 0, xm);
+    else syrk_kernel<16><<<grid, 256, 0, ctx->stream>>>(d_panel, ldp, nrows, ntile, nsplit, rps, d_part, Mp, accumulate ? 1 : 0, xm);
     OAK_HIP_CHECK(hipGetLastError());
     return OAK_OK;
 }
@@ -154,8 +206,8 @@ int syrk_panel(oak_ctx* ctx, const double* d_panel, int64_t ldp, int64_t nrows, 
 int syrk_reduce(oak_ctx* ctx, const double* d_part, int nsplit, int64_t M, double* d_phi, bool accumulate) {
     const int ntile = (int)((M + SY_T - 1) / SY_T);
     const int64_t Mp = (int64_t)ntile * SY_T;
-    dim3 grid((unsigned)((M + 255) / 256), (unsigned)M);
-    syrk_reduce_kernel<<<grid, 256, 0, ctx->stream>>>(d_part, nsplit, M, Mp, d_phi, accumulate ? 1 : 0);
+    dim3 grid((unsigned)(SY_T * SY_T / 256), (unsigned)(ntile * (ntile + 1) / 2));
+    syrk_reduce_kernel<<<grid, 256, 0, ctx->stream>>>(d_part, nsplit, M, Mp, ntile, d_phi, accumulate ? 1 : 0);
     OAK_HIP_CHECK(hipGetLastError());
     return OAK_OK;
 }

@@ -146,7 +146,7 @@ int gram_diag(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, double* d_o
 // dense linear algebra on the device (fp64) -------------------------------------------------------
 int syrk_panel(oak_ctx* ctx, const double* d_panel, int64_t ldp, int64_t nrows, int64_t M, double* d_part,
                int nsplit, bool accumulate);
-int syrk_plan_splits(oak_ctx* ctx, int64_t M);
+int syrk_plan_splits(oak_ctx* ctx, int64_t M, int64_t nrows);
 int syrk_reduce(oak_ctx* ctx, const double* d_part, int nsplit, int64_t M, double* d_phi /*[M*M]*/, bool accumulate);
 int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda);   // in place; strict upper zeroed
 // rows-trsm: each of the nrhs rows of BT (row stride ldb) is a right-hand side; solves L x = b (trans=0)

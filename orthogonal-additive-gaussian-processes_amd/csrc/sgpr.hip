@@ -97,7 +97,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     if (rows < 16) rows = 16;
     double* dPanel = nullptr;
     OAK_CHECK(get_buf_t(ctx, "panel", (size_t)rows * Mp, &dPanel));
-    const int nsplit = syrk_plan_splits(ctx, M);
+    const int nsplit = syrk_plan_splits(ctx, M, rows);
     double* dPart = nullptr;
     OAK_CHECK(get_buf_t(ctx, "syrk_part", (size_t)nsplit * Mp * Mp, &dPart));
     // Route: "phi" accumulates Phi = Kuf Kuf^T and whitens the M x M result in the tail (M^2 N flops; error grows with
