@@ -1,0 +1,91 @@
+"""GPU: BASELINE.json's full-size configuration (N = 1 048 576, D = 16, M = 1024, order 2) checked through
+size-independent properties, since the CPU oracle cannot finish that size in seconds:
+  * row-shard additivity of the sufficient statistics (the multi-GPU contract) and exact symmetry of Phi;
+  * bitwise determinism of repeated evaluations;
+  * the ELBO of a 1/16 row sample against the multi-core oracle at the full M (<= 1e-10);
+  * a directional finite difference of the HIP forward against the HIP analytic gradient;
+  * the explicit Gram panel against the oracle on sampled rows (<= 1e-12).
+"""
+import numpy as np
+import pytest
+
+from oak import _capi
+from oracle import c_oracle, oak_oracle as o
+
+pytestmark = pytest.mark.gpu
+N, D, M, R = 1 << 20, 16, 1024, 2
+
+
+@pytest.fixture(scope="module")
+def problem():
+    X, y, Z = o.synthetic_problem(N, D, M)
+    return X, y, Z, o.make_spec(D, R)
+
+
+def test_fullsize_statistics_additivity_symmetry_determinism(problem):
+    X, y, Z, spec = problem
+    ctx = _capi.HipContext(0)
+    d = _capi.KernelDesc(spec)
+    ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("phi")
+    ctx.sgpr_set_data(X, y)
+    ctx.sgpr_local_stats(d)
+    full = ctx.sgpr_get_stats()
+    e1 = ctx.sgpr_elbo(d, 0.01)
+    assert ctx.sgpr_elbo(d, 0.01) == e1                       # bitwise repeatable
+    Phi = full[:M * M].reshape(M, M)
+    np.testing.assert_array_equal(Phi, Phi.T)
+    assert full[-1] == N
+    acc = np.zeros_like(full)
+    cuts = [0, 300_001, 700_000, N]
+    for lo, hi in zip(cuts[:-1], cuts[1:]):
+        ctx.sgpr_set_data(X[lo:hi], y[lo:hi])
+        ctx.sgpr_local_stats(d)
+        acc += ctx.sgpr_get_stats()
+    np.testing.assert_allclose(acc, full, rtol=1e-12, atol=1e-12 * np.abs(full).max())
+    ctx.sgpr_set_stats(acc, False)
+    e2, terms = ctx.sgpr_tail(d, 0.01)
+    assert abs(e2 - e1) <= 1e-11 * abs(e1) and terms[5] == N
+    ctx.close()
+
+
+def test_fullsize_sample_against_multicore_oracle(problem):
+    X, y, Z, spec = problem
+    ns = N // 16
+    ref = c_oracle.sgpr_elbo_chunked(spec, X[:ns], y[:ns], Z, 0.01, chunk=16384)
+    ctx = _capi.HipContext(0)
+    d = _capi.KernelDesc(spec)
+    ctx.sgpr_set_data(X[:ns], y[:ns]); ctx.sgpr_set_inducing(Z)
+    for route in ("phi", "whitened"):
+        ctx.sgpr_set_route(route)
+        e = ctx.sgpr_elbo(d, 0.01)
+        assert abs(e - ref) <= 1e-10 * abs(ref), (route, e, ref)
+    # explicit Gram on sampled rows
+    rows = np.random.default_rng(0).choice(N, 2048, replace=False)
+    K = ctx.gram(d, X[rows], Z)
+    Kr = c_oracle.gram(spec, X[rows], Z)
+    assert np.abs(K - Kr).max() <= 1e-12 * np.abs(Kr).max()
+    ctx.close()
+
+
+def test_fullsize_gradient_directional_check(problem):
+    """<grad, v> from the analytic backward pass vs a central difference of the HIP forward along a random direction."""
+    import copy
+    X, y, Z, spec = problem
+    ctx = _capi.HipContext(0)
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("phi")
+    e, g = ctx.sgpr_elbo_grad(_capi.KernelDesc(spec), 0.01)
+    rng = np.random.default_rng(1)
+    v_ls, v_ov, v_n = rng.uniform(-1, 1, D), rng.uniform(-1, 1, R + 1), 0.01 * rng.uniform(-1, 1)
+
+    def forward(h):
+        s = copy.deepcopy(spec)
+        for i in range(D):
+            s["dims"][i]["lengthscale"] += h * v_ls[i]
+        s["order_variances"] = [s["order_variances"][r] + h * v_ov[r] for r in range(R + 1)]
+        return ctx.sgpr_elbo(_capi.KernelDesc(s), 0.01 + h * v_n)
+
+    h = 1e-5
+    fd = (forward(h) - forward(-h)) / (2 * h)
+    analytic = g[:D] @ v_ls + g[2 * D:2 * D + R + 1] @ v_ov + g[2 * D + R + 1] * v_n
+    np.testing.assert_allclose(analytic, fd, rtol=1e-5)
+    ctx.close()
