@@ -72,6 +72,8 @@ typedef struct oak_kernel_desc {
                                    factor (A - Ap Ap^T / p^T A p, ortho_categorical_kernel.py:34-42)
                                    followed by the C-vector p                                */
     int32_t meas_data_len;
+    int32_t grad_base_var;      /* gradient calls: also return d/d base_var (0 when the base variances are the
+                                   constants of share_var_across_orders=True, oak_kernel.py:163-166,179,187)  */
 } oak_kernel_desc;
 
 typedef struct oak_ctx oak_ctx;

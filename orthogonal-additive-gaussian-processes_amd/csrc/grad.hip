@@ -267,7 +267,7 @@ __device__ __forceinline__ void exp2_neg_tab4(const double (&t_in)[4], double (&
 // Fast path (1 <= R <= 4, D <= DMAX <= 16): one exp2 per pair per dimension.  Each lane walks its pairs one at a time,
 // keeps k_d and dk_d/dl_d of all dimensions in registers (vectorised 4 dimensions at a time for ILP), and accumulates the
 // per-dimension contractions in registers across the whole row range; one workgroup reduction at the very end.
-template <int R, int DMAX, bool ALLRBF>
+template <int R, int DMAX, bool ALLRBF, bool WANT_GK>
 __global__ void __launch_bounds__(256)
 gram_bwd_fast_kernel(const DevDesc dd, const GradDesc gd, const double* __restrict__ tables, int tablen,
                      const double* __restrict__ Axs, const double* __restrict__ Acn, const double* __restrict__ Adcn, int64_t a_ld,
@@ -276,6 +276,7 @@ gram_bwd_fast_kernel(const DevDesc dd, const GradDesc gd, const double* __restri
                      const double* __restrict__ yA, const double* __restrict__ avec, double g_scale, int rows_per_wg,
                      double* __restrict__ partial) {
     constexpr int CPT = 2, TJ = 64 * CPT, RT = 2, RS = 4 * RT;
+    constexpr int NGK = WANT_GK ? DMAX : 1;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int D = dd.D;
     double* Bx = smem;                  // [DMAX][TJ]
@@ -307,12 +308,15 @@ gram_bwd_fast_kernel(const DevDesc dd, const GradDesc gd, const double* __restri
     if (tid < 64) Tab[tid] = c_exp2_table_g[tid];
     if (tid < DMAX) Cst[tid] = (tid < D && dd.type[tid] == OAK_DIM_RBF) ? dd.log2bv[tid] : -1100.0;
     for (int idx = tid; idx < tablen; idx += 256) accT[idx] = 0.0;
-    double gl[DMAX], gk[DMAX], gw[R + 1];
+    double gl[DMAX], gk[NGK], gw[R + 1];
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) { gl[d] = 0.0; gk[d] = 0.0; }
+    for (int d = 0; d < DMAX; ++d) gl[d] = 0.0;
+#pragma unroll
+    for (int d = 0; d < NGK; ++d) gk[d] = 0.0;
 #pragma unroll
     for (int q = 0; q <= R; ++q) gw[q] = 0.0;
 
+    struct Chunk { double xa[4], xb[4], ca[4], cb[4], ad[4], bd[4], ct[4]; };
     for (int64_t i0 = ib; i0 < iend; i0 += RS) {
         __syncthreads();
         for (int idx = tid; idx < DMAX * RS; idx += 256) {
@@ -327,61 +331,69 @@ gram_bwd_fast_kernel(const DevDesc dd, const GradDesc gd, const double* __restri
         __syncthreads();
 #pragma unroll 1
         for (int pr = 0; pr < RT * CPT; ++pr) {      // one pair at a time: only one set of k[], dk[] is live
-            {
-                const int r = pr >> 1, c = pr & 1;
-                const int row = ty * RT + r, col = CPT * tx + c;
-                const int64_t gi = i0 + row, gj = jb + col;
-                double g = 0.0;
-                if (gi < iend && gj < nb) g = g_scale * G[gi * ldg + gj] + Ay[row] * Av[col];
-                double k[DMAX], dk[DMAX];
+            const int r = pr >> 1, c = pr & 1;
+            const int row = ty * RT + r, col = tx + 64 * c;       // lanes own adjacent columns: conflict-free LDS reads
+            const int64_t gi = i0 + row, gj = jb + col;
+            double g = 0.0;
+            if (gi < iend && gj < nb) g = g_scale * G[gi * ldg + gj] + Ay[row] * Av[col];
+            double k[DMAX], dk[DMAX];
+            auto fetch = [&](int d0, Chunk& ch) {
 #pragma unroll
-                for (int d0 = 0; d0 < DMAX; d0 += 4) {
-                    double t[4], u2[4], E[4], ca[4], cb[4], xa4[4], xb4[4];
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int d = d0 + v;
-                        xa4[v] = Ax[d * RS + row]; xb4[v] = Bx[d * TJ + col];
-                        ca[v] = Ac[d * RS + row]; cb[v] = Bc[d * TJ + col];
-                        const double u = xa4[v] - xb4[v];
-                        u2[v] = u * u;
-                        t[v] = Cst[d] - u2[v];              // log2(base variance); -1100 for the padding dims d >= D
-                    }
-                    exp2_neg_tab4(t, E, Tab);
-#pragma unroll
-                    for (int v = 0; v < 4; ++v) {
-                        const int d = d0 + v;
-                        double kv = __builtin_fma(-ca[v], cb[v], E[v]);
-                        double dv = __builtin_fma(E[v], u2[v], -__builtin_fma(Ad[d * RS + row], cb[v], ca[v] * Bd[d * TJ + col]));
-                        if constexpr (!ALLRBF) {
-                            if (d < D && dd.type[d] != OAK_DIM_RBF) { kv = tables[dd.tab_off[d] + (int)xa4[v] * dd.ncat[d] + (int)xb4[v]]; dv = 0.0; }
-                        }
-                        k[d] = kv; dk[d] = dv;
-                    }
+                for (int v = 0; v < 4; ++v) {
+                    const int d = d0 + v;
+                    ch.xa[v] = Ax[d * RS + row]; ch.ca[v] = Ac[d * RS + row]; ch.ad[v] = Ad[d * RS + row];
+                    ch.xb[v] = Bx[d * TJ + col]; ch.cb[v] = Bc[d * TJ + col]; ch.bd[v] = Bd[d * TJ + col];
+                    ch.ct[v] = Cst[d];
                 }
-                double e[R];
+            };
+            Chunk cur, nxt;
+            fetch(0, cur);
 #pragma unroll
-                for (int q = 0; q < R; ++q) e[q] = 0.0;
+            for (int d0 = 0; d0 < DMAX; d0 += 4) {
+                if (d0 + 4 < DMAX) fetch(d0 + 4, nxt);      // software prefetch of the next 4 dimensions' features
+                double t[4], u2[4], E[4];
 #pragma unroll
-                for (int d = 0; d < DMAX; ++d) {
-#pragma unroll
-                    for (int q = R - 1; q >= 1; --q) e[q] = __builtin_fma(k[d], e[q - 1], e[q]);
-                    e[0] += k[d];
+                for (int v = 0; v < 4; ++v) {
+                    const double u = cur.xa[v] - cur.xb[v];
+                    u2[v] = u * u;
+                    t[v] = cur.ct[v] - u2[v];               // log2(base variance) - u^2; -1100 for the padding dims d >= D
                 }
-                gw[0] += g;
+                exp2_neg_tab4(t, E, Tab);
 #pragma unroll
-                for (int q = 1; q <= R; ++q) gw[q] = __builtin_fma(g, e[q - 1], gw[q]);
-#pragma unroll
-                for (int d = 0; d < DMAX; ++d) {
-                    double f = 1.0, coef = dd.w[1];
-#pragma unroll
-                    for (int q = 1; q < R; ++q) { f = __builtin_fma(-k[d], f, e[q - 1]); coef = __builtin_fma(dd.w[q + 1], f, coef); }
-                    const double gc = g * coef;
-                    gl[d] = __builtin_fma(gc, dk[d], gl[d]);
-                    gk[d] = __builtin_fma(gc, k[d], gk[d]);
+                for (int v = 0; v < 4; ++v) {
+                    const int d = d0 + v;
+                    double kv = __builtin_fma(-cur.ca[v], cur.cb[v], E[v]);
+                    double dv = __builtin_fma(E[v], u2[v], -__builtin_fma(cur.ad[v], cur.cb[v], cur.ca[v] * cur.bd[v]));
                     if constexpr (!ALLRBF) {
-                        if (d < D && dd.type[d] == OAK_DIM_CATEGORICAL && gc != 0.0)
-                            atomicAdd(&accT[dd.tab_off[d] + (int)Ax[d * RS + row] * dd.ncat[d] + (int)Bx[d * TJ + col]], gc);
+                        if (d < D && dd.type[d] != OAK_DIM_RBF) { kv = tables[dd.tab_off[d] + (int)cur.xa[v] * dd.ncat[d] + (int)cur.xb[v]]; dv = 0.0; }
                     }
+                    k[d] = kv; dk[d] = dv;
+                }
+                if (d0 + 4 < DMAX) cur = nxt;
+            }
+            double e[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) e[q] = 0.0;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+#pragma unroll
+                for (int q = R - 1; q >= 1; --q) e[q] = __builtin_fma(k[d], e[q - 1], e[q]);
+                e[0] += k[d];
+            }
+            gw[0] += g;
+#pragma unroll
+            for (int q = 1; q <= R; ++q) gw[q] = __builtin_fma(g, e[q - 1], gw[q]);
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+                double f = 1.0, coef = dd.w[1];
+#pragma unroll
+                for (int q = 1; q < R; ++q) { f = __builtin_fma(-k[d], f, e[q - 1]); coef = __builtin_fma(dd.w[q + 1], f, coef); }
+                const double gc = g * coef;
+                gl[d] = __builtin_fma(gc, dk[d], gl[d]);
+                if constexpr (WANT_GK) gk[d] = __builtin_fma(gc, k[d], gk[d]);
+                if constexpr (!ALLRBF) {
+                    if (d < D && dd.type[d] == OAK_DIM_CATEGORICAL && gc != 0.0)
+                        atomicAdd(&accT[dd.tab_off[d] + (int)Ax[d * RS + row] * dd.ncat[d] + (int)Bx[d * TJ + col]], gc);
                 }
             }
         }
@@ -389,13 +401,15 @@ gram_bwd_fast_kernel(const DevDesc dd, const GradDesc gd, const double* __restri
     // workgroup reduction of the register accumulators
     constexpr int NACC = 2 * DMAX + R + 1;
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) { gl[d] = wave_sum(gl[d]); gk[d] = wave_sum(gk[d]); }
+    for (int d = 0; d < DMAX; ++d) gl[d] = wave_sum(gl[d]);
+#pragma unroll
+    for (int d = 0; d < NGK; ++d) gk[d] = wave_sum(gk[d]);
 #pragma unroll
     for (int q = 0; q <= R; ++q) gw[q] = wave_sum(gw[q]);
     __syncthreads();
     if (tx == 0) {
 #pragma unroll
-        for (int d = 0; d < DMAX; ++d) { red[ty * NACC + d] = gl[d]; red[ty * NACC + DMAX + d] = gk[d]; }
+        for (int d = 0; d < DMAX; ++d) { red[ty * NACC + d] = gl[d]; red[ty * NACC + DMAX + d] = WANT_GK ? gk[WANT_GK ? d : 0] : 0.0; }
 #pragma unroll
         for (int q = 0; q <= R; ++q) red[ty * NACC + 2 * DMAX + q] = gw[q];
     }
@@ -514,7 +528,7 @@ static int64_t record_len(const PreparedKernel& pk) { return 2 * pk.dd.D + (pk.d
 
 // d_rec[reclen] += contraction of G (na x nb block, + optional rank-1 yA avec^T) with dK/dtheta over pairs (A rows a0.., B)
 int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int64_t na, const Feat& B, const double* d_G,
-             int64_t ldg, double g_scale, const double* d_yA, const double* d_avec, double* d_rec) {
+             int64_t ldg, double g_scale, const double* d_yA, const double* d_avec, double* d_rec, bool want_gk = true) {
     if (na <= 0 || B.n <= 0) return OAK_OK;
     OAK_REQUIRE(A.dcn != nullptr && B.dcn != nullptr, "gram_bwd: features were not prepared for the backward pass");
     const int D = pk.dd.D, R = pk.dd.R;
@@ -551,10 +565,12 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
                                               B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part);                     \
     }
 #define OAK_BWD_FAST(RR, DM)                                                                                                      \
-    if (allrbf) gram_bwd_fast_kernel<RR, DM, true><<<grid, 256, lds, ctx->stream>>>(pk.dd, gd, pk.d_tables, tablen, A.xs, A.cn, A.dcn, \
-                        A.ld, a0, na, B.xs, B.cn, B.dcn, B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part);             \
-    else gram_bwd_fast_kernel<RR, DM, false><<<grid, 256, lds, ctx->stream>>>(pk.dd, gd, pk.d_tables, tablen, A.xs, A.cn, A.dcn,   \
-                        A.ld, a0, na, B.xs, B.cn, B.dcn, B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part);
+    if (allrbf && !want_gk) gram_bwd_fast_kernel<RR, DM, true, false><<<grid, 256, lds, ctx->stream>>>(pk.dd, gd, pk.d_tables, tablen, \
+                        A.xs, A.cn, A.dcn, A.ld, a0, na, B.xs, B.cn, B.dcn, B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part); \
+    else if (allrbf) gram_bwd_fast_kernel<RR, DM, true, true><<<grid, 256, lds, ctx->stream>>>(pk.dd, gd, pk.d_tables, tablen,        \
+                        A.xs, A.cn, A.dcn, A.ld, a0, na, B.xs, B.cn, B.dcn, B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part); \
+    else gram_bwd_fast_kernel<RR, DM, false, true><<<grid, 256, lds, ctx->stream>>>(pk.dd, gd, pk.d_tables, tablen,                    \
+                        A.xs, A.cn, A.dcn, A.ld, a0, na, B.xs, B.cn, B.dcn, B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part);
 #define OAK_BWD_CASE(RR) case RR: if (cpt == 2) OAK_BWD_LAUNCH(RR, 2) else OAK_BWD_LAUNCH(RR, 1) break;
     if (fast) {
         switch (R * 100 + dmax) {
@@ -760,14 +776,14 @@ int oak_sgpr_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_v
         }
         {
             PhaseTimer t(ctx, "bwd_gram");
-            OAK_CHECK(gram_bwd(ctx, pk, FX, a0, na, FZ, dG, Mp, 1.0 / s2, dY, d_as2, d_rec));
+            OAK_CHECK(gram_bwd(ctx, pk, FX, a0, na, FZ, dG, Mp, 1.0 / s2, dY, d_as2, d_rec, desc->grad_base_var != 0));
             t.stop();
         }
     }
     {
         PhaseTimer t(ctx, "bwd_small");
         // <G_uu, dKuu> is replicated on every rank; each contributes 1/nranks so the all-reduce below restores it once
-        OAK_CHECK(gram_bwd(ctx, pk, FZ, 0, M, FZ, dGuu, M, 1.0 / (double)(ctx->comm ? ctx->nranks : 1), nullptr, nullptr, d_rec));
+        OAK_CHECK(gram_bwd(ctx, pk, FZ, 0, M, FZ, dGuu, M, 1.0 / (double)(ctx->comm ? ctx->nranks : 1), nullptr, nullptr, d_rec, desc->grad_base_var != 0));
         OAK_CHECK(diag_bwd(ctx, pk, FX, -0.5 / s2, d_rec));                                      // -1/(2 s2) sum dKdiag
         t.stop();
     }

@@ -42,7 +42,7 @@ class KernelDescStruct(C.Structure):
         ("base_var", C.POINTER(C.c_double)), ("measure", C.POINTER(C.c_int32)),
         ("meas_p0", C.POINTER(C.c_double)), ("meas_p1", C.POINTER(C.c_double)),
         ("meas_k", C.POINTER(C.c_int32)), ("meas_off", C.POINTER(C.c_int32)),
-        ("meas_data", C.POINTER(C.c_double)), ("meas_data_len", C.c_int32),
+        ("meas_data", C.POINTER(C.c_double)), ("meas_data_len", C.c_int32), ("grad_base_var", C.c_int32),
     ]
 
 
@@ -247,6 +247,7 @@ class KernelDesc:
         s.meas_off = _ip(self.meas_off)
         s.meas_data = _dp(self.meas_data)
         s.meas_data_len = int(off)
+        s.grad_base_var = int(bool(spec.get("base_var_grad", not share)))
         self.struct = s
         self.D, self.R, self.share = D, R, share
         self.min_cols = int(self.active_col.max()) + 1

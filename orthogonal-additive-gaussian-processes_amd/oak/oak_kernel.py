@@ -53,7 +53,7 @@ def kernel_to_spec(kernel) -> dict:
         if isinstance(kernel, gpflow.RBF) and not isinstance(kernel.active_dims, slice) and len(kernel.active_dims) != 1:
             raise NotImplementedError("multi-column stand-alone RBF inside a model is not on the OAK path")
         return dict(dims=[_sub_kernel_spec(kernel, _first_col(kernel))], order_variances=[0.0, 1.0],
-                    max_interaction_depth=1, share_var_across_orders=True)
+                    max_interaction_depth=1, share_var_across_orders=True, base_var_grad=True)
     raise NotImplementedError(f"kernel {type(kernel).__name__} is not supported by the HIP path")
 
 
