@@ -34,23 +34,34 @@ CONFIGS = {
     "c2": dict(N=65536, D=8, M=512, R=2),
     "c3": dict(N=1 << 20, D=16, M=1024, R=3),
     "tiny": dict(N=8192, D=4, M=128, R=2),
+    # BASELINE.json configs[4] in fp64 (the reference is fp64-only): 20 continuous + 8 binary + 4 categorical (C=5) inputs
+    "c5": dict(N=262144, D=32, M=2048, R=4, mixed=True),
 }
 FP64_PEAK_TFLOPS = 78.6       # MI355X fp64 vector == matrix peak; measured ceiling 61-68 TF/s (tools/ubench)
 HBM_PEAK_GBPS = 8000.0
 
 
-def synthetic(N, D, M, seed=20240601):
-    """BASELINE.md section 3 synthetic inputs."""
+def synthetic(N, D, M, seed=20240601, mixed=False):
+    """BASELINE.md section 3 synthetic inputs (mixed: 20 continuous, 8 Bernoulli(0.3), 4 categorical C=5)."""
     rng = np.random.default_rng(seed)
     X = rng.standard_normal((N, D))
+    if mixed:
+        X[:, 20:28] = rng.random((N, 8)) < 0.3
+        X[:, 28:32] = rng.choice(5, size=(N, 4), p=[.1, .15, .2, .25, .3])
     eps = rng.standard_normal(N)
     y = np.sum(np.sin(X), axis=1) + 0.5 * X[:, 0] * X[:, 1 % D] + 0.1 * eps
     y = (y - y.mean()) / y.std()
     return X, y.reshape(-1, 1), X[:M].copy()
 
 
-def make_spec(D, R):
+def make_spec(D, R, mixed=False):
     dims = [dict(type="rbf", lengthscale=1.0, variance=1.0, measure=("gaussian", 0.0, 1.0)) for _ in range(D)]
+    if mixed:
+        W = np.random.default_rng(7).uniform(size=(5, 2))
+        for d in range(20, 28):
+            dims[d] = dict(type="binary", p0=0.7, variance=1.0)
+        for d in range(28, 32):
+            dims[d] = dict(type="categorical", p=np.array([.1, .15, .2, .25, .3]).reshape(-1, 1), W=W, kappa=np.ones(5), variance=1.0)
     return dict(dims=dims, order_variances=[1.0] * (R + 1), max_interaction_depth=R, share_var_across_orders=True)
 
 
@@ -90,7 +101,7 @@ def main():
     cfg = CONFIGS[args.config]
     N, D, M, R = cfg["N"], cfg["D"], cfg["M"], cfg["R"]
     noise, jitter = 0.01, 1e-6
-    X, y, Z = synthetic(N, D, M)
+    X, y, Z = synthetic(N, D, M, mixed=cfg.get("mixed", False))
     # strong scaling: the SAME N rows are sharded over the ranks in contiguous blocks
     lo, hi = (N * rank) // world, (N * (rank + 1)) // world
     Xl, yl = np.ascontiguousarray(X[lo:hi]), np.ascontiguousarray(y[lo:hi])
@@ -104,7 +115,7 @@ def main():
         dist.broadcast_object_list(ids, src=0)
         ctx.comm_init(ids[0], world, rank)
 
-    spec = make_spec(D, R)
+    spec = make_spec(D, R, mixed=cfg.get("mixed", False))
 
     def step():
         desc = _capi.KernelDesc(spec)      # hyper-parameters change every optimiser iteration: re-described per step

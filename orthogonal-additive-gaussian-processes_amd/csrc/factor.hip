@@ -3,8 +3,9 @@
 //
 // The tail is latency-bound at M <= 2048, so the design goal is few, wide launches:
 //   * gemm_mfma  : C = beta*C + alpha*A*op(B), 64x64 tiles, v_mfma_f64_16x16x4, LDS pitches chosen conflict-free.
-//   * potrf_lower: right-looking, NB = 32.  The 32x32 diagonal block is factored by ONE wave with its rows in
-//                  registers (v_readlane broadcasts, no barriers); panel rows are solved one per lane.
+//   * potrf_lower: right-looking, NB = 32.  The diagonal block is factored by ONE wave (lane = row, rows in
+//                  registers, finished entries mirrored to LDS for broadcast reads, no barriers); panel rows are
+//                  solved one per lane.  Every launch costs >= 5 us on this system, so the tail is launch-count bound.
 //   * trsm_rows  : NB = 128 blocked: small in-LDS leaf solves + MFMA GEMM updates.
 #include "oak_internal.h"
 
@@ -24,7 +25,7 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 //                            BT = 0: C[m x n] = beta*C + alpha * A[m x k] * B[k x n]
 // lower_only: skip 64x64 tiles strictly above the diagonal (symmetric rank-k updates).
 // ---------------------------------------------------------------------------------------------
-constexpr int GM_T = 64, GM_K = 16, GM_PA = GM_K + 2, GM_PB = GM_T + 16;
+constexpr int GM_T = 64, GM_K = 32, GM_PA = GM_K + 2, GM_PB = GM_T + 16;
 
 template <int BT>
 __global__ void __launch_bounds__(256) gemm_mfma_kernel(const double* __restrict__ A, const double* __restrict__ B,
@@ -43,15 +44,16 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(const double* __restrict
     for (int g = 0; g < 2; ++g)
 #pragma unroll
         for (int h = 0; h < 2; ++h) acc[g][h] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    // staging coordinates
-    const int ar = tid >> 2, ak = (tid & 3) * 4;             // A (and B when BT): row 0..63, k offset 0,4,8,12
-    const int bk = tid >> 4, bn = (tid & 15) * 4;            // B when !BT: k row 0..15, n offset 0..60
+    // staging coordinates: 64 rows x 32 k per tile, 8 doubles per thread
+    const int ar = tid >> 2, ak = (tid & 3) * 8;             // A (and B when BT): row 0..63, k offset 0,8,16,24
+    const int bk = tid >> 3, bn = (tid & 7) * 8;             // B when !BT: k row 0..31, n offset 0..56
     const int64_t arow = (r0 + ar < m) ? r0 + ar : m - 1;
     const int64_t brow = BT ? ((c0 + ar < n) ? c0 + ar : n - 1) : 0;
-    for (int64_t k0 = 0; k0 < k; k0 += GM_K) {
-        double va[4], vb[4];
+    double va[8], vb[8];
+    // branch-free (clamped) loads so that all 16 stay in flight; values outside the matrix are zeroed by selects
+    auto load_stage = [&](int64_t k0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 8; ++q) {
             const int64_t kk = k0 + ak + q;
             const int64_t kc = kk < k ? kk : k - 1;
             const double x = A[arow * lda + kc];
@@ -65,14 +67,18 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(const double* __restrict
                 vb[q] = (kr < k && nc < n) ? y : 0.0;
             }
         }
+    };
+    load_stage(0);
+    for (int64_t k0 = 0; k0 < k; k0 += GM_K) {
         __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < 8; ++q) {
             As[ar * GM_PA + ak + q] = va[q];
             if (BT) Bs[ar * GM_PA + ak + q] = vb[q];
             else Bs[bk * GM_PB + bn + q] = vb[q];
         }
         __syncthreads();
+        if (k0 + GM_K < k) load_stage(k0 + GM_K);            // register prefetch of the next K chunk under the MFMAs
 #pragma unroll
         for (int ks = 0; ks < GM_K / 4; ++ks) {
             double a[2], b[2];
@@ -219,63 +225,82 @@ int gemm_nt(oak_ctx* ctx, const double* dA, const double* dB, double* dC, int64_
 }
 
 // ---------------------------------------------------------------------------------------------
-// Cholesky (lower), right-looking, NB = 32
+// Cholesky (lower), right-looking
 // ---------------------------------------------------------------------------------------------
-constexpr int PO_NB = 32;
+constexpr int PO_NB = 32;          // panel width (32 and 64 measure the same end-to-end: fewer launches vs a slower one-wave factorisation)
 
-// One wave factors the 32x32 block held in LDS (row i in lane i's registers); lanes >= 32 idle.
-__device__ __forceinline__ void potf2_32_wave(double* Dg /*[32][33]*/, int lane, int64_t j0, int* info) {
-    const int i = lane & 31;
+// 1/sqrt(d) to full fp64 accuracy: hardware estimate + two Newton steps (cheaper than sqrt followed by a divide)
+__device__ __forceinline__ double rsqrt_newton(double d) {
+    double y = __builtin_amdgcn_rsq(d);
+    y = y * __builtin_fma(-0.5 * d * y, y, 1.5);
+    y = y * __builtin_fma(-0.5 * d * y, y, 1.5);
+    return y;
+}
+
+constexpr int PO_P = PO_NB + 2;    // LDS pitch of the diagonal block (even: 16-byte aligned row starts)
+
+// One wave factors the NB x NB diagonal block (Cholesky-Crout, column by column).  Lane i owns row i in registers and
+// mirrors each finished entry into LDS, so row j is available to every lane as broadcast ds_read_b128s: no barriers,
+// no cross-lane register traffic except one v_readlane of the pivot per column.  invd[j] = 1 / L_jj is kept for the
+// panel solve.  Two partial sums halve the dependent FMA chain of each column.
+__device__ __forceinline__ void potf2_wave(double* Dg /*[NB][PO_P]*/, double* invd /*[NB]*/, int lane, int64_t j0, int* info) {
+    const int i = lane % PO_NB;                 // with NB = 32 lanes 32..63 shadow lanes 0..31 and write nothing
+    const bool writer = lane < PO_NB;
     double a[PO_NB];
 #pragma unroll
-    for (int c = 0; c < PO_NB; ++c) a[c] = Dg[i * (PO_NB + 1) + c];
-    bool bad = false;
-    int bad_at = 0;
+    for (int c = 0; c < PO_NB; ++c) a[c] = Dg[i * PO_P + c];
+    int bad_at = -1;
 #pragma unroll
-    for (int k = 0; k < PO_NB; ++k) {
-        const double akk = readlane_f64(a[k], k);
-        if (!(akk > 0.0) && !bad) { bad = true; bad_at = k; }
-        const double s = sqrt(akk);
-        const double lik = (i == k) ? s : a[k] / s;
-        if (i >= k) a[k] = lik;
+    for (int j = 0; j < PO_NB; ++j) {
+        double s0 = a[j], s1 = 0.0;
 #pragma unroll
-        for (int j = k + 1; j < PO_NB; ++j) {
-            const double ljk = readlane_f64(a[k], j);
-            if (i >= j) a[j] = __builtin_fma(-a[k], ljk, a[j]);
+        for (int k = 0; k + 1 < j; k += 2) {
+            const double2 l2 = *reinterpret_cast<const double2*>(&Dg[j * PO_P + k]);
+            s0 = __builtin_fma(-a[k], l2.x, s0);
+            s1 = __builtin_fma(-a[k + 1], l2.y, s1);
         }
+        if (j & 1) s0 = __builtin_fma(-a[j - 1], Dg[j * PO_P + j - 1], s0);
+        const double s = s0 + s1;
+        const double d = readlane_f64(s, j);
+        if (!(d > 0.0) && bad_at < 0) bad_at = j;
+        const double r = rsqrt_newton(d);
+        a[j] = (i == j) ? d * r : s * r;
+        if (writer && i >= j) Dg[i * PO_P + j] = a[j];
+        if (lane == j) invd[j] = r;
     }
-    if (lane < PO_NB) {
 #pragma unroll
-        for (int c = 0; c < PO_NB; ++c) Dg[i * (PO_NB + 1) + c] = (c <= i) ? a[c] : 0.0;
-    }
-    if (bad && lane == 0 && info != nullptr) atomicMin(info, (int)(j0 + bad_at + 1));
+    for (int c = 0; c < PO_NB; ++c)
+        if (writer && c > i) Dg[i * PO_P + c] = 0.0;
+    if (bad_at >= 0 && lane == 0 && info != nullptr) atomicMin(info, (int)(j0 + bad_at + 1));
 }
 
 __global__ void __launch_bounds__(256) potrf_panel_kernel(double* __restrict__ A, int64_t n, int64_t lda, int64_t j0, int* __restrict__ info) {
-    __shared__ double Dg[PO_NB * (PO_NB + 1)];
+    __shared__ __attribute__((aligned(16))) double Dg[PO_NB * PO_P];
+    __shared__ double invd[PO_NB];
     const int tid = threadIdx.x;
     const int nb = (n - j0 < PO_NB) ? (int)(n - j0) : PO_NB;
     {
-        // 1024 entries, 4 per thread, clamped addresses (no divergent loads); identity padding beyond nb
-        double v[4];
+        // NB*NB entries, clamped addresses (no divergent loads); identity padding beyond nb
+        constexpr int PER = PO_NB * PO_NB / 256;
+        double v[PER];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
+        for (int q = 0; q < PER; ++q) {
             const int idx = tid + 256 * q;
-            const int i = idx >> 5, j = idx & 31;
+            const int i = idx / PO_NB, j = idx % PO_NB;
             const int ic = i < nb ? i : nb - 1, jc = j < nb ? j : nb - 1;
             const double x = A[(j0 + ic) * lda + j0 + jc];
             v[q] = (i < nb && j < nb) ? ((j <= i) ? x : 0.0) : ((i == j) ? 1.0 : 0.0);
         }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { const int idx = tid + 256 * q; Dg[(idx >> 5) * (PO_NB + 1) + (idx & 31)] = v[q]; }
+        for (int q = 0; q < PER; ++q) { const int idx = tid + 256 * q; Dg[(idx / PO_NB) * PO_P + (idx % PO_NB)] = v[q]; }
     }
     __syncthreads();
-    if (tid < 64) potf2_32_wave(Dg, tid, j0, blockIdx.x == 0 ? info : nullptr);
+    if (tid < 64) potf2_wave(Dg, invd, tid, j0, blockIdx.x == 0 ? info : nullptr);
     __syncthreads();
     if (blockIdx.x == 0) {
         for (int idx = tid; idx < nb * nb; idx += 256) {
             const int i = idx / nb, j = idx - i * nb;
-            A[(j0 + i) * lda + j0 + j] = Dg[i * (PO_NB + 1) + j];
+            A[(j0 + i) * lda + j0 + j] = Dg[i * PO_P + j];
         }
     }
     // rows below the diagonal block: X * L_jj^T = A_panel, one row per lane
@@ -287,10 +312,15 @@ __global__ void __launch_bounds__(256) potrf_panel_kernel(double* __restrict__ A
         for (int c = 0; c < PO_NB; ++c) x[c] = ap[c];
 #pragma unroll
         for (int c = 0; c < PO_NB; ++c) {
-            double s = x[c];
+            double s0 = x[c], s1 = 0.0;
 #pragma unroll
-            for (int p = 0; p < c; ++p) s = __builtin_fma(-x[p], Dg[c * (PO_NB + 1) + p], s);
-            x[c] = s / Dg[c * (PO_NB + 1) + c];
+            for (int p = 0; p + 1 < c; p += 2) {
+                const double2 l2 = *reinterpret_cast<const double2*>(&Dg[c * PO_P + p]);
+                s0 = __builtin_fma(-x[p], l2.x, s0);
+                s1 = __builtin_fma(-x[p + 1], l2.y, s1);
+            }
+            if (c & 1) s0 = __builtin_fma(-x[c - 1], Dg[c * PO_P + c - 1], s0);
+            x[c] = (s0 + s1) * invd[c];
         }
 #pragma unroll
         for (int c = 0; c < PO_NB; ++c) ap[c] = x[c];
@@ -379,9 +409,10 @@ __global__ void __launch_bounds__(256) trsm_leaf_kernel(const double* __restrict
             load_block(jb, jb);
             __syncthreads();
             double x = 0.0;
+            const double inv = 1.0 / Lt[i * 33 + i];        // one division per lane per block; pivots are scaled by it
 #pragma unroll
             for (int p = 0; p < 32; ++p) {
-                const double xp = __shfl(s, p, 32) / Lt[p * 33 + p];
+                const double xp = __shfl(s * inv, p, 32);
                 if (i == p) x = xp;
                 if (i > p) s = __builtin_fma(-Lt[i * 33 + p], xp, s);
             }
@@ -403,9 +434,10 @@ __global__ void __launch_bounds__(256) trsm_leaf_kernel(const double* __restrict
             load_block(jb, jb);
             __syncthreads();
             double x = 0.0;
+            const double inv = 1.0 / Lt[i * 33 + i];
 #pragma unroll
             for (int p = 31; p >= 0; --p) {
-                const double xp = __shfl(s, p, 32) / Lt[p * 33 + p];
+                const double xp = __shfl(s * inv, p, 32);
                 if (i == p) x = xp;
                 if (i < p) s = __builtin_fma(-Lt[p * 33 + i], xp, s);
             }
