@@ -88,6 +88,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as plain `python bench.py --gpus N`: run the one-process-per-GPU job as a child (nothing has touched the
+        # GPU yet in this process) and exit with its status
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29531"), str(Path(__file__).resolve())] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     dist = None
     if world > 1:

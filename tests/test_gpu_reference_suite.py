@@ -312,3 +312,80 @@ def test_initialize_kmeans_with_binary():
     X[:, 1] = np.random.normal(0, 4, 100)
     Z = initialize_kmeans_with_binary(X, [0, 2], [1], 50)
     assert Z.shape == (50, 3) and isinstance(Z, np.ndarray)
+
+
+@pytest.mark.parametrize("num_dims", (2, 7))
+@pytest.mark.parametrize("zfixed", (True, False))
+@pytest.mark.parametrize("share_var_across_orders", (True, False))
+def test_sobol_indices(num_dims, zfixed, concrete_normalised_10_rows_data, share_var_across_orders):
+    """tests/test_sobol_oak_kernel.py:204-243."""
+    X, y = concrete_normalised_10_rows_data
+    sgpr = create_model_oak((X, y), max_interaction_depth=2, constrain_orthogonal=True, inducing_pts=X[:3, :], optimise=False, zfixed=zfixed)
+    _, sobol = compute_sobol_oak(sgpr, 1, 0, share_var_across_orders=share_var_across_orders)
+    assert np.all(np.array(sobol) > 0)
+
+
+@pytest.mark.parametrize("is_sgpr", (False, True))
+@pytest.mark.parametrize("both_binary", (False, True))
+def test_compute_sobol_with_binary(is_sgpr, both_binary):
+    """tests/test_sobol_oak_kernel.py:246-365: closed-form Sobol indices with binary inputs (1 decimal)."""
+    delta, N, p1, p2 = 1, 200, 0.5, 0.9
+    np.random.seed(42)
+    X1 = np.reshape(np.random.binomial(1, p1, N), (N, 1))
+    X2 = np.reshape(np.random.binomial(1, p2, N), (N, 1)) if both_binary else np.reshape(np.random.normal(0, 1, N), (N, 1))
+    X_train = np.concatenate((X1, X2), 1).astype("float64")
+    Y_train = np.reshape(X_train[:, 0] + X_train[:, 1] + X_train[:, 0] * X_train[:, 1] + np.random.normal(0, 0.1, N), (-1, 1))
+    Y_train = Y_train - Y_train.mean()
+    # The reference draws Z from initialize_kmeans_with_binary(n_clusters=100); with the scikit-learn of this image k-means on
+    # a two-valued column returns 100 centres that all truncate to 0, which makes the sparse model blind to the binary input
+    # (the CPU oracle reproduces the same degenerate Sobol values).  The first 100 training rows are used instead.
+    Z = X_train[:100].copy() if is_sgpr else None
+    p0 = [1 - p1, 1 - p2] if both_binary else [1 - p1, None]
+    model = create_model_oak((X_train, Y_train), inducing_pts=Z, optimise=False, zfixed=True, p0=p0)
+    if not both_binary:
+        model.kernel.kernels[1].base_kernel.lengthscales.assign(9.20)
+    model_indices, sobol = compute_sobol_oak(model, delta, 0)
+    assert model_indices == [[0], [1], [0, 1]] and np.all(np.array(sobol) >= 0)
+    if both_binary:
+        s1, s2 = (1 + p2) ** 2 * p1 * (1 - p1), (1 + p1) ** 2 * p2 * (1 - p2)
+        tot = p1 - p1 ** 2 + p2 - p2 ** 2 + 5 * p1 * p2 - p1 ** 2 * p2 ** 2 - 2 * p1 ** 2 * p2 - 2 * p1 * p2 ** 2
+        expect = [s1, s2, tot - s1 - s2]
+    else:
+        s1, s2 = p1 * (1 - p1), delta * (1 + p1) ** 2
+        expect = [s1, s2, delta + p1 * (1 - p1) + 3 * p1 * delta - s1 - s2]
+    np.testing.assert_array_almost_equal(sobol, np.array(expect, dtype=float), decimal=1)
+
+
+@pytest.mark.parametrize("empirical_measure", [[0], [0, 1]])
+@pytest.mark.parametrize("share_var_across_orders", [True, False])
+def test_sobol_oak_kernel_empirical(empirical_measure, share_var_across_orders):
+    """tests/test_sobol_oak_kernel.py:158-201: with empirical measures the normalised Sobol indices equal the normalised sample
+    variances of the per-term predictions (1 decimal)."""
+    np.random.seed(44)
+    X = np.random.normal(0, 1, (100, 2))
+    y = np.reshape(X[:, 0] ** 2 + X[:, 1] * 2 + X[:, 0] * X[:, 1], (-1, 1))
+    oak = oak_model(max_interaction_depth=2, num_inducing=50, sparse=True, empirical_measure=empirical_measure,
+                    share_var_across_orders=share_var_across_orders)
+    oak.fit(X, y, optimise=False)
+    oak.m.kernel.kernels[0].base_kernel.lengthscales.assign(2)
+    oak.m.kernel.kernels[1].base_kernel.lengthscales.assign(5)
+    if share_var_across_orders:
+        for i, v in enumerate((1e-3, 90, 15)):
+            oak.m.kernel.variances[i].assign(v)
+    oak.get_sobol()
+    alpha = get_model_sufficient_statistics(oak.m, get_L=False)
+    comps = get_prediction_component(oak.m, alpha, oak._transform_x(X), share_var_across_orders=share_var_across_orders)
+    var_samples = np.array([np.var(c.numpy()) for c in comps[:3]])
+    np.testing.assert_array_almost_equal(var_samples / var_samples.sum(), oak.normalised_sobols, decimal=1)
+
+
+def test_oak_gmm_applied_without_flows(binary_5D_data):
+    """tests/test_oak_model.py:241-255."""
+    np.random.seed(44)
+    X, Y = binary_5D_data
+    X[:, :-1] = X[:, :-1] + np.random.normal(0, 1, (X.shape[0], 4))
+    oak = oak_model(gmm_measure=[0, 0, 0, 0, 2])
+    oak.fit(X, Y, optimise=False)
+    assert oak.estimated_gmm_measures[:-1] == [None] * 4 and isinstance(oak.estimated_gmm_measures[-1], MOGMeasure)
+    assert np.allclose(np.sort(oak.estimated_gmm_measures[-1].means), np.array([0, 1.0]))
+    assert oak.input_flows[-1] is None and sum(f is not None for f in oak.input_flows[:-1]) == 4
