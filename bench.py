@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--config", default="headline", choices=sorted(CONFIGS))
     ap.add_argument("--grad", action="store_true", help="time forward + analytic gradient instead of forward only")
     ap.add_argument("--route", default="phi", choices=["phi", "whitened"])
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "host"],
+                    help="N>1: 'rccl' = reduce-scatter + all-gather over xGMI inside liboak_hip (default); 'host' = debug path that "
+                         "sums the packed statistics through the gloo control plane (lets several ranks share one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=131072)
     args = ap.parse_args()
@@ -113,11 +116,12 @@ def main():
     lo, hi = (N * rank) // world, (N * (rank + 1)) // world
     Xl, yl = np.ascontiguousarray(X[lo:hi]), np.ascontiguousarray(y[lo:hi])
 
-    ctx = _capi.HipContext(local_rank)
+    ctx = _capi.HipContext(int(os.environ.get("OAK_BENCH_DEVICE", local_rank)))
     ctx.sgpr_set_data(Xl, yl)
     ctx.sgpr_set_inducing(Z)
     ctx.sgpr_set_route(args.route)
-    if world > 1:
+    host_exchange = world > 1 and args.exchange == "host"
+    if world > 1 and not host_exchange:
         ids = [_capi.HipContext.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         ctx.comm_init(ids[0], world, rank)
@@ -126,7 +130,14 @@ def main():
 
     def step():
         desc = _capi.KernelDesc(spec)      # hyper-parameters change every optimiser iteration: re-described per step
-        if args.grad:
+        if host_exchange:                  # debug path: same arithmetic, the all-reduce goes through the host
+            import torch
+            ctx.sgpr_local_stats(desc, jitter)
+            t = torch.from_numpy(ctx.sgpr_get_stats())
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            ctx.sgpr_set_stats(t.numpy(), False)
+            elbo, _ = ctx.sgpr_tail(desc, noise, jitter)
+        elif args.grad:
             elbo, g = ctx.sgpr_elbo_grad(desc, noise, jitter)
         else:
             elbo = ctx.sgpr_elbo(desc, noise, jitter)
@@ -160,7 +171,7 @@ def main():
 
     # ---- secondary measurement: forward + analytic gradient (what one BFGS iteration of the reference computes) ----
     grad_info = None
-    if not args.grad:
+    if not args.grad and not host_exchange:
         def grad_step():
             desc = _capi.KernelDesc(spec)
             elbo, g = ctx.sgpr_elbo_grad(desc, noise, jitter)
