@@ -85,8 +85,9 @@ int oak_device_count(int* count);
 int oak_ctx_create(int device, oak_ctx** out);
 int oak_ctx_destroy(oak_ctx* ctx);
 int oak_sync(oak_ctx* ctx);
-/* wall time (ms) of the last named phase measured with hipEvents on the ctx stream:
-   name in {"gram","syrk","tail","featurize","total","bwd_gemm","bwd_gram"}; count = launches */
+/* GPU time (ms, hipEvents on the ctx stream) accumulated per phase since oak_reset_timings; name in {"featurize","gram",
+   "trsm","syrk","reduce","allreduce","tail","total","bwd_tail","bwd_gemm","bwd_gram","bwd_small"}; count = number of
+   times the phase ran ("gram","syrk","bwd_gemm","bwd_gram" are single kernel launches per panel pass). */
 int oak_last_timing(oak_ctx* ctx, const char* name, double* ms, int32_t* count);
 int oak_reset_timings(oak_ctx* ctx);
 int oak_device_mem_info(oak_ctx* ctx, double* free_bytes, double* total_bytes);

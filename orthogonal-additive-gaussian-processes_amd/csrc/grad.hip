@@ -4,6 +4,8 @@
 //   F(Kuu, Phi, psi, kappa, s2) -> G_uu = dF/dKuu, H/(2 s2) = dF/dPhi, a/s2 = dF/dpsi, -1/(2 s2) = dF/dkappa, dF/ds2,
 //   Gfu = dF/dKfu = Kfu H / s2 + y a^T / s2                                  (one N x M x M GEMM, fp64 MFMA)
 //   dF/dtheta = <Gfu, dKfu/dtheta> + <G_uu, dKuu/dtheta> - 1/(2 s2) sum_n dKdiag_n/dtheta   (fused pair kernels below)
+// Lengthscale derivatives are formed in units of 2 ln2 / l_d (featurize pre-divides dcn by it; scatter_record multiplies
+// the finished sum back), so the pair kernels need no per-dimension derivative constant.
 // The pair kernel recomputes each base-kernel value and contracts G with dK/dk_d * dk_d/dtheta, where
 // dK/dk_d = sum_r w_r e_{r-1}^{(-d)} uses leave-one-out elementary symmetric polynomials (e^{(-d)}_q = e_q - k_d e^{(-d)}_{q-1}).
 #include "oak_internal.h"
@@ -50,10 +52,6 @@ __device__ __forceinline__ double exp2_neg_tab(double t, const double* __restric
     return __hiloint2double(hi, __double2loint(tv)) * p;
 }
 
-struct GradDesc {   // per-dim constants of the derivative formulas
-    double dE_scale[OAK_MAX_DIMS];   // 2 ln2 / lengthscale : dE/dl = E * (xs_a - xs_b)^2 * dE_scale
-};
-
 __device__ __forceinline__ double wave_sum(double v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
@@ -64,7 +62,7 @@ __device__ __forceinline__ double wave_sum(double v) {
 //   gw[r] = sum G e_r ; gtab[off + ia*C + ib] = sum G dK/dk_d  over pairs with categories (ia, ib)  (x base_var later)
 template <int R, int CPT>
 __global__ void __launch_bounds__(256)
-gram_bwd_kernel(const DevDesc dd, const GradDesc gd, const double* __restrict__ tables, int tablen,
+gram_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
                 const double* __restrict__ Axs, const double* __restrict__ Acn, const double* __restrict__ Adcn, int64_t a_ld,
                 int64_t a0, int64_t na, const double* __restrict__ Bxs, const double* __restrict__ Bcn,
                 const double* __restrict__ Bdcn, int64_t b_ld, int64_t nb, const double* __restrict__ G, int64_t ldg,
@@ -269,7 +267,7 @@ __device__ __forceinline__ void exp2_neg_tab4(const double (&t_in)[4], double (&
 // per-dimension contractions in registers across the whole row range; one workgroup reduction at the very end.
 template <int R, int DMAX, bool ALLRBF, bool WANT_GK>
 __global__ void __launch_bounds__(256)
-gram_bwd_fast_kernel(const DevDesc dd, const GradDesc gd, const double* __restrict__ tables, int tablen,
+gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
                      const double* __restrict__ Axs, const double* __restrict__ Acn, const double* __restrict__ Adcn, int64_t a_ld,
                      int64_t a0, int64_t na, const double* __restrict__ Bxs, const double* __restrict__ Bcn,
                      const double* __restrict__ Bdcn, int64_t b_ld, int64_t nb, const double* __restrict__ G, int64_t ldg,
@@ -516,14 +514,6 @@ __global__ void __launch_bounds__(256) reduce_records_kernel(const double* __res
     out[j] += s;
 }
 
-static GradDesc make_grad_desc(const PreparedKernel& pk) {
-    GradDesc gd;
-    for (int d = 0; d < OAK_MAX_DIMS; ++d) gd.dE_scale[d] = 0.0;
-    for (int d = 0; d < pk.dd.D; ++d)
-        if (pk.dd.type[d] == OAK_DIM_RBF) gd.dE_scale[d] = 2.0 * 0.6931471805599453094 / pk.dm.ls[d];
-    return gd;
-}
-
 static int64_t record_len(const PreparedKernel& pk) { return 2 * pk.dd.D + (pk.dd.R + 1) + (int64_t)pk.tables.size(); }
 
 // d_rec[reclen] += contraction of G (na x nb block, + optional rank-1 yA avec^T) with dK/dtheta over pairs (A rows a0.., B)
@@ -555,21 +545,20 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     const int64_t reclen = record_len(pk);
     double* d_part = nullptr;
     OAK_CHECK(get_buf_t(ctx, "bwd_part", (size_t)(nrb * ncb * reclen), &d_part));
-    const GradDesc gd = make_grad_desc(pk);
     dim3 grid((unsigned)ncb, (unsigned)nrb);
 #define OAK_BWD_LAUNCH(RR, CP)                                                                                                   \
     {                                                                                                                            \
         auto kern = gram_bwd_kernel<RR, CP>;                                                                                     \
         if (lds > 64 * 1024) OAK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        kern<<<grid, 256, lds, ctx->stream>>>(pk.dd, gd, pk.d_tables, tablen, A.xs, A.cn, A.dcn, A.ld, a0, na, B.xs, B.cn, B.dcn,  \
+        kern<<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen, A.xs, A.cn, A.dcn, A.ld, a0, na, B.xs, B.cn, B.dcn,  \
                                               B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part);                     \
     }
 #define OAK_BWD_FAST(RR, DM)                                                                                                      \
-    if (allrbf && !want_gk) gram_bwd_fast_kernel<RR, DM, true, false><<<grid, 256, lds, ctx->stream>>>(pk.dd, gd, pk.d_tables, tablen, \
+    if (allrbf && !want_gk) gram_bwd_fast_kernel<RR, DM, true, false><<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen, \
                         A.xs, A.cn, A.dcn, A.ld, a0, na, B.xs, B.cn, B.dcn, B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part); \
-    else if (allrbf) gram_bwd_fast_kernel<RR, DM, true, true><<<grid, 256, lds, ctx->stream>>>(pk.dd, gd, pk.d_tables, tablen,        \
+    else if (allrbf) gram_bwd_fast_kernel<RR, DM, true, true><<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen,        \
                         A.xs, A.cn, A.dcn, A.ld, a0, na, B.xs, B.cn, B.dcn, B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part); \
-    else gram_bwd_fast_kernel<RR, DM, false, true><<<grid, 256, lds, ctx->stream>>>(pk.dd, gd, pk.d_tables, tablen,                    \
+    else gram_bwd_fast_kernel<RR, DM, false, true><<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen,                    \
                         A.xs, A.cn, A.dcn, A.ld, a0, na, B.xs, B.cn, B.dcn, B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part);
 #define OAK_BWD_CASE(RR) case RR: if (cpt == 2) OAK_BWD_LAUNCH(RR, 2) else OAK_BWD_LAUNCH(RR, 1) break;
     if (fast) {

@@ -43,7 +43,7 @@ void* peek_buf(oak_ctx* ctx, const char* name) {
 
 PhaseTimer::PhaseTimer(oak_ctx* c, const char* n) : ctx(c), name(n), a(nullptr), b(nullptr), active(false) {
     if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) {
-        hipEventRecord(a, ctx->stream);
+        (void)hipEventRecord(a, ctx->stream);
         active = true;
     }
 }
@@ -51,7 +51,7 @@ struct PendingEvt { std::string name; hipEvent_t a, b; };
 static thread_local std::vector<PendingEvt> g_pending;
 void PhaseTimer::stop() {
     if (!active) return;
-    hipEventRecord(b, ctx->stream);
+    (void)hipEventRecord(b, ctx->stream);
     g_pending.push_back({name, a, b});
     active = false;
 }
@@ -62,7 +62,7 @@ static void flush_timings(oak_ctx* ctx) {
             Timing& t = ctx->timings[p.name];
             t.ms += ms; t.count += 1;
         }
-        hipEventDestroy(p.a); hipEventDestroy(p.b);
+        (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
     }
     g_pending.clear();
 }
@@ -390,12 +390,12 @@ int oak_ctx_create(int device, oak_ctx** out) {
 
 int oak_ctx_destroy(oak_ctx* ctx) {
     if (!ctx) return OAK_OK;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
     oak::reset_timings(ctx);
     oak_comm_destroy(ctx);
-    for (auto& kv : ctx->bufs) if (kv.second.p) hipFree(kv.second.p);
-    hipStreamDestroy(ctx->stream);
+    for (auto& kv : ctx->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
+    (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return OAK_OK;
 }
