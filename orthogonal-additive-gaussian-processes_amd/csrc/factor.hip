@@ -274,9 +274,14 @@ __device__ __forceinline__ void potf2_wave(double* Dg /*[NB][PO_P]*/, double* in
     if (bad_at >= 0 && lane == 0 && info != nullptr) atomicMin(info, (int)(j0 + bad_at + 1));
 }
 
-__global__ void __launch_bounds__(256) potrf_panel_kernel(double* __restrict__ A, int64_t n, int64_t lda, int64_t j0, int* __restrict__ info) {
+// Every workgroup re-factors the (tiny) diagonal block itself instead of waiting for one producer.  The factor must not
+// be written back over A_jj while a sibling workgroup may still be loading the unfactored block, so the LAST workgroup
+// to finish loading (arrival counter, one per panel) does the write-back.
+__global__ void __launch_bounds__(256) potrf_panel_kernel(double* __restrict__ A, int64_t n, int64_t lda, int64_t j0, int* __restrict__ info,
+                                                          int* __restrict__ arrivals) {
     __shared__ __attribute__((aligned(16))) double Dg[PO_NB * PO_P];
     __shared__ double invd[PO_NB];
+    __shared__ int last_loader;
     const int tid = threadIdx.x;
     const int nb = (n - j0 < PO_NB) ? (int)(n - j0) : PO_NB;
     {
@@ -295,9 +300,10 @@ __global__ void __launch_bounds__(256) potrf_panel_kernel(double* __restrict__ A
         for (int q = 0; q < PER; ++q) { const int idx = tid + 256 * q; Dg[(idx / PO_NB) * PO_P + (idx % PO_NB)] = v[q]; }
     }
     __syncthreads();
+    if (tid == 255) last_loader = (atomicAdd(arrivals, 1) == (int)gridDim.x - 1);
     if (tid < 64) potf2_wave(Dg, invd, tid, j0, blockIdx.x == 0 ? info : nullptr);
     __syncthreads();
-    if (blockIdx.x == 0) {
+    if (last_loader) {
         for (int idx = tid; idx < nb * nb; idx += 256) {
             const int i = idx / nb, j = idx - i * nb;
             A[(j0 + i) * lda + j0 + j] = Dg[i * PO_P + j];
@@ -333,15 +339,35 @@ __global__ void zero_upper_kernel(double* __restrict__ A, int64_t n, int64_t lda
     if (j < n && j > i) A[i * lda + j] = 0.0;
 }
 
-int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda) {
+static const int PO_BIG = 0x7fffffff;
+__global__ void set_int_kernel(int* p, int v) { *p = v; }
+
+int potrf_check(oak_ctx* ctx, int slot, int64_t n) {
+    int* d_info = (int*)peek_buf(ctx, "potrf_info");
+    int info = 0;
+    OAK_HIP_CHECK(hipMemcpyAsync(&info, d_info + slot, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (info != PO_BIG) {
+        set_error("Cholesky decomposition was not successful: leading minor of order %d is not positive definite (n=%lld)", info, (long long)n);
+        return OAK_E_NOTPD;
+    }
+    return OAK_OK;
+}
+
+int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, bool check) {
     int* d_info = nullptr;
-    OAK_CHECK(get_buf_t(ctx, "potrf_info", 1, &d_info));
-    const int big = 0x7fffffff;
-    OAK_HIP_CHECK(hipMemcpyAsync(d_info, &big, sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+    OAK_CHECK(get_buf_t(ctx, "potrf_info", 2, &d_info));
+    const int slot = (ctx->side != nullptr && ctx->stream == ctx->side) ? 1 : 0;
+    d_info += slot;
+    set_int_kernel<<<1, 1, 0, ctx->stream>>>(d_info, PO_BIG);
+    int* d_arr = nullptr;
+    const size_t npanel = (size_t)((n + PO_NB - 1) / PO_NB);
+    OAK_CHECK(get_buf_t(ctx, slot ? "potrf_arrivals_side" : "potrf_arrivals", npanel, &d_arr));
+    OAK_HIP_CHECK(hipMemsetAsync(d_arr, 0, sizeof(int) * npanel, ctx->stream));
     for (int64_t j0 = 0; j0 < n; j0 += PO_NB) {
         const int64_t below = n - j0 - PO_NB;
         const unsigned gp = below > 0 ? (unsigned)((below + 255) / 256) : 1u;
-        potrf_panel_kernel<<<gp, 256, 0, ctx->stream>>>(dA, n, lda, j0, d_info);
+        potrf_panel_kernel<<<gp, 256, 0, ctx->stream>>>(dA, n, lda, j0, d_info, d_arr + j0 / PO_NB);
         if (below > 0) {
             // trailing update A22 -= L21 L21^T (lower tiles only): MFMA GEMM, K = 32
             const double* L21 = dA + (j0 + PO_NB) * lda + j0;
@@ -352,14 +378,7 @@ int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda) {
     dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
     zero_upper_kernel<<<grid, 256, 0, ctx->stream>>>(dA, n, lda);
     OAK_HIP_CHECK(hipGetLastError());
-    int info = 0;
-    OAK_HIP_CHECK(hipMemcpyAsync(&info, d_info, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    if (info != big) {
-        set_error("Cholesky decomposition was not successful: leading minor of order %d is not positive definite (n=%lld)", info, (long long)n);
-        return OAK_E_NOTPD;
-    }
-    return OAK_OK;
+    return check ? potrf_check(ctx, slot, n) : OAK_OK;
 }
 
 // ---------------------------------------------------------------------------------------------

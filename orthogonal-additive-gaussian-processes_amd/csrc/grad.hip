@@ -681,10 +681,8 @@ int oak_sgpr_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_v
     OAK_CHECK(prepare_kernel(ctx, desc, &pk));
     PhaseTimer ttot(ctx, "total");
     // ---- forward ------------------------------------------------------------------------------------------
-    OAK_CHECK(sgpr_local_stats(ctx, pk, jitter));
-    if (ctx->comm != nullptr) OAK_CHECK(oak_comm_allreduce_stats(ctx));
     double elbo = 0.0, terms[8];
-    OAK_CHECK(sgpr_tail(ctx, pk, noise_var, jitter, &elbo, terms));
+    OAK_CHECK(sgpr_forward(ctx, pk, noise_var, jitter, &elbo, terms));
     OAK_CHECK(sgpr_ensure_alpha(ctx));
     const int64_t N = ctx->N, M = ctx->M, Mp = ((M + 127) / 128) * 128;
     const double s2 = noise_var;

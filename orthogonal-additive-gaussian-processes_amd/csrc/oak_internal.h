@@ -92,7 +92,8 @@ struct PreparedKernel {
 struct oak_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipStream_t side = nullptr;                  // side stream: Kuu factorisation overlapped with the N-sized stages
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;     // fork / join events for the side stream
     std::map<std::string, oak::DevBuf> bufs;     // named, grow-only device scratch
     std::map<std::string, oak::Timing> timings;
     // SGPR state
@@ -148,7 +149,8 @@ int syrk_panel(oak_ctx* ctx, const double* d_panel, int64_t ldp, int64_t nrows, 
                int nsplit, bool accumulate);
 int syrk_plan_splits(oak_ctx* ctx, int64_t M, int64_t nrows);
 int syrk_reduce(oak_ctx* ctx, const double* d_part, int nsplit, int64_t M, double* d_phi /*[M*M]*/, bool accumulate);
-int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda);   // in place; strict upper zeroed
+int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, bool check = true);   // in place; strict upper zeroed
+int potrf_check(oak_ctx* ctx, int slot, int64_t n);   // deferred status of a check=false factorisation (slot 1 = side stream)
 // rows-trsm: each of the nrhs rows of BT (row stride ldb) is a right-hand side; solves L x = b (trans=0)
 // or L^T x = b (trans=1) in place.
 int trsm_rows(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, double* dBT, int64_t nrhs, int64_t ldb, int trans);
@@ -170,7 +172,13 @@ int gemm_nt(oak_ctx* ctx, const double* dA, const double* dB, double* dC, int64_
 
 // SGPR pipeline pieces shared between translation units
 int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter);
-int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out);
+// l_state: 0 = the tail builds L = chol(Kuu + jitter I) itself; 1 = buffer "L" already holds it on the main stream
+// (whitened route); 2 = it is being factored on the side stream (sgpr_factor_kuu_async) and the tail joins on ev1.
+int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out,
+              int l_state = 0);
+bool sgpr_route_whitened(const oak_ctx* ctx);
+int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter);
+int sgpr_forward(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out);
 int sgpr_ensure_alpha(oak_ctx* ctx);
 
 // collectives --------------------------------------------------------------------------------------

@@ -383,7 +383,11 @@ int oak_ctx_create(int device, oak_ctx** out) {
     ctx->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
-    if (hipStreamCreate(&ctx->stream) != hipSuccess) { delete ctx; oak::set_error("hipStreamCreate failed"); return OAK_E_HIP; }
+    if (hipStreamCreate(&ctx->stream) != hipSuccess || hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev0, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev1, hipEventDisableTiming) != hipSuccess) {
+        delete ctx; oak::set_error("hipStreamCreate / hipEventCreate failed"); return OAK_E_HIP;
+    }
     *out = ctx;
     return OAK_OK;
 }
@@ -392,10 +396,14 @@ int oak_ctx_destroy(oak_ctx* ctx) {
     if (!ctx) return OAK_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->side);
     oak::reset_timings(ctx);
     oak_comm_destroy(ctx);
     for (auto& kv : ctx->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
     (void)hipStreamDestroy(ctx->stream);
+    (void)hipStreamDestroy(ctx->side);
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
     delete ctx;
     return OAK_OK;
 }

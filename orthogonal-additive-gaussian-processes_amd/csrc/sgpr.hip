@@ -103,7 +103,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     // Route: "phi" accumulates Phi = Kuf Kuf^T and whitens the M x M result in the tail (M^2 N flops; error grows with
     // cond(Kuu)); "whitened" applies L^-1 to every panel row first -- exactly GPflow's A = L^-1 Kuf (oak/utils.py:189),
     // 2x the flops, error independent of forming Phi.  Auto: whitened while the extra TRSM is cheap.
-    const bool whiten = ctx->route == 2 || (ctx->route == 0 && N * M <= ((int64_t)1 << 24));
+    const bool whiten = sgpr_route_whitened(ctx);
     double* dLw = nullptr;
     if (whiten) {
         OAK_CHECK(get_buf_t(ctx, "L", (size_t)M * M, &dLw));
@@ -148,7 +148,49 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     return OAK_OK;
 }
 
-int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out) {
+bool sgpr_route_whitened(const oak_ctx* ctx) {
+    return ctx->route == 2 || (ctx->route == 0 && ctx->N * ctx->M <= ((int64_t)1 << 24));
+}
+
+// L = chol(Kuu + jitter I) on the side stream.  It depends only on Z and the hyperparameters, so it runs concurrently
+// with the N-sized gram / SYRK stages; the tail joins on ev1 and reads the deferred Cholesky status (slot 1).
+int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
+    const int64_t M = ctx->M;
+    double* dL = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "L", (size_t)M * M, &dL));
+    int* d_info = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "potrf_info", 2, &d_info));
+    double* dZ = (double*)peek_buf(ctx, "Z");
+    OAK_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));            // fork: Z / tables uploads are ordered before
+    OAK_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ev0, 0));
+    hipStream_t main_stream = ctx->stream;
+    ctx->stream = ctx->side;
+    int rc = [&]() -> int {
+        Feat FZ;
+        OAK_CHECK(featurize(ctx, pk, dZ, M, ctx->ldx, "featZ_side", &FZ));
+        OAK_CHECK(gram(ctx, pk, FZ, 0, M, FZ, dL, M, nullptr, nullptr, 0));
+        OAK_CHECK(add_diag(ctx, dL, M, M, jitter));
+        OAK_CHECK(potrf_lower(ctx, dL, M, M, false));
+        return OAK_OK;
+    }();
+    ctx->stream = main_stream;
+    if (rc != OAK_OK) { (void)hipStreamSynchronize(ctx->side); return rc; }
+    OAK_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->side));
+    return OAK_OK;
+}
+
+// forward pass shared by oak_sgpr_elbo and oak_sgpr_elbo_grad
+int sgpr_forward(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out) {
+    int l_state = 1;                                    // whitened route: local_stats leaves L in place
+    if (!sgpr_route_whitened(ctx)) { OAK_CHECK(sgpr_factor_kuu_async(ctx, pk, jitter)); l_state = 2; }
+    int rc = sgpr_local_stats(ctx, pk, jitter);
+    if (rc == OAK_OK && ctx->comm != nullptr) rc = oak_comm_allreduce_stats(ctx);
+    if (rc != OAK_OK) { if (l_state == 2) (void)hipStreamSynchronize(ctx->side); return rc; }
+    return sgpr_tail(ctx, pk, noise_var, jitter, elbo_out, terms_out, l_state);
+}
+
+int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out,
+              int l_state) {
     OAK_REQUIRE(ctx->have_stats, "SGPR tail: no sufficient statistics (call local_stats / set_stats first)");
     OAK_REQUIRE(noise_var > 0.0, "noise variance must be positive");
     PhaseTimer t(ctx, "tail");
@@ -167,9 +209,13 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     OAK_CHECK(get_buf_t(ctx, "c", (size_t)M, &dc));
     OAK_CHECK(get_buf_t(ctx, "scal", 8, &dscal));
     // Kuu + jitter I -> L   (oak/utils.py:185,188)
-    OAK_CHECK(gram(ctx, pk, FZ, 0, M, FZ, dL, M, nullptr, nullptr, 0));
-    OAK_CHECK(add_diag(ctx, dL, M, M, jitter));
-    OAK_CHECK(potrf_lower(ctx, dL, M, M));
+    if (l_state == 2) {
+        OAK_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev1, 0));    // join the side-stream factorisation
+    } else if (l_state == 0) {
+        OAK_CHECK(gram(ctx, pk, FZ, 0, M, FZ, dL, M, nullptr, nullptr, 0));
+        OAK_CHECK(add_diag(ctx, dL, M, M, jitter));
+        OAK_CHECK(potrf_lower(ctx, dL, M, M));
+    }
     // W = L^-1 Phi L^-T  (= sigma^2 * A A^T, utils.py:189-190 without materialising A)
     if (ctx->stats_whitened) {
         OAK_CHECK(copy_d2d(ctx, dT2, st.phi, sizeof(double) * (size_t)M * M));   // statistics already hold W
@@ -185,7 +231,7 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     }
     // B = I + W / sigma^2 ; LB = chol(B)   (utils.py:190-193)
     OAK_CHECK(scale_add_eye(ctx, dT2, M, 1.0 / noise_var, dLB));
-    OAK_CHECK(potrf_lower(ctx, dLB, M, M));
+    OAK_CHECK(potrf_lower(ctx, dLB, M, M, false));            // status read with the scalars below: one host sync per tail
     // c = LB^-1 L^-1 psi / sigma^2   (utils.py:194-195: Aerr = L^-1 psi / sigma, c = LB^-1 Aerr / sigma)
     OAK_CHECK(copy_d2d(ctx, dc, dv1, sizeof(double) * (size_t)M));
     OAK_CHECK(trsm_rows(ctx, dLB, M, M, dc, 1, M, 0));
@@ -198,7 +244,8 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     OAK_CHECK(reduce_sum(ctx, dL, M, dscal + 6, 2, M + 1));     // sum log diag L
     double h[8] = {0};
     OAK_HIP_CHECK(hipMemcpyAsync(h, dscal, sizeof(double) * 7, hipMemcpyDeviceToHost, ctx->stream));
-    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    if (l_state == 2) OAK_CHECK(potrf_check(ctx, 1, M));      // Kuu (side stream) first: it is the upstream failure
+    OAK_CHECK(potrf_check(ctx, 0, M));                        // then B; both synchronise the main stream
     t.stop();
     const double sumlogLB = h[0], cTc = h[1], trAAT = h[2] / noise_var, kappa = h[3], yy = h[4], nrows = h[5];
     // gpflow SGPR.elbo, P = 1
@@ -367,9 +414,7 @@ int oak_sgpr_elbo(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, d
     PreparedKernel pk;
     OAK_CHECK(prepare_kernel(ctx, desc, &pk));
     PhaseTimer t(ctx, "total");
-    OAK_CHECK(sgpr_local_stats(ctx, pk, jitter));
-    if (ctx->comm != nullptr) OAK_CHECK(oak_comm_allreduce_stats(ctx));
-    OAK_CHECK(sgpr_tail(ctx, pk, noise_var, jitter, elbo_out, nullptr));
+    OAK_CHECK(sgpr_forward(ctx, pk, noise_var, jitter, elbo_out, nullptr));
     t.stop();
     return OAK_OK;
 }
