@@ -121,10 +121,30 @@ def main():
     ctx.sgpr_set_inducing(Z)
     ctx.sgpr_set_route(args.route)
     host_exchange = world > 1 and args.exchange == "host"
+    exchange_note = "none" if world == 1 else args.exchange
     if world > 1 and not host_exchange:
-        ids = [_capi.HipContext.comm_unique_id() if rank == 0 else None]
+        import torch
+        ok = 1
+        try:
+            ids = [_capi.HipContext.comm_unique_id() if rank == 0 else None]
+        except Exception as e:                                   # librccl missing / not loadable on rank 0
+            ids, ok = [None], 0
+            print(f"[bench] rank {rank}: RCCL unique id failed: {e}", file=sys.stderr)
         dist.broadcast_object_list(ids, src=0)
-        ctx.comm_init(ids[0], world, rank)
+        if ids[0] is None:
+            ok = 0
+        else:
+            try:
+                ctx.comm_init(ids[0], world, rank)
+            except Exception as e:
+                ok = 0
+                print(f"[bench] rank {rank}: RCCL communicator init failed: {e}", file=sys.stderr)
+        flag = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)              # every rank takes the same path
+        if int(flag.item()) == 0:
+            ctx.comm_destroy()
+            host_exchange = True
+            exchange_note = "host (RCCL init failed, statistics all-reduced over gloo)"
 
     spec = make_spec(D, R, mixed=cfg.get("mixed", False))
 
@@ -250,7 +270,8 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"{args.config}: SGPR ELBO, N={N} D={D} M={M} order={R}, Gaussian-measure ortho-RBF, "
                                f"Z=X[:M], noise=0.01, jitter=1e-6, route={args.route}",
-                   "N": N, "D": D, "M": M, "order": R, "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}"},
+                   "N": N, "D": D, "M": M, "order": R, "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}",
+                   "exchange": exchange_note},
         "loss": loss,
         "gram_GBps": gram_bytes / (gram_ms * 1e-3) / 1e9 if gram_ms else None,
         "gram_roofline": {"bound": "hbm", "achieved": gram_bytes / (gram_ms * 1e-3) / 1e9 if gram_ms else None,

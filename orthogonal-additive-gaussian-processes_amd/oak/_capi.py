@@ -516,6 +516,9 @@ class HipContext:
     def comm_init(self, unique_id: bytes, nranks: int, rank: int):
         _check(self._lib.oak_comm_init(self._h, unique_id, int(nranks), int(rank)))
 
+    def comm_destroy(self):
+        _check(self._lib.oak_comm_destroy(self._h))
+
     def comm_allreduce_stats(self):
         _check(self._lib.oak_comm_allreduce_stats(self._h))
 
