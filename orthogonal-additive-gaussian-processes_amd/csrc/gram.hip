@@ -74,6 +74,61 @@ __device__ __forceinline__ void exp2_neg_vec(const double (&t_in)[NV], double (&
 }
 
 
+// Gram-kernel form of the same evaluation, two VALU instructions shorter per pair.  The caller passes
+//   w = clamp01((xa' - xb')^2 + woff),   xa' = xs/32,   so that  t = n - 1024 w  is the base-2 exponent of the pair
+// (n = ceil(log2 bv) rides in `magic` = 1.5*2^36 + n/1024, woff = (n - log2 bv)/1024).  The clamp is the free VOP3
+// output modifier, so t >= n - 1024 needs no v_max.  a = magic - w rounds w to a multiple of 2^-16 (t to 1/64); the low
+// mantissa word of a is k = 64 n + 64 rint-part(t) exactly as in exp2_neg_vec.  The table entries are biased:
+//   Tb[j] = 4 * 2^(j/64) with (j << 14) subtracted from the high word, so that  hi + (k << 14) = hi(4 T[j]) + (e << 20)
+// patches the exponent with ONE v_lshl_add_u32 (no mask, no arithmetic shift); the factor 4 keeps the exponent field
+// positive down to e = -1024 and is folded into the polynomial (constant term 0.25, coefficients c_i * (-1024)^i / 4 in
+// the variable rw = w - rounded(w), |rw| <= 2^-17).
+__device__ __forceinline__ double biased_table_entry(int j) {
+    const double t4 = 4.0 * c_exp2_table[j];
+    return __hiloint2double(__double2hiint(t4) - (j << 14), __double2loint(t4));
+}
+
+__device__ __forceinline__ double fma_clamp01(double a, double b, double c) {
+    double r;
+    asm("v_fma_f64 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
+template <int NV>
+__device__ __forceinline__ void exp2_w_vec(const double (&w)[NV], const double magic, double (&out)[NV], const double* __restrict__ tab) {
+    constexpr double c1 = 6.931471805599453094e-01, c2 = 2.402265069591007123e-01, c3 = 5.550410866482157995e-02,
+                     c4 = 9.618129107628477162e-03, c5 = 1.333355814642844342e-03;
+    constexpr double S = -1024.0;
+    constexpr double C1 = 0.25 * c1 * S, C2 = 0.25 * c2 * S * S, C3 = 0.25 * c3 * S * S * S, C4 = 0.25 * c4 * S * S * S * S,
+                     C5 = 0.25 * c5 * S * S * S * S * S;
+    double a[NV], r[NV], p[NV], tv[NV];
+    int ki[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) a[v] = magic - w[v];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) ki[v] = __double2loint(a[v]);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) tv[v] = tab[ki[v] & 63];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) r[v] = w[v] + (a[v] - magic);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(C5, r[v], C4);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(p[v], r[v], C3);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(p[v], r[v], C2);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(p[v], r[v], C1);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(p[v], r[v], 0.25);
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        const int hi = __double2hiint(tv[v]) + (ki[v] << 14);
+        out[v] = __hiloint2double(hi, __double2loint(tv[v])) * p[v];
+    }
+}
+
+
 template <int R>
 __device__ __forceinline__ void esp_update(double (&e)[R > 0 ? R : 1], double k) {
     if constexpr (R > 0) {
@@ -97,8 +152,8 @@ __device__ __forceinline__ double esp_combine(const double (&e)[R > 0 ? R : 1], 
 //   CPT == 4: columns jb + 2*tx + {0,1} and jb + 128 + 2*tx + {0,1}   (two 16-byte stores per row)
 //   CPT == 2: columns jb + 2*tx + {0,1}
 // The B-side (column) features of all D dims stay in LDS for the whole workgroup; A-side (row) features are
-// restaged per row-step.  Dynamic LDS = (D*TJ*2 + D*4*RT*2 + 4*RT) doubles.
-template <int R, int RT, int CPT>
+// restaged per row-step.  Dynamic LDS = (64 + D*TJ*2 + D*4*RT*2 + 4*RT) doubles.
+template <int R, int RT, int CPT, bool ALLRBF>
 __global__ void __launch_bounds__(256)
 gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* __restrict__ Axs,
             const double* __restrict__ Acn, int64_t a_ld, int64_t a0, int64_t na, const double* __restrict__ Bxs,
@@ -108,12 +163,12 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
     constexpr int RS = 4 * RT;   // rows per row-step
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int D = dd.D;
-    double* Bx = smem;                 // [D][TJ]
+    double* Tab = smem;                // [64]  biased 4 * 2^(j/64); first, so the lookups use a constant LDS base
+    double* Bx = Tab + 64;             // [D][TJ]   (RBF dims: x * scale_d / 32)
     double* Bc = Bx + D * TJ;          // [D][TJ]
     double* Ax = Bc + D * TJ;          // [D][RS]
     double* Ac = Ax + D * RS;          // [D][RS]
     double* Ay = Ac + D * RS;          // [RS]
-    double* Tab = Ay + RS;             // [64]  2^(j/64)
     const int tid = threadIdx.x;
     const int tx = tid & 63;
     const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -126,10 +181,11 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
         const int d = idx / TJ, j = idx - d * TJ;
         const int64_t gj = jb + j;
         const bool ok = gj < nb;
-        Bx[idx] = ok ? Bxs[(int64_t)d * b_ld + gj] : 0.0;
+        const double pre = (ALLRBF || dd.type[d] == OAK_DIM_RBF) ? 0.03125 : 1.0;
+        Bx[idx] = ok ? Bxs[(int64_t)d * b_ld + gj] * pre : 0.0;
         Bc[idx] = ok ? Bcn[(int64_t)d * b_ld + gj] : 0.0;
     }
-    if (tid < 64) Tab[tid] = c_exp2_table[tid];
+    if (tid < 64) Tab[tid] = biased_table_entry(tid);
     double psi[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) psi[c] = 0.0;
@@ -140,7 +196,8 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
             const int d = idx / RS, r = idx - d * RS;
             const int64_t gi = i0 + r;
             const bool ok = gi < iend;
-            Ax[idx] = ok ? Axs[(int64_t)d * a_ld + a0 + gi] : 0.0;
+            const double pre = (ALLRBF || dd.type[d] == OAK_DIM_RBF) ? 0.03125 : 1.0;
+            Ax[idx] = ok ? Axs[(int64_t)d * a_ld + a0 + gi] * pre : 0.0;
             Ac[idx] = ok ? Acn[(int64_t)d * a_ld + a0 + gi] : 0.0;
         }
         if (yA != nullptr && tid < RS) Ay[tid] = (i0 + tid < iend) ? yA[a0 + i0 + tid] : 0.0;
@@ -169,17 +226,17 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
                     xa[r] = Ax[d * RS + ty * RT + r];
                     ca[r] = Ac[d * RS + ty * RT + r];
                 }
-                if (dd.type[d] == OAK_DIM_RBF) {
-                    const double l2 = dd.log2bv[d];
+                if (ALLRBF || dd.type[d] == OAK_DIM_RBF) {   // ALLRBF: no branch, so the e[] accumulators never change registers
+                    const double woff = dd.woff[d], magic = dd.magic[d];
 #pragma unroll
                     for (int r = 0; r < RT; ++r) {
-                        double t[CPT], E[CPT];
+                        double w[CPT], E[CPT];
 #pragma unroll
                         for (int c = 0; c < CPT; ++c) {
                             const double u = xa[r] - xb[c];
-                            t[c] = __builtin_fma(-u, u, l2);
+                            w[c] = fma_clamp01(u, u, woff);
                         }
-                        exp2_neg_vec<CPT>(t, E, Tab);
+                        exp2_w_vec<CPT>(w, magic, E, Tab);
 #pragma unroll
                         for (int c = 0; c < CPT; ++c) esp_update<R>(e[r][c], __builtin_fma(-ca[r], cb[c], E[c]));
                     }
@@ -303,7 +360,9 @@ static int launch_gram_t(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, 
     if (nrb > 65535) { rows = ((na + 65534) / 65535 + RS - 1) / RS * RS; nrb = (na + rows - 1) / rows; }
     double* d_part = nullptr;
     if (d_yA != nullptr) OAK_CHECK(get_buf_t(ctx, "psi_part", (size_t)(nrb * nb), &d_part));
-    auto kern = gram_kernel<R, RT, CPT>;
+    bool all_rbf = true;
+    for (int d = 0; d < D; ++d) all_rbf = all_rbf && pk.dd.type[d] == OAK_DIM_RBF;
+    auto kern = all_rbf ? gram_kernel<R, RT, CPT, true> : gram_kernel<R, RT, CPT, false>;
     if (lds > 64 * 1024) OAK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     dim3 grid((unsigned)ncb, (unsigned)nrb);
     kern<<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, A.xs, A.cn, A.ld, a0, na, B.xs, B.cn, B.ld, nb, d_out, ldo,

@@ -238,6 +238,12 @@ int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk
             OAK_REQUIRE(l > 0.0 && bv > 0.0, "dim %d: lengthscale and variance must be positive", d);
             dd.scale[d] = std::sqrt(0.5 * 1.4426950408889634074) / l;   // (x s - z s)^2 = (x-z)^2 log2(e) / (2 l^2)
             dd.log2bv[d] = std::log2(bv);
+            {
+                const double n = std::ceil(dd.log2bv[d]);
+                OAK_REQUIRE(std::fabs(n) <= 900.0, "dim %d: base variance out of range", d);
+                dd.woff[d] = (n - dd.log2bv[d]) / 1024.0;
+                dd.magic[d] = 103079215104.0 + n / 1024.0;      // 1.5 * 2^36
+            }
             dd.ncat[d] = 0; dd.tab_off[d] = 0;
             const int kind = desc->measure[d];
             dm.kind[d] = (unsigned char)kind;
@@ -329,7 +335,7 @@ int prepare_component(oak_ctx* ctx, const oak_kernel_desc* desc, const int32_t* 
         OAK_REQUIRE(s >= 0 && s < desc->num_dims, "subset entry %d out of range", s);
         dd.type[q] = full.dd.type[s]; dd.col[q] = full.dd.col[s]; dd.ncat[q] = full.dd.ncat[s];
         dd.tab_off[q] = full.dd.tab_off[s]; dd.scale[q] = full.dd.scale[s]; dd.log2bv[q] = full.dd.log2bv[s];
-        dd.bv[q] = full.dd.bv[s];
+        dd.bv[q] = full.dd.bv[s]; dd.woff[q] = full.dd.woff[s]; dd.magic[q] = full.dd.magic[s];
         dm.kind[q] = full.dm.kind[s]; dm.k[q] = full.dm.k[s]; dm.off[q] = full.dm.off[s]; dm.p0[q] = full.dm.p0[s];
         dm.p1[q] = full.dm.p1[s]; dm.ls[q] = full.dm.ls[s]; dm.inv_sqrt_v[q] = full.dm.inv_sqrt_v[s]; dm.dlogv[q] = full.dm.dlogv[s];
     }
