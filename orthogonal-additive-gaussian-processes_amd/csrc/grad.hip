@@ -9,6 +9,7 @@
 // The pair kernel recomputes each base-kernel value and contracts G with dK/dk_d * dk_d/dtheta, where
 // dK/dk_d = sum_r w_r e_{r-1}^{(-d)} uses leave-one-out elementary symmetric polynomials (e^{(-d)}_q = e_q - k_d e^{(-d)}_{q-1}).
 #include "oak_internal.h"
+#include "exp2w.h"
 #include <cmath>
 #include <cstdlib>
 
@@ -228,44 +229,15 @@ gram_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
     for (int idx = tid; idx < tablen; idx += 256) rec[2 * D + (R + 1) + idx] = accT[idx];
 }
 
-// 4 exp2 at once, interleaved (same algorithm as exp2_neg_tab / the Gram kernel's exp2_neg_vec)
-__device__ __forceinline__ void exp2_neg_tab4(const double (&t_in)[4], double (&out)[4], const double* __restrict__ tab) {
-    constexpr double c1 = 6.931471805599453094e-01, c2 = 2.402265069591007123e-01, c3 = 5.550410866482157995e-02,
-                     c4 = 9.618129107628477162e-03, c5 = 1.333355814642844342e-03;
-    constexpr double MAGIC = 105553116266496.0;
-    double t[4], a[4], r[4], p[4], tv[4];
-    int ki[4];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) t[v] = __builtin_fmax(t_in[v], -1020.0);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) a[v] = t[v] + MAGIC;
-#pragma unroll
-    for (int v = 0; v < 4; ++v) ki[v] = __double2loint(a[v]);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) tv[v] = tab[ki[v] & 63];
-#pragma unroll
-    for (int v = 0; v < 4; ++v) r[v] = t[v] - (a[v] - MAGIC);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) p[v] = __builtin_fma(c5, r[v], c4);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) p[v] = __builtin_fma(p[v], r[v], c3);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) p[v] = __builtin_fma(p[v], r[v], c2);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) p[v] = __builtin_fma(p[v], r[v], c1);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) p[v] = __builtin_fma(p[v], r[v], 1.0);
-#pragma unroll
-    for (int v = 0; v < 4; ++v) {
-        const int hi = __double2hiint(tv[v]) + (ki[v] >> 6) * 1048576;
-        out[v] = __hiloint2double(hi, __double2loint(tv[v])) * p[v];
-    }
-}
-
 // Fast path (1 <= R <= 4, D <= DMAX <= 16): one exp2 per pair per dimension.  Each lane walks its pairs one at a time,
 // keeps k_d and dk_d/dl_d of all dimensions in registers (vectorised 4 dimensions at a time for ILP), and accumulates the
 // per-dimension contractions in registers across the whole row range; one workgroup reduction at the very end.
-template <int R, int DMAX, bool ALLRBF, bool WANT_GK>
+// exp2 in the clamped-w form of exp2w.h: features are staged as x*scale/32, the lengthscale-derivative features dcn as
+// dcn/1024, so u^2 in the derivative is (w - woff) and the accumulated dF/dl comes out divided by 1024 (undone, exactly,
+// when the record is written).  Padding dimensions d >= D are staged as xa = -1, xb = +1 (w clamps to 1, E = 2^-1024).
+// UNITBV: every RBF dimension has base variance exactly 1 (OAK's share_var_across_orders default): woff = 0 and
+// magic = EW_MAGIC are compile-time constants, no per-dimension constant is read at all.
+template <int R, int DMAX, bool ALLRBF, bool WANT_GK, bool UNITBV>
 __global__ void __launch_bounds__(256)
 gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
                      const double* __restrict__ Axs, const double* __restrict__ Acn, const double* __restrict__ Adcn, int64_t a_ld,
@@ -285,9 +257,10 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
     double* Ad = Ac + DMAX * RS;
     double* Ay = Ad + DMAX * RS;        // [RS]
     double* Av = Ay + RS;               // [TJ]
-    double* Tab = Av + TJ;              // [64]
-    double* Cst = Tab + 64;             // [DMAX] log2(base variance) per dim
-    double* accT = Cst + DMAX;          // [tablen]
+    double* Tab = Av + TJ;              // [EW_N] biased exp2 table
+    double* Cw = Tab + EW_N;            // [DMAX] woff per dim
+    double* Cm = Cw + DMAX;             // [DMAX] magic per dim
+    double* accT = Cm + DMAX;           // [tablen]
     double* red = accT + tablen;        // [4][2*DMAX + R + 1]
     const int tid = threadIdx.x, tx = tid & 63;
     const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -298,13 +271,18 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
         const int d = idx / TJ, j = idx - d * TJ;
         const int64_t gj = jb + j;
         const bool ok = gj < nb && d < D;
-        Bx[idx] = ok ? Bxs[(int64_t)d * b_ld + gj] : 0.0;
+        const double pre = (ALLRBF || d >= D || dd.type[d] == OAK_DIM_RBF) ? 0.03125 : 1.0;
+        Bx[idx] = ok ? Bxs[(int64_t)d * b_ld + gj] * pre : (d < D ? 0.0 : 1.0);
         Bc[idx] = ok ? Bcn[(int64_t)d * b_ld + gj] : 0.0;
-        Bd[idx] = ok ? Bdcn[(int64_t)d * b_ld + gj] : 0.0;
+        Bd[idx] = ok ? Bdcn[(int64_t)d * b_ld + gj] * 0.0009765625 : 0.0;
     }
     for (int j = tid; j < TJ; j += 256) Av[j] = (avec != nullptr && jb + j < nb) ? avec[jb + j] : 0.0;
-    if (tid < 64) Tab[tid] = c_exp2_table_g[tid];
-    if (tid < DMAX) Cst[tid] = (tid < D && dd.type[tid] == OAK_DIM_RBF) ? dd.log2bv[tid] : -1100.0;
+    for (int j = tid; j < EW_N; j += 256) Tab[j] = biased_table_entry(j);
+    if (tid < DMAX) {
+        const bool rbf = tid < D && dd.type[tid] == OAK_DIM_RBF;
+        Cw[tid] = rbf ? dd.woff[tid] : 0.0;
+        Cm[tid] = rbf ? dd.magic[tid] : EW_MAGIC;
+    }
     for (int idx = tid; idx < tablen; idx += 256) accT[idx] = 0.0;
     double gl[DMAX], gk[NGK], gw[R + 1];
 #pragma unroll
@@ -314,16 +292,17 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
 #pragma unroll
     for (int q = 0; q <= R; ++q) gw[q] = 0.0;
 
-    struct Chunk { double xa[4], xb[4], ca[4], cb[4], ad[4], bd[4], ct[4]; };
+    struct Chunk { double xa[4], xb[4], ca[4], cb[4], ad[4], bd[4], cw[4], cm[4]; };
     for (int64_t i0 = ib; i0 < iend; i0 += RS) {
         __syncthreads();
         for (int idx = tid; idx < DMAX * RS; idx += 256) {
             const int d = idx / RS, r = idx - d * RS;
             const int64_t gi = i0 + r;
             const bool ok = gi < iend && d < D;
-            Ax[idx] = ok ? Axs[(int64_t)d * a_ld + a0 + gi] : 0.0;
+            const double pre = (ALLRBF || d >= D || dd.type[d] == OAK_DIM_RBF) ? 0.03125 : 1.0;
+            Ax[idx] = ok ? Axs[(int64_t)d * a_ld + a0 + gi] * pre : (d < D ? 0.0 : -1.0);
             Ac[idx] = ok ? Acn[(int64_t)d * a_ld + a0 + gi] : 0.0;
-            Ad[idx] = ok ? Adcn[(int64_t)d * a_ld + a0 + gi] : 0.0;
+            Ad[idx] = ok ? Adcn[(int64_t)d * a_ld + a0 + gi] * 0.0009765625 : 0.0;
         }
         if (tid < RS) Ay[tid] = (yA != nullptr && i0 + tid < iend) ? yA[a0 + i0 + tid] : 0.0;
         __syncthreads();
@@ -341,7 +320,7 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
                     const int d = d0 + v;
                     ch.xa[v] = Ax[d * RS + row]; ch.ca[v] = Ac[d * RS + row]; ch.ad[v] = Ad[d * RS + row];
                     ch.xb[v] = Bx[d * TJ + col]; ch.cb[v] = Bc[d * TJ + col]; ch.bd[v] = Bd[d * TJ + col];
-                    ch.ct[v] = Cst[d];
+                    if constexpr (!UNITBV) { ch.cw[v] = Cw[d]; ch.cm[v] = Cm[d]; }
                 }
             };
             Chunk cur, nxt;
@@ -349,14 +328,17 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
 #pragma unroll
             for (int d0 = 0; d0 < DMAX; d0 += 4) {
                 if (d0 + 4 < DMAX) fetch(d0 + 4, nxt);      // software prefetch of the next 4 dimensions' features
-                double t[4], u2[4], E[4];
+                double w[4], u2[4], mg[4], E[4];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const double u = cur.xa[v] - cur.xb[v];
-                    u2[v] = u * u;
-                    t[v] = cur.ct[v] - u2[v];               // log2(base variance) - u^2; -1100 for the padding dims d >= D
+                    if constexpr (UNITBV) {
+                        w[v] = fma_clamp01(u, u, 0.0); u2[v] = w[v]; mg[v] = EW_MAGIC;
+                    } else {
+                        w[v] = fma_clamp01(u, u, cur.cw[v]); u2[v] = w[v] - cur.cw[v]; mg[v] = cur.cm[v];
+                    }
                 }
-                exp2_neg_tab4(t, E, Tab);
+                exp2_w_vec<4>(w, mg, E, Tab);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int d = d0 + v;
@@ -415,7 +397,7 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
     const int64_t reclen = 2 * D + (R + 1) + tablen;
     double* rec = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * reclen;
     auto sum4 = [&](int j) { return ((red[j] + red[NACC + j]) + red[2 * NACC + j]) + red[3 * NACC + j]; };
-    for (int d = tid; d < D; d += 256) { rec[d] = sum4(d); rec[D + d] = sum4(DMAX + d); }
+    for (int d = tid; d < D; d += 256) { rec[d] = sum4(d) * 1024.0; rec[D + d] = sum4(DMAX + d); }
     if (tid <= R) rec[2 * D + tid] = sum4(2 * DMAX + tid);
     for (int idx = tid; idx < tablen; idx += 256) rec[2 * D + (R + 1) + idx] = accT[idx];
 }
@@ -530,7 +512,9 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     const int dmax = D <= 8 ? 8 : 16;
     const int cpt = (D <= 40) ? 2 : 1;
     const int TJ = 64 * cpt, RS = 8;
-    const size_t lds = fast ? sizeof(double) * ((size_t)3 * dmax * TJ + (size_t)3 * dmax * RS + RS + TJ + 64 + dmax + tablen + 4 * (2 * dmax + R + 1) + 8)
+    bool unitbv = true;
+    for (int d = 0; d < D; ++d) unitbv = unitbv && (pk.dd.type[d] != OAK_DIM_RBF || pk.dd.bv[d] == 1.0);
+    const size_t lds = fast ? sizeof(double) * ((size_t)3 * dmax * TJ + (size_t)3 * dmax * RS + RS + TJ + EW_N + 2 * dmax + tablen + 4 * (2 * dmax + R + 1) + 8)
                             : sizeof(double) * ((size_t)3 * D * TJ + (size_t)3 * D * RS + RS + TJ + 64 + 8 * D + tablen + 64);
     OAK_REQUIRE(lds <= 160 * 1024, "gram_bwd: LDS request %zu exceeds 160 KiB", lds);
     const int64_t nb = B.n;
@@ -553,13 +537,15 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
         kern<<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen, A.xs, A.cn, A.dcn, A.ld, a0, na, B.xs, B.cn, B.dcn,  \
                                               B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part);                     \
     }
-#define OAK_BWD_FAST(RR, DM)                                                                                                      \
-    if (allrbf && !want_gk) gram_bwd_fast_kernel<RR, DM, true, false><<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen, \
-                        A.xs, A.cn, A.dcn, A.ld, a0, na, B.xs, B.cn, B.dcn, B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part); \
-    else if (allrbf) gram_bwd_fast_kernel<RR, DM, true, true><<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen,        \
-                        A.xs, A.cn, A.dcn, A.ld, a0, na, B.xs, B.cn, B.dcn, B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part); \
-    else gram_bwd_fast_kernel<RR, DM, false, true><<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen,                    \
+#define OAK_BWD_FAST_K(RR, DM, AR, GK, UB)                                                                                         \
+    gram_bwd_fast_kernel<RR, DM, AR, GK, UB><<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen,                         \
                         A.xs, A.cn, A.dcn, A.ld, a0, na, B.xs, B.cn, B.dcn, B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part);
+#define OAK_BWD_FAST(RR, DM)                                                                                                      \
+    if (allrbf && !want_gk && unitbv) OAK_BWD_FAST_K(RR, DM, true, false, true)                                                   \
+    else if (allrbf && !want_gk) OAK_BWD_FAST_K(RR, DM, true, false, false)                                                       \
+    else if (allrbf) OAK_BWD_FAST_K(RR, DM, true, true, false)                                                                    \
+    else if (unitbv) OAK_BWD_FAST_K(RR, DM, false, true, true)                                                                    \
+    else OAK_BWD_FAST_K(RR, DM, false, true, false)
 #define OAK_BWD_CASE(RR) case RR: if (cpt == 2) OAK_BWD_LAUNCH(RR, 2) else OAK_BWD_LAUNCH(RR, 1) break;
     if (fast) {
         switch (R * 100 + dmax) {
@@ -577,6 +563,7 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
 #undef OAK_BWD_CASE
 #undef OAK_BWD_LAUNCH
 #undef OAK_BWD_FAST
+#undef OAK_BWD_FAST_K
     OAK_HIP_CHECK(hipGetLastError());
     reduce_records_kernel<<<(unsigned)((reclen + 255) / 256), 256, 0, ctx->stream>>>(d_part, nrb * ncb, reclen, d_rec);
     OAK_HIP_CHECK(hipGetLastError());

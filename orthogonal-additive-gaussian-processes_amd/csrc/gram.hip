@@ -6,128 +6,14 @@
 // RT x CPT block of (row, column) pairs and runs the e_r recurrence  e_r += k_d * e_{r-1}  (r = R..1) over d in
 // registers -- algebraically the same elementary symmetric polynomials, D*R FMAs per pair and no pow().
 //
-// Roofline: fp64-VALU bound (one software exp2 per pair per dimension: ~17 DP ops), not HBM bound.
+// Roofline: fp64-VALU bound (one software exp2 per pair per dimension, exp2w.h: 17 VALU instructions per pair per
+// dimension at R = 2 including the ESP update), not HBM bound.
 // fp64 MFMA shares the DP pipe with fp64 VALU on gfx950 (measured, tools/ubench), so there is nothing to
 // overlap with; the kernel is written to issue the minimum number of DP instructions per pair.
 #include "oak_internal.h"
+#include "exp2w.h"
 
 namespace oak {
-
-// 2^t for t <= 0, for CPT independent arguments at once (interleaved so the DP pipe always has independent work):
-//   a = t + 1.5*2^46 rounds t to a multiple of 1/64 (round-to-nearest); its low mantissa bits hold k = 64*rint-part, so
-//   j = k & 63 indexes a 64-entry table of 2^(j/64) (LDS), e = k >> 6 is added straight into the exponent field, and
-//   r = t - k/64, |r| <= 1/128, needs only a degree-5 polynomial: 2^t = 2^e * T[j] * (1 + r*(c1 + ... + r*c5)).
-// Max error 1.6 ulp against 50-digit arithmetic (tests/test_gpu_gram.py::test_exp2_accuracy); t is clamped at -1020 so the
-// exponent arithmetic cannot wrap (values below 2^-1020 are far under the 1e-12 parity tolerance of any Gram entry).
-__constant__ double c_exp2_table[64] = {
-    1.0, 1.01088928605170046, 1.0218971486541166782, 1.0330248790212284225,
-    1.0442737824274138403, 1.0556451783605571588, 1.0671404006768236182, 1.0787607977571197937,
-    1.0905077326652576592, 1.1023825833078409436, 1.1143867425958925363, 1.1265216186082418998,
-    1.1387886347566916537, 1.1511892299529827058, 1.1637248587775775138, 1.1763969916502812763,
-    1.1892071150027210667, 1.2021567314527031421, 1.2152473599804688781, 1.2284805361068700057,
-    1.2418578120734840486, 1.2553807570246910896, 1.2690509571917332226, 1.2828700160787782807,
-    1.2968395546510096659, 1.3109612115247643419, 1.3252366431597412946, 1.3396675240533030054,
-    1.3542555469368927283, 1.3690024229745906119, 1.3839098819638319549, 1.3989796725383111402,
-    1.4142135623730950488, 1.4296133383919700112, 1.44518080697704662, 1.4609177941806469887,
-    1.4768261459394993114, 1.4929077282912648492, 1.5091644275934227398, 1.5255981507445383069,
-    1.5422108254079408236, 1.559004400237836967, 1.5759808451078864865, 1.5931421513422668979,
-    1.6104903319492543082, 1.6280274218573477668, 1.6457554781539648445, 1.663676580326736435,
-    1.6817928305074290861, 1.7001063537185234695, 1.7186192981224779156, 1.737333835273706249,
-    1.7562521603732994831, 1.7753764925265212526, 1.7947090750031071864, 1.8142521755003987562,
-    1.8340080864093424635, 1.8539791250833855684, 1.8741676341102999013, 1.8945759815869656413,
-    1.9152065613971472939, 1.9360617934922944506, 1.957144124175400269, 1.9784560263879509683,
-};
-
-template <int NV>
-__device__ __forceinline__ void exp2_neg_vec(const double (&t_in)[NV], double (&out)[NV], const double* __restrict__ tab) {
-    constexpr double c1 = 6.931471805599453094e-01, c2 = 2.402265069591007123e-01, c3 = 5.550410866482157995e-02,
-                     c4 = 9.618129107628477162e-03, c5 = 1.333355814642844342e-03;
-    constexpr double MAGIC = 105553116266496.0;   // 1.5 * 2^46: ulp = 2^-6
-    double t[NV], a[NV], r[NV], p[NV], tv[NV];
-    int ki[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) t[v] = __builtin_fmax(t_in[v], -1020.0);
-#pragma unroll
-    for (int v = 0; v < NV; ++v) a[v] = t[v] + MAGIC;
-#pragma unroll
-    for (int v = 0; v < NV; ++v) ki[v] = __double2loint(a[v]);
-#pragma unroll
-    for (int v = 0; v < NV; ++v) tv[v] = tab[ki[v] & 63];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) r[v] = t[v] - (a[v] - MAGIC);
-#pragma unroll
-    for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(c5, r[v], c4);
-#pragma unroll
-    for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(p[v], r[v], c3);
-#pragma unroll
-    for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(p[v], r[v], c2);
-#pragma unroll
-    for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(p[v], r[v], c1);
-#pragma unroll
-    for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(p[v], r[v], 1.0);
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        // scale the table value by 2^e through its exponent field (T[j] in [1,2), e >= -1020: always a normal number)
-        const int hi = __double2hiint(tv[v]) + (ki[v] >> 6) * 1048576;
-        out[v] = __hiloint2double(hi, __double2loint(tv[v])) * p[v];
-    }
-}
-
-
-// Gram-kernel form of the same evaluation, two VALU instructions shorter per pair.  The caller passes
-//   w = clamp01((xa' - xb')^2 + woff),   xa' = xs/32,   so that  t = n - 1024 w  is the base-2 exponent of the pair
-// (n = ceil(log2 bv) rides in `magic` = 1.5*2^36 + n/1024, woff = (n - log2 bv)/1024).  The clamp is the free VOP3
-// output modifier, so t >= n - 1024 needs no v_max.  a = magic - w rounds w to a multiple of 2^-16 (t to 1/64); the low
-// mantissa word of a is k = 64 n + 64 rint-part(t) exactly as in exp2_neg_vec.  The table entries are biased:
-//   Tb[j] = 4 * 2^(j/64) with (j << 14) subtracted from the high word, so that  hi + (k << 14) = hi(4 T[j]) + (e << 20)
-// patches the exponent with ONE v_lshl_add_u32 (no mask, no arithmetic shift); the factor 4 keeps the exponent field
-// positive down to e = -1024 and is folded into the polynomial (constant term 0.25, coefficients c_i * (-1024)^i / 4 in
-// the variable rw = w - rounded(w), |rw| <= 2^-17).
-__device__ __forceinline__ double biased_table_entry(int j) {
-    const double t4 = 4.0 * c_exp2_table[j];
-    return __hiloint2double(__double2hiint(t4) - (j << 14), __double2loint(t4));
-}
-
-__device__ __forceinline__ double fma_clamp01(double a, double b, double c) {
-    double r;
-    asm("v_fma_f64 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
-
-template <int NV>
-__device__ __forceinline__ void exp2_w_vec(const double (&w)[NV], const double magic, double (&out)[NV], const double* __restrict__ tab) {
-    constexpr double c1 = 6.931471805599453094e-01, c2 = 2.402265069591007123e-01, c3 = 5.550410866482157995e-02,
-                     c4 = 9.618129107628477162e-03, c5 = 1.333355814642844342e-03;
-    constexpr double S = -1024.0;
-    constexpr double C1 = 0.25 * c1 * S, C2 = 0.25 * c2 * S * S, C3 = 0.25 * c3 * S * S * S, C4 = 0.25 * c4 * S * S * S * S,
-                     C5 = 0.25 * c5 * S * S * S * S * S;
-    double a[NV], r[NV], p[NV], tv[NV];
-    int ki[NV];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) a[v] = magic - w[v];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) ki[v] = __double2loint(a[v]);
-#pragma unroll
-    for (int v = 0; v < NV; ++v) tv[v] = tab[ki[v] & 63];
-#pragma unroll
-    for (int v = 0; v < NV; ++v) r[v] = w[v] + (a[v] - magic);
-#pragma unroll
-    for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(C5, r[v], C4);
-#pragma unroll
-    for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(p[v], r[v], C3);
-#pragma unroll
-    for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(p[v], r[v], C2);
-#pragma unroll
-    for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(p[v], r[v], C1);
-#pragma unroll
-    for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(p[v], r[v], 0.25);
-#pragma unroll
-    for (int v = 0; v < NV; ++v) {
-        const int hi = __double2hiint(tv[v]) + (ki[v] << 14);
-        out[v] = __hiloint2double(hi, __double2loint(tv[v])) * p[v];
-    }
-}
-
 
 template <int R>
 __device__ __forceinline__ void esp_update(double (&e)[R > 0 ? R : 1], double k) {
@@ -152,7 +38,7 @@ __device__ __forceinline__ double esp_combine(const double (&e)[R > 0 ? R : 1], 
 //   CPT == 4: columns jb + 2*tx + {0,1} and jb + 128 + 2*tx + {0,1}   (two 16-byte stores per row)
 //   CPT == 2: columns jb + 2*tx + {0,1}
 // The B-side (column) features of all D dims stay in LDS for the whole workgroup; A-side (row) features are
-// restaged per row-step.  Dynamic LDS = (64 + D*TJ*2 + D*4*RT*2 + 4*RT) doubles.
+// restaged per row-step.  Dynamic LDS = (EW_N + D*TJ*2 + D*4*RT*2 + 4*RT) doubles.
 template <int R, int RT, int CPT, bool ALLRBF>
 __global__ void __launch_bounds__(256)
 gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* __restrict__ Axs,
@@ -163,8 +49,8 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
     constexpr int RS = 4 * RT;   // rows per row-step
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int D = dd.D;
-    double* Tab = smem;                // [64]  biased 4 * 2^(j/64); first, so the lookups use a constant LDS base
-    double* Bx = Tab + 64;             // [D][TJ]   (RBF dims: x * scale_d / 32)
+    double* Tab = smem;                // [EW_N] biased exp2 table (exp2w.h); first, so the lookups use a constant LDS base
+    double* Bx = Tab + EW_N;             // [D][TJ]   (RBF dims: x * scale_d / 32)
     double* Bc = Bx + D * TJ;          // [D][TJ]
     double* Ax = Bc + D * TJ;          // [D][RS]
     double* Ac = Ax + D * RS;          // [D][RS]
@@ -185,7 +71,7 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
         Bx[idx] = ok ? Bxs[(int64_t)d * b_ld + gj] * pre : 0.0;
         Bc[idx] = ok ? Bcn[(int64_t)d * b_ld + gj] : 0.0;
     }
-    if (tid < 64) Tab[tid] = biased_table_entry(tid);
+    for (int j = tid; j < EW_N; j += 256) Tab[j] = biased_table_entry(j);
     double psi[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) psi[c] = 0.0;
@@ -236,7 +122,10 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
                             const double u = xa[r] - xb[c];
                             w[c] = fma_clamp01(u, u, woff);
                         }
-                        exp2_w_vec<CPT>(w, magic, E, Tab);
+                        double mg[CPT];
+#pragma unroll
+                        for (int c = 0; c < CPT; ++c) mg[c] = magic;
+                        exp2_w_vec<CPT>(w, mg, E, Tab);
 #pragma unroll
                         for (int c = 0; c < CPT; ++c) esp_update<R>(e[r][c], __builtin_fma(-ca[r], cb[c], E[c]));
                     }
@@ -342,7 +231,7 @@ static int launch_gram_t(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, 
     constexpr int TJ = 64 * CPT;
     constexpr int RS = 4 * RT;
     const int D = pk.dd.D;
-    size_t lds = sizeof(double) * ((size_t)D * TJ * 2 + (size_t)D * RS * 2 + RS + 64);
+    size_t lds = sizeof(double) * ((size_t)D * TJ * 2 + (size_t)D * RS * 2 + RS + EW_N);
     const size_t lds_red = sizeof(double) * 4 * TJ;
     if (lds < lds_red) lds = lds_red;
     if (lds > 160 * 1024) { set_error("gram: LDS request %zu exceeds 160 KiB (D=%d)", lds, D); return OAK_E_ARG; }

@@ -242,7 +242,7 @@ int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk
                 const double n = std::ceil(dd.log2bv[d]);
                 OAK_REQUIRE(std::fabs(n) <= 900.0, "dim %d: base variance out of range", d);
                 dd.woff[d] = (n - dd.log2bv[d]) / 1024.0;
-                dd.magic[d] = 103079215104.0 + n / 1024.0;      // 1.5 * 2^36
+                dd.magic[d] = 12884901888.0 + n / 1024.0;       // EW_MAGIC (exp2w.h) + n/1024
             }
             dd.ncat[d] = 0; dd.tab_off[d] = 0;
             const int kind = desc->measure[d];
