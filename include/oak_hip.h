@@ -197,6 +197,19 @@ int oak_comm_destroy(oak_ctx* ctx);
 int oak_comm_allreduce_stats(oak_ctx* ctx);                    /* in-place sum of packed stats */
 int oak_comm_allreduce_host(oak_ctx* ctx, double* buf, int64_t n); /* small host vector (gradients) */
 
+/* ---- inducing-point initialisation ----------------------------------------------------------- */
+/* Lloyd k-means from given seeds, following scikit-learn's single-run loop (_kmeans_single_lloyd) that the
+   reference reaches through sklearn.cluster.KMeans(n_clusters=K).fit(X).cluster_centers_
+   (oak/model_utils.py:31-41 get_kmeans_centers, used by oak_model.fit :377-391; oak/utils.py:533-574 for the
+   continuous block of the mixed-type initialisers).  X is N x D row-major (leading dimension ldx), D <= 64;
+   init_centres and centres_out are K x D; labels_out (N, may be NULL) are the labels w.r.t. the returned centres;
+   tol is ABSOLUTE (scikit-learn passes tol * mean(var(X, axis=0))).  Stops on unchanged labels, on
+   sum_k |c_new - c_old|^2 <= tol, or after max_iter iterations; *n_iter_out = iterations run.  Empty clusters take
+   the points farthest from their own centre (largest distance first, ties by lower index).  Deterministic. */
+int oak_kmeans(oak_ctx* ctx, const double* X, int64_t N, int32_t D, int32_t ldx, int32_t K,
+               const double* init_centres, int32_t max_iter, double tol, double* centres_out,
+               int32_t* labels_out, double* inertia_out, int32_t* n_iter_out);
+
 /* ---- device-resident benchmarking hooks (inputs already in HBM) ---------------------------- */
 /* Explicit Kuf panel for the rows set with oak_sgpr_set_data, written to a device buffer and not
    copied back: the "Gram GB/s" workload.  bytes_out = algorithmic bytes 8*(N*M + N*D + M*D). */

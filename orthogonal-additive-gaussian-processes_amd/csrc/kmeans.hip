@@ -1,0 +1,289 @@
+// Lloyd k-means on the device: inducing-point initialisation for the sparse model.
+//
+// Replaces the scikit-learn KMeans.fit calls of the reference (oak/model_utils.py:31-41 get_kmeans_centers, called from
+// oak_model.fit :377-391; oak/utils.py:533-574 for the continuous block of the mixed-type initialisers).  scikit-learn's
+// single-run Lloyd loop (sklearn/cluster/_kmeans.py::_kmeans_single_lloyd) is followed step for step:
+//     repeat:  E-step  labels_i = argmin_k |x_i - c_k|^2 (first minimum wins)
+//              M-step  c_k = mean of the points labelled k; empty clusters take the points farthest from their centre
+//              stop when the labels did not change (strict convergence) or sum_k |c_k_new - c_k|^2 <= tol
+//     if not strictly converged: one more E-step against the final centres;  inertia = sum_i min_k |x_i - c_k|^2
+// Seeding (k-means++) stays on the host: it is sequential in K and touches a subsample only.
+//
+// Kernels (all deterministic: no floating-point atomics, fixed reduction trees):
+//   kmeans_assign_kernel   lane = P points held in registers, centres streamed through LDS (broadcast reads), distance in
+//                          the direct form sum_d (x_d - c_d)^2 (2 DP instructions per point-centre-dimension).
+//                          fp64-VALU bound: N*K*D*2 instructions; HBM traffic is N*D*8 B (negligible).
+//   kmeans_sums_kernel     one WAVE per cluster scans the label array (L2 / MALL resident, N*4 B) and gathers its member
+//                          rows in ascending point order; per-lane partial sums, then a fixed butterfly.
+//   kmeans_finalize_kernel centres = sums / counts, per-cluster squared shift.
+#include "oak_internal.h"
+#include <algorithm>
+#include <vector>
+
+namespace oak {
+
+static constexpr int KM_LDS_DOUBLES = 4096;   // 32 KiB of centres per LDS chunk
+
+template <int DMAX, int P>
+__global__ void __launch_bounds__(256)
+kmeans_assign_kernel(const double* __restrict__ X, int64_t N, int D, int64_t ldx, const double* __restrict__ C /* K x DMAX, zero padded */,
+                     int K, const int32_t* __restrict__ labels_old, int32_t* __restrict__ labels, double* __restrict__ mind,
+                     int* __restrict__ changed) {
+    constexpr int KCH = KM_LDS_DOUBLES / DMAX;
+    __shared__ __attribute__((aligned(16))) double sC[KM_LDS_DOUBLES];
+    const int tid = threadIdx.x;
+    double x[P][DMAX];
+    int64_t pt[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        pt[p] = ((int64_t)blockIdx.x * P + p) * 256 + tid;
+        const int64_t i = pt[p] < N ? pt[p] : N - 1;          // clamped address: no divergent loads
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) x[p][d] = (d < D) ? X[i * ldx + d] : 0.0;
+    }
+    double best[P];
+    int bi[P];
+#pragma unroll
+    for (int p = 0; p < P; ++p) { best[p] = __builtin_inf(); bi[p] = 0; }
+    for (int k0 = 0; k0 < K; k0 += KCH) {
+        const int kc = (K - k0 < KCH) ? K - k0 : KCH;
+        __syncthreads();
+        for (int idx = tid; idx < kc * DMAX; idx += 256) sC[idx] = C[(int64_t)k0 * DMAX + idx];
+        __syncthreads();
+        for (int kk = 0; kk < kc; ++kk) {
+            double dist[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) dist[p] = 0.0;
+#pragma unroll
+            for (int d = 0; d < DMAX; d += 2) {
+                const double2 c2 = *reinterpret_cast<const double2*>(&sC[kk * DMAX + d]);   // uniform address: LDS broadcast
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const double t0 = x[p][d] - c2.x;
+                    dist[p] = __builtin_fma(t0, t0, dist[p]);
+                    const double t1 = x[p][d + 1] - c2.y;
+                    dist[p] = __builtin_fma(t1, t1, dist[p]);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                if (dist[p] < best[p]) { best[p] = dist[p]; bi[p] = k0 + kk; }      // strict <: the first minimum wins
+        }
+    }
+    int nchanged = 0;
+#pragma unroll
+    for (int p = 0; p < P; ++p) {
+        if (pt[p] < N) {
+            if (labels_old == nullptr || labels_old[pt[p]] != bi[p]) ++nchanged;
+            labels[pt[p]] = bi[p];
+            mind[pt[p]] = best[p];
+        }
+    }
+    if (nchanged) atomicAdd(changed, nchanged);    // integer count: order-independent
+}
+
+__device__ __forceinline__ double km_wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <int DMAX>
+__global__ void __launch_bounds__(256)
+kmeans_sums_kernel(const double* __restrict__ X, int64_t N, int D, int64_t ldx, const int32_t* __restrict__ labels, int K,
+                   double* __restrict__ sums /* K x DMAX */, int32_t* __restrict__ counts) {
+    const int lane = threadIdx.x & 63;
+    const int c = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
+    if (c >= K) return;
+    double s[DMAX];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) s[d] = 0.0;
+    int cnt = 0;
+    // lane l visits points l, l + 64, ... in ascending order; four label loads in flight per trip
+    int64_t i = lane;
+    for (; i + 192 < N; i += 256) {
+        const int32_t l0 = labels[i], l1 = labels[i + 64], l2 = labels[i + 128], l3 = labels[i + 192];
+        if (l0 == c) { const double* r = X + i * ldx;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) if (d < D) s[d] += r[d];
+            ++cnt; }
+        if (l1 == c) { const double* r = X + (i + 64) * ldx;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) if (d < D) s[d] += r[d];
+            ++cnt; }
+        if (l2 == c) { const double* r = X + (i + 128) * ldx;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) if (d < D) s[d] += r[d];
+            ++cnt; }
+        if (l3 == c) { const double* r = X + (i + 192) * ldx;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) if (d < D) s[d] += r[d];
+            ++cnt; }
+    }
+    for (; i < N; i += 64) {
+        if (labels[i] == c) { const double* r = X + i * ldx;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) if (d < D) s[d] += r[d];
+            ++cnt; }
+    }
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) s[d] = km_wave_sum(s[d]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) sums[(int64_t)c * DMAX + d] = s[d];
+        counts[c] = cnt;
+    }
+}
+
+// centres_new = sums / counts (empty cluster: keep the old centre; the host relocates those before calling this);
+// shift2[k] = |c_new - c_old|^2
+__global__ void kmeans_finalize_kernel(const double* __restrict__ sums, const int32_t* __restrict__ counts, const double* __restrict__ Cold,
+                                       double* __restrict__ Cnew, double* __restrict__ shift2, int K, int DMAX) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const int n = counts[k];
+    double sh = 0.0;
+    for (int d = 0; d < DMAX; ++d) {
+        const double co = Cold[(int64_t)k * DMAX + d];
+        const double cn = n > 0 ? sums[(int64_t)k * DMAX + d] / (double)n : co;
+        Cnew[(int64_t)k * DMAX + d] = cn;
+        const double t = cn - co;
+        sh = __builtin_fma(t, t, sh);
+    }
+    shift2[k] = sh;
+}
+
+template <int DMAX>
+static int km_launch_assign(oak_ctx* ctx, const double* dX, int64_t N, int D, int64_t ldx, const double* dC, int K,
+                            const int32_t* lab_old, int32_t* lab, double* mind, int* changed) {
+    constexpr int P = DMAX <= 16 ? 4 : (DMAX <= 32 ? 2 : 1);
+    const int64_t per_wg = 256 * P;
+    const unsigned grid = (unsigned)((N + per_wg - 1) / per_wg);
+    kmeans_assign_kernel<DMAX, P><<<grid, 256, 0, ctx->stream>>>(dX, N, D, ldx, dC, K, lab_old, lab, mind, changed);
+    OAK_HIP_CHECK(hipGetLastError());
+    return OAK_OK;
+}
+
+template <int DMAX>
+static int km_launch_sums(oak_ctx* ctx, const double* dX, int64_t N, int D, int64_t ldx, const int32_t* lab, int K, double* sums,
+                          int32_t* counts) {
+    kmeans_sums_kernel<DMAX><<<(unsigned)((K + 3) / 4), 256, 0, ctx->stream>>>(dX, N, D, ldx, lab, K, sums, counts);
+    OAK_HIP_CHECK(hipGetLastError());
+    return OAK_OK;
+}
+
+#define KM_DISPATCH(FN, ...)                                  \
+    (dmax == 8 ? FN<8>(__VA_ARGS__) : dmax == 16 ? FN<16>(__VA_ARGS__) : dmax == 32 ? FN<32>(__VA_ARGS__) : FN<64>(__VA_ARGS__))
+
+}  // namespace oak
+
+using namespace oak;
+
+extern "C" int oak_kmeans(oak_ctx* ctx, const double* X, int64_t N, int32_t D, int32_t ldx, int32_t K, const double* init_centres,
+                          int32_t max_iter, double tol, double* centres_out, int32_t* labels_out, double* inertia_out,
+                          int32_t* n_iter_out) {
+    if (!ctx) { set_error("ctx is NULL"); return OAK_E_ARG; }
+    OAK_HIP_CHECK(hipSetDevice(ctx->device));
+    OAK_REQUIRE(X && init_centres && centres_out, "oak_kmeans: NULL argument");
+    OAK_REQUIRE(N >= 1 && D >= 1 && D <= 64 && ldx >= D && K >= 1 && K <= N && max_iter >= 1 && tol >= 0.0,
+                "oak_kmeans: bad sizes (N=%lld D=%d ldx=%d K=%d max_iter=%d)", (long long)N, D, ldx, K, max_iter);
+    const int dmax = D <= 8 ? 8 : D <= 16 ? 16 : D <= 32 ? 32 : 64;
+    PhaseTimer ttot(ctx, "kmeans");
+    double *dX, *dC[2], *dSums, *dShift, *dMind, *dScal;
+    int32_t *dLab[2], *dCnt;
+    int* dChanged;
+    OAK_CHECK(get_buf_t(ctx, "km_X", (size_t)N * ldx, &dX));
+    OAK_CHECK(get_buf_t(ctx, "km_C0", (size_t)K * dmax, &dC[0]));
+    OAK_CHECK(get_buf_t(ctx, "km_C1", (size_t)K * dmax, &dC[1]));
+    OAK_CHECK(get_buf_t(ctx, "km_sums", (size_t)K * dmax, &dSums));
+    OAK_CHECK(get_buf_t(ctx, "km_shift", (size_t)K, &dShift));
+    OAK_CHECK(get_buf_t(ctx, "km_mind", (size_t)N, &dMind));
+    OAK_CHECK(get_buf_t(ctx, "km_scal", 4, &dScal));
+    OAK_CHECK(get_buf_t(ctx, "km_lab0", (size_t)N, &dLab[0]));
+    OAK_CHECK(get_buf_t(ctx, "km_lab1", (size_t)N, &dLab[1]));
+    OAK_CHECK(get_buf_t(ctx, "km_cnt", (size_t)K, &dCnt));
+    OAK_CHECK(get_buf_t(ctx, "km_changed", 2, &dChanged));
+    OAK_HIP_CHECK(hipMemcpyAsync(dX, X, sizeof(double) * (size_t)N * ldx, hipMemcpyHostToDevice, ctx->stream));
+    std::vector<double> hC((size_t)K * dmax, 0.0), hSums;
+    for (int k = 0; k < K; ++k)
+        for (int d = 0; d < D; ++d) hC[(size_t)k * dmax + d] = init_centres[(size_t)k * D + d];
+    OAK_HIP_CHECK(hipMemcpyAsync(dC[0], hC.data(), sizeof(double) * hC.size(), hipMemcpyHostToDevice, ctx->stream));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+
+    std::vector<int32_t> hCnt((size_t)K);
+    int cur = 0, lab = 0;            // dC[cur] = current centres; dLab[lab] receives this iteration's labels
+    bool strict = false, have_old = false;
+    int it = 0;
+    for (; it < max_iter; ++it) {
+        OAK_HIP_CHECK(hipMemsetAsync(dChanged, 0, sizeof(int), ctx->stream));
+        OAK_CHECK(KM_DISPATCH(km_launch_assign, ctx, dX, N, D, ldx, dC[cur], K, have_old ? dLab[lab ^ 1] : nullptr, dLab[lab], dMind, dChanged));
+        OAK_CHECK(KM_DISPATCH(km_launch_sums, ctx, dX, N, D, ldx, dLab[lab], K, dSums, dCnt));
+        OAK_HIP_CHECK(hipMemcpyAsync(hCnt.data(), dCnt, sizeof(int32_t) * (size_t)K, hipMemcpyDeviceToHost, ctx->stream));
+        int h_changed = 0;
+        OAK_HIP_CHECK(hipMemcpyAsync(&h_changed, dChanged, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        // empty clusters: give each the point farthest from its own centre, taken out of its donor cluster
+        // (sklearn _relocate_empty_clusters_dense; largest distances first, ties by lower index)
+        std::vector<int> empty;
+        for (int k = 0; k < K; ++k) if (hCnt[(size_t)k] == 0) empty.push_back(k);
+        if (!empty.empty()) {
+            std::vector<double> hMind((size_t)N);
+            std::vector<int32_t> hLab((size_t)N);
+            hSums.resize((size_t)K * dmax);
+            OAK_HIP_CHECK(hipMemcpy(hMind.data(), dMind, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost));
+            OAK_HIP_CHECK(hipMemcpy(hLab.data(), dLab[lab], sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
+            OAK_HIP_CHECK(hipMemcpy(hSums.data(), dSums, sizeof(double) * hSums.size(), hipMemcpyDeviceToHost));
+            std::vector<int64_t> order((size_t)N);
+            for (int64_t i = 0; i < N; ++i) order[(size_t)i] = i;
+            const size_t ne = empty.size();
+            std::partial_sort(order.begin(), order.begin() + (std::ptrdiff_t)ne, order.end(), [&](int64_t a, int64_t b) {
+                return hMind[(size_t)a] > hMind[(size_t)b] || (hMind[(size_t)a] == hMind[(size_t)b] && a < b);
+            });
+            for (size_t e = 0; e < ne; ++e) {
+                const int64_t far = order[e];
+                const int donor = hLab[(size_t)far], target = empty[e];
+                for (int d = 0; d < D; ++d) {
+                    hSums[(size_t)donor * dmax + d] -= X[(size_t)far * ldx + d];
+                    hSums[(size_t)target * dmax + d] = X[(size_t)far * ldx + d];
+                }
+                hCnt[(size_t)target] = 1;
+                hCnt[(size_t)donor] -= 1;
+            }
+            OAK_HIP_CHECK(hipMemcpy(dSums, hSums.data(), sizeof(double) * hSums.size(), hipMemcpyHostToDevice));
+            OAK_HIP_CHECK(hipMemcpy(dCnt, hCnt.data(), sizeof(int32_t) * (size_t)K, hipMemcpyHostToDevice));
+        }
+        kmeans_finalize_kernel<<<(unsigned)((K + 255) / 256), 256, 0, ctx->stream>>>(dSums, dCnt, dC[cur], dC[cur ^ 1], dShift, K, dmax);
+        OAK_HIP_CHECK(hipGetLastError());
+        OAK_CHECK(reduce_sum(ctx, dShift, K, dScal, 0, 1));
+        double shift_tot = 0.0;
+        OAK_HIP_CHECK(hipMemcpyAsync(&shift_tot, dScal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        cur ^= 1;                                        // centres <- centres_new
+        if (have_old && h_changed == 0) { strict = true; ++it; break; }
+        if (shift_tot <= tol) { lab ^= 1; have_old = true; ++it; break; }
+        lab ^= 1;                                        // this iteration's labels become labels_old
+        have_old = true;
+    }
+    // after the loop dLab[lab ^ 1] holds the most recent labels unless we broke out on strict convergence
+    int32_t* dFinalLab = strict ? dLab[lab] : dLab[lab ^ 1];
+    if (!strict) {
+        // E-step against the final centres so labels and inertia match them
+        OAK_HIP_CHECK(hipMemsetAsync(dChanged, 0, sizeof(int), ctx->stream));
+        OAK_CHECK(KM_DISPATCH(km_launch_assign, ctx, dX, N, D, ldx, dC[cur], K, nullptr, dLab[lab], dMind, dChanged));
+        dFinalLab = dLab[lab];
+    }
+    OAK_CHECK(reduce_sum(ctx, dMind, N, dScal, 0, 1));
+    double inertia = 0.0;
+    OAK_HIP_CHECK(hipMemcpyAsync(&inertia, dScal, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    OAK_HIP_CHECK(hipMemcpyAsync(hC.data(), dC[cur], sizeof(double) * hC.size(), hipMemcpyDeviceToHost, ctx->stream));
+    if (labels_out) OAK_HIP_CHECK(hipMemcpyAsync(labels_out, dFinalLab, sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost, ctx->stream));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ttot.stop();
+    for (int k = 0; k < K; ++k)
+        for (int d = 0; d < D; ++d) centres_out[(size_t)k * D + d] = hC[(size_t)k * dmax + d];
+    if (inertia_out) *inertia_out = inertia;
+    if (n_iter_out) *n_iter_out = it;
+    return OAK_OK;
+}

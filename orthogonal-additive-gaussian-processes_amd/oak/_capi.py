@@ -97,6 +97,8 @@ SIGNATURES = {
     "oak_comm_allreduce_stats": (C.c_int, [_CTX]),
     "oak_comm_allreduce_host": (C.c_int, [_CTX, _D, C.c_int64]),
     "oak_bench_gram_resident": (C.c_int, [_CTX, _DESC, _D]),
+    "oak_kmeans": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _D, C.c_int32, C.c_double, _D, _I,
+                             _D, _I]),
 }
 
 _lib = None
@@ -526,6 +528,23 @@ class HipContext:
         buf = _f64(buf, 1)
         _check(self._lib.oak_comm_allreduce_host(self._h, _dp(buf), buf.size))
         return buf
+
+    # -- inducing-point initialisation ----------------------------------------------------------
+    def kmeans(self, X: np.ndarray, init_centres: np.ndarray, max_iter: int = 300, tol: float = 0.0):
+        """Lloyd iterations from ``init_centres`` (scikit-learn's single-run loop; ``tol`` is absolute).
+        Returns (centres [K, D], labels [N] int32, inertia, n_iter)."""
+        X = _f64(X, 2)
+        C0 = _f64(init_centres, 2)
+        if C0.shape[1] != X.shape[1]:
+            raise ValueError("init_centres must have the same number of columns as X")
+        K = C0.shape[0]
+        centres = np.empty_like(C0)
+        labels = np.empty(X.shape[0], dtype=np.int32)
+        inertia = C.c_double()
+        n_iter = C.c_int32()
+        _check(self._lib.oak_kmeans(self._h, _dp(X), X.shape[0], X.shape[1], X.shape[1], K, _dp(C0), int(max_iter), float(tol),
+                                    _dp(centres), _ip(labels), C.byref(inertia), C.byref(n_iter)))
+        return centres, labels, inertia.value, n_iter.value
 
     # -- benchmarking -------------------------------------------------------------------------
     def bench_gram_resident(self, desc: KernelDesc) -> float:

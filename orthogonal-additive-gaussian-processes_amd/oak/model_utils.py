@@ -18,14 +18,13 @@ from .gpflow_lite import GPR, SGPR, GPModel, InducingPoints, set_trainable
 from .input_measures import MOGMeasure
 from .normalising_flow import Normalizer
 from .oak_kernel import OAKKernel, get_list_representation
-from .utils import compute_sobol_oak, initialize_kmeans_with_categorical
+from .utils import compute_sobol_oak, initialize_kmeans_with_categorical, kmeans_centres
 
 
 def get_kmeans_centers(X: np.ndarray, K: int = 500) -> np.ndarray:
-    """K-means centres of X (oak/model_utils.py:31-41)."""
-    from sklearn.cluster import KMeans
+    """K-means centres of X (oak/model_utils.py:31-41): k-means++ seeds + Lloyd iterations on the device."""
     np.random.seed(44)
-    return KMeans(n_clusters=K, random_state=0).fit(X).cluster_centers_
+    return kmeans_centres(X, K, random_state=0)
 
 
 def save_model(model: GPModel, filename: Path) -> None:

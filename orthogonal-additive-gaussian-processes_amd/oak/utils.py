@@ -132,7 +132,33 @@ def get_prediction_component(m, alpha, X: np.ndarray = None, share_var_across_or
     return [TensorLike(row) for row in out]
 
 
-# ---- inducing-point initialisation (oak/utils.py:533-574): scikit-learn on the host, as in the reference ----------
+# ---- inducing-point initialisation (oak/utils.py:533-574) -------------------------------------------------------------
+KMEANS_SEED_SAMPLE = 131072     # k-means++ seeding (sequential in K) looks at no more than this many rows
+
+
+def kmeans_centres(X, n_clusters: int, random_state: int = 0, max_iter: int = 300, tol: float = 1e-4) -> np.ndarray:
+    """``KMeans(n_clusters, random_state=random_state).fit(X).cluster_centers_`` with the Lloyd iterations on the device.
+
+    Same pipeline as scikit-learn's ``KMeans.fit`` (one k-means++ initialisation, the default since scikit-learn 1.4):
+    centre the data, draw k-means++ seeds with the given ``random_state``, run Lloyd (``oak_kmeans``) with the absolute
+    tolerance ``tol * mean(var(X, axis=0))``, add the mean back.  The seeding is scikit-learn's own ``kmeans_plusplus``
+    (host; it is sequential in K); above ``KMEANS_SEED_SAMPLE`` rows it sees a fixed random subsample, which is the only
+    departure from the reference call."""
+    from sklearn.cluster import kmeans_plusplus
+    X = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
+    if X.ndim != 2:
+        raise ValueError("X must be two-dimensional")
+    mean = X.mean(axis=0)
+    Xc = X - mean
+    pool = Xc
+    if Xc.shape[0] > KMEANS_SEED_SAMPLE:
+        pool = Xc[np.random.RandomState(random_state).choice(Xc.shape[0], KMEANS_SEED_SAMPLE, replace=False)]
+    seeds, _ = kmeans_plusplus(pool, n_clusters, random_state=random_state)
+    abs_tol = float(np.mean(np.var(X, axis=0)) * tol)
+    centres, _, _, _ = _capi.default_context().kmeans(Xc, seeds, max_iter, abs_tol)
+    return centres + mean
+
+
 def initialize_kmeans_with_binary(X, binary_index: list, continuous_index: Optional[list] = None, n_clusters: Optional[int] = 200):
     from sklearn.cluster import KMeans
     X = np.asarray(X)
@@ -141,8 +167,7 @@ def initialize_kmeans_with_binary(X, binary_index: list, continuous_index: Optio
         km = KMeans(n_clusters=n_clusters, random_state=0).fit(X[:, index][:, None])
         Z[:, index] = km.cluster_centers_.astype(int)[:, 0]
     if continuous_index is not None:
-        km = KMeans(n_clusters=n_clusters, random_state=0).fit(X[:, continuous_index])
-        Z[:, continuous_index] = km.cluster_centers_
+        Z[:, continuous_index] = kmeans_centres(X[:, continuous_index], n_clusters, random_state=0)
     return Z
 
 
@@ -154,6 +179,5 @@ def initialize_kmeans_with_categorical(X, binary_index: list, categorical_index:
     for index in binary_index + categorical_index:
         km = KMeans(n_clusters=n_clusters, random_state=0).fit(X[:, index][:, None])
         Z[:, index] = km.cluster_centers_.astype(int)[:, 0]
-    km = KMeans(n_clusters=n_clusters, random_state=0).fit(X[:, continuous_index])
-    Z[:, continuous_index] = km.cluster_centers_
+    Z[:, continuous_index] = kmeans_centres(X[:, continuous_index], n_clusters, random_state=0)
     return Z

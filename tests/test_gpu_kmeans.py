@@ -1,0 +1,147 @@
+"""HIP Lloyd k-means (oak_kmeans) against the oracle / scikit-learn on the same seeds.  Bit-exact labels and
+iteration counts; centres to 1e-10 (summation order), inertia to 1e-10 relative."""
+import numpy as np
+import pytest
+
+from oracle import kmeans_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+
+def _data(N, D, K, seed, spread=3.0):
+    rng = np.random.default_rng(seed)
+    centres = rng.normal(size=(K, D)) * spread
+    X = centres[rng.integers(0, K, N)] + rng.normal(size=(N, D))
+    seeds = X[rng.choice(N, K, replace=False)].copy()
+    return X, seeds
+
+
+@pytest.mark.parametrize("N,D,K,seed", [
+    (500, 2, 5, 0),          # dmax 8
+    (2000, 8, 20, 1),
+    (3001, 16, 50, 2),       # dmax 16, ragged N
+    (4097, 20, 33, 3),       # dmax 32
+    (1500, 40, 17, 4),       # dmax 64
+    (6000, 8, 700, 5),       # K > 512: two LDS chunks of centres
+    (5000, 16, 300, 6),      # K > 256 at dmax 16
+    (64, 3, 64, 7),          # K == N
+    (1, 1, 1, 8),
+])
+def test_kmeans_matches_oracle(hip, N, D, K, seed):
+    X, seeds = _data(N, D, K, seed)
+    tol = ko.sklearn_tolerance(X, 1e-4)
+    C0, l0, i0, n0 = ko.lloyd(X, seeds, 300, tol)
+    C, labels, inertia, n_iter = hip.kmeans(X, seeds, 300, tol)
+    assert n_iter == n0
+    np.testing.assert_array_equal(labels, l0)
+    np.testing.assert_allclose(C, C0, rtol=0, atol=1e-10)
+    assert abs(inertia - i0) <= 1e-10 * max(i0, 1e-300)
+
+
+def test_kmeans_matches_sklearn(hip):
+    sklearn_cluster = pytest.importorskip("sklearn.cluster")
+    X, seeds = _data(20000, 16, 128, 11)
+    km = sklearn_cluster.KMeans(n_clusters=128, init=seeds, n_init=1, algorithm="lloyd", max_iter=300, tol=1e-4).fit(X)
+    C, labels, inertia, n_iter = hip.kmeans(X, seeds, 300, ko.sklearn_tolerance(X, 1e-4))
+    assert n_iter == km.n_iter_
+    np.testing.assert_array_equal(labels, km.labels_)
+    np.testing.assert_allclose(C, km.cluster_centers_, rtol=0, atol=1e-9)
+    assert abs(inertia - km.inertia_) <= 1e-9 * km.inertia_
+
+
+def test_kmeans_max_iter_one_and_fixed_point(hip):
+    X, seeds = _data(3000, 5, 12, 21)
+    C1, l1, i1, n1 = hip.kmeans(X, seeds, 1, 0.0)
+    Co, lo, io, no = ko.lloyd(X, seeds, 1, 0.0)
+    assert n1 == 1 == no
+    np.testing.assert_array_equal(l1, lo)
+    np.testing.assert_allclose(C1, Co, atol=1e-12)
+    C, l, inertia, n = hip.kmeans(X, seeds, 300, 0.0)            # tol 0 -> strict convergence
+    C2, l2, inertia2, n2 = hip.kmeans(X, C, 300, 0.0)
+    assert n2 == 1                                             # zero centre shift on the first M-step
+    np.testing.assert_array_equal(l, l2)
+    np.testing.assert_array_equal(C, C2)                         # deterministic: bitwise fixed point
+    assert inertia2 == inertia
+
+
+def test_kmeans_empty_cluster_relocation(hip):
+    rng = np.random.default_rng(9)
+    X = rng.normal(size=(300, 2))
+    seeds = np.vstack([X[:4], [[50.0, 50.0]]])
+    Co, lo, io, no = ko.lloyd(X, seeds, 50, 0.0)
+    C, l, inertia, n = hip.kmeans(X, seeds, 50, 0.0)
+    assert n == no
+    np.testing.assert_array_equal(l, lo)
+    np.testing.assert_allclose(C, Co, atol=1e-12)
+    assert np.bincount(l, minlength=5).min() > 0
+
+
+def test_kmeans_deterministic_and_strided_input(hip):
+    X, seeds = _data(10000, 7, 40, 31)
+    Xw = np.hstack([X, np.full((X.shape[0], 2), 123.0)])[:, :7]   # non-contiguous view -> copied by the binding
+    a = hip.kmeans(Xw, seeds, 25, 0.0)
+    b = hip.kmeans(X, seeds, 25, 0.0)
+    for u, v in zip(a, b):
+        np.testing.assert_array_equal(np.asarray(u), np.asarray(v))
+
+
+def test_kmeans_bad_arguments(hip):
+    X = np.zeros((10, 3))
+    with pytest.raises(ValueError):
+        hip.kmeans(X, np.zeros((2, 4)))
+    with pytest.raises(ValueError):
+        hip.kmeans(X, np.zeros((11, 3)))          # K > N (OAK_E_ARG surfaces as ValueError, like sklearn)
+    with pytest.raises(ValueError):
+        hip.kmeans(np.zeros((10, 65)), np.zeros((2, 65)))   # D > 64
+
+
+def test_kmeans_headline_scale_properties(hip):
+    """N = 2^20, D = 16, K = 1024 (the headline inducing-point initialisation): Lloyd properties that need no oracle run.
+    Inertia is non-increasing in the iteration budget; returned centres are the means of their labelled points; labels are
+    nearest-centre assignments (checked on a sample)."""
+    rng = np.random.default_rng(20240601)
+    N, D, K = 1 << 20, 16, 1024
+    X = rng.normal(size=(N, D))
+    seeds = X[rng.choice(N, K, replace=False)].copy()
+    prev = np.inf
+    for iters in (1, 3, 6):
+        C, labels, inertia, n = hip.kmeans(X, seeds, iters, 0.0)
+        assert n == iters and inertia <= prev * (1 + 1e-12)
+        prev = inertia
+    # labels are argmin w.r.t. the returned centres (sample), inertia is their summed distance
+    idx = rng.choice(N, 2048, replace=False)
+    d2 = ((X[idx, None, :] - C[None, :, :]) ** 2).sum(axis=2)
+    np.testing.assert_array_equal(labels[idx], np.argmin(d2, axis=1))
+    # one more M-step from these labels reproduces hip's next centres
+    sums = np.zeros_like(C)
+    np.add.at(sums, labels, X)
+    cnt = np.bincount(labels, minlength=K)
+    C7, _, _, _ = hip.kmeans(X, C, 1, 0.0)
+    np.testing.assert_allclose(C7[cnt > 0], (sums / np.maximum(cnt, 1)[:, None])[cnt > 0], atol=1e-11)
+
+
+@pytest.mark.parametrize("N,D,K", [(5000, 6, 20), (3000, 16, 64), (2000, 1, 10)])
+def test_kmeans_centres_equals_sklearn_fit(hip, N, D, K):
+    """The host entry the model code calls (oak.utils.kmeans_centres) reproduces the reference's
+    KMeans(n_clusters=K, random_state=0).fit(X).cluster_centers_ (/root/reference/oak/model_utils.py:38-40)."""
+    sklearn_cluster = pytest.importorskip("sklearn.cluster")
+    from oak.utils import kmeans_centres
+    rng = np.random.default_rng(0)
+    X = rng.normal(size=(N, D)) * 2 + rng.integers(0, 4, (N, 1))
+    ref = sklearn_cluster.KMeans(n_clusters=K, random_state=0).fit(X).cluster_centers_
+    np.testing.assert_allclose(kmeans_centres(X, K, random_state=0), ref, rtol=0, atol=1e-9)
+
+
+def test_get_kmeans_centers_and_subsampled_seeding(hip, monkeypatch):
+    from oak import utils, model_utils
+    rng = np.random.default_rng(3)
+    X = rng.normal(size=(20000, 4))
+    Z = model_utils.get_kmeans_centers(X, 50)
+    assert Z.shape == (50, 4) and np.isfinite(Z).all()
+    # seeds drawn from a subsample: still a Lloyd fixed point of the FULL data within the tolerance
+    monkeypatch.setattr(utils, "KMEANS_SEED_SAMPLE", 2000)
+    Z2 = utils.kmeans_centres(X, 50, random_state=0)
+    C, labels, inertia, n = hip.kmeans(X, Z2, 1, 0.0)
+    assert np.abs(C - Z2).max() < 0.05
+    d_full = ((X[:, None, :] - Z[None]) ** 2).sum(-1).min(1).sum()
+    assert inertia < 1.05 * d_full          # as good a clustering as the all-rows seeding, within 5 %
