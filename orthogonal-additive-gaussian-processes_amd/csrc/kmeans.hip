@@ -13,8 +13,9 @@
 //   kmeans_assign_kernel   lane = P points held in registers, centres streamed through LDS (broadcast reads), distance in
 //                          the direct form sum_d (x_d - c_d)^2 (2 DP instructions per point-centre-dimension).
 //                          fp64-VALU bound: N*K*D*2 instructions; HBM traffic is N*D*8 B (negligible).
-//   kmeans_sums_kernel     one WAVE per cluster scans the label array (L2 / MALL resident, N*4 B) and gathers its member
-//                          rows in ascending point order; per-lane partial sums, then a fixed butterfly.
+//   kmeans_sums_kernel     one WORKGROUP per cluster scans the label array (L2 / MALL resident, N*4 B; a quarter per wave)
+//                          and gathers its member rows in ascending point order; per-lane partial sums, fixed butterfly,
+//                          then the four waves in order.
 //   kmeans_finalize_kernel centres = sums / counts, per-cluster squared shift.
 #include "oak_internal.h"
 #include <algorithm>
@@ -88,53 +89,55 @@ __device__ __forceinline__ double km_wave_sum(double v) {
     return v;
 }
 
+// One workgroup per cluster.  Wave w scans the w-th quarter of the label array (lane l visits points q0 + l, q0 + l + 64,
+// ... in ascending order, eight label loads in flight per trip to cover the L2 / MALL latency) and gathers the member
+// rows into per-lane partial sums; fixed butterfly within the wave, then the four waves are added in order 0..3.
 template <int DMAX>
 __global__ void __launch_bounds__(256)
 kmeans_sums_kernel(const double* __restrict__ X, int64_t N, int D, int64_t ldx, const int32_t* __restrict__ labels, int K,
                    double* __restrict__ sums /* K x DMAX */, int32_t* __restrict__ counts) {
+    __shared__ double part[4][DMAX];
+    __shared__ int pcnt[4];
     const int lane = threadIdx.x & 63;
-    const int c = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * 4 + (threadIdx.x >> 6)));
-    if (c >= K) return;
+    const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int c = blockIdx.x;
     double s[DMAX];
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) s[d] = 0.0;
     int cnt = 0;
-    // lane l visits points l, l + 64, ... in ascending order; four label loads in flight per trip
-    int64_t i = lane;
-    for (; i + 192 < N; i += 256) {
-        const int32_t l0 = labels[i], l1 = labels[i + 64], l2 = labels[i + 128], l3 = labels[i + 192];
-        if (l0 == c) { const double* r = X + i * ldx;
+    const int64_t q = ((N + 3) / 4 + 63) / 64 * 64;          // quarter length, multiple of 64
+    const int64_t q0 = (int64_t)w * q;
+    const int64_t q1 = (q0 + q < N) ? q0 + q : N;
+    auto take = [&](int64_t i) {
+        const double* r = X + i * ldx;
 #pragma unroll
-            for (int d = 0; d < DMAX; ++d) if (d < D) s[d] += r[d];
-            ++cnt; }
-        if (l1 == c) { const double* r = X + (i + 64) * ldx;
+        for (int d = 0; d < DMAX; ++d) if (d < D) s[d] += r[d];
+        ++cnt;
+    };
+    int64_t i = q0 + lane;
+    for (; i + 7 * 64 < q1; i += 512) {
+        int32_t l[8];
 #pragma unroll
-            for (int d = 0; d < DMAX; ++d) if (d < D) s[d] += r[d];
-            ++cnt; }
-        if (l2 == c) { const double* r = X + (i + 128) * ldx;
+        for (int u = 0; u < 8; ++u) l[u] = labels[i + 64 * u];
 #pragma unroll
-            for (int d = 0; d < DMAX; ++d) if (d < D) s[d] += r[d];
-            ++cnt; }
-        if (l3 == c) { const double* r = X + (i + 192) * ldx;
-#pragma unroll
-            for (int d = 0; d < DMAX; ++d) if (d < D) s[d] += r[d];
-            ++cnt; }
+        for (int u = 0; u < 8; ++u) if (l[u] == c) take(i + 64 * u);
     }
-    for (; i < N; i += 64) {
-        if (labels[i] == c) { const double* r = X + i * ldx;
-#pragma unroll
-            for (int d = 0; d < DMAX; ++d) if (d < D) s[d] += r[d];
-            ++cnt; }
-    }
+    for (; i < q1; i += 64) if (labels[i] == c) take(i);
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) s[d] = km_wave_sum(s[d]);
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
     if (lane == 0) {
 #pragma unroll
-        for (int d = 0; d < DMAX; ++d) sums[(int64_t)c * DMAX + d] = s[d];
-        counts[c] = cnt;
+        for (int d = 0; d < DMAX; ++d) part[w][d] = s[d];
+        pcnt[w] = cnt;
     }
+    __syncthreads();
+    if (threadIdx.x < DMAX) {
+        const int d = threadIdx.x;
+        sums[(int64_t)c * DMAX + d] = ((part[0][d] + part[1][d]) + part[2][d]) + part[3][d];
+    }
+    if (threadIdx.x == 0) counts[c] = ((pcnt[0] + pcnt[1]) + pcnt[2]) + pcnt[3];
 }
 
 // centres_new = sums / counts (empty cluster: keep the old centre; the host relocates those before calling this);
@@ -169,7 +172,7 @@ static int km_launch_assign(oak_ctx* ctx, const double* dX, int64_t N, int D, in
 template <int DMAX>
 static int km_launch_sums(oak_ctx* ctx, const double* dX, int64_t N, int D, int64_t ldx, const int32_t* lab, int K, double* sums,
                           int32_t* counts) {
-    kmeans_sums_kernel<DMAX><<<(unsigned)((K + 3) / 4), 256, 0, ctx->stream>>>(dX, N, D, ldx, lab, K, sums, counts);
+    kmeans_sums_kernel<DMAX><<<(unsigned)K, 256, 0, ctx->stream>>>(dX, N, D, ldx, lab, K, sums, counts);
     OAK_HIP_CHECK(hipGetLastError());
     return OAK_OK;
 }
