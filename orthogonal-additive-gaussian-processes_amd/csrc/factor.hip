@@ -277,8 +277,8 @@ __device__ __forceinline__ void potf2_wave(double* Dg /*[NB][PO_P]*/, double* in
 // Every workgroup re-factors the (tiny) diagonal block itself instead of waiting for one producer.  The factor must not
 // be written back over A_jj while a sibling workgroup may still be loading the unfactored block, so the LAST workgroup
 // to finish loading (arrival counter, one per panel) does the write-back.
-__global__ void __launch_bounds__(256) potrf_panel_kernel(double* __restrict__ A, int64_t n, int64_t lda, int64_t j0, int* __restrict__ info,
-                                                          int* __restrict__ arrivals) {
+__global__ void __launch_bounds__(256) potrf_panel_kernel(double* __restrict__ A, int64_t n, int64_t nrows, int64_t lda, int64_t j0,
+                                                          int* __restrict__ info, int* __restrict__ arrivals) {
     __shared__ __attribute__((aligned(16))) double Dg[PO_NB * PO_P];
     __shared__ double invd[PO_NB];
     __shared__ int last_loader;
@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(256) potrf_panel_kernel(double* __restrict__ A
     }
     // rows below the diagonal block: X * L_jj^T = A_panel, one row per lane
     const int64_t row = j0 + nb + (int64_t)blockIdx.x * 256 + tid;
-    if (row < n && nb == PO_NB) {
+    if (row < nrows && nb == PO_NB) {
         double x[PO_NB];
         double* ap = A + row * lda + j0;
 #pragma unroll
@@ -354,7 +354,9 @@ int potrf_check(oak_ctx* ctx, int slot, int64_t n) {
     return OAK_OK;
 }
 
-int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, bool check) {
+int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, bool check, int64_t nrows) {
+    if (nrows < n) nrows = n;
+    if (nrows > n && (n % PO_NB) != 0) { set_error("potrf_lower: extra rows need n to be a multiple of %d", PO_NB); return OAK_E_ARG; }
     int* d_info = nullptr;
     OAK_CHECK(get_buf_t(ctx, "potrf_info", 2, &d_info));
     const int slot = (ctx->side != nullptr && ctx->stream == ctx->side) ? 1 : 0;
@@ -365,14 +367,15 @@ int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, bool check) {
     OAK_CHECK(get_buf_t(ctx, slot ? "potrf_arrivals_side" : "potrf_arrivals", npanel, &d_arr));
     OAK_HIP_CHECK(hipMemsetAsync(d_arr, 0, sizeof(int) * npanel, ctx->stream));
     for (int64_t j0 = 0; j0 < n; j0 += PO_NB) {
-        const int64_t below = n - j0 - PO_NB;
-        const unsigned gp = below > 0 ? (unsigned)((below + 255) / 256) : 1u;
-        potrf_panel_kernel<<<gp, 256, 0, ctx->stream>>>(dA, n, lda, j0, d_info, d_arr + j0 / PO_NB);
+        const int64_t below = n - j0 - PO_NB;              // trailing columns
+        const int64_t below_rows = nrows - j0 - PO_NB;     // rows under the diagonal block (extra rows included)
+        const unsigned gp = below_rows > 0 ? (unsigned)((below_rows + 255) / 256) : 1u;
+        potrf_panel_kernel<<<gp, 256, 0, ctx->stream>>>(dA, n, nrows, lda, j0, d_info, d_arr + j0 / PO_NB);
         if (below > 0) {
             // trailing update A22 -= L21 L21^T (lower tiles only): MFMA GEMM, K = 32
             const double* L21 = dA + (j0 + PO_NB) * lda + j0;
             double* A22 = dA + (j0 + PO_NB) * lda + (j0 + PO_NB);
-            OAK_CHECK(gemm_nt(ctx, L21, L21, A22, below, below, PO_NB, lda, lda, lda, -1.0, 1.0, 1));
+            OAK_CHECK(gemm_nt(ctx, L21, L21, A22, below_rows, below, PO_NB, lda, lda, lda, -1.0, 1.0, 1));
         }
     }
     dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);

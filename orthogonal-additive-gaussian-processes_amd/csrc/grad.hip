@@ -693,8 +693,12 @@ int oak_sgpr_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_v
         OAK_CHECK(get_buf_t(ctx, "g_Kuu", (size_t)M * M, &dKuu));
         OAK_CHECK(get_buf_t(ctx, "g_sc", 8, &dsc));
         OAK_CHECK(get_buf_t(ctx, "g_vec", (size_t)M, &dvec));
-        OAK_CHECK(set_identity(ctx, dLinvT, M));
-        OAK_CHECK(trsm_rows(ctx, dL, M, M, dLinvT, M, M, 0));                       // rows = columns of L^-1
+        if (ctx->have_linv) {
+            dLinvT = (double*)peek_buf(ctx, "LinvT");                                 // left by the forward tail
+        } else {
+            OAK_CHECK(set_identity(ctx, dLinvT, M));
+            OAK_CHECK(trsm_rows(ctx, dL, M, M, dLinvT, M, M, 0));                   // rows = columns of L^-1
+        }
         OAK_CHECK(copy_d2d(ctx, dPT, dLinvT, sizeof(double) * (size_t)M * M));
         OAK_CHECK(trsm_rows(ctx, dLB, M, M, dPT, M, M, 0));                         // rows = columns of LB^-1 L^-1
         OAK_CHECK(gemm_nt(ctx, dLinvT, dLinvT, dKinv, M, M, M, M, M, M, 1.0, 0.0, 0));     // Kuu^-1

@@ -104,6 +104,7 @@ struct oak_ctx {
     int32_t ldx = 0;
     int64_t panel_rows = 0;
     bool have_data = false, have_Z = false, have_stats = false, have_post = false, stats_whitened = false, have_alpha = false;
+    bool have_linv = false;          // buffers "Linv" / "LinvT" hold L^-1 and its transpose for the current L
     int route = 0;   // 0 auto, 1 phi, 2 whitened
     double noise_var = 0, jitter = 0;
     // GPR state
@@ -152,7 +153,10 @@ int syrk_panel(oak_ctx* ctx, const double* d_panel, int64_t ldp, int64_t nrows, 
                int nsplit, bool accumulate);
 int syrk_plan_splits(oak_ctx* ctx, int64_t M, int64_t nrows);
 int syrk_reduce(oak_ctx* ctx, const double* d_part, int nsplit, int64_t M, double* d_phi /*[M*M]*/, bool accumulate);
-int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, bool check = true);   // in place; strict upper zeroed
+// in place; strict upper zeroed.  nrows > n carries nrows - n extra rows through the panel solves and trailing updates
+// (row r >= n ends up as  A[r, :n] L^-T,  i.e. the solution of L x = A[r, :n]^T: a right-hand side rides for free).
+int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, bool check = true, int64_t nrows = -1);
+int set_identity(oak_ctx* ctx, double* dA, int64_t n);
 int potrf_check(oak_ctx* ctx, int slot, int64_t n);   // deferred status of a check=false factorisation (slot 1 = side stream)
 // rows-trsm: each of the nrhs rows of BT (row stride ldb) is a right-hand side; solves L x = b (trans=0)
 // or L^T x = b (trans=1) in place.

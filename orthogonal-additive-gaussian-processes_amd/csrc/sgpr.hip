@@ -152,12 +152,27 @@ bool sgpr_route_whitened(const oak_ctx* ctx) {
     return ctx->route == 2 || (ctx->route == 0 && ctx->N * ctx->M <= ((int64_t)1 << 24));
 }
 
+// L^-1 (and its transpose) from L, on the current ctx stream: LinvT rows = columns of L^-1 (rows-TRSM against I).
+// With it the M x M whitening of the phi route is two MFMA GEMMs instead of two latency-bound blocked TRSMs, and the
+// backward pass reuses it.
+static int build_linv(oak_ctx* ctx, const double* dL, int64_t M) {
+    double *dLinvT, *dLinv;
+    OAK_CHECK(get_buf_t(ctx, "LinvT", (size_t)M * M, &dLinvT));
+    OAK_CHECK(get_buf_t(ctx, "Linv", (size_t)M * M, &dLinv));
+    OAK_CHECK(set_identity(ctx, dLinvT, M));
+    OAK_CHECK(trsm_rows(ctx, dL, M, M, dLinvT, M, M, 0));
+    OAK_CHECK(transpose(ctx, dLinvT, M, M, M, dLinv, M));
+    return OAK_OK;
+}
+
 // L = chol(Kuu + jitter I) on the side stream.  It depends only on Z and the hyperparameters, so it runs concurrently
 // with the N-sized gram / SYRK stages; the tail joins on ev1 and reads the deferred Cholesky status (slot 1).
 int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     const int64_t M = ctx->M;
-    double* dL = nullptr;
+    double *dL = nullptr, *dtmp = nullptr;
     OAK_CHECK(get_buf_t(ctx, "L", (size_t)M * M, &dL));
+    OAK_CHECK(get_buf_t(ctx, "LinvT", (size_t)M * M, &dtmp));      // allocate on the host side of the fork
+    OAK_CHECK(get_buf_t(ctx, "Linv", (size_t)M * M, &dtmp));
     int* d_info = nullptr;
     OAK_CHECK(get_buf_t(ctx, "potrf_info", 2, &d_info));
     double* dZ = (double*)peek_buf(ctx, "Z");
@@ -171,6 +186,7 @@ int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter)
         OAK_CHECK(gram(ctx, pk, FZ, 0, M, FZ, dL, M, nullptr, nullptr, 0));
         OAK_CHECK(add_diag(ctx, dL, M, M, jitter));
         OAK_CHECK(potrf_lower(ctx, dL, M, M, false));
+        OAK_CHECK(build_linv(ctx, dL, M));
         return OAK_OK;
     }();
     ctx->stream = main_stream;
@@ -203,24 +219,35 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     double *dL, *dT1, *dT2, *dLB, *dv1, *dc, *dscal;
     OAK_CHECK(get_buf_t(ctx, "L", (size_t)M * M, &dL));
     OAK_CHECK(get_buf_t(ctx, "T1", (size_t)(M + 1) * M, &dT1));
-    OAK_CHECK(get_buf_t(ctx, "T2", (size_t)M * M, &dT2));
-    OAK_CHECK(get_buf_t(ctx, "LB", (size_t)M * M, &dLB));
+    OAK_CHECK(get_buf_t(ctx, "T2", (size_t)(M + 1) * M, &dT2));
+    OAK_CHECK(get_buf_t(ctx, "LB", (size_t)(M + 1) * M, &dLB));
     OAK_CHECK(get_buf_t(ctx, "v1", (size_t)M, &dv1));
     OAK_CHECK(get_buf_t(ctx, "c", (size_t)M, &dc));
     OAK_CHECK(get_buf_t(ctx, "scal", 8, &dscal));
+    const bool aug = !ctx->stats_whitened && (M % 32) == 0;     // phi route: explicit L^-1, right-hand side rides in the Cholesky
     // Kuu + jitter I -> L   (oak/utils.py:185,188)
     if (l_state == 2) {
-        OAK_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev1, 0));    // join the side-stream factorisation
+        OAK_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev1, 0));    // join the side-stream factorisation (L, L^-1)
     } else if (l_state == 0) {
         OAK_CHECK(gram(ctx, pk, FZ, 0, M, FZ, dL, M, nullptr, nullptr, 0));
         OAK_CHECK(add_diag(ctx, dL, M, M, jitter));
         OAK_CHECK(potrf_lower(ctx, dL, M, M));
+        if (aug) OAK_CHECK(build_linv(ctx, dL, M));
     }
+    ctx->have_linv = aug && l_state != 1;
     // W = L^-1 Phi L^-T  (= sigma^2 * A A^T, utils.py:189-190 without materialising A)
     if (ctx->stats_whitened) {
         OAK_CHECK(copy_d2d(ctx, dT2, st.phi, sizeof(double) * (size_t)M * M));   // statistics already hold W
         OAK_CHECK(copy_d2d(ctx, dv1, st.psi, sizeof(double) * (size_t)M));
         OAK_CHECK(trsm_rows(ctx, dL, M, M, dv1, 1, M, 0));
+    } else if (aug) {
+        // S = L^-1 Phi (rows 0..M-1 of T1; Phi is symmetric, so gemm_nt against it is the plain product), row M = psi^T;
+        // [W ; (L^-1 psi)^T] = T1 L^-T in one (M+1) x M x M GEMM
+        double* dLinv = (double*)peek_buf(ctx, "Linv");
+        OAK_CHECK(gemm_nt(ctx, dLinv, st.phi, dT1, M, M, M, M, M, M, 1.0, 0.0, 0));
+        OAK_CHECK(copy_d2d(ctx, dT1 + M * M, st.psi, sizeof(double) * (size_t)M));
+        OAK_CHECK(gemm_nt(ctx, dT1, dLinv, dT2, M + 1, M, M, M, M, M, 1.0, 0.0, 0));
+        OAK_CHECK(copy_d2d(ctx, dv1, dT2 + M * M, sizeof(double) * (size_t)M));
     } else {
         // rows 0..M-1 of T1 = Phi (symmetric), row M = psi: one blocked solve gives (L^-1 Phi)^T and L^-1 psi together
         OAK_CHECK(copy_d2d(ctx, dT1, st.phi, sizeof(double) * (size_t)(M * M + M)));
@@ -229,12 +256,19 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
         OAK_CHECK(transpose(ctx, dT1, M, M, M, dT2, M));        // T2 = L^-1 Phi
         OAK_CHECK(trsm_rows(ctx, dL, M, M, dT2, M, M, 0));      // rows of T2 = L^-1 (L^-1 Phi)^T[:, r] -> T2 = W^T = W
     }
-    // B = I + W / sigma^2 ; LB = chol(B)   (utils.py:190-193)
+    // B = I + W / sigma^2 ; LB = chol(B)   (utils.py:190-193);  c = LB^-1 L^-1 psi / sigma^2   (utils.py:194-195:
+    // Aerr = L^-1 psi / sigma, c = LB^-1 Aerr / sigma).  Status is read with the scalars below: one host sync per tail.
     OAK_CHECK(scale_add_eye(ctx, dT2, M, 1.0 / noise_var, dLB));
-    OAK_CHECK(potrf_lower(ctx, dLB, M, M, false));            // status read with the scalars below: one host sync per tail
-    // c = LB^-1 L^-1 psi / sigma^2   (utils.py:194-195: Aerr = L^-1 psi / sigma, c = LB^-1 Aerr / sigma)
-    OAK_CHECK(copy_d2d(ctx, dc, dv1, sizeof(double) * (size_t)M));
-    OAK_CHECK(trsm_rows(ctx, dLB, M, M, dc, 1, M, 0));
+    if (aug) {
+        // row M of the (M+1) x M array = (L^-1 psi)^T: the panel solves turn it into (LB^-1 L^-1 psi)^T
+        OAK_CHECK(copy_d2d(ctx, dLB + M * M, dv1, sizeof(double) * (size_t)M));
+        OAK_CHECK(potrf_lower(ctx, dLB, M, M, false, M + 1));
+        OAK_CHECK(copy_d2d(ctx, dc, dLB + M * M, sizeof(double) * (size_t)M));
+    } else {
+        OAK_CHECK(potrf_lower(ctx, dLB, M, M, false));
+        OAK_CHECK(copy_d2d(ctx, dc, dv1, sizeof(double) * (size_t)M));
+        OAK_CHECK(trsm_rows(ctx, dLB, M, M, dc, 1, M, 0));
+    }
     OAK_CHECK(scale_vec(ctx, 1.0 / noise_var, dc, M));
     // scalars
     OAK_CHECK(reduce_sum(ctx, dLB, M, dscal + 0, 2, M + 1));    // sum log diag LB

@@ -1,0 +1,31 @@
+"""Per-rank forward step time for the row shards of the headline problem (N/g rows, g = 1, 2, 4, 8) on ONE GPU:
+an upper bound on strong scaling (the all-reduce is not included)."""
+import sys, time
+from pathlib import Path
+import numpy as np
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT / "orthogonal-additive-gaussian-processes_amd"))
+sys.path.insert(0, str(ROOT))
+from oak import _capi
+import bench
+
+N, D, M, R = 1 << 20, 16, 1024, 2
+X, y, Z = bench.synthetic(N, D, M)
+spec = bench.make_spec(D, R)
+ctx = _capi.default_context()
+PH = ["featurize", "gram", "syrk", "reduce", "tail", "total"]
+for g in (1, 2, 4, 8):
+    n = N // g
+    ctx.sgpr_set_data(np.ascontiguousarray(X[:n]), np.ascontiguousarray(y[:n]))
+    ctx.sgpr_set_inducing(Z)
+    ctx.sgpr_set_route("phi")
+    for _ in range(2):
+        ctx.sgpr_elbo(_capi.KernelDesc(spec), 0.01, 1e-6)
+    ctx.reset_timings()
+    ctx.sync(); t0 = time.perf_counter()
+    K = 10
+    for _ in range(K):
+        ctx.sgpr_elbo(_capi.KernelDesc(spec), 0.01, 1e-6)
+    ctx.sync(); dt = (time.perf_counter() - t0) / K
+    ph = {k: round(ctx.timing(k)[0] / K, 3) for k in PH}
+    print(f"g={g} rows={n} wall={dt*1e3:.2f} ms  ideal={33.3/g:.2f}  {ph}")
