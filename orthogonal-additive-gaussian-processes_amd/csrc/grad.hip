@@ -229,6 +229,29 @@ gram_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
     for (int idx = tid; idx < tablen; idx += 256) rec[2 * D + (R + 1) + idx] = accT[idx];
 }
 
+// Row-major pack of the backward features of rows a0 .. a0+na-1:  out[i][q][d],  q = (xs32, cn, dcs),  d < DP;
+// padding dimensions d >= D hold (-1, 0, 0) so that against the column-side padding (+1) the pair clamps to E = 2^-1024.
+__global__ void __launch_bounds__(256) pack_rows_kernel(const double* __restrict__ xs32, const double* __restrict__ cn,
+                                                        const double* __restrict__ dcs, int64_t ld, int64_t a0, int64_t na, int D,
+                                                        int DP, double* __restrict__ out) {
+    __shared__ double tile[48][65];
+    const int64_t i0 = (int64_t)blockIdx.x * 64;
+    const int W = 3 * DP;
+    for (int idx = threadIdx.x; idx < W * 64; idx += 256) {       // coalesced over rows
+        const int j = idx >> 6, r = idx & 63;
+        const int q = j / DP, d = j - q * DP;
+        const int64_t i = i0 + r;
+        double v = (q == 0) ? -1.0 : 0.0;
+        if (d < D && i < na) v = (q == 0 ? xs32 : (q == 1 ? cn : dcs))[(int64_t)d * ld + a0 + i];
+        tile[j][r] = v;
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < W * 64; idx += 256) {       // coalesced over the packed row
+        const int r = idx / W, j = idx - r * W;
+        if (i0 + r < na) out[(i0 + r) * W + j] = tile[j][r];
+    }
+}
+
 // Fast path (1 <= R <= 4, D <= DMAX <= 16): one exp2 per pair per dimension.  Each lane walks its pairs one at a time,
 // keeps k_d and dk_d/dl_d of all dimensions in registers (vectorised 4 dimensions at a time for ILP), and accumulates the
 // per-dimension contractions in registers across the whole row range; one workgroup reduction at the very end.
@@ -240,11 +263,12 @@ gram_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
 template <int R, int DMAX, bool ALLRBF, bool WANT_GK, bool UNITBV>
 __global__ void __launch_bounds__(256)
 gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
-                     const double* __restrict__ Axs, const double* __restrict__ Acn, const double* __restrict__ Adcn, int64_t a_ld,
-                     int64_t a0, int64_t na, const double* __restrict__ Bxs, const double* __restrict__ Bcn,
-                     const double* __restrict__ Bdcn, int64_t b_ld, int64_t nb, const double* __restrict__ G, int64_t ldg,
-                     const double* __restrict__ yA, const double* __restrict__ avec, double g_scale, int rows_per_wg,
-                     double* __restrict__ partial) {
+                     const double* __restrict__ Apack, int64_t a0, int64_t na, const double* __restrict__ Bxs,
+                     const double* __restrict__ Bcn, const double* __restrict__ Bdcn, int64_t b_ld, int64_t nb,
+                     const double* __restrict__ G, int64_t ldg, const double* __restrict__ yA, const double* __restrict__ avec,
+                     double g_scale, int rows_per_wg, double* __restrict__ partial) {
+    // Apack: row-major [na][3][DMAX] = (xs32 | cn | dcs) of rows a0.. (pack_rows_kernel; padding dims hold -1, 0, 0).
+    // Bxs is the PRE-SCALED array Feat::xs32, Bdcn is Feat::dcs.
     constexpr int CPT = 2, TJ = 64 * CPT, RT = 2, RS = 4 * RT;
     constexpr int NGK = WANT_GK ? DMAX : 1;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -252,16 +276,13 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
     double* Bx = smem;                  // [DMAX][TJ]
     double* Bc = Bx + DMAX * TJ;
     double* Bd = Bc + DMAX * TJ;
-    double* Ax = Bd + DMAX * TJ;        // [DMAX][RS]
-    double* Ac = Ax + DMAX * RS;
-    double* Ad = Ac + DMAX * RS;
-    double* Ay = Ad + DMAX * RS;        // [RS]
-    double* Av = Ay + RS;               // [TJ]
+    double* Av = Bd + DMAX * TJ;        // [TJ]
     double* Tab = Av + TJ;              // [EW_N] biased exp2 table
-    double* Cw = Tab + EW_N;            // [DMAX] woff per dim
+    double* Cw = Tab + EW_N;            // [DMAX] woff per dim    (not allocated when UNITBV)
     double* Cm = Cw + DMAX;             // [DMAX] magic per dim
-    double* accT = Cm + DMAX;           // [tablen]
-    double* red = accT + tablen;        // [4][2*DMAX + R + 1]
+    double* accT = UNITBV ? Tab + EW_N : Cm + DMAX;     // [tablen]
+    double* red = Bx;                   // [4][2*DMAX + R + 1], aliases the column features once the row loop is done
+                                        // (54 272 B at DMAX = 16 without discrete tables: three workgroups per CU)
     const int tid = threadIdx.x, tx = tid & 63;
     const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t jb = (int64_t)blockIdx.x * TJ;
@@ -271,17 +292,18 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
         const int d = idx / TJ, j = idx - d * TJ;
         const int64_t gj = jb + j;
         const bool ok = gj < nb && d < D;
-        const double pre = (ALLRBF || d >= D || dd.type[d] == OAK_DIM_RBF) ? 0.03125 : 1.0;
-        Bx[idx] = ok ? Bxs[(int64_t)d * b_ld + gj] * pre : (d < D ? 0.0 : 1.0);
+        Bx[idx] = ok ? Bxs[(int64_t)d * b_ld + gj] : (d < D ? 0.0 : 1.0);
         Bc[idx] = ok ? Bcn[(int64_t)d * b_ld + gj] : 0.0;
-        Bd[idx] = ok ? Bdcn[(int64_t)d * b_ld + gj] * 0.0009765625 : 0.0;
+        Bd[idx] = ok ? Bdcn[(int64_t)d * b_ld + gj] : 0.0;
     }
     for (int j = tid; j < TJ; j += 256) Av[j] = (avec != nullptr && jb + j < nb) ? avec[jb + j] : 0.0;
     for (int j = tid; j < EW_N; j += 256) Tab[j] = biased_table_entry(j);
-    if (tid < DMAX) {
-        const bool rbf = tid < D && dd.type[tid] == OAK_DIM_RBF;
-        Cw[tid] = rbf ? dd.woff[tid] : 0.0;
-        Cm[tid] = rbf ? dd.magic[tid] : EW_MAGIC;
+    if constexpr (!UNITBV) {
+        if (tid < DMAX) {
+            const bool rbf = tid < D && dd.type[tid] == OAK_DIM_RBF;
+            Cw[tid] = rbf ? dd.woff[tid] : 0.0;
+            Cm[tid] = rbf ? dd.magic[tid] : EW_MAGIC;
+        }
     }
     for (int idx = tid; idx < tablen; idx += 256) accT[idx] = 0.0;
     double gl[DMAX], gk[NGK], gw[R + 1];
@@ -291,34 +313,31 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
     for (int d = 0; d < NGK; ++d) gk[d] = 0.0;
 #pragma unroll
     for (int q = 0; q <= R; ++q) gw[q] = 0.0;
+    __syncthreads();
 
+    // The row-side features of a pair are wave-uniform (a wave owns whole rows): they are read straight from the packed
+    // row-major array with uniform addresses, i.e. as wide SCALAR loads into SGPRs, and never touch LDS.  The kernel is co-limited by
+    // VALU issue and LDS bandwidth; this halves its LDS traffic (3 column-side reads per pair-dimension instead of 6)
+    // and removes the per-row-step staging barriers.
     struct Chunk { double xa[4], xb[4], ca[4], cb[4], ad[4], bd[4], cw[4], cm[4]; };
     for (int64_t i0 = ib; i0 < iend; i0 += RS) {
-        __syncthreads();
-        for (int idx = tid; idx < DMAX * RS; idx += 256) {
-            const int d = idx / RS, r = idx - d * RS;
-            const int64_t gi = i0 + r;
-            const bool ok = gi < iend && d < D;
-            const double pre = (ALLRBF || d >= D || dd.type[d] == OAK_DIM_RBF) ? 0.03125 : 1.0;
-            Ax[idx] = ok ? Axs[(int64_t)d * a_ld + a0 + gi] * pre : (d < D ? 0.0 : -1.0);
-            Ac[idx] = ok ? Acn[(int64_t)d * a_ld + a0 + gi] : 0.0;
-            Ad[idx] = ok ? Adcn[(int64_t)d * a_ld + a0 + gi] * 0.0009765625 : 0.0;
-        }
-        if (tid < RS) Ay[tid] = (yA != nullptr && i0 + tid < iend) ? yA[a0 + i0 + tid] : 0.0;
-        __syncthreads();
 #pragma unroll 1
         for (int pr = 0; pr < RT * CPT; ++pr) {      // one pair at a time: only one set of k[], dk[] is live
             const int r = pr >> 1, c = pr & 1;
-            const int row = ty * RT + r, col = tx + 64 * c;       // lanes own adjacent columns: conflict-free LDS reads
-            const int64_t gi = i0 + row, gj = jb + col;
-            double g = 0.0;
-            if (gi < iend && gj < nb) g = g_scale * G[gi * ldg + gj] + Ay[row] * Av[col];
+            const int col = tx + 64 * c;                          // lanes own adjacent columns: conflict-free LDS reads
+            const int64_t gi = i0 + ty * RT + r, gj = jb + col;
+            const int64_t gr = gi < iend ? gi : iend - 1;         // uniform; rows past the end contribute g = 0
+            const double* __restrict__ prow = Apack + gr * (3 * DMAX);
+            // adjoint of this pair: unconditional (clamped) load issued here, consumed only after the k / dk loop so its
+            // HBM latency hides under ~400 DP instructions instead of stalling every pair
+            const double graw = G[gr * ldg + (gj < nb ? gj : nb - 1)];
+            const double yrow = yA != nullptr ? yA[a0 + gr] : 0.0;
             double k[DMAX], dk[DMAX];
             auto fetch = [&](int d0, Chunk& ch) {
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const int d = d0 + v;
-                    ch.xa[v] = Ax[d * RS + row]; ch.ca[v] = Ac[d * RS + row]; ch.ad[v] = Ad[d * RS + row];
+                    ch.xa[v] = prow[d]; ch.ca[v] = prow[DMAX + d]; ch.ad[v] = prow[2 * DMAX + d];
                     ch.xb[v] = Bx[d * TJ + col]; ch.cb[v] = Bc[d * TJ + col]; ch.bd[v] = Bd[d * TJ + col];
                     if constexpr (!UNITBV) { ch.cw[v] = Cw[d]; ch.cm[v] = Cm[d]; }
                 }
@@ -328,6 +347,7 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
 #pragma unroll
             for (int d0 = 0; d0 < DMAX; d0 += 4) {
                 if (d0 + 4 < DMAX) fetch(d0 + 4, nxt);      // software prefetch of the next 4 dimensions' features
+                asm volatile("" ::: "memory");              // keep later chunks' loads below this point: bounds the live SGPRs
                 double w[4], u2[4], mg[4], E[4];
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
@@ -360,6 +380,7 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
                 for (int q = R - 1; q >= 1; --q) e[q] = __builtin_fma(k[d], e[q - 1], e[q]);
                 e[0] += k[d];
             }
+            const double g = (gi < iend && gj < nb) ? __builtin_fma(g_scale, graw, yrow * Av[col]) : 0.0;
             gw[0] += g;
 #pragma unroll
             for (int q = 1; q <= R; ++q) gw[q] = __builtin_fma(g, e[q - 1], gw[q]);
@@ -373,7 +394,7 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
                 if constexpr (WANT_GK) gk[d] = __builtin_fma(gc, k[d], gk[d]);
                 if constexpr (!ALLRBF) {
                     if (d < D && dd.type[d] == OAK_DIM_CATEGORICAL && gc != 0.0)
-                        atomicAdd(&accT[dd.tab_off[d] + (int)Ax[d * RS + row] * dd.ncat[d] + (int)Bx[d * TJ + col]], gc);
+                        atomicAdd(&accT[dd.tab_off[d] + (int)prow[d] * dd.ncat[d] + (int)Bx[d * TJ + col]], gc);
                 }
             }
         }
@@ -514,7 +535,7 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     const int TJ = 64 * cpt, RS = 8;
     bool unitbv = true;
     for (int d = 0; d < D; ++d) unitbv = unitbv && (pk.dd.type[d] != OAK_DIM_RBF || pk.dd.bv[d] == 1.0);
-    const size_t lds = fast ? sizeof(double) * ((size_t)3 * dmax * TJ + (size_t)3 * dmax * RS + RS + TJ + EW_N + 2 * dmax + tablen + 4 * (2 * dmax + R + 1) + 8)
+    const size_t lds = fast ? sizeof(double) * ((size_t)3 * dmax * TJ + TJ + EW_N + (unitbv ? 0 : 2 * dmax) + tablen)
                             : sizeof(double) * ((size_t)3 * D * TJ + (size_t)3 * D * RS + RS + TJ + 64 + 8 * D + tablen + 64);
     OAK_REQUIRE(lds <= 160 * 1024, "gram_bwd: LDS request %zu exceeds 160 KiB", lds);
     const int64_t nb = B.n;
@@ -530,6 +551,13 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     double* d_part = nullptr;
     OAK_CHECK(get_buf_t(ctx, "bwd_part", (size_t)(nrb * ncb * reclen), &d_part));
     dim3 grid((unsigned)ncb, (unsigned)nrb);
+    double* d_pack = nullptr;
+    if (fast) {
+        OAK_REQUIRE(A.xs32 != nullptr && B.xs32 != nullptr, "gram_bwd: features were not prepared for the backward pass");
+        OAK_CHECK(get_buf_t(ctx, "bwd_pack", (size_t)na * 3 * dmax, &d_pack));
+        pack_rows_kernel<<<(unsigned)((na + 63) / 64), 256, 0, ctx->stream>>>(A.xs32, A.cn, A.dcs, A.ld, a0, na, D, dmax, d_pack);
+        OAK_HIP_CHECK(hipGetLastError());
+    }
 #define OAK_BWD_LAUNCH(RR, CP)                                                                                                   \
     {                                                                                                                            \
         auto kern = gram_bwd_kernel<RR, CP>;                                                                                     \
@@ -539,7 +567,7 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     }
 #define OAK_BWD_FAST_K(RR, DM, AR, GK, UB)                                                                                         \
     gram_bwd_fast_kernel<RR, DM, AR, GK, UB><<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen,                         \
-                        A.xs, A.cn, A.dcn, A.ld, a0, na, B.xs, B.cn, B.dcn, B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part);
+                        d_pack, a0, na, B.xs32, B.cn, B.dcs, B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part);
 #define OAK_BWD_FAST(RR, DM)                                                                                                      \
     if (allrbf && !want_gk && unitbv) OAK_BWD_FAST_K(RR, DM, true, false, true)                                                   \
     else if (allrbf && !want_gk) OAK_BWD_FAST_K(RR, DM, true, false, false)                                                       \

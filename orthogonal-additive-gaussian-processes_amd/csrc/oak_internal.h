@@ -70,6 +70,8 @@ struct Feat {
     double* xs = nullptr;
     double* cn = nullptr;
     double* dcn = nullptr;     // d cn / d lengthscale_d (only when featurized for the backward pass)
+    double* xs32 = nullptr;    // backward pass only: xs / 32 (RBF dims; category index otherwise) and dcn / 1024, the
+    double* dcs = nullptr;     //   pre-scaled forms the fast backward kernel consumes (exp2w.h) without a multiply
     int64_t n = 0;
     int64_t ld = 0;
 };

@@ -82,7 +82,8 @@ int fill_zero(oak_ctx* ctx, void* dst, size_t bytes) {
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) featurize_kernel(DevDesc dd, DevMeasure dm, const double* __restrict__ meas,
                                                         const double* __restrict__ X, int64_t n, int ldx, int64_t ld,
-                                                        double* __restrict__ xs, double* __restrict__ cn, double* __restrict__ dcn) {
+                                                        double* __restrict__ xs, double* __restrict__ cn, double* __restrict__ dcn,
+                                                        double* __restrict__ xs32, double* __restrict__ dcs) {
     const int d = blockIdx.y;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ld) return;
@@ -153,7 +154,11 @@ __global__ void __launch_bounds__(256) featurize_kernel(DevDesc dd, DevMeasure d
     }
     xs[(int64_t)d * ld + i] = vx;
     cn[(int64_t)d * ld + i] = vc;
-    if (dcn != nullptr) dcn[(int64_t)d * ld + i] = vd;
+    if (dcn != nullptr) {
+        dcn[(int64_t)d * ld + i] = vd;
+        xs32[(int64_t)d * ld + i] = dd.type[d] == OAK_DIM_RBF ? vx * 0.03125 : vx;
+        dcs[(int64_t)d * ld + i] = vd * 0.0009765625;
+    }
 }
 
 // tmp[k] = w_k * sum_l w_l * bv * exp(-(loc_k-loc_l)^2 / (2 l^2))   (var_s of the empirical measure, :109-120)
@@ -347,11 +352,14 @@ int featurize(oak_ctx* ctx, const PreparedKernel& pk, const double* dX, int64_t 
     const int D = pk.dd.D;
     const int64_t ld = ((n + 63) / 64) * 64 + 64;   // padded so tile loads never run past the array
     double* base = nullptr;
-    OAK_CHECK(get_buf_t(ctx, bufname, (size_t)((with_grad ? 3 : 2) * D * ld), &base));
+    OAK_CHECK(get_buf_t(ctx, bufname, (size_t)((with_grad ? 5 : 2) * D * ld), &base));
     out->xs = base; out->cn = base + (size_t)D * ld; out->n = n; out->ld = ld;
     out->dcn = with_grad ? base + (size_t)2 * D * ld : nullptr;
+    out->xs32 = with_grad ? base + (size_t)3 * D * ld : nullptr;
+    out->dcs = with_grad ? base + (size_t)4 * D * ld : nullptr;
     dim3 grid((unsigned)((ld + 255) / 256), (unsigned)D);
-    featurize_kernel<<<grid, 256, 0, ctx->stream>>>(pk.dd, pk.dm, pk.d_meas, dX, n, ldx, ld, out->xs, out->cn, out->dcn);
+    featurize_kernel<<<grid, 256, 0, ctx->stream>>>(pk.dd, pk.dm, pk.d_meas, dX, n, ldx, ld, out->xs, out->cn, out->dcn, out->xs32,
+                                                     out->dcs);
     OAK_HIP_CHECK(hipGetLastError());
     return OAK_OK;
 }
