@@ -234,7 +234,7 @@ gram_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
 __global__ void __launch_bounds__(256) pack_rows_kernel(const double* __restrict__ xs32, const double* __restrict__ cn,
                                                         const double* __restrict__ dcs, int64_t ld, int64_t a0, int64_t na, int D,
                                                         int DP, double* __restrict__ out) {
-    __shared__ double tile[48][65];
+    __shared__ double tile[96][65];                               // 3 * DP <= 96
     const int64_t i0 = (int64_t)blockIdx.x * 64;
     const int W = 3 * DP;
     for (int idx = threadIdx.x; idx < W * 64; idx += 256) {       // coalesced over rows
@@ -260,8 +260,8 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const double* __restrict
 // when the record is written).  Padding dimensions d >= D are staged as xa = -1, xb = +1 (w clamps to 1, E = 2^-1024).
 // UNITBV: every RBF dimension has base variance exactly 1 (OAK's share_var_across_orders default): woff = 0 and
 // magic = EW_MAGIC are compile-time constants, no per-dimension constant is read at all.
-template <int R, int DMAX, bool ALLRBF, bool WANT_GK, bool UNITBV>
-__global__ void __launch_bounds__(256)
+template <int R, int DMAX, int CPT, bool ALLRBF, bool WANT_GK, bool UNITBV>
+__global__ void __launch_bounds__(256, (DMAX <= 16 ? 2 : 1))      // <= 16 dims: hold the register budget at two waves per SIMD
 gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
                      const double* __restrict__ Apack, int64_t a0, int64_t na, const double* __restrict__ Bxs,
                      const double* __restrict__ Bcn, const double* __restrict__ Bdcn, int64_t b_ld, int64_t nb,
@@ -269,7 +269,7 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
                      double g_scale, int rows_per_wg, double* __restrict__ partial) {
     // Apack: row-major [na][3][DMAX] = (xs32 | cn | dcs) of rows a0.. (pack_rows_kernel; padding dims hold -1, 0, 0).
     // Bxs is the PRE-SCALED array Feat::xs32, Bdcn is Feat::dcs.
-    constexpr int CPT = 2, TJ = 64 * CPT, RT = 2, RS = 4 * RT;
+    constexpr int TJ = 64 * CPT, RT = 2, RS = 4 * RT;       // CPT = 2 up to 16 dims, 1 at 32 (LDS: 3 * DMAX * TJ doubles)
     constexpr int NGK = WANT_GK ? DMAX : 1;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int D = dd.D;
@@ -281,6 +281,8 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
     double* Cw = Tab + EW_N;            // [DMAX] woff per dim    (not allocated when UNITBV)
     double* Cm = Cw + DMAX;             // [DMAX] magic per dim
     double* accT = UNITBV ? Tab + EW_N : Cm + DMAX;     // [tablen]
+    int* meta = reinterpret_cast<int*>(accT + tablen);   // [2*DMAX] (tab_off, ncat) of the discrete dims: read from LDS
+                                        // inside the rare branch instead of living in ~100 SGPRs (they spilled to VGPR lanes)
     double* red = Bx;                   // [4][2*DMAX + R + 1], aliases the column features once the row loop is done
                                         // (54 272 B at DMAX = 16 without discrete tables: three workgroups per CU)
     const int tid = threadIdx.x, tx = tid & 63;
@@ -306,6 +308,14 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
         }
     }
     for (int idx = tid; idx < tablen; idx += 256) accT[idx] = 0.0;
+    unsigned rbf_mask = 0xffffffffu, cat_mask = 0u;
+    if constexpr (!ALLRBF) {
+        if (tid < DMAX) { meta[2 * tid] = tid < D ? dd.tab_off[tid] : 0; meta[2 * tid + 1] = tid < D ? dd.ncat[tid] : 0; }
+        for (int d = 0; d < D; ++d) {
+            if (dd.type[d] != OAK_DIM_RBF) rbf_mask &= ~(1u << d);
+            if (dd.type[d] == OAK_DIM_CATEGORICAL) cat_mask |= 1u << d;
+        }
+    }
     double gl[DMAX], gk[NGK], gw[R + 1];
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) gl[d] = 0.0;
@@ -320,18 +330,24 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
     // VALU issue and LDS bandwidth; this halves its LDS traffic (3 column-side reads per pair-dimension instead of 6)
     // and removes the per-row-step staging barriers.
     struct Chunk { double xa[4], xb[4], ca[4], cb[4], ad[4], bd[4], cw[4], cm[4]; };
+    // The adjoint G of a pair is loaded one pair AHEAD (clamped address, no branch), so its HBM latency hides under the
+    // ~400 DP instructions of the pair in flight instead of stalling every pair.
+    auto g_addr = [&](int64_t i0n, int prn) -> const double* {
+        const int64_t gin = i0n + ty * RT + prn / CPT, gjn = jb + tx + 64 * (prn % CPT);
+        return G + (gin < iend ? gin : iend - 1) * ldg + (gjn < nb ? gjn : nb - 1);
+    };
+    double graw_next = ib < iend ? *g_addr(ib, 0) : 0.0;
     for (int64_t i0 = ib; i0 < iend; i0 += RS) {
 #pragma unroll 1
         for (int pr = 0; pr < RT * CPT; ++pr) {      // one pair at a time: only one set of k[], dk[] is live
-            const int r = pr >> 1, c = pr & 1;
+            const int r = pr / CPT, c = pr % CPT;
             const int col = tx + 64 * c;                          // lanes own adjacent columns: conflict-free LDS reads
             const int64_t gi = i0 + ty * RT + r, gj = jb + col;
             const int64_t gr = gi < iend ? gi : iend - 1;         // uniform; rows past the end contribute g = 0
             const double* __restrict__ prow = Apack + gr * (3 * DMAX);
-            // adjoint of this pair: unconditional (clamped) load issued here, consumed only after the k / dk loop so its
-            // HBM latency hides under ~400 DP instructions instead of stalling every pair
-            const double graw = G[gr * ldg + (gj < nb ? gj : nb - 1)];
             const double yrow = yA != nullptr ? yA[a0 + gr] : 0.0;
+            const double g = (gi < iend && gj < nb) ? __builtin_fma(g_scale, graw_next, yrow * Av[col]) : 0.0;
+            graw_next = (pr + 1 < RT * CPT) ? *g_addr(i0, pr + 1) : *g_addr(i0 + RS, 0);
             double k[DMAX], dk[DMAX];
             auto fetch = [&](int d0, Chunk& ch) {
 #pragma unroll
@@ -365,7 +381,7 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
                     double kv = __builtin_fma(-cur.ca[v], cur.cb[v], E[v]);
                     double dv = __builtin_fma(E[v], u2[v], -__builtin_fma(cur.ad[v], cur.cb[v], cur.ca[v] * cur.bd[v]));
                     if constexpr (!ALLRBF) {
-                        if (d < D && dd.type[d] != OAK_DIM_RBF) { kv = tables[dd.tab_off[d] + (int)cur.xa[v] * dd.ncat[d] + (int)cur.xb[v]]; dv = 0.0; }
+                        if (!((rbf_mask >> d) & 1u)) { kv = tables[meta[2 * d] + (int)cur.xa[v] * meta[2 * d + 1] + (int)cur.xb[v]]; dv = 0.0; }
                     }
                     k[d] = kv; dk[d] = dv;
                 }
@@ -380,7 +396,6 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
                 for (int q = R - 1; q >= 1; --q) e[q] = __builtin_fma(k[d], e[q - 1], e[q]);
                 e[0] += k[d];
             }
-            const double g = (gi < iend && gj < nb) ? __builtin_fma(g_scale, graw, yrow * Av[col]) : 0.0;
             gw[0] += g;
 #pragma unroll
             for (int q = 1; q <= R; ++q) gw[q] = __builtin_fma(g, e[q - 1], gw[q]);
@@ -393,8 +408,8 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
                 gl[d] = __builtin_fma(gc, dk[d], gl[d]);
                 if constexpr (WANT_GK) gk[d] = __builtin_fma(gc, k[d], gk[d]);
                 if constexpr (!ALLRBF) {
-                    if (d < D && dd.type[d] == OAK_DIM_CATEGORICAL && gc != 0.0)
-                        atomicAdd(&accT[dd.tab_off[d] + (int)prow[d] * dd.ncat[d] + (int)Bx[d * TJ + col]], gc);
+                    if (((cat_mask >> d) & 1u) && gc != 0.0)
+                        atomicAdd(&accT[meta[2 * d] + (int)prow[d] * meta[2 * d + 1] + (int)Bx[d * TJ + col]], gc);
                 }
             }
         }
@@ -527,15 +542,15 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     const int D = pk.dd.D, R = pk.dd.R;
     const int tablen = (int)pk.tables.size();
     OAK_REQUIRE(tablen <= 4096, "gradient: discrete tables too large (%d doubles)", tablen);
-    const bool fast = (R >= 1 && R <= 4 && D <= 16 && getenv("OAK_BWD_GENERIC") == nullptr);
+    const bool fast = (R >= 1 && R <= 4 && D <= 32 && getenv("OAK_BWD_GENERIC") == nullptr);
     bool allrbf = true;
     for (int d = 0; d < D; ++d) allrbf = allrbf && pk.dd.type[d] == OAK_DIM_RBF;
-    const int dmax = D <= 8 ? 8 : 16;
-    const int cpt = (D <= 40) ? 2 : 1;
+    const int dmax = D <= 8 ? 8 : (D <= 16 ? 16 : 32);
+    const int cpt = fast ? (dmax <= 16 ? 2 : 1) : ((D <= 40) ? 2 : 1);
     const int TJ = 64 * cpt, RS = 8;
     bool unitbv = true;
     for (int d = 0; d < D; ++d) unitbv = unitbv && (pk.dd.type[d] != OAK_DIM_RBF || pk.dd.bv[d] == 1.0);
-    const size_t lds = fast ? sizeof(double) * ((size_t)3 * dmax * TJ + TJ + EW_N + (unitbv ? 0 : 2 * dmax) + tablen)
+    const size_t lds = fast ? sizeof(double) * ((size_t)3 * dmax * TJ + TJ + EW_N + (unitbv ? 0 : 2 * dmax) + tablen + (allrbf ? 0 : dmax))
                             : sizeof(double) * ((size_t)3 * D * TJ + (size_t)3 * D * RS + RS + TJ + 64 + 8 * D + tablen + 64);
     OAK_REQUIRE(lds <= 160 * 1024, "gram_bwd: LDS request %zu exceeds 160 KiB", lds);
     const int64_t nb = B.n;
@@ -566,14 +581,15 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
                                               B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part);                     \
     }
 #define OAK_BWD_FAST_K(RR, DM, AR, GK, UB)                                                                                         \
-    gram_bwd_fast_kernel<RR, DM, AR, GK, UB><<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen,                         \
-                        d_pack, a0, na, B.xs32, B.cn, B.dcs, B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part);
-#define OAK_BWD_FAST(RR, DM)                                                                                                      \
-    if (allrbf && !want_gk && unitbv) OAK_BWD_FAST_K(RR, DM, true, false, true)                                                   \
-    else if (allrbf && !want_gk) OAK_BWD_FAST_K(RR, DM, true, false, false)                                                       \
-    else if (allrbf) OAK_BWD_FAST_K(RR, DM, true, true, false)                                                                    \
-    else if (unitbv) OAK_BWD_FAST_K(RR, DM, false, true, true)                                                                    \
-    else OAK_BWD_FAST_K(RR, DM, false, true, false)
+    {                                                                                                                             \
+        auto kern = gram_bwd_fast_kernel<RR, DM, (DM <= 16 ? 2 : 1), AR, GK, UB>;                                                 \
+        if (lds > 64 * 1024) OAK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        kern<<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen, d_pack, a0, na, B.xs32, B.cn, B.dcs, B.ld, nb, d_G, ldg, \
+                                              d_yA, d_avec, g_scale, (int)rows, d_part);                                          \
+    }
+#define OAK_BWD_FAST_U(RR, DM, AR, GK) { if (unitbv) OAK_BWD_FAST_K(RR, DM, AR, GK, true) else OAK_BWD_FAST_K(RR, DM, AR, GK, false) }
+#define OAK_BWD_FAST_G(RR, DM, AR) { if (want_gk) OAK_BWD_FAST_U(RR, DM, AR, true) else OAK_BWD_FAST_U(RR, DM, AR, false) }
+#define OAK_BWD_FAST(RR, DM) { if (allrbf) OAK_BWD_FAST_G(RR, DM, true) else OAK_BWD_FAST_G(RR, DM, false) }
 #define OAK_BWD_CASE(RR) case RR: if (cpt == 2) OAK_BWD_LAUNCH(RR, 2) else OAK_BWD_LAUNCH(RR, 1) break;
     if (fast) {
         switch (R * 100 + dmax) {
@@ -581,6 +597,8 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
             case 208: OAK_BWD_FAST(2, 8) break;   case 216: OAK_BWD_FAST(2, 16) break;
             case 308: OAK_BWD_FAST(3, 8) break;   case 316: OAK_BWD_FAST(3, 16) break;
             case 408: OAK_BWD_FAST(4, 8) break;   case 416: OAK_BWD_FAST(4, 16) break;
+            case 132: OAK_BWD_FAST(1, 32) break;  case 232: OAK_BWD_FAST(2, 32) break;
+            case 332: OAK_BWD_FAST(3, 32) break;  case 432: OAK_BWD_FAST(4, 32) break;
         }
     } else
     switch (R) {
@@ -592,6 +610,8 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
 #undef OAK_BWD_LAUNCH
 #undef OAK_BWD_FAST
 #undef OAK_BWD_FAST_K
+#undef OAK_BWD_FAST_U
+#undef OAK_BWD_FAST_G
     OAK_HIP_CHECK(hipGetLastError());
     reduce_records_kernel<<<(unsigned)((reclen + 255) / 256), 256, 0, ctx->stream>>>(d_part, nrb * ncb, reclen, d_rec);
     OAK_HIP_CHECK(hipGetLastError());
