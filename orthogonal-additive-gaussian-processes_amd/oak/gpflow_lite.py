@@ -556,7 +556,14 @@ class models:
 class Scipy:
     """gpflow.optimizers.Scipy: scipy.optimize.minimize over the packed unconstrained variables."""
 
-    def minimize(self, closure, variables, method="L-BFGS-B", step_callback=None, compile=True, **scipy_kwargs):
+    def minimize(self, closure, variables, method="L-BFGS-B", step_callback=None, compile=True, on_linalg_error="raise",
+                 **scipy_kwargs):
+        """``on_linalg_error="raise"`` (default) lets a failed Cholesky at a trial point abort the optimisation, as the
+        reference does (TensorFlow raises InvalidArgumentError through GPflow's Scipy wrapper; callers wrap ``fit`` in
+        try/except, examples/uci/uci_classification_train.py:146-159).  ``"inf"`` is an extension: the trial point is
+        reported to scipy as +inf with a zero gradient so that the line search backtracks instead."""
+        if on_linalg_error not in ("raise", "inf"):
+            raise ValueError("on_linalg_error must be 'raise' or 'inf'")
         variables = tuple(variables)
         if not variables:
             raise ValueError("no variables to optimise")
@@ -574,10 +581,15 @@ class Scipy:
 
         def fun(x):
             unpack(x)
-            if has_grad:
-                loss, grads = closure.value_and_grad(variables)
-                return float(loss), np.concatenate([np.asarray(g, dtype=np.float64).reshape(-1) for g in grads])
-            return float(closure())
+            try:
+                if has_grad:
+                    loss, grads = closure.value_and_grad(variables)
+                    return float(loss), np.concatenate([np.asarray(g, dtype=np.float64).reshape(-1) for g in grads])
+                return float(closure())
+            except _capi.NotPositiveDefiniteError:
+                if on_linalg_error == "raise":
+                    raise
+                return (np.inf, np.zeros_like(x)) if has_grad else np.inf
 
         res = scipy.optimize.minimize(fun, x0, jac=True if has_grad else None, method=method, **scipy_kwargs)
         unpack(res.x)

@@ -231,8 +231,8 @@ class oak_model:
             if initialise_inducing_points:
                 if (p0 is None) and (p is None):
                     print("all features are continuous")
-                    from sklearn.cluster import KMeans
-                    Z = KMeans(n_clusters=self.num_inducing, random_state=0).fit(self.X_scaled).cluster_centers_
+                    # reference: KMeans(n_clusters=num_inducing, random_state=0).fit(X_scaled) (:377-383); Lloyd on the device
+                    Z = kmeans_centres(self.X_scaled, self.num_inducing, random_state=0)
                 else:
                     Z = initialize_kmeans_with_categorical(
                         self.X_scaled, binary_index=self.binary_index, categorical_index=self.categorical_index,
