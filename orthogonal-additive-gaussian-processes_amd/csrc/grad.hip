@@ -459,48 +459,68 @@ diag_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
     for (int q = 0; q <= R; ++q) gw[q] = 0.0;
     const int64_t i_begin = (int64_t)blockIdx.x * rows_per_wg;
     const int64_t i_end = (i_begin + rows_per_wg < n) ? i_begin + rows_per_wg : n;
-    for (int64_t i0 = i_begin; i0 < i_end; i0 += 256) {
-        const int64_t i = i0 + tid;
-        const bool ok = i < i_end;
-        const double g = ok ? gconst : 0.0;
-        const int64_t ic = ok ? i : i_begin;
-        double e[RR];
+    // DT points per lane per trip: pass 1 keeps their ESPs in registers, pass 2 runs dimension-outer so the two wave
+    // reductions per dimension are paid once per DT * 64 points instead of once per 64
+    constexpr int DT = 8;
+    for (int64_t i0 = i_begin; i0 < i_end; i0 += 256 * DT) {
+        double g[DT], e[DT][RR];
+        int64_t ic[DT];
 #pragma unroll
-        for (int q = 0; q < RR; ++q) e[q] = 0.0;
+        for (int t = 0; t < DT; ++t) {
+            const int64_t i = i0 + t * 256 + tid;
+            const bool ok = i < i_end;
+            g[t] = ok ? gconst : 0.0;
+            ic[t] = ok ? i : i_begin;
+#pragma unroll
+            for (int q = 0; q < RR; ++q) e[t][q] = 0.0;
+        }
         if constexpr (R > 0) {
             for (int d = 0; d < D; ++d) {
-                double k;
-                if (dd.type[d] == OAK_DIM_RBF) { const double c = Acn[(int64_t)d * a_ld + ic]; k = __builtin_fma(-c, c, dd.bv[d]); }
-                else k = tables[dd.tab_off[d] + dd.ncat[d] * dd.ncat[d] + (int)Axs[(int64_t)d * a_ld + ic]];
+                const bool rbf = dd.type[d] == OAK_DIM_RBF;
 #pragma unroll
-                for (int q = R - 1; q >= 1; --q) e[q] = __builtin_fma(k, e[q - 1], e[q]);
-                e[0] += k;
+                for (int t = 0; t < DT; ++t) {
+                    double k;
+                    if (rbf) { const double c = Acn[(int64_t)d * a_ld + ic[t]]; k = __builtin_fma(-c, c, dd.bv[d]); }
+                    else k = tables[dd.tab_off[d] + dd.ncat[d] * dd.ncat[d] + (int)Axs[(int64_t)d * a_ld + ic[t]]];
+#pragma unroll
+                    for (int q = R - 1; q >= 1; --q) e[t][q] = __builtin_fma(k, e[t][q - 1], e[t][q]);
+                    e[t][0] += k;
+                }
             }
         }
-        gw[0] += g;
 #pragma unroll
-        for (int q = 1; q <= R; ++q) gw[q] = __builtin_fma(g, e[q - 1], gw[q]);
+        for (int t = 0; t < DT; ++t) {
+            gw[0] += g[t];
+#pragma unroll
+            for (int q = 1; q <= R; ++q) gw[q] = __builtin_fma(g[t], e[t][q - 1], gw[q]);
+        }
         if constexpr (R > 0) {
             for (int d = 0; d < D; ++d) {
-                double k, dkl = 0.0;
-                int tidx = 0;
                 const bool rbf = dd.type[d] == OAK_DIM_RBF;
-                if (rbf) {
-                    const double c = Acn[(int64_t)d * a_ld + ic];
-                    k = __builtin_fma(-c, c, dd.bv[d]);
-                    dkl = -2.0 * c * Adcn[(int64_t)d * a_ld + ic];
-                } else {
-                    const int C = dd.ncat[d];
-                    const int xi = (int)Axs[(int64_t)d * a_ld + ic];
-                    k = tables[dd.tab_off[d] + C * C + xi];
-                    tidx = dd.tab_off[d] + xi * C + xi;
-                }
-                double f = 1.0, coef = dd.w[1];
+                double cl = 0.0, ck = 0.0;
 #pragma unroll
-                for (int q = 1; q < R; ++q) { f = __builtin_fma(-k, f, e[q - 1]); coef = __builtin_fma(dd.w[q + 1], f, coef); }
-                const double gc = g * coef;
-                double cl = wave_sum(gc * dkl), ck = wave_sum(gc * k);
-                if (!rbf && dd.type[d] == OAK_DIM_CATEGORICAL && gc != 0.0) atomicAdd(&accT[tidx], gc);
+                for (int t = 0; t < DT; ++t) {
+                    double k, dkl = 0.0;
+                    int tidx = 0;
+                    if (rbf) {
+                        const double c = Acn[(int64_t)d * a_ld + ic[t]];
+                        k = __builtin_fma(-c, c, dd.bv[d]);
+                        dkl = -2.0 * c * Adcn[(int64_t)d * a_ld + ic[t]];
+                    } else {
+                        const int C = dd.ncat[d];
+                        const int xi = (int)Axs[(int64_t)d * a_ld + ic[t]];
+                        k = tables[dd.tab_off[d] + C * C + xi];
+                        tidx = dd.tab_off[d] + xi * C + xi;
+                    }
+                    double f = 1.0, coef = dd.w[1];
+#pragma unroll
+                    for (int q = 1; q < R; ++q) { f = __builtin_fma(-k, f, e[t][q - 1]); coef = __builtin_fma(dd.w[q + 1], f, coef); }
+                    const double gc = g[t] * coef;
+                    cl = __builtin_fma(gc, dkl, cl);
+                    ck = __builtin_fma(gc, k, ck);
+                    if (!rbf && dd.type[d] == OAK_DIM_CATEGORICAL && gc != 0.0) atomicAdd(&accT[tidx], gc);
+                }
+                cl = wave_sum(cl); ck = wave_sum(ck);
                 if (tx == 0) { accL[ty * D + d] += cl; accK[ty * D + d] += ck; }
             }
         }
@@ -522,14 +542,21 @@ diag_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
     for (int idx = tid; idx < tablen; idx += 256) rec[2 * D + (R + 1) + idx] = accT[idx];
 }
 
-// out[j] += sum_w partial[w][j]   (fixed order)
+// out[j] += sum_w partial[w][j]: one workgroup per entry j, thread t adds records t, t + 256, ... in order, then a fixed
+// LDS tree -- deterministic, and 2048 records take microseconds instead of one serial chain per entry.
 __global__ void __launch_bounds__(256) reduce_records_kernel(const double* __restrict__ partial, int64_t nrec, int64_t reclen,
                                                              double* __restrict__ out) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= reclen) return;
+    __shared__ double red[256];
+    const int64_t j = blockIdx.x;
     double s = 0.0;
-    for (int64_t w = 0; w < nrec; ++w) s += partial[w * reclen + j];
-    out[j] += s;
+    for (int64_t w = threadIdx.x; w < nrec; w += 256) s += partial[w * reclen + j];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[j] += red[0];
 }
 
 static int64_t record_len(const PreparedKernel& pk) { return 2 * pk.dd.D + (pk.dd.R + 1) + (int64_t)pk.tables.size(); }
@@ -613,7 +640,7 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
 #undef OAK_BWD_FAST_U
 #undef OAK_BWD_FAST_G
     OAK_HIP_CHECK(hipGetLastError());
-    reduce_records_kernel<<<(unsigned)((reclen + 255) / 256), 256, 0, ctx->stream>>>(d_part, nrb * ncb, reclen, d_rec);
+    reduce_records_kernel<<<(unsigned)reclen, 256, 0, ctx->stream>>>(d_part, nrb * ncb, reclen, d_rec);
     OAK_HIP_CHECK(hipGetLastError());
     return OAK_OK;
 }
@@ -623,10 +650,10 @@ int diag_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, double gcons
     const int D = pk.dd.D, R = pk.dd.R;
     const int tablen = (int)pk.tables.size();
     const int64_t reclen = record_len(pk);
-    int64_t nwg = (A.n + 4095) / 4096;
-    if (nwg > 2048) nwg = 2048;
+    int64_t nwg = (A.n + 2047) / 2048;              // one trip of 8 points per lane per workgroup
+    if (nwg > 4096) nwg = 4096;
     int64_t rows = (A.n + nwg - 1) / nwg;
-    rows = ((rows + 255) / 256) * 256;
+    rows = ((rows + 2047) / 2048) * 2048;
     nwg = (A.n + rows - 1) / rows;
     double* d_part = nullptr;
     OAK_CHECK(get_buf_t(ctx, "bwd_part_diag", (size_t)(nwg * reclen), &d_part));
@@ -639,7 +666,7 @@ int diag_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, double gcons
     }
 #undef OAK_DB_CASE
     OAK_HIP_CHECK(hipGetLastError());
-    reduce_records_kernel<<<(unsigned)((reclen + 255) / 256), 256, 0, ctx->stream>>>(d_part, nwg, reclen, d_rec);
+    reduce_records_kernel<<<(unsigned)reclen, 256, 0, ctx->stream>>>(d_part, nwg, reclen, d_rec);
     OAK_HIP_CHECK(hipGetLastError());
     return OAK_OK;
 }
