@@ -210,6 +210,17 @@ int oak_kmeans(oak_ctx* ctx, const double* X, int64_t N, int32_t D, int32_t ldx,
                const double* init_centres, int32_t max_iter, double tol, double* centres_out,
                int32_t* labels_out, double* inertia_out, int32_t* n_iter_out);
 
+/* k-means++ seeding (greedy, with local trials) as scikit-learn's _kmeans_plusplus runs it inside KMeans.fit
+   before the Lloyd loop above.  The caller draws the randomness from ITS generator in scikit-learn's order
+   (first_index = rs.choice(N, p=uniform); uniforms = rs.uniform(size=(K-1, n_trials)), n_trials = 2 + int(log K),
+   at most 16) so that a numpy RandomState reproduces scikit-learn's picks; everything else runs on the device
+   without a host synchronisation per centre.  N <= 2^24, D <= 64.  centres_out K x D, indices_out (K, may be NULL).
+   Indices can differ from scikit-learn's only when a random threshold lands within rounding of a cumulative-sum
+   boundary (direct-form distances and blocked sums here vs GEMM-form distances and a sequential cumsum there). */
+int oak_kmeans_plusplus(oak_ctx* ctx, const double* X, int64_t N, int32_t D, int32_t ldx, int32_t K,
+                        int64_t first_index, const double* uniforms, int32_t n_trials, double* centres_out,
+                        int64_t* indices_out);
+
 /* ---- device-resident benchmarking hooks (inputs already in HBM) ---------------------------- */
 /* Explicit Kuf panel for the rows set with oak_sgpr_set_data, written to a device buffer and not
    copied back: the "Gram GB/s" workload.  bytes_out = algorithmic bytes 8*(N*M + N*D + M*D). */

@@ -290,3 +290,261 @@ extern "C" int oak_kmeans(oak_ctx* ctx, const double* X, int64_t N, int32_t D, i
     if (n_iter_out) *n_iter_out = it;
     return OAK_OK;
 }
+
+// =====================================================================================================================
+// k-means++ seeding on the device (greedy variant with local trials), following scikit-learn's _kmeans_plusplus
+// (sklearn/cluster/_kmeans.py) that KMeans.fit runs before Lloyd:
+//     first centre = given index; closest_i = |x_i - c_0|^2; pot = sum closest
+//     for c = 1..K-1:  r_t = u[c-1][t] * pot (t < n_trials; the uniforms are drawn by the HOST from the caller's RandomState,
+//                      in scikit-learn's order);  candidate_t = searchsorted(cumsum(closest), r_t), clipped to N-1;
+//                      pot_t = sum_i min(closest_i, |x_i - x_cand_t|^2);  best = argmin_t pot_t (first minimum);
+//                      closest <- min(closest, dist_best); pot <- pot_best; centre_c = candidate_best
+// The whole loop is enqueued without a host synchronisation (five small kernels per centre).  Distances use the direct
+// form; cumulative sums are two-level (4096-element blocks, fixed order): against scikit-learn the chosen indices can
+// differ only when a random threshold falls within rounding distance of a cumulative-sum boundary.
+// =====================================================================================================================
+namespace oak {
+
+static constexpr int KPP_BLOCK = 4096;      // elements per cumulative-sum block (16 per thread)
+static constexpr int KPP_MAXT = 16;         // max local trials (2 + log K <= 16 for K <= 1.2e6)
+
+__device__ __forceinline__ double kpp_block_reduce(double v, double* red /*[256]*/) {
+    red[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+// closest_i = |x_i - x_first|^2 and the per-block sums of closest
+template <int DMAX>
+__global__ void __launch_bounds__(256)
+kpp_init_kernel(const double* __restrict__ X, int64_t N, int D, int64_t ldx, int64_t first, double* __restrict__ closest,
+                double* __restrict__ bsum, int64_t* __restrict__ indices) {
+    __shared__ double red[256];
+    if (blockIdx.x == 0 && threadIdx.x == 0) indices[0] = first;
+    const int64_t b0 = (int64_t)blockIdx.x * KPP_BLOCK;
+    double c[DMAX];
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) c[d] = d < D ? X[first * ldx + d] : 0.0;
+    double s = 0.0;
+    for (int q = 0; q < KPP_BLOCK / 256; ++q) {
+        const int64_t i = b0 + (int64_t)threadIdx.x * (KPP_BLOCK / 256) + q;      // 16 consecutive elements per thread
+        if (i < N) {
+            double dist = 0.0;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) { const double t = (d < D ? X[i * ldx + d] : 0.0) - c[d]; dist = __builtin_fma(t, t, dist); }
+            closest[i] = dist;
+            s += dist;
+        }
+    }
+    s = kpp_block_reduce(s, red);
+    if (threadIdx.x == 0) bsum[blockIdx.x] = s;
+}
+
+// One workgroup: prefix over the block sums, then for each trial the candidate index = first i with cumsum_i >= r_t.
+// state[0] = current potential (in: from the previous selection; the cumulative total is NOT used, as in scikit-learn).
+__global__ void __launch_bounds__(256)
+kpp_pick_kernel(const double* __restrict__ closest, const double* __restrict__ bsum, int nb, int64_t N,
+                const double* __restrict__ state, const double* __restrict__ uniforms, int n_trials, int64_t* __restrict__ cand) {
+    extern __shared__ double sm[];          // [nb + 1] exclusive prefix of the block sums, then [256] scratch
+    double* pref = sm;
+    double* scr = sm + nb + 1;
+    if (threadIdx.x == 0) {                 // nb <= 4096 (N <= 2^24): a short sequential pass, same order as a running sum
+        double a = 0.0;
+        for (int b = 0; b < nb; ++b) { pref[b] = a; a += bsum[b]; }
+        pref[nb] = a;
+    }
+    __syncthreads();
+    const double pot = state[0];
+    for (int t = 0; t < n_trials; ++t) {
+        const double r = uniforms[t] * pot;
+        // block: last b with pref[b] < r  (so that the answer lies inside block b); r <= 0 -> element 0
+        int lo = 0, hi = nb;                // invariant: pref[lo] < r or lo == 0
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pref[mid] < r) lo = mid; else hi = mid; }
+        const int b = lo;
+        const int64_t e0 = (int64_t)b * KPP_BLOCK + (int64_t)threadIdx.x * (KPP_BLOCK / 256);
+        double v[KPP_BLOCK / 256], ls = 0.0;
+#pragma unroll
+        for (int q = 0; q < KPP_BLOCK / 256; ++q) { v[q] = (e0 + q < N) ? closest[e0 + q] : 0.0; ls += v[q]; }
+        scr[threadIdx.x] = ls;
+        __syncthreads();
+        if (threadIdx.x == 0) {             // exclusive prefix of the 256 thread sums, sequential
+            double a = pref[b];
+            for (int j = 0; j < 256; ++j) { const double x = scr[j]; scr[j] = a; a += x; }
+        }
+        __syncthreads();
+        // each thread checks its 16 elements; the smallest qualifying index wins
+        double a = scr[threadIdx.x];
+        long long mine = (long long)N;      // "not found"
+#pragma unroll
+        for (int q = 0; q < KPP_BLOCK / 256; ++q) {
+            a += v[q];
+            if (a >= r && e0 + q < N && mine == (long long)N) mine = (long long)(e0 + q);
+        }
+        __syncthreads();
+        long long* imin = reinterpret_cast<long long*>(scr);
+        imin[threadIdx.x] = mine;
+        __syncthreads();
+        for (int off = 128; off >= 1; off >>= 1) {
+            if ((int)threadIdx.x < off && imin[threadIdx.x + off] < imin[threadIdx.x]) imin[threadIdx.x] = imin[threadIdx.x + off];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            long long id = imin[0];
+            if (id >= (long long)N) {       // rounding pushed r past this block's end: first element of the next block, clipped
+                id = (long long)(b + 1) * KPP_BLOCK;
+                if (id > (long long)N - 1) id = (long long)N - 1;
+            }
+            cand[t] = (int64_t)id;
+        }
+        __syncthreads();
+    }
+}
+
+// newmin[t][i] = min(closest_i, |x_i - x_cand_t|^2) and per-block sums part[t][block].  Each point is read once and
+// tested against all candidates (their coordinates sit in LDS, broadcast reads).
+template <int DMAX>
+__global__ void __launch_bounds__(256)
+kpp_dist_kernel(const double* __restrict__ X, int64_t N, int D, int64_t ldx, const int64_t* __restrict__ cand, int n_trials,
+                const double* __restrict__ closest, double* __restrict__ newmin, double* __restrict__ part) {
+    __shared__ double red[256];
+    __shared__ double cs[KPP_MAXT][DMAX];
+    for (int idx = threadIdx.x; idx < n_trials * DMAX; idx += 256) {
+        const int t = idx / DMAX, d = idx - t * DMAX;
+        cs[t][d] = d < D ? X[cand[t] * ldx + d] : 0.0;
+    }
+    __syncthreads();
+    const int64_t b0 = (int64_t)blockIdx.x * KPP_BLOCK;
+    double s[KPP_MAXT];
+#pragma unroll
+    for (int t = 0; t < KPP_MAXT; ++t) s[t] = 0.0;
+    for (int q = 0; q < KPP_BLOCK / 256; ++q) {
+        const int64_t i = b0 + (int64_t)q * 256 + threadIdx.x;
+        if (i < N) {
+            double x[DMAX];
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) x[d] = d < D ? X[i * ldx + d] : 0.0;
+            const double cl = closest[i];
+#pragma unroll
+            for (int t = 0; t < KPP_MAXT; ++t) {
+                if (t < n_trials) {
+                    double dist = 0.0;
+#pragma unroll
+                    for (int d = 0; d < DMAX; ++d) { const double u = x[d] - cs[t][d]; dist = __builtin_fma(u, u, dist); }
+                    const double m = dist < cl ? dist : cl;
+                    newmin[(int64_t)t * N + i] = m;
+                    s[t] += m;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < KPP_MAXT; ++t) {
+        if (t < n_trials) {
+            const double r = kpp_block_reduce(s[t], red);
+            if (threadIdx.x == 0) part[(int64_t)t * gridDim.x + blockIdx.x] = r;
+        }
+    }
+}
+
+// One workgroup: potentials of the trials (fixed order), first minimum wins; records the chosen index and potential.
+__global__ void __launch_bounds__(256)
+kpp_select_kernel(const double* __restrict__ part, int nb, int n_trials, const int64_t* __restrict__ cand, double* __restrict__ state,
+                  int64_t* __restrict__ indices, int c) {
+    __shared__ double red[256];
+    __shared__ double pots[KPP_MAXT];
+    for (int t = 0; t < n_trials; ++t) {
+        double s = 0.0;
+        for (int b = threadIdx.x; b < nb; b += 256) s += part[(int64_t)t * nb + b];
+        s = kpp_block_reduce(s, red);
+        if (threadIdx.x == 0) pots[t] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int best = 0;
+        for (int t = 1; t < n_trials; ++t) if (pots[t] < pots[best]) best = t;
+        state[0] = pots[best];
+        state[1] = (double)best;
+        indices[c] = cand[best];
+    }
+}
+
+// closest <- newmin[best]; block sums of the new closest
+__global__ void __launch_bounds__(256)
+kpp_commit_kernel(const double* __restrict__ newmin, const double* __restrict__ part, int64_t N, const double* __restrict__ state,
+                  double* __restrict__ closest, double* __restrict__ bsum) {
+    const int best = (int)state[1];
+    const int64_t b0 = (int64_t)blockIdx.x * KPP_BLOCK;
+    for (int q = 0; q < KPP_BLOCK / 256; ++q) {
+        const int64_t i = b0 + (int64_t)q * 256 + threadIdx.x;                     // coalesced copy
+        if (i < N) closest[i] = newmin[(int64_t)best * N + i];
+    }
+    if (threadIdx.x == 0) bsum[blockIdx.x] = part[(int64_t)best * gridDim.x + blockIdx.x];
+}
+
+template <int DMAX>
+static int kpp_run(oak_ctx* ctx, const double* dX, int64_t N, int D, int64_t ldx, int K, int64_t first, const double* dU, int n_trials,
+                   int64_t* dIdx) {
+    const int nb = (int)((N + KPP_BLOCK - 1) / KPP_BLOCK);
+    double *dClosest, *dBsum, *dNewmin, *dPart, *dState;
+    int64_t* dCand;
+    OAK_CHECK(get_buf_t(ctx, "kpp_closest", (size_t)N, &dClosest));
+    OAK_CHECK(get_buf_t(ctx, "kpp_bsum", (size_t)nb, &dBsum));
+    OAK_CHECK(get_buf_t(ctx, "kpp_newmin", (size_t)N * n_trials, &dNewmin));
+    OAK_CHECK(get_buf_t(ctx, "kpp_part", (size_t)nb * n_trials, &dPart));
+    OAK_CHECK(get_buf_t(ctx, "kpp_state", 2, &dState));
+    OAK_CHECK(get_buf_t(ctx, "kpp_cand", (size_t)KPP_MAXT, &dCand));
+    kpp_init_kernel<DMAX><<<nb, 256, 0, ctx->stream>>>(dX, N, D, ldx, first, dClosest, dBsum, dIdx);
+    OAK_HIP_CHECK(hipGetLastError());
+    OAK_CHECK(reduce_sum(ctx, dBsum, nb, dState, 0, 1));                           // initial potential
+    const size_t lds_pick = sizeof(double) * ((size_t)nb + 1 + 256);
+    for (int c = 1; c < K; ++c) {
+        kpp_pick_kernel<<<1, 256, lds_pick, ctx->stream>>>(dClosest, dBsum, nb, N, dState, dU + (size_t)(c - 1) * n_trials, n_trials, dCand);
+        kpp_dist_kernel<DMAX><<<nb, 256, 0, ctx->stream>>>(dX, N, D, ldx, dCand, n_trials, dClosest, dNewmin, dPart);
+        kpp_select_kernel<<<1, 256, 0, ctx->stream>>>(dPart, nb, n_trials, dCand, dState, dIdx, c);
+        kpp_commit_kernel<<<nb, 256, 0, ctx->stream>>>(dNewmin, dPart, N, dState, dClosest, dBsum);
+    }
+    OAK_HIP_CHECK(hipGetLastError());
+    return OAK_OK;
+}
+
+}  // namespace oak
+
+extern "C" int oak_kmeans_plusplus(oak_ctx* ctx, const double* X, int64_t N, int32_t D, int32_t ldx, int32_t K, int64_t first_index,
+                                   const double* uniforms, int32_t n_trials, double* centres_out, int64_t* indices_out) {
+    if (!ctx) { set_error("ctx is NULL"); return OAK_E_ARG; }
+    OAK_HIP_CHECK(hipSetDevice(ctx->device));
+    OAK_REQUIRE(X && centres_out && (uniforms || K == 1), "oak_kmeans_plusplus: NULL argument");
+    OAK_REQUIRE(N >= 1 && N <= ((int64_t)1 << 24) && D >= 1 && D <= 64 && ldx >= D && K >= 1 && K <= N && first_index >= 0 &&
+                    first_index < N && n_trials >= 1 && n_trials <= KPP_MAXT,
+                "oak_kmeans_plusplus: bad sizes (N=%lld D=%d K=%d first=%lld trials=%d)", (long long)N, D, K, (long long)first_index,
+                n_trials);
+    PhaseTimer t(ctx, "kmeans_pp");
+    const int dmax = D <= 8 ? 8 : D <= 16 ? 16 : D <= 32 ? 32 : 64;
+    double *dX, *dU;
+    int64_t* dIdx;
+    OAK_CHECK(get_buf_t(ctx, "km_X", (size_t)N * ldx, &dX));
+    OAK_CHECK(get_buf_t(ctx, "kpp_u", (size_t)(K > 1 ? (K - 1) : 1) * n_trials, &dU));
+    OAK_CHECK(get_buf_t(ctx, "kpp_idx", (size_t)K, &dIdx));
+    OAK_HIP_CHECK(hipMemcpyAsync(dX, X, sizeof(double) * (size_t)N * ldx, hipMemcpyHostToDevice, ctx->stream));
+    if (K > 1) OAK_HIP_CHECK(hipMemcpyAsync(dU, uniforms, sizeof(double) * (size_t)(K - 1) * n_trials, hipMemcpyHostToDevice, ctx->stream));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    const int64_t first = first_index;
+    OAK_CHECK(KM_DISPATCH(kpp_run, ctx, dX, N, D, ldx, K, first, dU, n_trials, dIdx));
+    std::vector<int64_t> hIdx((size_t)K);
+    OAK_HIP_CHECK(hipMemcpyAsync(hIdx.data(), dIdx, sizeof(int64_t) * (size_t)K, hipMemcpyDeviceToHost, ctx->stream));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    t.stop();
+    for (int k = 0; k < K; ++k) {
+        const int64_t i = hIdx[(size_t)k];
+        if (i < 0 || i >= N) { set_error("oak_kmeans_plusplus: internal error, index %lld out of range", (long long)i); return OAK_E_STATE; }
+        for (int d = 0; d < D; ++d) centres_out[(size_t)k * D + d] = X[(size_t)i * ldx + d];
+        if (indices_out) indices_out[k] = i;
+    }
+    return OAK_OK;
+}

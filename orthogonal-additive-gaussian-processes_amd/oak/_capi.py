@@ -97,6 +97,8 @@ SIGNATURES = {
     "oak_comm_allreduce_stats": (C.c_int, [_CTX]),
     "oak_comm_allreduce_host": (C.c_int, [_CTX, _D, C.c_int64]),
     "oak_bench_gram_resident": (C.c_int, [_CTX, _DESC, _D]),
+    "oak_kmeans_plusplus": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64, _D, C.c_int32, _D,
+                                      C.POINTER(C.c_int64)]),
     "oak_kmeans": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _D, C.c_int32, C.c_double, _D, _I,
                              _D, _I]),
 }
@@ -545,6 +547,22 @@ class HipContext:
         _check(self._lib.oak_kmeans(self._h, _dp(X), X.shape[0], X.shape[1], X.shape[1], K, _dp(C0), int(max_iter), float(tol),
                                     _dp(centres), _ip(labels), C.byref(inertia), C.byref(n_iter)))
         return centres, labels, inertia.value, n_iter.value
+
+    def kmeans_plusplus(self, X: np.ndarray, n_clusters: int, random_state=None):
+        """scikit-learn's greedy k-means++ (``sklearn.cluster.kmeans_plusplus``) on the device.  ``random_state`` is an int
+        seed or a ``numpy.random.RandomState``; the draws are made in scikit-learn's order, so the same seed gives the same
+        picks.  Returns (centres [K, D], indices [K])."""
+        X = _f64(X, 2)
+        N, K = X.shape[0], int(n_clusters)
+        rs = random_state if isinstance(random_state, np.random.RandomState) else np.random.RandomState(random_state)
+        n_trials = 2 + int(np.log(K))
+        first = int(rs.choice(N, p=np.full(N, 1.0 / N)))
+        U = np.ascontiguousarray(rs.uniform(size=(max(K - 1, 0), n_trials))) if K > 1 else np.zeros((1, n_trials))
+        centres = np.empty((K, X.shape[1]))
+        idx = np.empty(K, dtype=np.int64)
+        _check(self._lib.oak_kmeans_plusplus(self._h, _dp(X), N, X.shape[1], X.shape[1], K, first, _dp(U), n_trials, _dp(centres),
+                                             idx.ctypes.data_as(C.POINTER(C.c_int64))))
+        return centres, idx
 
     # -- benchmarking -------------------------------------------------------------------------
     def bench_gram_resident(self, desc: KernelDesc) -> float:

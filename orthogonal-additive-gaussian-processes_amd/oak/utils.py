@@ -133,29 +133,30 @@ def get_prediction_component(m, alpha, X: np.ndarray = None, share_var_across_or
 
 
 # ---- inducing-point initialisation (oak/utils.py:533-574) -------------------------------------------------------------
-KMEANS_SEED_SAMPLE = 131072     # k-means++ seeding (sequential in K) looks at no more than this many rows
+KMEANS_SEED_SAMPLE = 1 << 24     # rows the device k-means++ accepts; above it the seeds come from a fixed random subsample
 
 
 def kmeans_centres(X, n_clusters: int, random_state: int = 0, max_iter: int = 300, tol: float = 1e-4) -> np.ndarray:
-    """``KMeans(n_clusters, random_state=random_state).fit(X).cluster_centers_`` with the Lloyd iterations on the device.
+    """``KMeans(n_clusters, random_state=random_state).fit(X).cluster_centers_`` on the device.
 
     Same pipeline as scikit-learn's ``KMeans.fit`` (one k-means++ initialisation, the default since scikit-learn 1.4):
-    centre the data, draw k-means++ seeds with the given ``random_state``, run Lloyd (``oak_kmeans``) with the absolute
-    tolerance ``tol * mean(var(X, axis=0))``, add the mean back.  The seeding is scikit-learn's own ``kmeans_plusplus``
-    (host; it is sequential in K); above ``KMEANS_SEED_SAMPLE`` rows it sees a fixed random subsample, which is the only
-    departure from the reference call."""
-    from sklearn.cluster import kmeans_plusplus
+    centre the data, draw the greedy k-means++ seeds from ``RandomState(random_state)`` (``oak_kmeans_plusplus``; the
+    random numbers are drawn on the host in scikit-learn's order), run Lloyd (``oak_kmeans``) with the absolute tolerance
+    ``tol * mean(var(X, axis=0))``, add the mean back.  Reproduces the reference call to 1e-9
+    (tests/test_gpu_kmeans.py); above ``KMEANS_SEED_SAMPLE`` rows the seeding sees a fixed random subsample."""
     X = np.ascontiguousarray(np.asarray(X, dtype=np.float64))
     if X.ndim != 2:
         raise ValueError("X must be two-dimensional")
     mean = X.mean(axis=0)
     Xc = X - mean
+    rs = np.random.RandomState(random_state)
     pool = Xc
     if Xc.shape[0] > KMEANS_SEED_SAMPLE:
         pool = Xc[np.random.RandomState(random_state).choice(Xc.shape[0], KMEANS_SEED_SAMPLE, replace=False)]
-    seeds, _ = kmeans_plusplus(pool, n_clusters, random_state=random_state)
+    ctx = _capi.default_context()
+    seeds, _ = ctx.kmeans_plusplus(pool, n_clusters, random_state=rs)
     abs_tol = float(np.mean(np.var(X, axis=0)) * tol)
-    centres, _, _, _ = _capi.default_context().kmeans(Xc, seeds, max_iter, abs_tol)
+    centres, _, _, _ = ctx.kmeans(Xc, seeds, max_iter, abs_tol)
     return centres + mean
 
 

@@ -145,3 +145,30 @@ def test_get_kmeans_centers_and_subsampled_seeding(hip, monkeypatch):
     assert np.abs(C - Z2).max() < 0.05
     d_full = ((X[:, None, :] - Z[None]) ** 2).sum(-1).min(1).sum()
     assert inertia < 1.05 * d_full          # as good a clustering as the all-rows seeding, within 5 %
+
+
+@pytest.mark.parametrize("N,D,K,seed", [(3000, 2, 8, 0), (5000, 6, 40, 1), (20000, 16, 128, 2), (4097, 20, 30, 3),
+                                         (9000, 40, 12, 4), (50, 3, 50, 5), (7, 1, 1, 6)])
+def test_kmeans_plusplus_matches_sklearn(hip, N, D, K, seed):
+    """Device k-means++ with the caller's RandomState picks scikit-learn's indices (the seeding KMeans.fit runs inside
+    the reference's get_kmeans_centers, /root/reference/oak/model_utils.py:38-40)."""
+    sklearn_cluster = pytest.importorskip("sklearn.cluster")
+    rng = np.random.default_rng(100 + seed)
+    X = rng.normal(size=(N, D)) * rng.uniform(0.5, 3.0, size=D)
+    ref_c, ref_idx = sklearn_cluster.kmeans_plusplus(X, K, random_state=seed)
+    c, idx = hip.kmeans_plusplus(X, K, random_state=seed)
+    np.testing.assert_array_equal(idx, ref_idx)
+    np.testing.assert_array_equal(c, X[ref_idx])
+
+
+def test_kmeans_plusplus_properties_at_scale(hip):
+    """N = 2^20, K = 1024: distinct, valid indices; potential well below random seeding's (needs no oracle run)."""
+    rng = np.random.default_rng(7)
+    N, D, K = 1 << 20, 16, 1024
+    X = rng.normal(size=(N, D))
+    c, idx = hip.kmeans_plusplus(X, K, random_state=0)
+    assert len(np.unique(idx)) == K and idx.min() >= 0 and idx.max() < N
+    np.testing.assert_array_equal(c, X[idx])
+    sub = X[rng.choice(N, 20000, replace=False)]
+    pot = lambda C: ((sub[:, None, :] - C[None, :256, :]) ** 2).sum(-1).min(1).sum()
+    assert pot(c) < pot(X[rng.choice(N, K, replace=False)]) * 1.02
