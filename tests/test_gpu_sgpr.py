@@ -158,3 +158,29 @@ def test_gpr_matches_oracle(hip):
         mr, vr = o.gpr_predict_f(spec, X, y, 0.01, Xs)
         assert np.abs(m - mr[:, 0]).max() <= 1e-9 and np.abs(v - vr[:, 0]).max() <= 1e-9
         np.testing.assert_allclose(hip.gpr_alpha(N), o.gpr_alpha(spec, X, y, 0.01)[:, 0], rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("route", ["phi", "auto"])
+def test_large_batch_prediction_matches_literal_path_and_oracle(hip, route):
+    """Above Ns*M = 2^24 predict_f applies explicit inverses with two GEMMs; below it follows GPflow's two triangular
+    solves literally.  Same posterior, both paths, against each other and the oracle (1e-9)."""
+    N, D, M, R = 6000, 6, 512, 2
+    X, y, Z = o.synthetic_problem(N, D, M, seed=11)
+    spec = o.make_spec(D, R, lengthscales=[1.1, 0.9, 1.4, 1.0, 1.2, 0.8])
+    d = _capi.KernelDesc(spec)
+    setup(hip, X, y, Z, route)
+    hip.sgpr_elbo(d, 0.02)
+    Xs = np.random.default_rng(5).standard_normal((40000, D))            # 40000 * 512 > 2^24 -> GEMM path
+    m_big, v_big = hip.sgpr_predict(d, Xs)
+    m_lit = np.concatenate([hip.sgpr_predict(d, Xs[a:a + 8000])[0] for a in range(0, 40000, 8000)])   # literal path
+    v_lit = np.concatenate([hip.sgpr_predict(d, Xs[a:a + 8000])[1] for a in range(0, 40000, 8000)])
+    scale = max(1.0, np.abs(v_lit).max())
+    assert np.abs(m_big - m_lit).max() <= 1e-9 * max(1.0, np.abs(m_lit).max())
+    assert np.abs(v_big - v_lit).max() <= 1e-9 * scale
+    mr, vr = o.sgpr_predict_f(spec, X, y, Z, 0.02, Xs[:3000])
+    # "auto" whitens at this size (N*M <= 2^24): posterior exact to 1e-9; the phi route's posterior carries cond(Kuu)*eps
+    cond = np.linalg.cond(o.oak_K(spec, Z) + 1e-6 * np.eye(M))
+    ptol = 1e-9 if route == "auto" else max(1e-9, 1e-16 * cond * 100)
+    assert np.abs(m_big[:3000] - mr[:, 0]).max() <= ptol * max(1.0, np.abs(mr).max()), f"cond={cond:.2e}"
+    assert np.abs(v_big[:3000] - vr[:, 0]).max() <= ptol * scale, f"cond={cond:.2e}"
+    assert v_big.min() > 0
