@@ -83,7 +83,7 @@ def main():
                     help="N>1: 'rccl' = reduce-scatter + all-gather over xGMI inside liboak_hip (default); 'host' = debug path that "
                          "sums the packed statistics through the gloo control plane (lets several ranks share one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-rows", type=int, default=131072)
+    ap.add_argument("--cpu-sample-rows", type=int, default=262144)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
