@@ -53,10 +53,11 @@ def test_sgpr_gradient_continuous(hip, route, R):
     check(g[2 * D + R + 1], fd(lambda h: o.sgpr_elbo(spec, X, y, Z, s2 + h), h=1e-6))
 
 
-@pytest.mark.parametrize("D,R", [(12, 2), (16, 3), (20, 2), (9, 5)])
+@pytest.mark.parametrize("D,R", [(12, 2), (16, 3), (20, 2), (32, 4), (33, 2), (9, 5)])
 def test_sgpr_gradient_kernel_variants(hip, D, R):
-    """D <= 8 / <= 16 take the register-resident fast backward kernel, larger D or R > 4 the generic two-pass kernel:
-    all must agree with finite differences of the oracle (a subset of parameters is probed)."""
+    """D <= 8 / <= 16 / <= 32 take the register-resident fast backward kernel (one column per lane above 16), larger D or
+    R > 4 the generic two-pass kernel: all must agree with finite differences of the oracle (a subset of parameters is
+    probed)."""
     rng = np.random.default_rng(D * 10 + R)
     N, M = 260, 20
     X, y, Z = o.synthetic_problem(N, D, M, seed=D)
