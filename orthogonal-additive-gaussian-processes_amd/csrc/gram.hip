@@ -112,7 +112,10 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
                     xa[r] = Ax[d * RS + ty * RT + r];
                     ca[r] = Ac[d * RS + ty * RT + r];
                 }
-                if (ALLRBF || dd.type[d] == OAK_DIM_RBF) {   // ALLRBF: no branch, so the e[] accumulators never change registers
+                // k_d of this lane's RT x CPT pairs first, ESP update after the branch re-joins: in the mixed-type kernel only
+                // these RT*CPT values cross the merge (not the RT*CPT*R accumulators, which cost a v_mov each per dimension)
+                double kk[RT][CPT];
+                if (ALLRBF || dd.type[d] == OAK_DIM_RBF) {
                     const double woff = dd.woff[d], magic = dd.magic[d];
 #pragma unroll
                     for (int r = 0; r < RT; ++r) {
@@ -127,7 +130,7 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
                         for (int c = 0; c < CPT; ++c) mg[c] = magic;
                         exp2_w_vec<CPT>(w, mg, E, Tab);
 #pragma unroll
-                        for (int c = 0; c < CPT; ++c) esp_update<R>(e[r][c], __builtin_fma(-ca[r], cb[c], E[c]));
+                        for (int c = 0; c < CPT; ++c) kk[r][c] = __builtin_fma(-ca[r], cb[c], E[c]);
                     }
                 } else {
                     const int C = dd.ncat[d];
@@ -135,11 +138,12 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
 #pragma unroll
                     for (int r = 0; r < RT; ++r)
 #pragma unroll
-                        for (int c = 0; c < CPT; ++c) {
-                            const double k = tab[(int)xa[r] * C + (int)xb[c]];
-                            esp_update<R>(e[r][c], k);
-                        }
+                        for (int c = 0; c < CPT; ++c) kk[r][c] = tab[(int)xa[r] * C + (int)xb[c]];
                 }
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int c = 0; c < CPT; ++c) esp_update<R>(e[r][c], kk[r][c]);
             }
         }
         // epilogue: combine orders, optional psi accumulation, store
@@ -274,7 +278,7 @@ static int launch_gram_r(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, 
         return launch_gram_t<R, 4, 2>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
     } else if constexpr (R <= 4) {
         if (D <= 16) return launch_gram_t<R, 2, 4>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
-        return launch_gram_t<R, 2, 2>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+        return launch_gram_t<R, 4, 2>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
     } else {
         if (D <= 16) return launch_gram_t<R, 1, 4>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
         return launch_gram_t<R, 1, 2>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
