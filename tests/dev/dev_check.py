@@ -1,7 +1,7 @@
 """Developer smoke script: HIP path vs oracle at small sizes + timing at the headline size."""
 import sys, time, os
 from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT / "orthogonal-additive-gaussian-processes_amd"))
 sys.path.insert(0, str(ROOT))
 import numpy as np

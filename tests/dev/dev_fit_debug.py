@@ -1,7 +1,7 @@
 import sys, time
 from pathlib import Path
 import numpy as np
-ROOT = Path(__file__).resolve().parents[1]
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT / "orthogonal-additive-gaussian-processes_amd")); sys.path.insert(0, str(ROOT))
 from oak import gpflow_lite as gpflow
 from oak.model_utils import oak_model

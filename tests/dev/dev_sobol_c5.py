@@ -1,6 +1,6 @@
 """Developer script: Sobol indices at BASELINE config-5 scale (D=32 mixed, M=2048, order 4 -> 41 448 terms)."""
 import sys, time; from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT / "orthogonal-additive-gaussian-processes_amd")); sys.path.insert(0, str(ROOT))
 import numpy as np
 import bench

@@ -1,6 +1,6 @@
 """Developer script: repeat the O(M^3) SGPR tail at M=1024 for kernel-level profiling."""
 import sys; from pathlib import Path
-ROOT = Path(__file__).resolve().parent.parent
+ROOT = Path(__file__).resolve().parents[2]
 sys.path.insert(0, str(ROOT / "orthogonal-additive-gaussian-processes_amd")); sys.path.insert(0, str(ROOT))
 import numpy as np
 from oak import _capi
