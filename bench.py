@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default="headline", choices=sorted(CONFIGS))
     ap.add_argument("--grad", action="store_true", help="time forward + analytic gradient instead of forward only")
-    ap.add_argument("--route", default="phi", choices=["phi", "whitened"])
+    ap.add_argument("--route", default="phi", choices=["phi", "whitened", "auto"])
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "host"],
                     help="N>1: 'rccl' = reduce-scatter + all-gather over xGMI inside liboak_hip (default); 'host' = debug path that "
                          "sums the packed statistics through the gloo control plane (lets several ranks share one GPU)")

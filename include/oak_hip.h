@@ -127,7 +127,10 @@ int oak_sgpr_local_stats(oak_ctx* ctx, const oak_kernel_desc* desc, double jitte
 /* Solve route.  1 = "phi": accumulate Phi = Kuf Kuf^T (M^2 N flops) and whiten the M x M result in the
    tail; deviation from GPflow's op order grows like cond(Kuu)*eps.  2 = "whitened": apply L^-1 to each
    Kuf column first, exactly GPflow's A = L^-1 Kuf (oak/utils.py:189), 2x the flops; the packed Phi slot
-   then holds W = L^-1 Phi L^-T.  0 = auto (whitened while N*M <= 2^24). All ranks must agree. */
+   then holds W = L^-1 Phi L^-T.  0 = auto: whitened while N*M <= 2^24; above that oak_sgpr_elbo and
+   oak_sgpr_elbo_grad whiten only when chol(Kuu) looks ill-conditioned, (max diag L / min diag L)^2 > 1e3,
+   which keeps the result within ~1e-10 of the literal route (the stand-alone oak_sgpr_local_stats uses the
+   size rule alone).  Every rank sees the same Kuu, so all ranks take the same route. */
 int oak_sgpr_set_route(oak_ctx* ctx, int32_t route);
 int oak_sgpr_stats_whitened(oak_ctx* ctx, int32_t* flag);
 int64_t oak_sgpr_stats_len(oak_ctx* ctx);                    /* M*M + M + 3 */

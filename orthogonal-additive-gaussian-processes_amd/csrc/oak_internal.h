@@ -109,6 +109,10 @@ struct oak_ctx {
     bool have_linv = false;          // buffers "Linv" / "LinvT" hold L^-1 and its transpose for the current L
     bool have_lbinv = false;         // buffer "LBinv" holds LB^-1 for the current posterior (large-batch prediction)
     int route = 0;   // 0 auto, 1 phi, 2 whitened
+    int auto_whiten = -1;            // decision of the conditioning check for this evaluation (-1: none, use the size rule)
+    bool auto_pending = false;       // the check's result (cond_mm) is still in flight on the side stream
+    double cond_mm[2] = {1.0, 1.0};  // min / max of diag chol(Kuu), written by the side stream
+    hipEvent_t ev2 = nullptr;        // side stream: conditioning estimate ready
     double noise_var = 0, jitter = 0;
     // GPR state
     int64_t gN = 0; int32_t gldx = 0; bool g_have_data = false, g_have_post = false; double g_noise = 0;
@@ -187,7 +191,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter);
 int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out,
               int l_state = 0);
 bool sgpr_route_whitened(const oak_ctx* ctx);
-int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter);
+int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter, double* cond_out = nullptr);
 int sgpr_forward(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out);
 int sgpr_ensure_alpha(oak_ctx* ctx);
 

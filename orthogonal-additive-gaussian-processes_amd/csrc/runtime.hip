@@ -399,7 +399,8 @@ int oak_ctx_create(int device, oak_ctx** out) {
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
     if (hipStreamCreate(&ctx->stream) != hipSuccess || hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev0, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev1, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&ctx->ev1, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev2, hipEventDisableTiming) != hipSuccess) {
         delete ctx; oak::set_error("hipStreamCreate / hipEventCreate failed"); return OAK_E_HIP;
     }
     *out = ctx;
@@ -418,6 +419,7 @@ int oak_ctx_destroy(oak_ctx* ctx) {
     (void)hipStreamDestroy(ctx->side);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
+    (void)hipEventDestroy(ctx->ev2);
     delete ctx;
     return OAK_OK;
 }

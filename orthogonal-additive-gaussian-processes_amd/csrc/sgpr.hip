@@ -6,6 +6,7 @@
 namespace oak {
 
 static inline int64_t pad128(int64_t m) { return ((m + 127) / 128) * 128; }
+static constexpr double AUTO_WHITEN_DIAG_RATIO2 = 1e3;   // auto route: whiten when (max diag L / min diag L)^2 exceeds this
 
 struct HostUpload {   // host -> device copy into a named scratch buffer
     static int run(oak_ctx* ctx, const char* name, const double* h, size_t count, double** d) {
@@ -103,7 +104,11 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     // Route: "phi" accumulates Phi = Kuf Kuf^T and whitens the M x M result in the tail (M^2 N flops; error grows with
     // cond(Kuu)); "whitened" applies L^-1 to every panel row first -- exactly GPflow's A = L^-1 Kuf (oak/utils.py:189),
     // 2x the flops, error independent of forming Phi.  Auto: whitened while the extra TRSM is cheap.
-    const bool whiten = sgpr_route_whitened(ctx);
+    // In the auto route of a large problem the decision is still in flight (sgpr_forward started chol(Kuu) and the
+    // diagonal-ratio estimate on the side stream): the first Gram panel is needed either way, so it is launched first and
+    // the host waits for the estimate underneath it.
+    const bool lazy = ctx->auto_pending;
+    bool whiten = lazy ? false : sgpr_route_whitened(ctx);
     double* dLw = nullptr;
     if (whiten) {
         OAK_CHECK(get_buf_t(ctx, "L", (size_t)M * M, &dLw));
@@ -118,6 +123,17 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
             PhaseTimer t(ctx, "gram");
             OAK_CHECK(gram(ctx, pk, FX, a0, na, FZ, dPanel, Mp, dY, st.psi, Mp));
             t.stop();
+        }
+        if (ctx->auto_pending) {
+            OAK_HIP_CHECK(hipEventSynchronize(ctx->ev2));
+            const double ratio = ctx->cond_mm[1] / ctx->cond_mm[0];
+            ctx->auto_whiten = (ratio * ratio > AUTO_WHITEN_DIAG_RATIO2) ? 1 : 0;
+            ctx->auto_pending = false;
+            whiten = ctx->auto_whiten > 0;
+            if (whiten) {                                   // the side stream's L serves: join it (L^-1 comes along)
+                OAK_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev1, 0));
+                dLw = (double*)peek_buf(ctx, "L");
+            }
         }
         if (whiten) {
             PhaseTimer t(ctx, "trsm");
@@ -148,8 +164,37 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     return OAK_OK;
 }
 
+// Route of this evaluation.  Explicit routes are honoured.  Auto: whitened (GPflow's literal A = L^-1 Kuf) while the extra
+// N-sized TRSM is cheap (N*M <= 2^24); above that the fused entry points (oak_sgpr_elbo / _elbo_grad) look at the
+// conditioning of Kuu first -- the phi route's deviation from GPflow's op order grows like 4e-16 * cond(Kuu) -- and
+// whiten when (max diag L / min diag L)^2 > 1e3.  That ratio UNDER-estimates cond(Kuu + jitter I) by 20-600x on the
+// problems measured (tests/dev), so the switch keeps the ELBO within ~1e-10 of the literal route.
 bool sgpr_route_whitened(const oak_ctx* ctx) {
-    return ctx->route == 2 || (ctx->route == 0 && ctx->N * ctx->M <= ((int64_t)1 << 24));
+    if (ctx->route == 2) return true;
+    if (ctx->route == 1) return false;
+    if (ctx->N * ctx->M <= ((int64_t)1 << 24)) return true;
+    return ctx->auto_whiten > 0;
+}
+
+// min and max of the diagonal of an n x n factor (one workgroup; fixed tree)
+__global__ void __launch_bounds__(256) diag_minmax_kernel(const double* __restrict__ L, int64_t n, double* __restrict__ out2) {
+    __shared__ double smin[256], smax[256];
+    double lo = __builtin_inf(), hi = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) {
+        const double v = L[i * n + i];
+        lo = v < lo ? v : lo;            // NaN (failed factorisation) never wins: the route then stays phi and the
+        hi = v > hi ? v : hi;            // Cholesky status reports the failure
+    }
+    smin[threadIdx.x] = lo; smax[threadIdx.x] = hi;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            smin[threadIdx.x] = smin[threadIdx.x + off] < smin[threadIdx.x] ? smin[threadIdx.x + off] : smin[threadIdx.x];
+            smax[threadIdx.x] = smax[threadIdx.x + off] > smax[threadIdx.x] ? smax[threadIdx.x + off] : smax[threadIdx.x];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out2[0] = smin[0]; out2[1] = smax[0]; }
 }
 
 // L^-1 (and its transpose) from L, on the current ctx stream: LinvT rows = columns of L^-1 (rows-TRSM against I).
@@ -167,8 +212,11 @@ static int build_linv(oak_ctx* ctx, const double* dL, int64_t M) {
 
 // L = chol(Kuu + jitter I) on the side stream.  It depends only on Z and the hyperparameters, so it runs concurrently
 // with the N-sized gram / SYRK stages; the tail joins on ev1 and reads the deferred Cholesky status (slot 1).
-int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
+int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter, double* cond_out /* [2] min, max diag L; may be NULL */) {
     const int64_t M = ctx->M;
+    const bool want_cond = cond_out != nullptr;
+    double* dmm = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "L_minmax", 2, &dmm));
     double *dL = nullptr, *dtmp = nullptr;
     OAK_CHECK(get_buf_t(ctx, "L", (size_t)M * M, &dL));
     OAK_CHECK(get_buf_t(ctx, "LinvT", (size_t)M * M, &dtmp));      // allocate on the host side of the fork
@@ -186,6 +234,12 @@ int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter)
         OAK_CHECK(gram(ctx, pk, FZ, 0, M, FZ, dL, M, nullptr, nullptr, 0));
         OAK_CHECK(add_diag(ctx, dL, M, M, jitter));
         OAK_CHECK(potrf_lower(ctx, dL, M, M, false));
+        if (want_cond) {
+            diag_minmax_kernel<<<1, 256, 0, ctx->stream>>>(dL, M, dmm);
+            OAK_HIP_CHECK(hipGetLastError());
+            OAK_HIP_CHECK(hipMemcpyAsync(cond_out, dmm, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            OAK_HIP_CHECK(hipEventRecord(ctx->ev2, ctx->stream));
+        }
         OAK_CHECK(build_linv(ctx, dL, M));
         return OAK_OK;
     }();
@@ -198,11 +252,23 @@ int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter)
 // forward pass shared by oak_sgpr_elbo and oak_sgpr_elbo_grad
 int sgpr_forward(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out) {
     int l_state = 1;                                    // whitened route: local_stats leaves L in place
-    if (!sgpr_route_whitened(ctx)) { OAK_CHECK(sgpr_factor_kuu_async(ctx, pk, jitter)); l_state = 2; }
+    ctx->auto_whiten = -1;
+    const bool auto_big = ctx->route == 0 && ctx->N * ctx->M > ((int64_t)1 << 24);
+    ctx->auto_pending = false;
+    if (auto_big || !sgpr_route_whitened(ctx)) {
+        // auto on a large problem: the side stream also reports min / max of diag L; local_stats decides under its first
+        // Gram panel and, if it whitens, uses the side stream's L
+        OAK_CHECK(sgpr_factor_kuu_async(ctx, pk, jitter, auto_big ? ctx->cond_mm : nullptr));
+        ctx->auto_pending = auto_big;
+        l_state = 2;
+    }
     int rc = sgpr_local_stats(ctx, pk, jitter);
+    ctx->auto_pending = false;
     if (rc == OAK_OK && ctx->comm != nullptr) rc = oak_comm_allreduce_stats(ctx);
-    if (rc != OAK_OK) { if (l_state == 2) (void)hipStreamSynchronize(ctx->side); return rc; }
-    return sgpr_tail(ctx, pk, noise_var, jitter, elbo_out, terms_out, l_state);
+    if (rc != OAK_OK) { if (l_state == 2) (void)hipStreamSynchronize(ctx->side); ctx->auto_whiten = -1; return rc; }
+    rc = sgpr_tail(ctx, pk, noise_var, jitter, elbo_out, terms_out, l_state);
+    ctx->auto_whiten = -1;              // the decision belongs to this evaluation only
+    return rc;
 }
 
 int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out,

@@ -184,3 +184,23 @@ def test_large_batch_prediction_matches_literal_path_and_oracle(hip, route):
     assert np.abs(m_big[:3000] - mr[:, 0]).max() <= ptol * max(1.0, np.abs(mr).max()), f"cond={cond:.2e}"
     assert np.abs(v_big[:3000] - vr[:, 0]).max() <= ptol * scale, f"cond={cond:.2e}"
     assert v_big.min() > 0
+
+
+def test_auto_route_checks_conditioning_on_large_problems(hip):
+    """N*M > 2^24: auto keeps the phi route on a well-conditioned Kuu and whitens an ill-conditioned one, so that both stay
+    within 1e-10 of the GPflow-order oracle (the explicit phi route on the second problem does not)."""
+    N, M, R = 40000, 512, 2
+    for D, expect_whitened in ((16, False), (5, True)):
+        X, y, Z = o.synthetic_problem(N, D, M, seed=D)
+        spec = o.make_spec(D, R)
+        d = _capi.KernelDesc(spec)
+        er = c_oracle.sgpr_elbo_chunked(spec, X, y, Z, 0.01, 1e-6, chunk=8192)
+        setup(hip, X, y, Z, "auto")
+        e = hip.sgpr_elbo(d, 0.01)
+        assert hip.sgpr_stats_whitened() == expect_whitened
+        assert rel(e, er) <= 1e-10
+        eg, g = hip.sgpr_elbo_grad(d, 0.01)
+        assert hip.sgpr_stats_whitened() == expect_whitened and rel(eg, er) <= 1e-10
+        if expect_whitened:
+            setup(hip, X, y, Z, "phi")
+            assert rel(hip.sgpr_elbo(d, 0.01), er) > 1e-10      # why the check exists
