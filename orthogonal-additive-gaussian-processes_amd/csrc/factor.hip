@@ -471,8 +471,91 @@ __global__ void __launch_bounds__(256) trsm_leaf_kernel(const double* __restrict
         for (int64_t c = i; c < n; c += 32) BT[rhs * ldb + c] = xr[c];
 }
 
+// Same forward substitution for MANY right-hand sides (the N-sized whitening of the Kuf panel): a group of 32 lanes owns
+// RPG right-hand sides at once, so every L element fetched from LDS feeds RPG FMAs and the RPG dependent pivot chains
+// interleave (the one-rhs kernel above is latency-bound: 2.8 TFLOP/s at nrhs = 2^20).
+template <int RPG>
+__global__ void __launch_bounds__(256) trsm_leaf_many_kernel(const double* __restrict__ L, int64_t n, int64_t ldl,
+                                                             double* __restrict__ BT, int64_t nrhs, int64_t ldb, int nblk) {
+    extern __shared__ __attribute__((aligned(16))) double sm[];
+    double* Lt = sm;                       // [32][33]
+    double* xs = sm + 32 * 33;             // [8 * RPG][nblk*32]
+    const int tid = threadIdx.x;
+    const int rr = tid >> 5, i = tid & 31;
+    const int64_t npad = (int64_t)nblk * 32;
+    const int64_t rhs0 = ((int64_t)blockIdx.x * 8 + rr) * RPG;
+    double* xr = xs + (int64_t)rr * RPG * npad;
+#pragma unroll
+    for (int q = 0; q < RPG; ++q)
+        for (int64_t c = i; c < npad; c += 32) xr[q * npad + c] = (rhs0 + q < nrhs && c < n) ? BT[(rhs0 + q) * ldb + c] : 0.0;
+    auto load_block = [&](int rbk, int cbk) {   // Lt[a][b] = L[rbk*32+a][cbk*32+b]; identity padding past n
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int idx = tid + 256 * q;
+            const int a = idx >> 5, b = idx & 31;
+            const int64_t gr = (int64_t)rbk * 32 + a, gc = (int64_t)cbk * 32 + b;
+            const double x = L[(gr < n ? gr : n - 1) * ldl + (gc < n ? gc : n - 1)];
+            v[q] = (gr < n && gc < n) ? ((gc <= gr) ? x : 0.0) : ((gr == gc) ? 1.0 : 0.0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int idx = tid + 256 * q; Lt[(idx >> 5) * 33 + (idx & 31)] = v[q]; }
+    };
+    for (int jb = 0; jb < nblk; ++jb) {
+        __syncthreads();
+        double s[RPG];
+#pragma unroll
+        for (int q = 0; q < RPG; ++q) s[q] = xr[q * npad + jb * 32 + i];
+        for (int kb = 0; kb < jb; ++kb) {
+            __syncthreads();
+            load_block(jb, kb);
+            __syncthreads();
+#pragma unroll
+            for (int k2 = 0; k2 < 32; ++k2) {
+                const double l = Lt[i * 33 + k2];
+#pragma unroll
+                for (int q = 0; q < RPG; ++q) s[q] = __builtin_fma(-l, xr[q * npad + kb * 32 + k2], s[q]);
+            }
+        }
+        __syncthreads();
+        load_block(jb, jb);
+        __syncthreads();
+        double x[RPG];
+#pragma unroll
+        for (int q = 0; q < RPG; ++q) x[q] = 0.0;
+        const double inv = 1.0 / Lt[i * 33 + i];
+#pragma unroll
+        for (int p = 0; p < 32; ++p) {
+            const double lp = Lt[i * 33 + p];
+#pragma unroll
+            for (int q = 0; q < RPG; ++q) {
+                const double xp = __shfl(s[q] * inv, p, 32);
+                if (i == p) x[q] = xp;
+                if (i > p) s[q] = __builtin_fma(-lp, xp, s[q]);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < RPG; ++q) xr[q * npad + jb * 32 + i] = x[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RPG; ++q)
+        if (rhs0 + q < nrhs)
+            for (int64_t c = i; c < n; c += 32) BT[(rhs0 + q) * ldb + c] = xr[q * npad + c];
+}
+
 static int trsm_leaf(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, double* dBT, int64_t nrhs, int64_t ldb, int trans) {
     const int nblk = (int)((n + 31) / 32);
+    if (!trans && nrhs >= 4096) {
+        constexpr int RPG = 4;
+        const size_t lds = sizeof(double) * ((size_t)8 * RPG * nblk * 32 + 32 * 33);
+        const unsigned grid = (unsigned)((nrhs + 8 * RPG - 1) / (8 * RPG));
+        auto kern = trsm_leaf_many_kernel<RPG>;
+        if (lds > 64 * 1024) OAK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        kern<<<grid, 256, lds, ctx->stream>>>(dL, n, ldl, dBT, nrhs, ldb, nblk);
+        OAK_HIP_CHECK(hipGetLastError());
+        return OAK_OK;
+    }
     int rb = 8;
     while (rb > 1 && rb / 2 >= nrhs) rb >>= 1;
     const size_t lds = sizeof(double) * ((size_t)rb * nblk * 32 + 32 * 33);
