@@ -193,14 +193,24 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
     }
 }
 
-// column sums of a [rows x cols] row-major matrix in fixed order, accumulated onto out
+// column sums of a [rows x cols] row-major matrix in fixed order, accumulated onto out: 32 columns per workgroup, eight
+// interleaved row groups per column, combined in order through LDS
 __global__ void __launch_bounds__(256) colsum_accum_kernel(const double* __restrict__ part, int64_t rows, int64_t cols,
                                                            double* __restrict__ out) {
-    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= cols) return;
+    __shared__ double red[8][33];
+    const int cx = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int64_t j = (int64_t)blockIdx.x * 32 + cx;
     double s = 0.0;
-    for (int64_t r = 0; r < rows; ++r) s += part[r * cols + j];
-    out[j] += s;
+    if (j < cols)
+        for (int64_t r = g; r < rows; r += 8) s += part[r * cols + j];
+    red[g][cx] = s;
+    __syncthreads();
+    if (g == 0 && j < cols) {
+        double t = red[0][cx];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += red[q][cx];
+        out[j] += t;
+    }
 }
 
 template <int R>
@@ -262,7 +272,7 @@ static int launch_gram_t(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, 
                                           (int)rows, d_yA, d_part, zero_pad_to);
     OAK_HIP_CHECK(hipGetLastError());
     if (d_yA != nullptr) {
-        colsum_accum_kernel<<<(unsigned)((nb + 255) / 256), 256, 0, ctx->stream>>>(d_part, nrb, nb, d_psi);
+        colsum_accum_kernel<<<(unsigned)((nb + 31) / 32), 256, 0, ctx->stream>>>(d_part, nrb, nb, d_psi);
         OAK_HIP_CHECK(hipGetLastError());
     }
     return OAK_OK;
