@@ -572,6 +572,42 @@ int trsm_rows(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, double* dB
     constexpr int64_t NB = 128;
     if (n <= 2 * NB) return trsm_leaf(ctx, dL, n, ldl, dBT, nrhs, ldb, trans);
     if (!trans) {
+        // Many right-hand sides (the N-sized whitening of the panel): the 128 x 128 diagonal solves dominate when done by
+        // substitution on the vector pipe.  Invert each diagonal block once (substitution against I: exact to the block's
+        // own conditioning) and apply it as an MFMA GEMM -- the usual blocked-TRSM formulation of GPU BLAS libraries; the
+        // coupling between blocks is still eliminated block by block.
+        const bool by_inverse = nrhs >= 8192;
+        double *dInvT = nullptr, *dInv = nullptr, *dTmp = nullptr;
+        const int64_t nfull = n / NB;
+        if (by_inverse && nfull > 0) {
+            OAK_CHECK(get_buf_t(ctx, "trsm_invT", (size_t)nfull * NB * NB, &dInvT));
+            OAK_CHECK(get_buf_t(ctx, "trsm_inv", (size_t)nfull * NB * NB, &dInv));
+            OAK_CHECK(get_buf_t(ctx, "trsm_tmp", (size_t)nrhs * NB, &dTmp));
+            for (int64_t b = 0; b < nfull; ++b) {
+                double* it = dInvT + b * NB * NB;
+                OAK_CHECK(set_identity(ctx, it, NB));
+                OAK_CHECK(trsm_leaf(ctx, dL + (b * NB) * ldl + b * NB, NB, ldl, it, NB, NB, 0));   // rows = columns of L_bb^-1
+                OAK_CHECK(transpose(ctx, it, NB, NB, NB, dInv + b * NB * NB, NB));
+            }
+        }
+        if (by_inverse) {
+            // LEFT-looking: block j first receives all earlier blocks' contributions in ONE GEMM with K = j0 (reads the
+            // finished columns once, writes 128 columns), then its diagonal solve.  The right-looking order re-reads and
+            // re-writes every trailing column at each step with K = 128: twice the HBM traffic for the same flops.
+            for (int64_t j0 = 0; j0 < n; j0 += NB) {
+                const int64_t nbj = (n - j0 < NB) ? n - j0 : NB;
+                if (j0 > 0)     // B[:, j] -= X[:, 0:j0] L[j, 0:j0]^T
+                    OAK_CHECK(gemm_nt(ctx, dBT, dL + j0 * ldl, dBT + j0, nrhs, nbj, j0, ldb, ldl, ldb, -1.0, 1.0, 0));
+                if (nbj == NB) {
+                    OAK_HIP_CHECK(hipMemcpy2DAsync(dTmp, sizeof(double) * NB, dBT + j0, sizeof(double) * (size_t)ldb, sizeof(double) * NB,
+                                                   (size_t)nrhs, hipMemcpyDeviceToDevice, ctx->stream));
+                    OAK_CHECK(gemm_nt(ctx, dTmp, dInv + (j0 / NB) * NB * NB, dBT + j0, nrhs, NB, NB, NB, NB, ldb, 1.0, 0.0, 0));
+                } else {
+                    OAK_CHECK(trsm_leaf(ctx, dL + j0 * ldl + j0, nbj, ldl, dBT + j0, nrhs, ldb, 0));
+                }
+            }
+            return OAK_OK;
+        }
         for (int64_t j0 = 0; j0 < n; j0 += NB) {
             const int64_t nbj = (n - j0 < NB) ? n - j0 : NB;
             OAK_CHECK(trsm_leaf(ctx, dL + j0 * ldl + j0, nbj, ldl, dBT + j0, nrhs, ldb, 0));
