@@ -107,7 +107,6 @@ struct oak_ctx {
     int64_t panel_rows = 0;
     bool have_data = false, have_Z = false, have_stats = false, have_post = false, stats_whitened = false, have_alpha = false;
     bool have_linv = false;          // buffers "Linv" / "LinvT" hold L^-1 and its transpose for the current L
-    bool have_lbinv = false;         // buffer "LBinv" holds LB^-1 for the current posterior (large-batch prediction)
     int route = 0;   // 0 auto, 1 phi, 2 whitened
     int auto_whiten = -1;            // decision of the conditioning check for this evaluation (-1: none, use the size rule)
     bool auto_pending = false;       // the check's result (cond_mm) is still in flight on the side stream

@@ -366,7 +366,6 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     ctx->noise_var = noise_var; ctx->jitter = jitter;
     ctx->have_post = true;
     ctx->have_alpha = false;
-    ctx->have_lbinv = false;
     return OAK_OK;
 }
 
@@ -548,26 +547,9 @@ int oak_sgpr_predict(oak_ctx* ctx, const oak_kernel_desc* desc, const double* Xs
     int64_t chunk = (int64_t)(((size_t)1 << 29) / (size_t)M);    // <= 4 GiB of Ksu per pass
     if (chunk > Ns) chunk = Ns;
     if (chunk < 8) chunk = 8;
-    // Small batches follow GPflow's predict_f literally (two triangular solves per batch).  Large batches (serving) apply
-    // the explicit inverses instead: tmp1 = Ksu L^-T and tmp2 = tmp1 LB^-T are two MFMA GEMMs (2 Ns M^2 flops each at the
-    // MFMA rate instead of latency-bound blocked TRSMs); the variance keeps GPflow's sum-of-squares form.  The whitened
-    // route (oak_sgpr_set_route) always takes the literal path.
-    const bool by_gemm = ctx->route != 2 && Ns * M > ((int64_t)1 << 24);
-    double *dLinv = nullptr, *dLBinv = nullptr, *dK2 = nullptr;
-    if (by_gemm) {
-        if (!ctx->have_linv) { OAK_CHECK(build_linv(ctx, dL, M)); ctx->have_linv = true; }
-        dLinv = (double*)peek_buf(ctx, "Linv");
-        OAK_CHECK(get_buf_t(ctx, "LBinv", (size_t)M * M, &dLBinv));
-        if (!ctx->have_lbinv) {
-            double* dtmp = nullptr;
-            OAK_CHECK(get_buf_t(ctx, "LBinvT", (size_t)M * M, &dtmp));
-            OAK_CHECK(set_identity(ctx, dtmp, M));
-            OAK_CHECK(trsm_rows(ctx, dLB, M, M, dtmp, M, M, 0));
-            OAK_CHECK(transpose(ctx, dtmp, M, M, M, dLBinv, M));
-            ctx->have_lbinv = true;
-        }
-        OAK_CHECK(get_buf_t(ctx, "pK2", (size_t)chunk * M, &dK2));
-    }
+    // GPflow's predict_f, literally: two triangular solves per batch (trsm_rows: for large batches a left-looking blocked
+    // TRSM whose diagonal blocks are applied as MFMA GEMMs -- faster than multiplying by explicit L^-1, LB^-1, which was
+    // tried: 87 vs 77 ms for 2^20 rows)
     double *dXs, *dK, *ds1, *ds2, *dkd, *dmean, *dvar;
     OAK_CHECK(get_buf_t(ctx, "pXs", (size_t)chunk * ldx, &dXs));
     OAK_CHECK(get_buf_t(ctx, "pK", (size_t)chunk * M, &dK));
@@ -583,15 +565,9 @@ int oak_sgpr_predict(oak_ctx* ctx, const oak_kernel_desc* desc, const double* Xs
         OAK_CHECK(featurize(ctx, pk, dXs, na, ldx, "featS", &FS));
         OAK_CHECK(gram(ctx, pk, FS, 0, na, FZ, dK, M, nullptr, nullptr, 0));       // rows = K(x*, Z) = Kus^T
         OAK_CHECK(gram_diag(ctx, pk, FS, dkd, nullptr));
-        if (by_gemm) {
-            OAK_CHECK(gemm_nt(ctx, dK, dLinv, dK2, na, M, M, M, M, M, 1.0, 0.0, 0));   // tmp1^T = Ksu L^-T
-            OAK_CHECK(row_sumsq(ctx, dK2, na, M, M, ds1));
-            OAK_CHECK(gemm_nt(ctx, dK2, dLBinv, dK, na, M, M, M, M, M, 1.0, 0.0, 0));  // tmp2^T = tmp1^T LB^-T
-        } else {
-            OAK_CHECK(trsm_rows(ctx, dL, M, M, dK, na, M, 0));                     // tmp1 = L^-1 Kus
-            OAK_CHECK(row_sumsq(ctx, dK, na, M, M, ds1));
-            OAK_CHECK(trsm_rows(ctx, dLB, M, M, dK, na, M, 0));                    // tmp2 = LB^-1 tmp1
-        }
+        OAK_CHECK(trsm_rows(ctx, dL, M, M, dK, na, M, 0));                         // tmp1 = L^-1 Kus
+        OAK_CHECK(row_sumsq(ctx, dK, na, M, M, ds1));
+        OAK_CHECK(trsm_rows(ctx, dLB, M, M, dK, na, M, 0));                        // tmp2 = LB^-1 tmp1
         OAK_CHECK(row_sumsq(ctx, dK, na, M, M, ds2));
         OAK_CHECK(gemv_rows(ctx, dK, na, M, M, dc, dmean));                        // mean = tmp2^T c
         predict_var_kernel<<<(unsigned)((na + 255) / 256), 256, 0, ctx->stream>>>(dkd, ds2, ds1, dvar, na);

@@ -16,6 +16,7 @@ d = _capi.KernelDesc(spec)
 ctx.sgpr_elbo(d, 0.01, 1e-6)
 Xs = np.random.default_rng(5).normal(size=(Ns, D))
 ctx.sgpr_predict(d, Xs[:1000])
+if len(sys.argv) > 2: ctx.sgpr_set_route(sys.argv[2])
 for _ in range(2):
     ctx.reset_timings()
     t0 = time.perf_counter(); mean, var = ctx.sgpr_predict(d, Xs); dt = time.perf_counter() - t0
