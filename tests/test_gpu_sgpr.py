@@ -207,3 +207,29 @@ def test_auto_route_checks_conditioning_on_large_problems(hip):
         if expect_whitened:
             setup(hip, X, y, Z, "phi")
             assert rel(hip.sgpr_elbo(d, 0.01), er) > 100 * rel(e, er)      # why the check exists
+
+
+def test_context_reuse_across_problem_shapes(hip):
+    """One context, a sequence of unrelated problems (N, D, M, depth, route change every time; buffers grow and shrink,
+    cached descriptors / inverses must be invalidated): ELBO, gradient value and predictions stay on the oracle."""
+    rng = np.random.default_rng(99)
+    shapes = [(3000, 4, 130, 2, "phi"), (500, 9, 64, 3, "whitened"), (9000, 6, 260, 1, "auto"), (1200, 3, 33, 2, "phi"),
+              (7000, 12, 384, 2, "phi"), (800, 5, 128, 4, "auto"), (3000, 4, 130, 2, "whitened")]
+    for (N, D, M, R, route) in shapes:
+        X, y, Z = o.synthetic_problem(N, D, M, seed=N + D)
+        spec = o.make_spec(D, R, lengthscales=list(rng.uniform(0.9, 1.6, D)), order_variances=list(rng.uniform(0.5, 1.5, R + 1)))
+        cond = np.linalg.cond(o.oak_K(spec, Z) + 1e-6 * np.eye(M))
+        d = _capi.KernelDesc(spec)
+        setup(hip, X, y, Z, route)
+        er = o.sgpr_elbo(spec, X, y, Z, 0.05)
+        exact = route != "phi"                      # auto whitens at these sizes
+        tol = 1e-10 if (exact or cond < 1e5) else 1e-16 * cond * 100
+        assert rel(hip.sgpr_elbo(d, 0.05), er) <= tol, (N, D, M, R, route, cond)
+        eg, g = hip.sgpr_elbo_grad(d, 0.05)
+        assert rel(eg, er) <= tol and np.isfinite(g).all()
+        Xs = rng.standard_normal((50, D))
+        m, v = hip.sgpr_predict(d, Xs)
+        mr, vr = o.sgpr_predict_f(spec, X, y, Z, 0.05, Xs)
+        ptol = 1e-9 if (exact or cond < 1e5) else max(1e-9, 1e-16 * cond * 100)
+        assert np.abs(m - mr[:, 0]).max() <= ptol * max(1.0, np.abs(mr).max())
+        assert np.abs(v - vr[:, 0]).max() <= ptol * max(1.0, np.abs(vr).max())
