@@ -200,6 +200,16 @@ int oak_comm_destroy(oak_ctx* ctx);
 int oak_comm_allreduce_stats(oak_ctx* ctx);                    /* in-place sum of packed stats */
 int oak_comm_allreduce_host(oak_ctx* ctx, double* buf, int64_t n); /* small host vector (gradients) */
 
+/* ---- input preprocessing ----------------------------------------------------------------------- */
+/* KL objective of the per-feature normalising flow and its gradient (oak/normalising_flow.py:79-85
+   Normalizer.KL_objective, minimised per continuous feature in oak_model.fit, oak/model_utils.py:305-317):
+   y = sinh((asinh(z) + skewness) * tailweight), z = scale * (g + shift); KL = mean(y^2)/2 - mean(log|dy/dx|).
+   g = log(x - offset) (use_log = 1; the host forms it once, offset = min(x) - 1) or x itself (use_log = 0).
+   Pass g on the first call for a sample; pass NULL afterwards to evaluate on the device-resident copy.
+   grad_out[4] = d KL / d (scale, shift, skewness, tailweight), constrained values; may be NULL. */
+int oak_flow_objective(oak_ctx* ctx, const double* g, int64_t n, int32_t use_log, double scale, double shift,
+                       double skewness, double tailweight, double* objective_out, double* grad_out);
+
 /* ---- inducing-point initialisation ----------------------------------------------------------- */
 /* Lloyd k-means from given seeds, following scikit-learn's single-run loop (_kmeans_single_lloyd) that the
    reference reaches through sklearn.cluster.KMeans(n_clusters=K).fit(X).cluster_centers_

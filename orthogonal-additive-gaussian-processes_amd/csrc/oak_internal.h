@@ -118,6 +118,7 @@ struct oak_ctx {
     // communicator (RCCL, dlopen'ed)
     void* comm = nullptr; int nranks = 1, rank = 0;
     int num_cu = 256;
+    int64_t flow_n = 0;              // length of the resident normalising-flow sample "flow_g"
     int syrk_desc_ntile = -1;        // ntile the device descriptor table "syrk_desc" was built for
 };
 

@@ -97,6 +97,7 @@ SIGNATURES = {
     "oak_comm_allreduce_stats": (C.c_int, [_CTX]),
     "oak_comm_allreduce_host": (C.c_int, [_CTX, _D, C.c_int64]),
     "oak_bench_gram_resident": (C.c_int, [_CTX, _DESC, _D]),
+    "oak_flow_objective": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, _D, _D]),
     "oak_kmeans_plusplus": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64, _D, C.c_int32, _D,
                                       C.POINTER(C.c_int64)]),
     "oak_kmeans": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _D, C.c_int32, C.c_double, _D, _I,
@@ -530,6 +531,18 @@ class HipContext:
         buf = _f64(buf, 1)
         _check(self._lib.oak_comm_allreduce_host(self._h, _dp(buf), buf.size))
         return buf
+
+    # -- input preprocessing ---------------------------------------------------------------------
+    def flow_objective(self, g: Optional[np.ndarray], n: int, use_log: bool, scale: float, shift: float, skewness: float,
+                       tailweight: float):
+        """KL objective of the normalising flow and its gradient w.r.t. (scale, shift, skewness, tailweight).
+        ``g`` (the sample after the optional log) is uploaded when given; ``None`` evaluates on the resident copy."""
+        obj = C.c_double()
+        grad = np.empty(4)
+        gp = None if g is None else _dp(_f64(g, 1))
+        _check(self._lib.oak_flow_objective(self._h, gp, int(n), 1 if use_log else 0, float(scale), float(shift), float(skewness),
+                                            float(tailweight), C.byref(obj), _dp(grad)))
+        return obj.value, grad
 
     # -- inducing-point initialisation ----------------------------------------------------------
     def kmeans(self, X: np.ndarray, init_centres: np.ndarray, max_iter: int = 300, tol: float = 0.0):

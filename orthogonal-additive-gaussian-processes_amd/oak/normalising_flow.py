@@ -1,14 +1,16 @@
-"""Per-feature normalising flow (host mirror of oak/normalising_flow.py:16-85), NumPy on the host.
+"""Per-feature normalising flow (host mirror of oak/normalising_flow.py:16-85).
 
-This is O(N) input preprocessing, outside the accelerated hot path: the reference's TFP chain
-SinhArcsinh o Scale o Shift o Log o Shift(-offset) and its KL objective are restated with closed-form
-log-Jacobians.
+The reference's TFP chain SinhArcsinh o Scale o Shift o Log o Shift(-offset) is restated with closed-form
+log-Jacobians.  The elementwise transforms (forward, inverse, log-det: applied once per feature) are NumPy; the KL
+objective that ``oak_model.fit`` minimises with L-BFGS-B -- tens of O(N) evaluations per feature -- and its gradient are
+one HIP reduction kernel over the device-resident sample (``oak_flow_objective``, csrc/flow.hip).
 """
 from __future__ import annotations
 
 import numpy as np
 from scipy import stats
 
+from . import _capi
 from .gpflow_lite import Module, Parameter, TensorLike, Transform
 
 try:  # the reference imports pyplot at module level; plotting is optional here
@@ -64,8 +66,40 @@ class FlowBijector:
         return ld
 
 
+class _KLObjective:
+    """Callable objective with an analytic gradient (``gpflow_lite.Scipy`` uses ``value_and_grad`` when present, as GPflow's
+    Scipy wrapper uses TensorFlow's gradients in the reference)."""
+    _ORDER = ("scale", "shift", "skewness", "tailweight")      # gradient layout of oak_flow_objective
+
+    def __init__(self, owner):
+        self._o = owner
+
+    def _evaluate(self):
+        o = self._o
+        ctx = _capi.default_context()
+        resident = getattr(ctx, "_flow_owner", None) == o._token      # tokens are never reused (ids can be, after GC)
+        val, g = ctx.flow_objective(None if resident else o._g, o._g.size, o.bijector.log, float(o.scale.numpy()),
+                                    float(o.shift.numpy()), float(o.skewness.numpy()), float(o.tailweight.numpy()))
+        ctx._flow_owner = o._token
+        return val, g
+
+    def __call__(self):
+        return self._evaluate()[0]
+
+    def value_and_grad(self, variables):
+        val, g = self._evaluate()
+        by_param = {id(getattr(self._o, name)): g[i] for i, name in enumerate(self._ORDER)}
+        grads = []
+        for v in variables:
+            if id(v) not in by_param:
+                raise ValueError("variable does not belong to this Normalizer")
+            grads.append(np.asarray(by_param[id(v)] * v.transform.dforward(v.unconstrained_variable)))   # chain to unconstrained
+        return val, grads
+
+
 class Normalizer(Module):
     """Flow that maps the sample `x` towards N(0, 1) (oak/normalising_flow.py:30-85)."""
+    _tokens = iter(range(1, 1 << 62))
 
     def __init__(self, x, log=True, **kwargs):
         self.x = x
@@ -77,14 +111,13 @@ class Normalizer(Module):
         self.scale = Parameter(1.0 / np.std(base), transform=Exp())
         self.shift = Parameter(-np.mean(base))
         self.bijector = FlowBijector(self, bool(log), offset)
+        self._g = np.ascontiguousarray(base, dtype=np.float64).reshape(-1)     # the sample the objective runs over
+        self._token = next(Normalizer._tokens)
+        self.KL_objective = _KLObjective(self)
 
     def _children(self):   # the bijector is a view on the four parameters, not a parameter container
         for key in ("scale", "shift", "skewness", "tailweight"):
             yield key, getattr(self, key)
-
-    def KL_objective(self):
-        y = self.bijector(self.x)
-        return float(0.5 * np.mean(np.square(y)) - np.mean(self.bijector.forward_log_det_jacobian(self.x, event_ndims=0)))
 
     def kstest(self):
         s, pvalue = stats.kstest(np.asarray(self.bijector(self.x)).reshape(-1), "norm")
