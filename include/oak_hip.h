@@ -210,6 +210,13 @@ int oak_comm_allreduce_host(oak_ctx* ctx, double* buf, int64_t n); /* small host
 int oak_flow_objective(oak_ctx* ctx, const double* g, int64_t n, int32_t use_log, double scale, double shift,
                        double skewness, double tailweight, double* objective_out, double* grad_out);
 
+/* Column-wise forward transform of a design matrix (oak_model._transform_x / apply_normalise_flow,
+   oak/model_utils.py:179-191, :462-476).  X, out: N x ldx row-major (out may alias nothing); columns >= D are
+   copied.  kind[d]: 0 copy, 1 flow on x, 2 flow on log(x - offset), 3 affine (x - mean) / std.
+   params[5*d ..]: {offset, scale, shift, skewness, tailweight} for flows, {mean, std, 0, 0, 0} for affine. */
+int oak_flow_forward(oak_ctx* ctx, const double* X, int64_t N, int32_t ldx, int32_t D, const int32_t* kind,
+                     const double* params, double* out);
+
 /* ---- inducing-point initialisation ----------------------------------------------------------- */
 /* Lloyd k-means from given seeds, following scikit-learn's single-run loop (_kmeans_single_lloyd) that the
    reference reaches through sklearn.cluster.KMeans(n_clusters=K).fit(X).cluster_centers_

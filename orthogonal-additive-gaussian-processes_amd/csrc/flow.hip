@@ -97,3 +97,64 @@ extern "C" int oak_flow_objective(oak_ctx* ctx, const double* g_host, int64_t n,
     if (grad_out) for (int q = 0; q < 4; ++q) grad_out[q] = h[1 + q];
     return OAK_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Column-wise forward transform of a whole design matrix: what oak_model._transform_x / apply_normalise_flow do with
+// one NumPy pass per column (oak/model_utils.py:179-191, :462-476).  kind[d]: 0 = copy, 1 = flow without log, 2 = flow
+// with log(x - offset), 3 = affine (x - mean) / std (the StandardScaler columns).  params[d] = {offset, scale, shift,
+// skewness, tailweight} for flows, {mean, std, -, -, -} for affine columns.  Elementwise, HBM/PCIe bound.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace oak {
+
+__global__ void __launch_bounds__(256)
+flow_forward_kernel(const double* __restrict__ X, int64_t n, int ld, int D, const int* __restrict__ kind, const double* __restrict__ params,
+                    double* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;     // element of the N x ld array (row-major)
+    if (e >= n * ld) return;
+    const int d = (int)(e % ld);
+    double x = X[e];
+    if (d < D) {
+        const int kd = kind[d];
+        const double* p = params + 5 * d;
+        if (kd == 1 || kd == 2) {
+            const double g = kd == 2 ? log(x - p[0]) : x;
+            const double z = (g + p[2]) * p[1];
+            x = sinh((asinh(z) + p[3]) * p[4]);
+        } else if (kd == 3) {
+            x = (x - p[0]) / p[1];
+        }
+    }
+    out[e] = x;
+}
+
+}  // namespace oak
+
+extern "C" int oak_flow_forward(oak_ctx* ctx, const double* X, int64_t N, int32_t ldx, int32_t D, const int32_t* kind,
+                                const double* params, double* out) {
+    if (!ctx) { set_error("ctx is NULL"); return OAK_E_ARG; }
+    OAK_HIP_CHECK(hipSetDevice(ctx->device));
+    OAK_REQUIRE(X && out && kind && params && N >= 0 && D >= 1 && D <= 4096 && ldx >= D, "oak_flow_forward: bad arguments");
+    for (int d = 0; d < D; ++d) OAK_REQUIRE(kind[d] >= 0 && kind[d] <= 3, "oak_flow_forward: kind[%d] = %d", d, kind[d]);
+    if (N == 0) return OAK_OK;
+    PhaseTimer t(ctx, "flow_forward");
+    int* dKind;
+    double *dPar, *dX, *dOut;
+    const int64_t chunk_rows = (((int64_t)1 << 28) / ldx) > 0 ? (((int64_t)1 << 28) / ldx) : 1;      // <= 2 GiB per pass
+    const int64_t cr = chunk_rows < N ? chunk_rows : N;
+    OAK_CHECK(get_buf_t(ctx, "ff_kind", (size_t)D, &dKind));
+    OAK_CHECK(get_buf_t(ctx, "ff_par", (size_t)5 * D, &dPar));
+    OAK_CHECK(get_buf_t(ctx, "ff_x", (size_t)cr * ldx, &dX));
+    OAK_CHECK(get_buf_t(ctx, "ff_out", (size_t)cr * ldx, &dOut));
+    OAK_HIP_CHECK(hipMemcpyAsync(dKind, kind, sizeof(int) * (size_t)D, hipMemcpyHostToDevice, ctx->stream));
+    OAK_HIP_CHECK(hipMemcpyAsync(dPar, params, sizeof(double) * 5 * (size_t)D, hipMemcpyHostToDevice, ctx->stream));
+    for (int64_t r0 = 0; r0 < N; r0 += cr) {
+        const int64_t nr = (r0 + cr <= N) ? cr : N - r0;
+        OAK_HIP_CHECK(hipMemcpyAsync(dX, X + r0 * ldx, sizeof(double) * (size_t)nr * ldx, hipMemcpyHostToDevice, ctx->stream));
+        flow_forward_kernel<<<(unsigned)((nr * ldx + 255) / 256), 256, 0, ctx->stream>>>(dX, nr, ldx, D, dKind, dPar, dOut);
+        OAK_HIP_CHECK(hipGetLastError());
+        OAK_HIP_CHECK(hipMemcpyAsync(out + r0 * ldx, dOut, sizeof(double) * (size_t)nr * ldx, hipMemcpyDeviceToHost, ctx->stream));
+        OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    t.stop();
+    return OAK_OK;
+}

@@ -98,6 +98,7 @@ SIGNATURES = {
     "oak_comm_allreduce_host": (C.c_int, [_CTX, _D, C.c_int64]),
     "oak_bench_gram_resident": (C.c_int, [_CTX, _DESC, _D]),
     "oak_flow_objective": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, _D, _D]),
+    "oak_flow_forward": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32, C.c_int32, _I, _D, _D]),
     "oak_kmeans_plusplus": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64, _D, C.c_int32, _D,
                                       C.POINTER(C.c_int64)]),
     "oak_kmeans": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32, C.c_int32, C.c_int32, _D, C.c_int32, C.c_double, _D, _I,
@@ -543,6 +544,18 @@ class HipContext:
         _check(self._lib.oak_flow_objective(self._h, gp, int(n), 1 if use_log else 0, float(scale), float(shift), float(skewness),
                                             float(tailweight), C.byref(obj), _dp(grad)))
         return obj.value, grad
+
+    def flow_forward(self, X: np.ndarray, kind, params) -> np.ndarray:
+        """Column-wise transform of X [N, D]: kind[d] in {0 copy, 1 flow, 2 flow after log(x - offset), 3 affine};
+        params [D, 5] = (offset, scale, shift, skewness, tailweight) or (mean, std, 0, 0, 0)."""
+        X = _f64(X, 2)
+        kind = np.ascontiguousarray(kind, dtype=np.int32)
+        params = _f64(params, 2)
+        if kind.shape != (X.shape[1],) or params.shape != (X.shape[1], 5):
+            raise ValueError("kind must have D entries and params shape [D, 5]")
+        out = np.empty_like(X)
+        _check(self._lib.oak_flow_forward(self._h, _dp(X), X.shape[0], X.shape[1], X.shape[1], _ip(kind), _dp(params), _dp(out)))
+        return out
 
     # -- inducing-point initialisation ----------------------------------------------------------
     def kmeans(self, X: np.ndarray, init_centres: np.ndarray, max_iter: int = 300, tol: float = 0.0):

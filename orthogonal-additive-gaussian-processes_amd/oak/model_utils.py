@@ -13,6 +13,7 @@ from typing import Callable, List, Optional, Union
 
 import numpy as np
 
+from . import _capi
 from . import gpflow_lite as gpflow
 from .gpflow_lite import GPR, SGPR, GPModel, InducingPoints, set_trainable
 from .input_measures import MOGMeasure
@@ -102,11 +103,25 @@ def create_model_oak(
 
 def apply_normalise_flow(X, input_flows: List[Normalizer]):
     """Column-wise application of the fitted flows; columns without a flow pass through (oak/model_utils.py:179-191)."""
-    X = np.asarray(X)
-    X_scaled = np.zeros(X.shape)
-    for ii in range(X.shape[1]):
-        X_scaled[:, ii] = X[:, ii] if input_flows[ii] is None else input_flows[ii].bijector(X[:, ii])
-    return X_scaled
+    X = np.asarray(X, dtype=np.float64)
+    kind, params = _flow_columns(X.shape[1], input_flows)
+    return _capi.default_context().flow_forward(X, kind, params)
+
+
+def _flow_columns(D: int, input_flows, affine=None):
+    """(kind[D], params[D, 5]) of oak_flow_forward for a list of fitted flows; ``affine`` maps column -> (mean, std)."""
+    kind = np.zeros(D, dtype=np.int32)
+    params = np.zeros((D, 5))
+    for ii in range(D):
+        f = input_flows[ii]
+        if f is not None:
+            b = f.bijector
+            kind[ii] = 2 if b.log else 1
+            params[ii] = (b.offset, float(f.scale.numpy()), float(f.shift.numpy()), float(f.skewness.numpy()), float(f.tailweight.numpy()))
+    for ii, (mean, std) in (affine or {}).items():
+        kind[ii] = 3
+        params[ii] = (mean, std, 0.0, 0.0, 0.0)
+    return kind, params
 
 
 class _Standardizer:
@@ -279,12 +294,20 @@ class oak_model:
         return float(np.mean(self.m.predict_log_density((X_scaled, self.scaler_y.transform(y)))))
 
     def _transform_x(self, X):
-        X = apply_normalise_flow(X, self.input_flows)
+        """Flows, then the standard scalers of the empirical-measure / no-flow columns (oak/model_utils.py:462-476): one
+        elementwise pass on the device (a column has a flow or a scaler, never both)."""
+        X = np.asarray(X, dtype=np.float64)
+        affine = {}
         if self.empirical_measure is not None:
-            X[:, self.empirical_measure] = self.scaler_X_empirical.transform(X[:, self.empirical_measure])
+            for j, col in enumerate(self.empirical_measure):
+                affine[col] = (float(self.scaler_X_empirical.mean_[j]), float(self.scaler_X_empirical.scale_[j]))
         if not self.use_normalising_flow:
-            X[:, self.continuous_index] = self.scaler_X_continuous.transform(X[:, self.continuous_index])
-        return X
+            for j, col in enumerate(self.continuous_index):
+                affine[col] = (float(self.scaler_X_continuous.mean_[j]), float(self.scaler_X_continuous.scale_[j]))
+        for col in affine:
+            assert self.input_flows[col] is None, "a column has either a flow or a scaler"
+        kind, params = _flow_columns(X.shape[1], self.input_flows, affine)
+        return _capi.default_context().flow_forward(X, kind, params)
 
     def _get_x_inverse_transformer(self, i: int) -> Optional[Union[Normalizer, Callable]]:
         assert i in self.continuous_index

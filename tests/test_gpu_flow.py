@@ -69,3 +69,47 @@ def test_flow_fit_at_scale_is_fast_and_gaussianises(hip):
     y = np.asarray(n.bijector(x))
     assert abs(y.mean()) < 0.01 and abs(y.std() - 1) < 0.01
     assert dt < 5.0, f"flow fit took {dt:.1f} s"
+
+
+def test_flow_forward_matches_numpy_transforms(hip):
+    """oak_flow_forward against the NumPy bijectors / scalers column by column (flows with and without log, affine, copy)."""
+    rng = np.random.default_rng(8)
+    N = 10007
+    X = np.column_stack([np.exp(rng.normal(size=N)), rng.normal(3, 2, size=N), rng.integers(0, 2, N).astype(float),
+                         rng.normal(-1, 0.3, size=N), rng.integers(0, 5, N).astype(float)])
+    f0 = Normalizer(X[:, 0], log=True); f0.skewness.assign(0.2); f0.tailweight.assign(1.3); f0.shift.assign(0.1)
+    f1 = Normalizer(X[:, 1], log=False); f1.skewness.assign(-0.4); f1.tailweight.assign(0.7)
+    kind = np.array([2, 1, 0, 3, 0], dtype=np.int32)
+    params = np.zeros((5, 5))
+    for i, f in ((0, f0), (1, f1)):
+        params[i] = (f.bijector.offset, float(f.scale.numpy()), float(f.shift.numpy()), float(f.skewness.numpy()), float(f.tailweight.numpy()))
+    params[3] = (X[:, 3].mean(), X[:, 3].std(), 0, 0, 0)
+    out = hip.flow_forward(X, kind, params)
+    np.testing.assert_allclose(out[:, 0], np.asarray(f0.bijector(X[:, 0])), rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(out[:, 1], np.asarray(f1.bijector(X[:, 1])), rtol=1e-12, atol=1e-13)
+    np.testing.assert_array_equal(out[:, 2], X[:, 2])
+    np.testing.assert_allclose(out[:, 3], (X[:, 3] - X[:, 3].mean()) / X[:, 3].std(), rtol=1e-13, atol=1e-14)
+    np.testing.assert_array_equal(out[:, 4], X[:, 4])
+    assert hip.flow_forward(X[:0], kind, params).shape == (0, 5)
+    with pytest.raises(ValueError):
+        hip.flow_forward(X, kind[:3], params)
+
+
+def test_model_transform_x_matches_host_formulas(hip):
+    """oak_model._transform_x (flows on continuous columns, untouched discrete ones) against the NumPy bijectors."""
+    from oak.model_utils import oak_model
+    rng = np.random.default_rng(5)
+    N = 3000
+    X = np.column_stack([np.exp(rng.normal(size=N)), rng.integers(0, 2, N).astype(float), rng.normal(size=N)])
+    y = (np.log(X[:, 0]) + X[:, 1] + 0.1 * rng.normal(size=N))[:, None]
+    m = oak_model(num_inducing=30, binary_feature=[1], sparse=True)
+    m.fit(X, y, optimise=False)
+    Xt = m._transform_x(X)
+    for c in (0, 2):
+        np.testing.assert_allclose(Xt[:, c], np.asarray(m.input_flows[c].bijector(X[:, c])), rtol=1e-12, atol=1e-13)
+    np.testing.assert_array_equal(Xt[:, 1], X[:, 1])
+    m2 = oak_model(num_inducing=30, binary_feature=[1], sparse=True, use_normalising_flow=False)
+    m2.fit(X, y, optimise=False)
+    Xt2 = m2._transform_x(X)
+    np.testing.assert_allclose(Xt2[:, [0, 2]], (X[:, [0, 2]] - X[:, [0, 2]].mean(0)) / X[:, [0, 2]].std(0), rtol=1e-12, atol=1e-13)
+    np.testing.assert_array_equal(Xt2[:, 1], X[:, 1])
