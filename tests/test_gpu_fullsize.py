@@ -89,3 +89,32 @@ def test_fullsize_gradient_directional_check(problem):
     analytic = g[:D] @ v_ls + g[2 * D:2 * D + R + 1] @ v_ov + g[2 * D + R + 1] * v_n
     np.testing.assert_allclose(analytic, fd, rtol=1e-5)
     ctx.close()
+
+
+def test_fullsize_prediction_properties(problem):
+    """predict_f of 2^18 rows at the full model: the mean equals K(X*, Z) alpha with alpha from oak_sgpr_alpha (the identity
+    the reference's tests/test_utils.py:42-75 pins), the variance lies in (0, K_diag(X*)], the whole batch (blocked TRSM)
+    agrees with 4096-row batches (substitution leaf), and whitened and phi posteriors agree."""
+    X, y, Z, spec = problem
+    ctx = _capi.HipContext(0)
+    d = _capi.KernelDesc(spec)
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("phi")
+    ctx.sgpr_elbo(d, 0.01)
+    rng = np.random.default_rng(17)
+    Xs = rng.standard_normal((1 << 18, D))
+    mean, var = ctx.sgpr_predict(d, Xs)
+    alpha = ctx.sgpr_alpha(M)
+    idx = rng.choice(Xs.shape[0], 4096, replace=False)
+    Ks = ctx.gram(d, Xs[idx], Z)
+    np.testing.assert_allclose(mean[idx], Ks @ alpha, rtol=1e-8, atol=1e-9 * np.abs(mean).max())
+    kdiag = ctx.gram_diag(d, Xs[idx])
+    assert var.min() > 0 and (var[idx] <= kdiag * (1 + 1e-12)).all()
+    m2, v2 = ctx.sgpr_predict(d, Xs[idx])                      # small batch: substitution path
+    np.testing.assert_allclose(m2, mean[idx], rtol=1e-9, atol=1e-10 * np.abs(mean).max())
+    np.testing.assert_allclose(v2, var[idx], rtol=1e-9, atol=1e-10 * np.abs(var).max())
+    ctx.sgpr_set_route("whitened")
+    ctx.sgpr_elbo(d, 0.01)
+    m3, v3 = ctx.sgpr_predict(d, Xs[idx])
+    np.testing.assert_allclose(m3, mean[idx], rtol=1e-8, atol=1e-9 * np.abs(mean).max())
+    np.testing.assert_allclose(v3, var[idx], rtol=1e-8, atol=1e-9 * np.abs(var).max())
+    ctx.close()
