@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256) sobol_terms_kernel(const double* __restri
     __shared__ int sdim[OAK_MAX_DIMS];
     const int s = blockIdx.x;
     const int len = off[s + 1] - off[s];
-    if (threadIdx.x < len) sdim[threadIdx.x] = slot[subsets[off[s] + threadIdx.x]];
+    if ((int)threadIdx.x < len) sdim[threadIdx.x] = slot[subsets[off[s] + threadIdx.x]];
     __syncthreads();
     const int64_t nn = n * n;
     double acc = 0.0;
