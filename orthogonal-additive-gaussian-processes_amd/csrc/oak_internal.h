@@ -82,6 +82,7 @@ struct DevBuf {
 };
 
 struct Timing { double ms = 0; int count = 0; };
+struct PendingEvt { std::string name; hipEvent_t a, b; };   // a recorded phase whose elapsed time has not been read yet
 
 struct PreparedKernel {
     DevDesc dd;
@@ -101,6 +102,7 @@ struct oak_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;     // fork / join events for the side stream
     std::map<std::string, oak::DevBuf> bufs;     // named, grow-only device scratch
     std::map<std::string, oak::Timing> timings;
+    std::vector<oak::PendingEvt> pending;       // harvested without blocking once it grows (PhaseTimer::stop), read by oak_last_timing
     // SGPR state
     int64_t N = 0, M = 0;
     int32_t ldx = 0;
@@ -134,6 +136,7 @@ void* peek_buf(oak_ctx* ctx, const char* name);
 struct PhaseTimer {   // hipEvent timing of a phase on the ctx stream (accumulates into ctx->timings)
     oak_ctx* ctx; const char* name; hipEvent_t a, b; bool active;
     PhaseTimer(oak_ctx* c, const char* n);
+    ~PhaseTimer();      // a phase abandoned on an error path releases its events
     void stop();
 };
 void reset_timings(oak_ctx* ctx);

@@ -47,16 +47,13 @@ PhaseTimer::PhaseTimer(oak_ctx* c, const char* n) : ctx(c), name(n), a(nullptr),
         active = true;
     }
 }
-struct PendingEvt { std::string name; hipEvent_t a, b; };
-static thread_local std::vector<PendingEvt> g_pending;
-void PhaseTimer::stop() {
-    if (!active) return;
-    (void)hipEventRecord(b, ctx->stream);
-    g_pending.push_back({name, a, b});
-    active = false;
-}
-static void flush_timings(oak_ctx* ctx) {
-    for (auto& p : g_pending) {
+// Finished phases are folded into ctx->timings.  `block` waits for every pending phase (oak_last_timing / reset / destroy);
+// otherwise only phases whose end event has already completed are harvested, so a caller that never reads the timings does
+// not accumulate events.
+static void flush_timings(oak_ctx* ctx, bool block = true) {
+    std::vector<PendingEvt> keep;
+    for (auto& p : ctx->pending) {
+        if (!block && hipEventQuery(p.b) != hipSuccess) { keep.push_back(p); continue; }
         float ms = 0;
         if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
             Timing& t = ctx->timings[p.name];
@@ -64,7 +61,18 @@ static void flush_timings(oak_ctx* ctx) {
         }
         (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b);
     }
-    g_pending.clear();
+    ctx->pending.swap(keep);
+}
+PhaseTimer::~PhaseTimer() {
+    if (active) { (void)hipEventDestroy(a); (void)hipEventDestroy(b); active = false; }
+    else if (a != nullptr && b == nullptr) (void)hipEventDestroy(a);
+}
+void PhaseTimer::stop() {
+    if (!active) return;
+    (void)hipEventRecord(b, ctx->stream);
+    ctx->pending.push_back({name, a, b});
+    active = false;
+    if (ctx->pending.size() > 64) flush_timings(ctx, false);
 }
 void reset_timings(oak_ctx* ctx) { flush_timings(ctx); ctx->timings.clear(); }
 

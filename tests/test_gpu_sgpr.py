@@ -233,3 +233,18 @@ def test_context_reuse_across_problem_shapes(hip):
         ptol = 1e-9 if (exact or cond < 1e5) else max(1e-9, 1e-16 * cond * 100)
         assert np.abs(m - mr[:, 0]).max() <= ptol * max(1.0, np.abs(mr).max())
         assert np.abs(v - vr[:, 0]).max() <= ptol * max(1.0, np.abs(vr).max())
+
+
+def test_many_evaluations_without_reading_timings(hip):
+    """Phase timers are harvested in the background: a long optimisation that never asks for timings neither leaks events
+    nor loses the accumulated statistics."""
+    X, y, Z = o.synthetic_problem(400, 3, 20, seed=2)
+    spec = o.make_spec(3, 2)
+    d = _capi.KernelDesc(spec)
+    setup(hip, X, y, Z, "phi")
+    hip.reset_timings()
+    e0 = hip.sgpr_elbo(d, 0.1)
+    for _ in range(600):
+        assert hip.sgpr_elbo(d, 0.1) == e0
+    ms, count = hip.timing("total")
+    assert count == 601 and ms > 0
