@@ -1,6 +1,6 @@
 // exp2 for the pair kernels (gram.hip, grad.hip): 2^t for t <= n, evaluated from the CLAMPED quantity
 //     w = clamp01(u'^2 + woff),   u' = (x - z) * scale_d / 32,   t = n - 1024 w,
-// where log2(base variance) = n + f with n = ceil, f in (-1, 0], woff = -f/1024 and n rides in `magic`
+// where log2(base variance) = n - 1024 woff with n = max(ceil(log2 bv), 0) riding in `magic` and woff >= 0
 // (= 1.5*2^33 + n/1024).  The clamp is the free VOP3 output modifier of the v_fma_f64 that forms w, so no v_max is
 // spent on keeping the exponent in range (t >= n - 1024).
 //

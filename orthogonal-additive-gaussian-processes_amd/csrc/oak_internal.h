@@ -47,9 +47,9 @@ struct DevDesc {
     double scale[OAK_MAX_DIMS];    // sqrt(log2(e)/2)/lengthscale     (RBF)
     double log2bv[OAK_MAX_DIMS];   // log2(base variance)             (RBF)
     double bv[OAK_MAX_DIMS];       // base variance
-    // gram kernel exponent form (see gram.hip exp2_w_vec): log2(bv) = n + f, n = ceil, f in (-1, 0]
-    double woff[OAK_MAX_DIMS];     // -f / 1024 >= 0
-    double magic[OAK_MAX_DIMS];    // 1.5 * 2^36 + n / 1024
+    // pair-kernel exponent form (exp2w.h): log2(bv) = n - 1024 woff, n = max(ceil(log2 bv), 0)
+    double woff[OAK_MAX_DIMS];     // (n - log2 bv) / 1024 >= 0
+    double magic[OAK_MAX_DIMS];    // 1.5 * 2^33 + n / 1024
 };
 
 // measure parameters used only by the featurize kernels

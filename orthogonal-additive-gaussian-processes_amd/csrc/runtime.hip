@@ -252,8 +252,10 @@ int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk
             dd.scale[d] = std::sqrt(0.5 * 1.4426950408889634074) / l;   // (x s - z s)^2 = (x-z)^2 log2(e) / (2 l^2)
             dd.log2bv[d] = std::log2(bv);
             {
-                const double n = std::ceil(dd.log2bv[d]);
-                OAK_REQUIRE(std::fabs(n) <= 900.0, "dim %d: base variance out of range", d);
+                // n >= 0: the clamp w <= 1 bounds the exponent at n - 1024 and the biased table (x4) keeps the exponent field
+                // positive only down to -1024; a base variance below 1 therefore goes entirely into woff
+                OAK_REQUIRE(std::fabs(dd.log2bv[d]) <= 900.0, "dim %d: base variance out of range", d);
+                const double n = std::fmax(std::ceil(dd.log2bv[d]), 0.0);
                 dd.woff[d] = (n - dd.log2bv[d]) / 1024.0;
                 dd.magic[d] = 12884901888.0 + n / 1024.0;       // EW_MAGIC (exp2w.h) + n/1024
             }

@@ -185,3 +185,39 @@ def test_exp2_accuracy(hip):
     assert ulp[near].max() <= 24.0, ulp[near].max()
     assert K[-3] == 1.0 and K[-2] == 1.0
     assert np.all(K[~ok] < 1e-289)
+
+
+@pytest.mark.parametrize("variances", [(0.3, 0.02, 1e-4), (1.0, 7.5, 300.0), (2.0 ** -20, 2.0 ** 20, 0.999)])
+def test_far_apart_pairs_with_non_unit_base_variance(hip, variances):
+    """Pairs further apart than ~38 lengthscales drive the kernels' clamped exponent form to its floor (2^-1024); with a base
+    variance below 1 that floor used to fall outside the biased table's exponent range.  Gram, its diagonal and the ELBO
+    gradient stay on the oracle for tiny lengthscales and base variances on both sides of 1."""
+    import copy
+    rng = np.random.default_rng(5)
+    D = len(variances)
+    spec = o.make_spec(D, 2, lengthscales=[0.01, 0.05, 0.002])
+    spec["share_var_across_orders"] = False
+    spec["order_variances"] = [0.8]                          # only sigma2_0 exists when the orders do not share variances
+    for d_, v in zip(spec["dims"], variances):
+        d_["variance"] = v
+    X = rng.normal(size=(300, D)) * 2.0                       # |x - z| / l up to ~ 4000
+    Z = X[:37] + 1e-3 * rng.normal(size=(37, D))              # a few near pairs as well
+    dsc = _capi.KernelDesc(spec)
+    K, Kr = hip.gram(dsc, X, Z), o.oak_K(spec, X, Z)
+    assert np.isfinite(K).all()
+    # lengthscales of 0.002: x / l ~ 1e3, so the scaled difference of near pairs loses ~3 digits in ANY fp64 evaluation
+    # (the oracle's GPflow-form square distance more than the kernel's direct form): 1e-9, not the usual 1e-12
+    close(K, Kr, tol=1e-9)
+    # K_diag: the oracle follows the reference's Newton-Girard power sums, e_2 = (s_1^2 - s_2) / 2, which cancel when one
+    # k_d (here up to 2^20) dwarfs the others -- 9e-11 off a 40-digit evaluation, the HIP recurrence 2e-16 (tests/dev/dev_diag_check.py)
+    close(hip.gram_diag(dsc, X), o.oak_K_diag(spec, X), tol=1e-9)
+    y = rng.normal(size=(300, 1))
+    hip.sgpr_set_data(X, y); hip.sgpr_set_inducing(Z); hip.sgpr_set_route("whitened")
+    e, g = hip.sgpr_elbo_grad(dsc, 0.3)
+    er = o.sgpr_elbo(spec, X, y, Z, 0.3)
+    assert abs(e - er) <= 1e-8 * abs(er) and np.isfinite(g).all()
+    h = 1e-6 * variances[1]
+    sp, sm = copy.deepcopy(spec), copy.deepcopy(spec)
+    sp["dims"][1]["variance"] += h; sm["dims"][1]["variance"] -= h
+    fd = (o.sgpr_elbo(sp, X, y, Z, 0.3) - o.sgpr_elbo(sm, X, y, Z, 0.3)) / (2 * h)
+    assert abs(g[D + 1] - fd) <= 1e-4 * max(abs(fd), 1e-8)
