@@ -1,0 +1,58 @@
+"""Randomised Gram parity: many random kernels (dimension count, depth, sub-kernel types and measures, shared / separate
+variances, lengthscales and base variances over several decades, ragged sizes) against a BRUTE-FORCE elementary-symmetric
+combination of the oracle's per-dimension matrices -- independent of both the HIP recurrence and the reference's
+Newton-Girard power sums (whose cancellation error the oracle inherits when the k_d differ by many orders of magnitude)."""
+import itertools
+
+import numpy as np
+import pytest
+
+import cases
+from oak import _capi
+from oracle import oak_oracle as o
+
+pytestmark = pytest.mark.gpu
+KINDS = ("gaussian", "uniform", "mog", "none", "gauss2", "binary", "categorical")
+
+
+def brute_force_K(spec, X, X2, diag=False):
+    D, R = len(spec["dims"]), spec["max_interaction_depth"]
+    ks = []
+    for d, dim in enumerate(spec["dims"]):
+        c = o.active_col(spec, d)
+        ks.append(o.base_K_diag(X[:, [c]], dim) if diag else o.base_K(X[:, [c]], X2[:, [c]], dim))
+    ov = spec["order_variances"]
+    share = spec.get("share_var_across_orders", True)
+    out = np.full_like(ks[0], ov[0], dtype=np.float64)
+    for r in range(1, R + 1):
+        e = np.zeros_like(ks[0], dtype=np.float64)
+        for S in itertools.combinations(range(D), r):
+            t = np.ones_like(ks[0], dtype=np.float64)
+            for d in S:
+                t = t * ks[d]
+            e += t
+        out = out + (ov[r] if share else 1.0) * e
+    return out
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_kernels_against_brute_force(hip, seed):
+    rng = np.random.default_rng(1000 + seed)
+    D = int(rng.integers(1, 9))
+    R = int(rng.integers(0, min(D, 4) + 1))
+    share = bool(rng.integers(0, 2))
+    kinds = tuple(rng.choice(KINDS, size=D))
+    spec = cases.random_spec(rng, D, R, kinds, share=share)
+    for dim in spec["dims"]:
+        if dim["type"] == "rbf":
+            dim["lengthscale"] = float(10 ** rng.uniform(-1.0, 1.3))
+        if not share:
+            dim["variance"] = float(10 ** rng.uniform(-3, 3))
+    n1, n2 = int(rng.integers(1, 200)), int(rng.integers(1, 150))
+    X, X2 = cases.random_inputs(rng, spec, n1), cases.random_inputs(rng, spec, n2)
+    d = _capi.KernelDesc(spec)
+    for got, ref in ((hip.gram(d, X, X2), brute_force_K(spec, X, X2)), (hip.gram(d, X), brute_force_K(spec, X, X)),
+                     (hip.gram_diag(d, X), brute_force_K(spec, X, None, diag=True))):
+        scale = max(np.abs(ref).max(), 1e-300)
+        err = np.abs(got - ref).max() / scale
+        assert err <= 5e-12, f"seed {seed}: D={D} R={R} share={share} kinds={kinds} err={err:.2e}"
