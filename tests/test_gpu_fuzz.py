@@ -56,3 +56,50 @@ def test_random_kernels_against_brute_force(hip, seed):
         scale = max(np.abs(ref).max(), 1e-300)
         err = np.abs(got - ref).max() / scale
         assert err <= 5e-12, f"seed {seed}: D={D} R={R} share={share} kinds={kinds} err={err:.2e}"
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_kernels_gradient_against_forward_differences(hip, seed):
+    """Analytic ELBO gradient (both backward kernels, every sub-kernel type, shared and separate variances) against central
+    differences of the HIP forward pass itself, parameter by parameter.  Relative steps of 1e-4: the forward value carries
+    ~1e-13 |F| of rounding noise, which a 1e-6 step would turn into 1e-5-level noise in the difference quotient."""
+    import copy
+    rng = np.random.default_rng(5000 + seed)
+    D = int(rng.integers(2, 8))
+    R = int(rng.integers(1, min(D, 5) + 1))          # depth 5 exercises the generic two-pass backward kernel
+    share = bool(rng.integers(0, 2))
+    kinds = tuple(rng.choice(KINDS, size=D))
+    spec = cases.random_spec(rng, D, R, kinds, share=share)
+    N, M = 240, 18
+    X = cases.random_inputs(rng, spec, N)
+    Z = cases.random_inputs(rng, spec, M)
+    y = rng.standard_normal((N, 1))
+    hip.sgpr_set_data(X, y); hip.sgpr_set_inducing(Z); hip.sgpr_set_route("whitened")
+    s2 = 0.2
+    e, g = hip.sgpr_elbo_grad(_capi.KernelDesc(spec), s2)
+
+    def fwd(sp, noise=s2):
+        return hip.sgpr_elbo(_capi.KernelDesc(sp), noise)
+
+    def check(analytic, make, h, what=""):
+        fd = (fwd(*make(+h)) - fwd(*make(-h))) / (2 * h)
+        assert abs(analytic - fd) <= 2e-5 * max(1.0, abs(fd)), f"seed {seed} D={D} R={R} share={share} kinds={kinds} {what}: {analytic} vs {fd}"
+
+    for d, dim in enumerate(spec["dims"]):
+        if dim["type"] == "rbf":
+            def mk(h, d=d):
+                sp = copy.deepcopy(spec); sp["dims"][d]["lengthscale"] += h
+                return (sp,)
+            check(g[d], mk, 1e-4 * dim["lengthscale"], f"lengthscale[{d}]")
+        if not share:
+            def mkv(h, d=d):
+                sp = copy.deepcopy(spec); sp["dims"][d]["variance"] += h
+                return (sp,)
+            check(g[D + d], mkv, 1e-4 * dim["variance"], f"variance[{d}]")
+    n_ov = len(spec["order_variances"])
+    for r in range(n_ov):
+        def mko(h, r=r):
+            sp = copy.deepcopy(spec); sp["order_variances"][r] += h
+            return (sp,)
+        check(g[2 * D + r], mko, 1e-4, f"order_variance[{r}]")
+    check(g[2 * D + n_ov], lambda h: (spec, s2 + h), 1e-5, "noise")
