@@ -103,3 +103,25 @@ def test_random_kernels_gradient_against_forward_differences(hip, seed):
             return (sp,)
         check(g[2 * D + r], mko, 1e-4, f"order_variance[{r}]")
     check(g[2 * D + n_ov], lambda h: (spec, s2 + h), 1e-5, "noise")
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_kernels_sobol_and_components(hip, seed):
+    """Sobol indices and per-component predictions of random kernels over the measure types that have a closed form
+    (Gaussian N(0,1), binary, categorical), shared and separate variances, against the oracle (1e-9)."""
+    rng = np.random.default_rng(9000 + seed)
+    D = int(rng.integers(2, 7))
+    R = int(rng.integers(1, min(D, 3) + 1))
+    share = bool(rng.integers(0, 2))
+    kinds = tuple(rng.choice(("gaussian", "binary", "categorical"), size=D))
+    spec = cases.random_spec(rng, D, R, kinds, share=share)
+    M = int(rng.integers(8, 40))
+    Z = cases.random_inputs(rng, spec, M)
+    alpha = rng.standard_normal((M, 1))
+    subsets, ref = o.compute_sobol_oak(spec, Z, alpha, share_var_across_orders=share)
+    got = hip.sobol(_capi.KernelDesc(spec), Z, alpha[:, 0], subsets, use_order_var=share)
+    np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-12 * max(np.abs(ref).max(), 1e-300))
+    Xs = cases.random_inputs(rng, spec, 30)
+    comp = hip.component_predict(_capi.KernelDesc(spec), Xs, Z, alpha[:, 0], subsets, use_order_var=share)
+    refc = np.array(o.prediction_components(spec, Z, alpha, Xs, share_var_across_orders=share))
+    np.testing.assert_allclose(comp, refc, rtol=1e-9, atol=1e-11)
