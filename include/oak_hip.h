@@ -155,6 +155,12 @@ int oak_sgpr_predict(oak_ctx* ctx, const oak_kernel_desc* desc,
 int64_t oak_grad_len(const oak_kernel_desc* desc);
 int oak_sgpr_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, double jitter,
                        double* elbo_out, double* grad_out);
+/* Same, plus the gradient with respect to the inducing inputs (create_model_oak(zfixed=False),
+   oak/model_utils.py:156-157; TensorFlow autodiff through Kuf and Kuu in the reference).  gradZ_out is M x ldx
+   row-major like Z; columns that no RBF sub-kernel reads, and binary / categorical columns, get 0.  Costs one more
+   pass over the N x M pairs; supported for 1 <= max_depth <= 4 and num_dims <= 32.  gradZ_out may be NULL. */
+int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, double jitter,
+                         double* elbo_out, double* grad_out, double* gradZ_out);
 
 /* ---- GPR (replaces gpflow.models.GPR constructed at oak/model_utils.py:159;
  *      in-tree mirror oak/utils.py:206-211) -------------------------------------------------- */

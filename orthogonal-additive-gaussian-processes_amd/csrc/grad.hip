@@ -438,6 +438,217 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
     for (int idx = tid; idx < tablen; idx += 256) rec[2 * D + (R + 1) + idx] = accT[idx];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Gradient with respect to the INDUCING INPUTS (create_model_oak(zfixed=False), oak/model_utils.py:156-157; the reference
+// gets it from TensorFlow's autodiff through Kuf and Kuu).  Same pair walk as the fast kernel, but the accumulators belong
+// to the COLUMN (inducing point) a lane owns instead of being summed over the workgroup:
+//     dF/dz_{m,d} = sum_n g_nm * dK/dk_d(n,m) * dk_d/dz_m,      dk_d/dz_m = E * 64 ln2 s_d u' - cn_d(x_n) * dcn_d/dz (z_m)
+// (u' = (xs_n - xs_m)/32, E the RBF factor incl. base variance, exp2w.h).  The constant 64 ln2 s_d is divided out of the
+// staged column feature dzb = (dcn/dz) / (64 ln2 s_d) and multiplied back on the host; discrete dimensions contribute 0.
+// A second pass over the pairs, paid only when the inducing inputs are trainable.
+// ---------------------------------------------------------------------------------------------------------------------
+// d cn / d x of the normalised constraint term cn = cov_X_s(x) / sqrt(var_s), per RBF dimension (featurize_kernel's cn)
+__global__ void __launch_bounds__(256) featurize_dx_kernel(DevDesc dd, DevMeasure dm, const double* __restrict__ meas,
+                                                           const double* __restrict__ X, int64_t n, int ldx, int64_t ld,
+                                                           double* __restrict__ dzb) {
+    const int d = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ld) return;
+    double v = 0.0;
+    if (i < n && dd.type[d] == OAK_DIM_RBF) {
+        const double x = X[i * ldx + dd.col[d]];
+        const double l = dm.ls[d], bv = dd.bv[d];
+        double dc = 0.0;                       // d cov_X_s / dx
+        switch (dm.kind[d]) {
+            case OAK_MEAS_GAUSSIAN: {
+                const double mu = dm.p0[d], s = l * l + dm.p1[d];
+                dc = -bv * l / sqrt(s) * exp(-0.5 * (x - mu) * (x - mu) / s) * (x - mu) / s;
+            } break;
+            case OAK_MEAS_UNIFORM: {
+                const double a = dm.p0[d], b = dm.p1[d], il2 = 0.5 / (l * l);
+                dc = bv / (b - a) * (exp(-(a - x) * (a - x) * il2) - exp(-(b - x) * (b - x) * il2));
+            } break;
+            case OAK_MEAS_EMPIRICAL: {
+                const int K = dm.k[d];
+                const double* loc = meas + dm.off[d];
+                const double* w = loc + K;
+                const double il2 = 0.5 / (l * l);
+                double acc = 0.0;
+                for (int k = 0; k < K; ++k) { const double u = x - loc[k]; acc += w[k] * exp(-u * u * il2) * (-u); }
+                dc = bv * acc / (l * l);
+            } break;
+            case OAK_MEAS_MOG: {
+                const int K = dm.k[d];
+                const double* mu = meas + dm.off[d];
+                const double* var = mu + K;
+                const double* w = var + K;
+                double acc = 0.0;
+                for (int k = 0; k < K; ++k) {
+                    const double s = l * l + var[k], u = x - mu[k];
+                    acc += w[k] * exp(-0.5 * u * u / s) / sqrt(s) * (-u / s);
+                }
+                dc = bv * l * acc;
+            } break;
+            default: dc = 0.0;
+        }
+        v = dc * dm.inv_sqrt_v[d] / (64.0 * 0.6931471805599453094 * dd.scale[d]);
+    }
+    dzb[(int64_t)d * ld + i] = v;
+}
+
+template <int R, int DMAX, int CPT, bool ALLRBF, bool UNITBV>
+__global__ void __launch_bounds__(256, (DMAX <= 16 ? 2 : 1))
+gram_bwd_z_kernel(const DevDesc dd, const double* __restrict__ tables, const double* __restrict__ Apack, int64_t a0, int64_t na,
+                  const double* __restrict__ Bxs, const double* __restrict__ Bcn, const double* __restrict__ Bdz, int64_t b_ld,
+                  int64_t nb, const double* __restrict__ G, int64_t ldg, const double* __restrict__ yA,
+                  const double* __restrict__ avec, double g_scale, int rows_per_wg, double* __restrict__ partial /* [nrb][nb][DMAX] */) {
+    constexpr int TJ = 64 * CPT, RT = 2, RS = 4 * RT;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int D = dd.D;
+    double* Bx = smem;                  // [DMAX][TJ]
+    double* Bc = Bx + DMAX * TJ;
+    double* Bd = Bc + DMAX * TJ;        // (dcn/dz) / (64 ln2 s_d)
+    double* Av = Bd + DMAX * TJ;        // [TJ]
+    double* Tab = Av + TJ;              // [EW_N]
+    double* Cw = Tab + EW_N;            // [DMAX]  (not allocated when UNITBV)
+    double* Cm = Cw + DMAX;
+    int* meta = reinterpret_cast<int*>(UNITBV ? Tab + EW_N : Cm + DMAX);   // [2*DMAX] when !ALLRBF
+    double* accum = Bx;                 // [TJ][DMAX] cross-wave accumulation, aliases the column features after the row loop
+    const int tid = threadIdx.x, tx = tid & 63;
+    const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t jb = (int64_t)blockIdx.x * TJ;
+    const int64_t ib = (int64_t)blockIdx.y * rows_per_wg;
+    const int64_t iend = (ib + rows_per_wg < na) ? ib + rows_per_wg : na;
+    for (int idx = tid; idx < DMAX * TJ; idx += 256) {
+        const int d = idx / TJ, j = idx - d * TJ;
+        const int64_t gj = jb + j;
+        const bool ok = gj < nb && d < D;
+        Bx[idx] = ok ? Bxs[(int64_t)d * b_ld + gj] : (d < D ? 0.0 : 1.0);
+        Bc[idx] = ok ? Bcn[(int64_t)d * b_ld + gj] : 0.0;
+        Bd[idx] = ok ? Bdz[(int64_t)d * b_ld + gj] : 0.0;
+    }
+    for (int j = tid; j < TJ; j += 256) Av[j] = (avec != nullptr && jb + j < nb) ? avec[jb + j] : 0.0;
+    for (int j = tid; j < EW_N; j += 256) Tab[j] = biased_table_entry(j);
+    if constexpr (!UNITBV) {
+        if (tid < DMAX) {
+            const bool rbf = tid < D && dd.type[tid] == OAK_DIM_RBF;
+            Cw[tid] = rbf ? dd.woff[tid] : 0.0;
+            Cm[tid] = rbf ? dd.magic[tid] : EW_MAGIC;
+        }
+    }
+    unsigned rbf_mask = 0xffffffffu;
+    if constexpr (!ALLRBF) {
+        if (tid < DMAX) { meta[2 * tid] = tid < D ? dd.tab_off[tid] : 0; meta[2 * tid + 1] = tid < D ? dd.ncat[tid] : 0; }
+        for (int d = 0; d < D; ++d) if (dd.type[d] != OAK_DIM_RBF) rbf_mask &= ~(1u << d);
+    }
+    double gz[CPT][DMAX];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c)
+#pragma unroll
+        for (int d = 0; d < DMAX; ++d) gz[c][d] = 0.0;
+    __syncthreads();
+
+    struct Chunk { double xa[4], xb[4], ca[4], cb[4], bd[4], cw[4], cm[4]; };
+    auto g_addr = [&](int64_t i0n, int prn) -> const double* {
+        const int64_t gin = i0n + ty * RT + prn / CPT, gjn = jb + tx + 64 * (prn % CPT);
+        return G + (gin < iend ? gin : iend - 1) * ldg + (gjn < nb ? gjn : nb - 1);
+    };
+    double graw_next = ib < iend ? *g_addr(ib, 0) : 0.0;
+    for (int64_t i0 = ib; i0 < iend; i0 += RS) {
+#pragma unroll 1
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {                  // c is static: it selects the accumulator set
+            const int pr = r * CPT + c;
+            const int col = tx + 64 * c;
+            const int64_t gi = i0 + ty * RT + r, gj = jb + col;
+            const int64_t gr = gi < iend ? gi : iend - 1;
+            const double* __restrict__ prow = Apack + gr * (3 * DMAX);
+            const double yrow = yA != nullptr ? yA[a0 + gr] : 0.0;
+            const double g = (gi < iend && gj < nb) ? __builtin_fma(g_scale, graw_next, yrow * Av[col]) : 0.0;
+            graw_next = (pr + 1 < RT * CPT) ? *g_addr(i0, pr + 1) : *g_addr(i0 + RS, 0);
+            double k[DMAX], zc[DMAX];
+            auto fetch = [&](int d0, Chunk& ch) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int d = d0 + v;
+                    ch.xa[v] = prow[d]; ch.ca[v] = prow[DMAX + d];
+                    ch.xb[v] = Bx[d * TJ + col]; ch.cb[v] = Bc[d * TJ + col]; ch.bd[v] = Bd[d * TJ + col];
+                    if constexpr (!UNITBV) { ch.cw[v] = Cw[d]; ch.cm[v] = Cm[d]; }
+                }
+            };
+            Chunk cur, nxt;
+            fetch(0, cur);
+#pragma unroll
+            for (int d0 = 0; d0 < DMAX; d0 += 4) {
+                if (d0 + 4 < DMAX) fetch(d0 + 4, nxt);
+                asm volatile("" ::: "memory");
+                double w[4], up[4], mg[4], E[4];
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    up[v] = cur.xa[v] - cur.xb[v];
+                    if constexpr (UNITBV) { w[v] = fma_clamp01(up[v], up[v], 0.0); mg[v] = EW_MAGIC; }
+                    else { w[v] = fma_clamp01(up[v], up[v], cur.cw[v]); mg[v] = cur.cm[v]; }
+                }
+                exp2_w_vec<4>(w, mg, E, Tab);
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const int d = d0 + v;
+                    double kv = __builtin_fma(-cur.ca[v], cur.cb[v], E[v]);
+                    double zv = __builtin_fma(-cur.ca[v], cur.bd[v], E[v] * up[v]);
+                    if constexpr (!ALLRBF) {
+                        if (!((rbf_mask >> d) & 1u)) { kv = tables[meta[2 * d] + (int)cur.xa[v] * meta[2 * d + 1] + (int)cur.xb[v]]; zv = 0.0; }
+                    }
+                    k[d] = kv; zc[d] = zv;
+                }
+                if (d0 + 4 < DMAX) cur = nxt;
+            }
+            double e[R];
+#pragma unroll
+            for (int q = 0; q < R; ++q) e[q] = 0.0;
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+#pragma unroll
+                for (int q = R - 1; q >= 1; --q) e[q] = __builtin_fma(k[d], e[q - 1], e[q]);
+                e[0] += k[d];
+            }
+#pragma unroll
+            for (int d = 0; d < DMAX; ++d) {
+                double f = 1.0, coef = dd.w[1];
+#pragma unroll
+                for (int q = 1; q < R; ++q) { f = __builtin_fma(-k[d], f, e[q - 1]); coef = __builtin_fma(dd.w[q + 1], f, coef); }
+                gz[c][d] = __builtin_fma(g * coef, zc[d], gz[c][d]);
+            }
+        }
+    }
+    // the four waves hold partial sums for the SAME columns: add them in wave order through LDS, then one store per column
+    __syncthreads();
+    for (int wv = 0; wv < 4; ++wv) {
+        if (ty == wv) {
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+#pragma unroll
+                for (int d = 0; d < DMAX; ++d) {
+                    double* q = &accum[(tx + 64 * c) * DMAX + d];
+                    *q = (wv == 0) ? gz[c][d] : *q + gz[c][d];
+                }
+        }
+        __syncthreads();
+    }
+    double* out = partial + ((int64_t)blockIdx.y * nb + jb) * DMAX;
+    for (int idx = tid; idx < TJ * DMAX; idx += 256)
+        if (jb + idx / DMAX < nb) out[idx] = accum[idx];
+}
+
+// gz[m][d] += sum over row blocks (fixed order)
+__global__ void __launch_bounds__(256) reduce_gz_kernel(const double* __restrict__ partial, int64_t nrb, int64_t len, double* __restrict__ gz) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= len) return;
+    double s = 0.0;
+    for (int64_t b = 0; b < nrb; ++b) s += partial[b * len + i];
+    gz[i] += s;
+}
+
 // Diagonal term: sum_n gconst * dKdiag_n / dtheta, one point per lane.
 template <int R>
 __global__ void __launch_bounds__(256)
@@ -645,6 +856,59 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     return OAK_OK;
 }
 
+// d_gz[nb][dmax] += column-side contraction of G (+ optional rank-1 yA avec^T) with dK/dz over the pairs (A rows a0.., B);
+// d_dzb = featurize_dx of the B points.  Supported for 1 <= R <= 4 and D <= 32 (the register-resident pair walk).
+int gram_bwd_z(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int64_t na, const Feat& B, const double* d_dzb,
+               const double* d_G, int64_t ldg, double g_scale, const double* d_yA, const double* d_avec, double* d_gz, int dmax) {
+    if (na <= 0 || B.n <= 0) return OAK_OK;
+    const int D = pk.dd.D, R = pk.dd.R;
+    OAK_REQUIRE(R >= 1 && R <= 4 && D <= 32, "gradient w.r.t. inducing inputs needs 1 <= max_interaction_depth <= 4 and <= 32 dims (got %d, %d)", R, D);
+    OAK_REQUIRE(A.xs32 != nullptr && B.xs32 != nullptr, "gram_bwd_z: features were not prepared for the backward pass");
+    bool allrbf = true, unitbv = true;
+    for (int d = 0; d < D; ++d) {
+        allrbf = allrbf && pk.dd.type[d] == OAK_DIM_RBF;
+        unitbv = unitbv && (pk.dd.type[d] != OAK_DIM_RBF || pk.dd.bv[d] == 1.0);
+    }
+    const int cpt = dmax <= 16 ? 2 : 1;
+    const int TJ = 64 * cpt, RS = 8;
+    const size_t lds = sizeof(double) * ((size_t)3 * dmax * TJ + TJ + EW_N + (unitbv ? 0 : 2 * dmax) + (allrbf ? 0 : dmax));
+    const int64_t nb = B.n;
+    const int64_t ncb = (nb + TJ - 1) / TJ;
+    int64_t nrb = ((int64_t)ctx->num_cu * 8 + ncb - 1) / ncb;
+    int64_t rows = (na + nrb - 1) / nrb;
+    rows = ((rows + RS - 1) / RS) * RS;
+    if (rows < RS) rows = RS;
+    if (rows > 4096) rows = 4096;
+    nrb = (na + rows - 1) / rows;
+    if (nrb > 65535) { rows = (((na + 65534) / 65535 + RS - 1) / RS) * RS; nrb = (na + rows - 1) / rows; }
+    double *d_pack = nullptr, *d_part = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "bwd_pack", (size_t)na * 3 * dmax, &d_pack));
+    OAK_CHECK(get_buf_t(ctx, "bwdz_part", (size_t)nrb * nb * dmax, &d_part));
+    pack_rows_kernel<<<(unsigned)((na + 63) / 64), 256, 0, ctx->stream>>>(A.xs32, A.cn, A.dcs, A.ld, a0, na, D, dmax, d_pack);
+    OAK_HIP_CHECK(hipGetLastError());
+    dim3 grid((unsigned)ncb, (unsigned)nrb);
+#define OAK_BZ_K(RR, DM, AR, UB)                                                                                                  \
+    gram_bwd_z_kernel<RR, DM, (DM <= 16 ? 2 : 1), AR, UB><<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, d_pack, a0, na,   \
+        B.xs32, B.cn, d_dzb, B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part);
+#define OAK_BZ_U(RR, DM, AR) { if (unitbv) OAK_BZ_K(RR, DM, AR, true) else OAK_BZ_K(RR, DM, AR, false) }
+#define OAK_BZ(RR, DM) { if (allrbf) OAK_BZ_U(RR, DM, true) else OAK_BZ_U(RR, DM, false) }
+    switch (R * 100 + dmax) {
+        case 108: OAK_BZ(1, 8) break;   case 116: OAK_BZ(1, 16) break;   case 132: OAK_BZ(1, 32) break;
+        case 208: OAK_BZ(2, 8) break;   case 216: OAK_BZ(2, 16) break;   case 232: OAK_BZ(2, 32) break;
+        case 308: OAK_BZ(3, 8) break;   case 316: OAK_BZ(3, 16) break;   case 332: OAK_BZ(3, 32) break;
+        case 408: OAK_BZ(4, 8) break;   case 416: OAK_BZ(4, 16) break;   case 432: OAK_BZ(4, 32) break;
+        default: set_error("gram_bwd_z: unsupported configuration"); return OAK_E_ARG;
+    }
+#undef OAK_BZ
+#undef OAK_BZ_U
+#undef OAK_BZ_K
+    OAK_HIP_CHECK(hipGetLastError());
+    const int64_t len = nb * dmax;
+    reduce_gz_kernel<<<(unsigned)((len + 255) / 256), 256, 0, ctx->stream>>>(d_part, nrb, len, d_gz);
+    OAK_HIP_CHECK(hipGetLastError());
+    return OAK_OK;
+}
+
 int diag_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, double gconst, double* d_rec) {
     if (A.n <= 0) return OAK_OK;
     const int D = pk.dd.D, R = pk.dd.R;
@@ -735,6 +999,11 @@ int64_t oak_grad_len(const oak_kernel_desc* desc) {
 }
 
 int oak_sgpr_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, double jitter, double* elbo_out, double* grad_out) {
+    return oak_sgpr_elbo_grad_z(ctx, desc, noise_var, jitter, elbo_out, grad_out, nullptr);
+}
+
+int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, double jitter, double* elbo_out, double* grad_out,
+                         double* gradZ_out) {
     if (!ctx) { set_error("ctx is NULL"); return OAK_E_ARG; }
     OAK_HIP_CHECK(hipSetDevice(ctx->device));
     OAK_REQUIRE(grad_out != nullptr, "grad_out is NULL");
@@ -803,6 +1072,17 @@ int oak_sgpr_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_v
     Feat FX, FZ;
     OAK_CHECK(featurize(ctx, pk, (double*)peek_buf(ctx, "Z"), M, ctx->ldx, "featZg", &FZ, true));
     OAK_CHECK(featurize(ctx, pk, (double*)peek_buf(ctx, "X"), N, ctx->ldx, "featXg", &FX, true));
+    // optional: gradient w.r.t. the inducing inputs (second pair pass, column-side accumulators)
+    const int zdmax = pk.dd.D <= 8 ? 8 : (pk.dd.D <= 16 ? 16 : 32);
+    double *d_dzb = nullptr, *d_gz = nullptr;
+    if (gradZ_out != nullptr) {
+        OAK_CHECK(get_buf_t(ctx, "featZ_dx", (size_t)pk.dd.D * FZ.ld, &d_dzb));
+        dim3 gdx((unsigned)((FZ.ld + 255) / 256), (unsigned)pk.dd.D);
+        featurize_dx_kernel<<<gdx, 256, 0, ctx->stream>>>(pk.dd, pk.dm, pk.d_meas, (double*)peek_buf(ctx, "Z"), M, ctx->ldx, FZ.ld, d_dzb);
+        OAK_HIP_CHECK(hipGetLastError());
+        OAK_CHECK(get_buf_t(ctx, "g_gz", (size_t)M * zdmax, &d_gz));
+        OAK_CHECK(fill_zero(ctx, d_gz, sizeof(double) * (size_t)M * zdmax));
+    }
     // a / s2 as the rank-1 partner of y
     double* d_as2 = nullptr;
     OAK_CHECK(get_buf_t(ctx, "g_as2", (size_t)M, &d_as2));
@@ -832,6 +1112,11 @@ int oak_sgpr_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_v
             OAK_CHECK(gram_bwd(ctx, pk, FX, a0, na, FZ, dG, Mp, 1.0 / s2, dY, d_as2, d_rec, desc->grad_base_var != 0));
             t.stop();
         }
+        if (gradZ_out != nullptr) {
+            PhaseTimer t(ctx, "bwd_z");
+            OAK_CHECK(gram_bwd_z(ctx, pk, FX, a0, na, FZ, d_dzb, dG, Mp, 1.0 / s2, dY, d_as2, d_gz, zdmax));
+            t.stop();
+        }
     }
     {
         PhaseTimer t(ctx, "bwd_small");
@@ -839,6 +1124,12 @@ int oak_sgpr_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_v
         OAK_CHECK(gram_bwd(ctx, pk, FZ, 0, M, FZ, dGuu, M, 1.0 / (double)(ctx->comm ? ctx->nranks : 1), nullptr, nullptr, d_rec, desc->grad_base_var != 0));
         OAK_CHECK(diag_bwd(ctx, pk, FX, -0.5 / s2, d_rec));                                      // -1/(2 s2) sum dKdiag
         t.stop();
+    }
+    if (gradZ_out != nullptr) {
+        // <G_uu, dKuu/dz_m>: Kuu depends on z_m through its row AND its column m; G_uu and Kuu are symmetric, so the total is
+        // twice the column-side sum (replicated on every rank, hence the 1/nranks before the all-reduce)
+        OAK_CHECK(gram_bwd_z(ctx, pk, FZ, 0, M, FZ, d_dzb, dGuu, M, 2.0 / (double)(ctx->comm ? ctx->nranks : 1), nullptr, nullptr, d_gz, zdmax));
+        if (ctx->comm != nullptr) OAK_CHECK(comm_allreduce_dev(ctx, d_gz, M * zdmax));
     }
     if (ctx->comm != nullptr) OAK_CHECK(comm_allreduce_dev(ctx, d_rec, reclen));
     std::vector<double> rec((size_t)reclen);
@@ -850,6 +1141,17 @@ int oak_sgpr_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_v
     const double dnoise = -0.5 * n_tot / s2 + 0.5 * (yy + kappa) / (s2 * s2) - 0.5 * trW / (s2 * s2) - psia / (s2 * s2) +
                           0.5 * ((double)M - trSK) / s2 + 0.5 * (psia - s2 * aKa) / (s2 * s2);
     scatter_record(desc, pk, rec, dnoise, grad_out);
+    if (gradZ_out != nullptr) {
+        std::vector<double> gz((size_t)M * zdmax);
+        OAK_HIP_CHECK(hipMemcpy(gz.data(), d_gz, sizeof(double) * gz.size(), hipMemcpyDeviceToHost));
+        const int32_t ldz = ctx->ldx;
+        for (int64_t i = 0; i < M * (int64_t)ldz; ++i) gradZ_out[i] = 0.0;
+        for (int d = 0; d < pk.dd.D; ++d) {
+            if (pk.dd.type[d] != OAK_DIM_RBF) continue;                       // discrete inputs have no derivative
+            const double cd = 64.0 * 0.6931471805599453094 * pk.dd.scale[d];  // divided out in featurize_dx_kernel / the pair kernel
+            for (int64_t m = 0; m < M; ++m) gradZ_out[m * ldz + pk.dd.col[d]] += cd * gz[(size_t)m * zdmax + d];
+        }
+    }
     if (elbo_out) *elbo_out = elbo;
     return OAK_OK;
 }

@@ -81,6 +81,7 @@ SIGNATURES = {
     "oak_sgpr_predict": (C.c_int, [_CTX, _DESC, _D, C.c_int64, C.c_int32, _D, _D]),
     "oak_grad_len": (C.c_int64, [_DESC]),
     "oak_sgpr_elbo_grad": (C.c_int, [_CTX, _DESC, C.c_double, C.c_double, _D, _D]),
+    "oak_sgpr_elbo_grad_z": (C.c_int, [_CTX, _DESC, C.c_double, C.c_double, _D, _D, _D]),
     "oak_gpr_set_data": (C.c_int, [_CTX, _D, _D, C.c_int64, C.c_int32]),
     "oak_gpr_log_marginal": (C.c_int, [_CTX, _DESC, C.c_double, _D]),
     "oak_gpr_alpha": (C.c_int, [_CTX, _D]),
@@ -430,6 +431,14 @@ class HipContext:
 
     def grad_len(self, desc: KernelDesc) -> int:
         return int(self._lib.oak_grad_len(desc.ref))
+
+    def sgpr_elbo_grad_z(self, desc: KernelDesc, noise_var: float, M: int, ldx: int, jitter: float = 1e-6):
+        """(elbo, grad, gradZ [M, ldx]): as sgpr_elbo_grad plus the gradient w.r.t. the inducing inputs."""
+        e = C.c_double()
+        g = np.empty(self.grad_len(desc))
+        gz = np.empty((int(M), int(ldx)))
+        _check(self._lib.oak_sgpr_elbo_grad_z(self._h, desc.ref, float(noise_var), float(jitter), C.byref(e), _dp(g), _dp(gz)))
+        return e.value, g, gz
 
     def sgpr_elbo_grad(self, desc: KernelDesc, noise_var: float, jitter: float = 1e-6):
         e = C.c_double()

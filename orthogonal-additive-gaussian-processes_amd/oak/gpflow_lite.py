@@ -450,13 +450,16 @@ class GPModel(Module):
     def _training_loss_and_grad(self, variables):
         """loss and d loss / d u for each variable in ``variables`` (analytic, HIP backward pass)."""
         from .oak_kernel import scatter_gradient
+        self._want_extra = variables
         obj, gvec, desc = self._objective_and_constrained_grad()
         grads = scatter_gradient(self.kernel, self.likelihood, desc, gvec, variables)
+        extra = getattr(self, "_extra_grads", {})                    # e.g. the inducing inputs (SGPR, zfixed=False)
+        grads = [extra.get(id(p), g) if g is None else g for p, g in zip(variables, grads)]
         loss = -(obj + self.log_prior_density())
         out = []
         for p, g in zip(variables, grads):
             if g is None:
-                raise NotImplementedError(f"no analytic gradient for parameter {p!r} (e.g. trainable inducing inputs)")
+                raise NotImplementedError(f"no analytic gradient for parameter {p!r}")
             g = np.asarray(g, dtype=np.float64).reshape(p.shape)
             if p.prior is not None and hasattr(p.prior, "dlog_prob"):
                 g = g + p.prior.dlog_prob(p.numpy())
@@ -539,7 +542,15 @@ class SGPR(GPModel):
     def _objective_and_constrained_grad(self):
         self._sync_Z()
         desc = self._desc()
-        obj, g = self._hip.sgpr_elbo_grad(desc, float(self.likelihood.variance.numpy()), default_jitter())
+        Zp = self.inducing_variable.Z
+        want_z = any(v is Zp for v in getattr(self, "_want_extra", ()))
+        self._extra_grads = {}
+        if want_z:      # trainable inducing inputs (create_model_oak(zfixed=False)): one more pass over the pairs
+            Z = Zp.numpy()
+            obj, g, gz = self._hip.sgpr_elbo_grad_z(desc, float(self.likelihood.variance.numpy()), Z.shape[0], Z.shape[1], default_jitter())
+            self._extra_grads[id(Zp)] = gz
+        else:
+            obj, g = self._hip.sgpr_elbo_grad(desc, float(self.likelihood.variance.numpy()), default_jitter())
         return obj, g, desc
 
 
