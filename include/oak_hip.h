@@ -146,6 +146,9 @@ int oak_sgpr_elbo(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, d
                   double* elbo_out);
 /* alpha [M] of oak/utils.py:197-198; valid after a successful tail/elbo call. */
 int oak_sgpr_alpha(oak_ctx* ctx, double* alpha_out);
+/* The "effective L" that get_model_sufficient_statistics(m, get_L=True) returns for a sparse model
+   (oak/utils.py:199-204): inv(L^-1 - LB^-1 L^-1), M x M row-major.  After oak_sgpr_elbo / _tail. */
+int oak_sgpr_effective_L(oak_ctx* ctx, double* L_out);
 /* SGPR.predict_f(full_cov=False): mean[Ns], var[Ns]; valid after tail/elbo with the same desc. */
 int oak_sgpr_predict(oak_ctx* ctx, const oak_kernel_desc* desc,
                      const double* Xs, int64_t Ns, int32_t ldx, double* mean, double* var);
@@ -166,7 +169,10 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
  *      in-tree mirror oak/utils.py:206-211) -------------------------------------------------- */
 int oak_gpr_set_data(oak_ctx* ctx, const double* X, const double* Y, int64_t N, int32_t ldx);
 int oak_gpr_log_marginal(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, double* out);
-int oak_gpr_alpha(oak_ctx* ctx, double* alpha_out);         /* cholesky_solve(L, Y), utils.py:211 */
+int oak_gpr_alpha(oak_ctx* ctx, double* alpha_out);
+/* L = chol(K + noise I) of the full GP, N x N row-major (get_model_sufficient_statistics(get_L=True),
+   oak/utils.py:206-211).  After oak_gpr_log_marginal. */
+int oak_gpr_chol(oak_ctx* ctx, double* L_out);         /* cholesky_solve(L, Y), utils.py:211 */
 int oak_gpr_predict(oak_ctx* ctx, const oak_kernel_desc* desc,
                     const double* Xs, int64_t Ns, int32_t ldx, double* mean, double* var);
 int oak_gpr_log_marginal_grad(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var,

@@ -624,6 +624,45 @@ int oak_gpr_log_marginal(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
     return OAK_OK;
 }
 
+// "Effective L" of get_model_sufficient_statistics(get_L=True) (oak/utils.py:199-204):
+//     LAi = L^-1,  LBiLAi = LB^-1 L^-1,  L_eff = inv(LAi - LBiLAi)
+// = inv((I - LB^-1) L^-1) = L LB (LB - I)^-1: LB - I is lower triangular with positive diagonal, so the general inverse
+// of the reference becomes one triangular inverse and two GEMMs.
+int oak_sgpr_effective_L(oak_ctx* ctx, double* L_out) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(L_out != nullptr, "L_out is NULL");
+    if (!ctx->have_post) { set_error("SGPR posterior not available: call oak_sgpr_elbo/oak_sgpr_tail first"); return OAK_E_STATE; }
+    const int64_t M = ctx->M;
+    double* dL = (double*)peek_buf(ctx, "L");
+    double* dLB = (double*)peek_buf(ctx, "LB");
+    double *dT, *dTi, *dP, *dE;
+    OAK_CHECK(get_buf_t(ctx, "effL_T", (size_t)M * M, &dT));
+    OAK_CHECK(get_buf_t(ctx, "effL_Ti", (size_t)M * M, &dTi));
+    OAK_CHECK(get_buf_t(ctx, "effL_P", (size_t)M * M, &dP));
+    OAK_CHECK(get_buf_t(ctx, "effL_E", (size_t)M * M, &dE));
+    OAK_CHECK(copy_d2d(ctx, dT, dLB, sizeof(double) * (size_t)M * M));
+    OAK_CHECK(add_diag(ctx, dT, M, M, -1.0));                               // LB - I
+    OAK_CHECK(set_identity(ctx, dTi, M));
+    OAK_CHECK(trsm_rows(ctx, dT, M, M, dTi, M, M, 0));                      // rows = columns of (LB - I)^-1
+    OAK_CHECK(transpose(ctx, dTi, M, M, M, dT, M));                         // dT = (LB - I)^-1
+    OAK_CHECK(gemm_nn(ctx, dLB, dT, dP, M, M, M, M, M, M, 1.0, 0.0));       // LB (LB - I)^-1
+    OAK_CHECK(gemm_nn(ctx, dL, dP, dE, M, M, M, M, M, M, 1.0, 0.0));        // L LB (LB - I)^-1
+    OAK_HIP_CHECK(hipMemcpyAsync(L_out, dE, sizeof(double) * (size_t)M * M, hipMemcpyDeviceToHost, ctx->stream));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return OAK_OK;
+}
+
+// L = chol(K + sigma^2 I) of the full GP (get_model_sufficient_statistics(get_L=True), oak/utils.py:206-211)
+int oak_gpr_chol(oak_ctx* ctx, double* L_out) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(L_out != nullptr, "L_out is NULL");
+    if (!ctx->g_have_post) { set_error("GPR posterior not available: call oak_gpr_log_marginal first"); return OAK_E_STATE; }
+    const int64_t N = ctx->gN;
+    OAK_HIP_CHECK(hipMemcpyAsync(L_out, peek_buf(ctx, "gprL"), sizeof(double) * (size_t)N * N, hipMemcpyDeviceToHost, ctx->stream));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return OAK_OK;
+}
+
 int oak_gpr_alpha(oak_ctx* ctx, double* alpha_out) {
     OAK_CHECK(guard(ctx));
     if (!ctx->g_have_post) { set_error("GPR posterior not available: call oak_gpr_log_marginal first"); return OAK_E_STATE; }

@@ -81,6 +81,8 @@ SIGNATURES = {
     "oak_sgpr_predict": (C.c_int, [_CTX, _DESC, _D, C.c_int64, C.c_int32, _D, _D]),
     "oak_grad_len": (C.c_int64, [_DESC]),
     "oak_sgpr_elbo_grad": (C.c_int, [_CTX, _DESC, C.c_double, C.c_double, _D, _D]),
+    "oak_sgpr_effective_L": (C.c_int, [_CTX, _D]),
+    "oak_gpr_chol": (C.c_int, [_CTX, _D]),
     "oak_sgpr_elbo_grad_z": (C.c_int, [_CTX, _DESC, C.c_double, C.c_double, _D, _D, _D]),
     "oak_gpr_set_data": (C.c_int, [_CTX, _D, _D, C.c_int64, C.c_int32]),
     "oak_gpr_log_marginal": (C.c_int, [_CTX, _DESC, C.c_double, _D]),
@@ -431,6 +433,16 @@ class HipContext:
 
     def grad_len(self, desc: KernelDesc) -> int:
         return int(self._lib.oak_grad_len(desc.ref))
+
+    def sgpr_effective_L(self, M: int) -> np.ndarray:
+        out = np.empty((int(M), int(M)))
+        _check(self._lib.oak_sgpr_effective_L(self._h, _dp(out)))
+        return out
+
+    def gpr_chol(self, N: int) -> np.ndarray:
+        out = np.empty((int(N), int(N)))
+        _check(self._lib.oak_gpr_chol(self._h, _dp(out)))
+        return out
 
     def sgpr_elbo_grad_z(self, desc: KernelDesc, noise_var: float, M: int, ldx: int, jitter: float = 1e-6):
         """(elbo, grad, gradZ [M, ldx]): as sgpr_elbo_grad plus the gradient w.r.t. the inducing inputs."""

@@ -493,6 +493,11 @@ class GPR(GPModel):
         self._hip.gpr_log_marginal(self._desc(), float(self.likelihood.variance.numpy()))
         return TensorLike(self._hip.gpr_alpha(self.data[0].shape[0])[:, None])
 
+    def effective_L(self):
+        """chol(K + noise I) of oak/utils.py:206-211."""
+        self._hip.gpr_log_marginal(self._desc(), float(self.likelihood.variance.numpy()))
+        return self._hip.gpr_chol(self.data[0].shape[0])
+
     def _objective_and_constrained_grad(self):
         desc = self._desc()
         obj, g = self._hip.gpr_log_marginal_grad(desc, float(self.likelihood.variance.numpy()))
@@ -538,6 +543,11 @@ class SGPR(GPModel):
         """alpha of oak/utils.py:180-198."""
         self.elbo()
         return TensorLike(self._hip.sgpr_alpha(len(self.inducing_variable))[:, None])
+
+    def effective_L(self):
+        """inv(L^-1 - LB^-1 L^-1) of oak/utils.py:199-204."""
+        self.elbo()
+        return self._hip.sgpr_effective_L(len(self.inducing_variable))
 
     def _objective_and_constrained_grad(self):
         self._sync_Z()

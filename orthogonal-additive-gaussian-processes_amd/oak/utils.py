@@ -84,13 +84,15 @@ def compute_L_empirical_measure(x, w, kernel: OrthogonalRBFKernel, z) -> np.ndar
 
 # ---- sufficient statistics (oak/utils.py:168-218) ------------------------------------------------------------
 def get_model_sufficient_statistics(m, get_L=True):
-    """alpha such that the predictive mean is K(x*, Xc) alpha.  The "effective L" (get_L=True) is only consumed by
-    plotting_utils, which is out of scope for this build."""
-    if get_L:
-        raise NotImplementedError("get_L=True (effective Cholesky factor) is only used by plotting_utils; call with get_L=False")
-    if isinstance(m, (gpflow.SGPR, gpflow.GPR)):
-        return m.alpha()
-    raise NotImplementedError
+    """alpha such that the predictive mean is K(x*, Xc) alpha and, with ``get_L`` (the reference's default), the matrix L
+    of oak/utils.py:168-218: the "effective" factor inv(L^-1 - LB^-1 L^-1) of a sparse model, chol(K + noise I) of a full
+    one."""
+    if not isinstance(m, (gpflow.SGPR, gpflow.GPR)):
+        raise NotImplementedError
+    alpha = m.alpha()
+    if not get_L:
+        return alpha
+    return alpha, TensorLike(m.effective_L())
 
 
 def _sobol_inputs(model):

@@ -248,3 +248,28 @@ def test_many_evaluations_without_reading_timings(hip):
         assert hip.sgpr_elbo(d, 0.1) == e0
     ms, count = hip.timing("total")
     assert count == 601 and ms > 0
+
+
+def test_effective_L_of_get_model_sufficient_statistics(hip):
+    """get_model_sufficient_statistics(m, get_L=True) (oak/utils.py:168-218): the sparse model's effective factor
+    inv(L^-1 - LB^-1 L^-1) and the full model's chol(K + noise I) against NumPy on the oracle's L, LB."""
+    import scipy.linalg as sla
+    from oak.model_utils import create_model_oak
+    from oak.oak_kernel import kernel_to_spec
+    from oak.utils import get_model_sufficient_statistics
+    rng = np.random.default_rng(4)
+    X = rng.normal(size=(300, 3)); y = np.sin(X[:, :1]) + 0.1 * rng.normal(size=(300, 1))
+    Z = X[:15].copy()
+    m = create_model_oak((X, y), inducing_pts=Z, optimise=False)
+    alpha, L = get_model_sufficient_statistics(m)
+    spec = kernel_to_spec(m.kernel)
+    c = o.sgpr_common(spec, X, y, Z, float(m.likelihood.variance.numpy()))
+    LAi = sla.solve_triangular(c["L"], np.eye(15), lower=True)
+    ref = np.linalg.inv(LAi - sla.solve_triangular(c["LB"], LAi, lower=True))
+    np.testing.assert_allclose(np.asarray(L), ref, rtol=1e-7, atol=1e-9 * np.abs(ref).max())
+    np.testing.assert_allclose(np.asarray(alpha), o.sgpr_alpha(spec, X, y, Z, float(m.likelihood.variance.numpy())), rtol=1e-7, atol=1e-10)
+    mf = create_model_oak((X[:80], y[:80]), optimise=False)
+    a2, L2 = get_model_sufficient_statistics(mf, get_L=True)
+    K = o.oak_K(kernel_to_spec(mf.kernel), X[:80]) + float(mf.likelihood.variance.numpy()) * np.eye(80)
+    np.testing.assert_allclose(np.asarray(L2), np.linalg.cholesky(K), rtol=1e-9, atol=1e-11)
+    assert np.asarray(get_model_sufficient_statistics(mf, get_L=False)).shape == (80, 1)
