@@ -208,6 +208,10 @@ int oak_component_predict(oak_ctx* ctx, const oak_kernel_desc* desc, const doubl
  *      statistics are summed with one RCCL all-reduce (reduce-scatter + all-gather) over xGMI. */
 int oak_comm_unique_id(char* id_out_128);                      /* ncclGetUniqueId on rank 0   */
 int oak_comm_init(oak_ctx* ctx, const char* id_128, int32_t nranks, int32_t rank);
+/* Test communicator: pretends `nranks` ranks hold the SAME local rows, so every all-reduce multiplies by nranks.
+   Runs the whole N > 1 code path on one GPU: the result must equal a single-rank run on the rows stacked nranks times
+   (tests/test_gpu_distributed.py). */
+int oak_comm_init_loopback(oak_ctx* ctx, int32_t nranks);
 int oak_comm_destroy(oak_ctx* ctx);
 int oak_comm_allreduce_stats(oak_ctx* ctx);                    /* in-place sum of packed stats */
 int oak_comm_allreduce_host(oak_ctx* ctx, double* buf, int64_t n); /* small host vector (gradients) */

@@ -52,8 +52,15 @@ static int load_rccl() {
 
 // In-place sum over ranks of d_buf[0..n): reduce-scatter of equal slices, then all-gather.  The scratch tail that
 // pads n up to a multiple of nranks lives in a separate zeroed staging buffer so d_buf need not be over-allocated.
+// Test communicator (oak_comm_init_loopback): every "rank" is assumed to hold the same local buffer, so the sum over ranks
+// is nranks * local.  It runs the complete N > 1 code path (scaling of the replicated terms, placement of the reductions)
+// on ONE GPU: a loopback run on data X must equal a single-rank run on X stacked nranks times.
+static char g_loopback_tag;
+static inline bool is_loopback(const oak_ctx* ctx) { return ctx->comm == (void*)&g_loopback_tag; }
+
 int comm_allreduce_dev(oak_ctx* ctx, double* d_buf, int64_t n) {
     if (ctx->comm == nullptr || ctx->nranks <= 1) return OAK_OK;
+    if (is_loopback(ctx)) return scale_vec(ctx, (double)ctx->nranks, d_buf, n);
     OAK_CHECK(load_rccl());
     const int64_t P = ctx->nranks;
     const int64_t slice = (n + P - 1) / P;
@@ -98,9 +105,17 @@ int oak_comm_init(oak_ctx* ctx, const char* id_128, int32_t nranks, int32_t rank
     return OAK_OK;
 }
 
+int oak_comm_init_loopback(oak_ctx* ctx, int32_t nranks) {
+    if (!ctx) { set_error("ctx is NULL"); return OAK_E_ARG; }
+    OAK_REQUIRE(nranks >= 1, "nranks %d invalid", nranks);
+    if (ctx->comm) oak_comm_destroy(ctx);
+    ctx->comm = (void*)&g_loopback_tag; ctx->nranks = nranks; ctx->rank = 0;
+    return OAK_OK;
+}
+
 int oak_comm_destroy(oak_ctx* ctx) {
     if (!ctx || !ctx->comm) return OAK_OK;
-    if (g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)ctx->comm);
+    if (!is_loopback(ctx) && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)ctx->comm);
     ctx->comm = nullptr; ctx->nranks = 1; ctx->rank = 0;
     return OAK_OK;
 }

@@ -97,6 +97,7 @@ SIGNATURES = {
     "oak_comm_unique_id": (C.c_int, [C.c_char_p]),
     "oak_comm_init": (C.c_int, [_CTX, C.c_char_p, C.c_int32, C.c_int32]),
     "oak_comm_destroy": (C.c_int, [_CTX]),
+    "oak_comm_init_loopback": (C.c_int, [_CTX, C.c_int32]),
     "oak_comm_allreduce_stats": (C.c_int, [_CTX]),
     "oak_comm_allreduce_host": (C.c_int, [_CTX, _D, C.c_int64]),
     "oak_bench_gram_resident": (C.c_int, [_CTX, _DESC, _D]),
@@ -542,6 +543,10 @@ class HipContext:
 
     def comm_init(self, unique_id: bytes, nranks: int, rank: int):
         _check(self._lib.oak_comm_init(self._h, unique_id, int(nranks), int(rank)))
+
+    def comm_init_loopback(self, nranks: int):
+        """Test communicator: `nranks` identical ranks (every all-reduce multiplies by nranks)."""
+        _check(self._lib.oak_comm_init_loopback(self._h, int(nranks)))
 
     def comm_destroy(self):
         _check(self._lib.oak_comm_destroy(self._h))

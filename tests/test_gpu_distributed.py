@@ -48,3 +48,29 @@ def test_sharded_sgpr_host_reducer_matches_single_context():
         lo, hi = D.shard_bounds(len(X), r, world)
         m = D.ShardedSGPR(c, X[lo:hi], y[lo:hi], Z, len(X), reducer=lambda p, t=total: t)
         assert abs(m.elbo(d, 0.01) - ref) <= 1e-10 * abs(ref)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("route", ["phi", "whitened"])
+def test_loopback_ranks_equal_stacked_rows(world, route):
+    """The N > 1 arithmetic on one GPU: with the loopback communicator (`world` ranks holding the SAME rows, every
+    all-reduce multiplies by `world`) ELBO, hyper-parameter gradient and inducing-input gradient must equal a single-rank
+    run on the rows stacked `world` times -- this exercises the all-reduce placement, the 1/nranks scaling of the
+    replicated <G_uu, dKuu> terms and the replicated tail."""
+    X, y, Z = o.synthetic_problem(1500, 4, 40, seed=9)
+    spec = o.make_spec(4, 2, lengthscales=[1.1, 0.8, 1.5, 1.0], order_variances=[0.7, 1.2, 0.9])
+    d = _capi.KernelDesc(spec)
+    ref_ctx = _capi.HipContext(0)
+    ref_ctx.sgpr_set_data(np.tile(X, (world, 1)), np.tile(y, (world, 1))); ref_ctx.sgpr_set_inducing(Z); ref_ctx.sgpr_set_route(route)
+    e_ref, g_ref, gz_ref = ref_ctx.sgpr_elbo_grad_z(d, 0.05, 40, 4)
+    ctx = _capi.HipContext(0)
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route(route)
+    ctx.comm_init_loopback(world)
+    e = ctx.sgpr_elbo(d, 0.05)
+    e2, g, gz = ctx.sgpr_elbo_grad_z(d, 0.05, 40, 4)
+    assert abs(e - e_ref) <= 1e-11 * abs(e_ref) and abs(e2 - e_ref) <= 1e-11 * abs(e_ref)
+    np.testing.assert_allclose(g, g_ref, rtol=1e-9, atol=1e-9 * np.abs(g_ref).max())
+    np.testing.assert_allclose(gz, gz_ref, rtol=1e-9, atol=1e-9 * np.abs(gz_ref).max())
+    ctx.comm_destroy()
+    assert abs(ctx.sgpr_elbo(d, 0.05) - e_ref) > 1e-3 * abs(e_ref)       # without the communicator it is a different problem
+    ctx.close(); ref_ctx.close()
