@@ -12,8 +12,9 @@
  *   - every function returns an int status (OAK_OK == 0, negative == error) and records a
  *     thread-local message retrievable with oak_last_error();
  *   - all host buffers are caller-owned, C-contiguous, row-major, float64 (int32 where stated);
- *   - the library owns all device memory behind an opaque oak_ctx (one per device, one HIP
- *     stream); a ctx is not thread-safe, distinct ctxs are independent;
+ *   - the library owns all device memory behind an opaque oak_ctx (one per device; a main HIP
+ *     stream plus a side stream for work that overlaps it); a ctx is not thread-safe, distinct
+ *     ctxs are independent;
  *   - there is NO CPU fallback: without a usable HIP device every compute call fails with
  *     OAK_E_HIP.
  */
@@ -86,7 +87,8 @@ int oak_ctx_create(int device, oak_ctx** out);
 int oak_ctx_destroy(oak_ctx* ctx);
 int oak_sync(oak_ctx* ctx);
 /* GPU time (ms, hipEvents on the ctx stream) accumulated per phase since oak_reset_timings; name in {"featurize","gram",
-   "trsm","syrk","reduce","allreduce","tail","total","bwd_tail","bwd_gemm","bwd_gram","bwd_small"}; count = number of
+   "trsm","syrk","reduce","allreduce","tail","total","bwd_tail","bwd_gemm","bwd_gram","bwd_small","bwd_z","predict",
+   "kmeans","kmeans_pp","flow_forward"}; count = number of
    times the phase ran ("gram","syrk","bwd_gemm","bwd_gram" are single kernel launches per panel pass). */
 int oak_last_timing(oak_ctx* ctx, const char* name, double* ms, int32_t* count);
 int oak_reset_timings(oak_ctx* ctx);
