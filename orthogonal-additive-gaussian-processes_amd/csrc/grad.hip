@@ -793,7 +793,9 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     OAK_REQUIRE(lds <= 160 * 1024, "gram_bwd: LDS request %zu exceeds 160 KiB", lds);
     const int64_t nb = B.n;
     const int64_t ncb = (nb + TJ - 1) / TJ;
-    int64_t nrb = ((int64_t)ctx->num_cu * 8 + ncb - 1) / ncb;
+    int wg_per_cu = 16;      // measured: 16.99 / 16.68 / 16.55 ms at 8 / 16 / 32 per CU (headline size)
+    if (const char* e = getenv("OAK_BWD_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 64) wg_per_cu = v; }   // tuning knob
+    int64_t nrb = ((int64_t)ctx->num_cu * wg_per_cu + ncb - 1) / ncb;
     int64_t rows = (na + nrb - 1) / nrb;
     rows = ((rows + RS - 1) / RS) * RS;
     if (rows < RS) rows = RS;

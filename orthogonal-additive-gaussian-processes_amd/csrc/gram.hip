@@ -12,6 +12,7 @@
 // overlap with; the kernel is written to issue the minimum number of DP instructions per pair.
 #include "oak_internal.h"
 #include "exp2w.h"
+#include <cstdlib>
 
 namespace oak {
 
@@ -251,8 +252,10 @@ static int launch_gram_t(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, 
     if (lds > 160 * 1024) { set_error("gram: LDS request %zu exceeds 160 KiB (D=%d)", lds, D); return OAK_E_ARG; }
     const int64_t nb = B.n;
     const int64_t ncb = (nb + TJ - 1) / TJ;
-    // rows per workgroup: enough row-blocks to fill the chip (~8 WGs per CU), at least one row-step
-    int64_t target_wg = (int64_t)ctx->num_cu * 8;
+    // rows per workgroup: enough row-blocks to fill the chip several times over (16 WGs per CU measured best at 2^20 rows:
+    // shorter workgroups leave smaller tails and let the side stream's small kernels in sooner), at least one row-step
+    int64_t target_wg = (int64_t)ctx->num_cu * 16;
+    if (const char* e = getenv("OAK_GRAM_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 64) target_wg = (int64_t)ctx->num_cu * v; }   // tuning knob
     int64_t nrb = (target_wg + ncb - 1) / ncb;
     if (nrb < 1) nrb = 1;
     int64_t rows = (na + nrb - 1) / nrb;
