@@ -274,48 +274,151 @@ __device__ __forceinline__ void potf2_wave(double* Dg /*[NB][PO_P]*/, double* in
     if (bad_at >= 0 && lane == 0 && info != nullptr) atomicMin(info, (int)(j0 + bad_at + 1));
 }
 
-// Every workgroup re-factors the (tiny) diagonal block itself instead of waiting for one producer.  The factor must not
-// be written back over A_jj while a sibling workgroup may still be loading the unfactored block, so the LAST workgroup
+// Every role-A workgroup re-factors the (tiny) diagonal block itself instead of waiting for one producer.  The factor must
+// not be written back over A_jj while a sibling workgroup may still be loading the unfactored block, so the LAST workgroup
 // to finish loading (arrival counter, one per panel) does the write-back.
-__global__ void __launch_bounds__(256) potrf_panel_kernel(double* __restrict__ A, int64_t n, int64_t nrows, int64_t lda, int64_t j0,
-                                                          int* __restrict__ info, int* __restrict__ arrivals) {
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused right-looking step: ONE launch per 32-column panel instead of two (panel kernel + trailing GEMM).
+//   role A (first nA workgroups, 256 rows each): panel j.  Its columns still lack the rank-32 update of panel j-1 (all
+//           earlier panels were applied by role B of earlier launches); the workgroup applies it to its own rows and --
+//           redundantly, 32 x 32 x 32 -- to the diagonal block, then factors the block and solves its rows as before.
+//   role B (remaining workgroups, one 64 x 64 lower tile each): the rank-32 update of panel j-1 on the trailing matrix
+//           BEHIND panel j (columns >= j0 + 32), MFMA.
+// The two roles touch disjoint columns and only read panel j-1, so there is no dependency inside a launch; the dependent
+// chain of the factorisation is 32 launches of ~max(role A, role B) instead of 64 launches.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(320) potrf_step_kernel(double* __restrict__ A, int64_t n, int64_t nrows, int64_t lda, int64_t j0,
+                                                         int* __restrict__ info, int* __restrict__ arrivals, int nA, int ntc) {
     __shared__ __attribute__((aligned(16))) double Dg[PO_NB * PO_P];
+    __shared__ __attribute__((aligned(16))) double Pj[64 * PO_P];       // role A: rows j0.. of panel j-1 (32 used); role B: A-side tile
+    __shared__ __attribute__((aligned(16))) double Pc[64 * PO_P];       // role B: B-side tile
     __shared__ double invd[PO_NB];
     __shared__ int last_loader;
     const int tid = threadIdx.x;
+    const int64_t p0 = j0 - PO_NB;                                      // previous panel's first column (valid when j0 > 0)
+    if ((int)blockIdx.x >= nA) {
+        // ---------------- role B: C[r0:+64, c0:+64] -= P[r0:+64, :] P[c0:+64, :]^T,  P = A[:, p0:p0+32] ----------------
+        const int t = blockIdx.x - nA;
+        const int by = t / ntc, bx = t - by * ntc;
+        if (bx > by || tid >= 256) return;                              // the fifth wave only exists for role A
+        const int64_t s0 = j0 + PO_NB;
+        const int64_t r0 = s0 + 64 * (int64_t)by, c0 = s0 + 64 * (int64_t)bx;
+        {   // stage both 64 x 32 operand tiles (clamped rows; rows past the matrix contribute to outputs that are not stored)
+            const int r = tid >> 2, k8 = (tid & 3) * 8;
+            const int64_t ra = (r0 + r < nrows) ? r0 + r : nrows - 1, rb = (c0 + r < n) ? c0 + r : n - 1;
+            double va[8], vb[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { va[q] = A[ra * lda + p0 + k8 + q]; vb[q] = A[rb * lda + p0 + k8 + q]; }
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { Pj[r * PO_P + k8 + q] = va[q]; Pc[r * PO_P + k8 + q] = vb[q]; }
+        }
+        __syncthreads();
+        const int lane = tid & 63;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int wr = wave >> 1, wc = wave & 1, fi = lane & 15, fk = lane >> 4;
+        double4_t acc[2][2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) acc[g][h] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < PO_NB / 4; ++ks) {
+            double a[2], b[2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) a[g] = Pj[(wr * 32 + 16 * g + fi) * PO_P + 4 * ks + fk];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) b[h] = Pc[(wc * 32 + 16 * h + fi) * PO_P + 4 * ks + fk];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) acc[g][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g], b[h], acc[g][h], 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int64_t row = r0 + wr * 32 + 16 * g + 4 * reg + fk, col = c0 + wc * 32 + 16 * h + fi;
+                    if (row < nrows && col < n) A[row * lda + col] -= acc[g][h][reg];
+                }
+        return;
+    }
+    // ---------------- role A: panel j ----------------
+    // 320 threads: wave 0 factors the diagonal block while the 256 workers (waves 1..4, one row each) apply the pending
+    // update to their rows -- the two halves of the step's critical path overlap.
+    const int wid = tid - 64;                                           // worker id, < 0 for the factor wave
+    const bool worker = wid >= 0;
     const int nb = (n - j0 < PO_NB) ? (int)(n - j0) : PO_NB;
-    {
-        // NB*NB entries, clamped addresses (no divergent loads); identity padding beyond nb
+    const bool pre = j0 > 0;
+    if (pre && worker) {   // rows j0 .. j0+31 of panel j-1
+        const int r = wid >> 3, k4 = (wid & 7) * 4;
+        const int64_t rr = (j0 + r < n) ? j0 + r : n - 1;
+        double v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = A[rr * lda + p0 + k4 + q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Pj[r * PO_P + k4 + q] = (j0 + r < n) ? v[q] : 0.0;
+    }
+    __syncthreads();
+    if (worker) {
+        // NB*NB entries of the diagonal block, clamped addresses; identity padding beyond nb; pending update applied
         constexpr int PER = PO_NB * PO_NB / 256;
         double v[PER];
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
-            const int idx = tid + 256 * q;
+            const int idx = wid + 256 * q;
             const int i = idx / PO_NB, j = idx % PO_NB;
             const int ic = i < nb ? i : nb - 1, jc = j < nb ? j : nb - 1;
-            const double x = A[(j0 + ic) * lda + j0 + jc];
+            double x = A[(j0 + ic) * lda + j0 + jc];
+            if (pre) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < PO_NB; k += 2) {
+                    const double2 a2 = *reinterpret_cast<const double2*>(&Pj[ic * PO_P + k]);
+                    const double2 b2 = *reinterpret_cast<const double2*>(&Pj[jc * PO_P + k]);
+                    s = __builtin_fma(a2.x, b2.x, s);
+                    s = __builtin_fma(a2.y, b2.y, s);
+                }
+                x -= s;
+            }
             v[q] = (i < nb && j < nb) ? ((j <= i) ? x : 0.0) : ((i == j) ? 1.0 : 0.0);
         }
 #pragma unroll
-        for (int q = 0; q < PER; ++q) { const int idx = tid + 256 * q; Dg[(idx / PO_NB) * PO_P + (idx % PO_NB)] = v[q]; }
+        for (int q = 0; q < PER; ++q) { const int idx = wid + 256 * q; Dg[(idx / PO_NB) * PO_P + (idx % PO_NB)] = v[q]; }
     }
     __syncthreads();
-    if (tid == 255) last_loader = (atomicAdd(arrivals, 1) == (int)gridDim.x - 1);
-    if (tid < 64) potf2_wave(Dg, invd, tid, j0, blockIdx.x == 0 ? info : nullptr);
-    __syncthreads();
-    if (last_loader) {
-        for (int idx = tid; idx < nb * nb; idx += 256) {
-            const int i = idx / nb, j = idx - i * nb;
-            A[(j0 + i) * lda + j0 + j] = Dg[i * PO_P + j];
-        }
-    }
-    // rows below the diagonal block: X * L_jj^T = A_panel, one row per lane
-    const int64_t row = j0 + nb + (int64_t)blockIdx.x * 256 + tid;
-    if (row < nrows && nb == PO_NB) {
-        double x[PO_NB];
-        double* ap = A + row * lda + j0;
+    if (tid == 319) last_loader = (atomicAdd(arrivals, 1) == nA - 1);
+    const int64_t row = j0 + nb + (int64_t)blockIdx.x * 256 + wid;
+    const bool has_row = worker && row < nrows && nb == PO_NB;
+    double x[PO_NB];
+    if (!worker) {
+        potf2_wave(Dg, invd, tid, j0, blockIdx.x == 0 ? info : nullptr);
+    } else if (has_row) {
+        // this row of panel j with the pending update of panel j-1 applied (reads its own row and LDS only)
+        const double* ap = A + row * lda + j0;
 #pragma unroll
         for (int c = 0; c < PO_NB; ++c) x[c] = ap[c];
+        if (pre) {
+            double pr[PO_NB];
+            const double* pp = A + row * lda + p0;
+#pragma unroll
+            for (int k = 0; k < PO_NB; ++k) pr[k] = pp[k];
+#pragma unroll
+            for (int c = 0; c < PO_NB; ++c) {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int k = 0; k < PO_NB; k += 2) {
+                    const double2 l2 = *reinterpret_cast<const double2*>(&Pj[c * PO_P + k]);
+                    s0 = __builtin_fma(pr[k], l2.x, s0);
+                    s1 = __builtin_fma(pr[k + 1], l2.y, s1);
+                }
+                x[c] -= s0 + s1;
+            }
+        }
+    }
+    __syncthreads();
+    if (has_row) {   // X * L_jj^T = A_panel, one row per lane
 #pragma unroll
         for (int c = 0; c < PO_NB; ++c) {
             double s0 = x[c], s1 = 0.0;
@@ -328,8 +431,15 @@ __global__ void __launch_bounds__(256) potrf_panel_kernel(double* __restrict__ A
             if (c & 1) s0 = __builtin_fma(-x[c - 1], Dg[c * PO_P + c - 1], s0);
             x[c] = (s0 + s1) * invd[c];
         }
+        double* ap = A + row * lda + j0;
 #pragma unroll
         for (int c = 0; c < PO_NB; ++c) ap[c] = x[c];
+    }
+    if (last_loader && worker) {
+        for (int idx = wid; idx < nb * nb; idx += 256) {
+            const int i = idx / nb, j = idx - i * nb;
+            A[(j0 + i) * lda + j0 + j] = Dg[i * PO_P + j];
+        }
     }
 }
 
@@ -367,16 +477,14 @@ int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, bool check, in
     OAK_CHECK(get_buf_t(ctx, slot ? "potrf_arrivals_side" : "potrf_arrivals", npanel, &d_arr));
     OAK_HIP_CHECK(hipMemsetAsync(d_arr, 0, sizeof(int) * npanel, ctx->stream));
     for (int64_t j0 = 0; j0 < n; j0 += PO_NB) {
-        const int64_t below = n - j0 - PO_NB;              // trailing columns
         const int64_t below_rows = nrows - j0 - PO_NB;     // rows under the diagonal block (extra rows included)
-        const unsigned gp = below_rows > 0 ? (unsigned)((below_rows + 255) / 256) : 1u;
-        potrf_panel_kernel<<<gp, 256, 0, ctx->stream>>>(dA, n, nrows, lda, j0, d_info, d_arr + j0 / PO_NB);
-        if (below > 0) {
-            // trailing update A22 -= L21 L21^T (lower tiles only): MFMA GEMM, K = 32
-            const double* L21 = dA + (j0 + PO_NB) * lda + j0;
-            double* A22 = dA + (j0 + PO_NB) * lda + (j0 + PO_NB);
-            OAK_CHECK(gemm_nt(ctx, L21, L21, A22, below_rows, below, PO_NB, lda, lda, lda, -1.0, 1.0, 1));
-        }
+        const int nA = below_rows > 0 ? (int)((below_rows + 255) / 256) : 1;
+        // role B applies panel j-1 to the trailing matrix behind panel j: columns >= j0 + 32 (none on the first step)
+        const int64_t tc = n - j0 - PO_NB, tr = nrows - j0 - PO_NB;
+        const int ntc = (j0 > 0 && tc > 0) ? (int)((tc + 63) / 64) : 0;
+        const int ntr = (j0 > 0 && tc > 0) ? (int)((tr + 63) / 64) : 0;
+        potrf_step_kernel<<<(unsigned)(nA + ntr * ntc), 320, 0, ctx->stream>>>(dA, n, nrows, lda, j0, d_info, d_arr + j0 / PO_NB, nA,
+                                                                                 ntc > 0 ? ntc : 1);
     }
     dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
     zero_upper_kernel<<<grid, 256, 0, ctx->stream>>>(dA, n, lda);

@@ -5,7 +5,7 @@ sys.path.insert(0, str(ROOT / "orthogonal-additive-gaussian-processes_amd")); sy
 import numpy as np
 from oak import _capi
 from oracle import oak_oracle as o
-X, y, Z = o.synthetic_problem(65536, 16, 1024)
+X, y, Z = o.synthetic_problem(65536, 16, int(sys.argv[1]) if len(sys.argv) > 1 else 1024)
 spec = o.make_spec(16, 2); d = _capi.KernelDesc(spec)
 ctx = _capi.HipContext(0); ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("phi")
 ctx.sgpr_local_stats(d)
