@@ -392,6 +392,18 @@ int oak_device_count(int* count) {
     return OAK_OK;
 }
 
+namespace oak {
+// The side stream carries the latency-bound chol(Kuu) / L^-1 chain next to the DP-saturating Gram and SYRK kernels: give it
+// the highest queue priority so its small kernels are dispatched as soon as their predecessors retire.
+static hipError_t create_side_stream(hipStream_t* s) {
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && hi != lo &&
+        hipStreamCreateWithPriority(s, hipStreamNonBlocking, hi) == hipSuccess)
+        return hipSuccess;
+    return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+}  // namespace oak
+
 int oak_ctx_create(int device, oak_ctx** out) {
     if (!out) { oak::set_error("out is NULL"); return OAK_E_ARG; }
     *out = nullptr;
@@ -407,7 +419,7 @@ int oak_ctx_create(int device, oak_ctx** out) {
     ctx->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
-    if (hipStreamCreate(&ctx->stream) != hipSuccess || hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess ||
+    if (hipStreamCreate(&ctx->stream) != hipSuccess || oak::create_side_stream(&ctx->side) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev0, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev1, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev2, hipEventDisableTiming) != hipSuccess) {
