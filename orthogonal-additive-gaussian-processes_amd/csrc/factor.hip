@@ -288,7 +288,7 @@ __device__ __forceinline__ void potf2_wave(double* Dg /*[NB][PO_P]*/, double* in
 // chain of the factorisation is 32 launches of ~max(role A, role B) instead of 64 launches.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(320) potrf_step_kernel(double* __restrict__ A, int64_t n, int64_t nrows, int64_t lda, int64_t j0,
-                                                         int* __restrict__ info, int* __restrict__ arrivals, int nA, int ntc) {
+                                                         int* __restrict__ info, int* __restrict__ arrivals, int nA, int ntc, int pending) {
     __shared__ __attribute__((aligned(16))) double Dg[PO_NB * PO_P];
     __shared__ __attribute__((aligned(16))) double Pj[64 * PO_P];       // role A: rows j0.. of panel j-1 (32 used); role B: A-side tile
     __shared__ __attribute__((aligned(16))) double Pc[64 * PO_P];       // role B: B-side tile
@@ -350,7 +350,7 @@ __global__ void __launch_bounds__(320) potrf_step_kernel(double* __restrict__ A,
     const int wid = tid - 64;                                           // worker id, < 0 for the factor wave
     const bool worker = wid >= 0;
     const int nb = (n - j0 < PO_NB) ? (int)(n - j0) : PO_NB;
-    const bool pre = j0 > 0;
+    const bool pre = j0 > 0 && pending;                                 // pending = 0: the caller already applied panel j-1
     if (pre && worker) {   // rows j0 .. j0+31 of panel j-1
         const int r = wid >> 3, k4 = (wid & 7) * 4;
         const int64_t rr = (j0 + r < n) ? j0 + r : n - 1;
@@ -476,15 +476,28 @@ int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, bool check, in
     const size_t npanel = (size_t)((n + PO_NB - 1) / PO_NB);
     OAK_CHECK(get_buf_t(ctx, slot ? "potrf_arrivals_side" : "potrf_arrivals", npanel, &d_arr));
     OAK_HIP_CHECK(hipMemsetAsync(d_arr, 0, sizeof(int) * npanel, ctx->stream));
+    // Fused mode (one launch per panel) is launch-latency optimal and wins up to n ~ 6000; beyond that the trailing updates
+    // are HBM-bound and the pipelined 64 x 64 GEMM kernel moves them faster than the single-stage role-B tiles
+    // (n = 16384: 253 ms fused vs 182 ms), so large factorisations fall back to panel + GEMM per step.
+    const bool fused = n <= 6144;
     for (int64_t j0 = 0; j0 < n; j0 += PO_NB) {
         const int64_t below_rows = nrows - j0 - PO_NB;     // rows under the diagonal block (extra rows included)
         const int nA = below_rows > 0 ? (int)((below_rows + 255) / 256) : 1;
-        // role B applies panel j-1 to the trailing matrix behind panel j: columns >= j0 + 32 (none on the first step)
         const int64_t tc = n - j0 - PO_NB, tr = nrows - j0 - PO_NB;
-        const int ntc = (j0 > 0 && tc > 0) ? (int)((tc + 63) / 64) : 0;
-        const int ntr = (j0 > 0 && tc > 0) ? (int)((tr + 63) / 64) : 0;
-        potrf_step_kernel<<<(unsigned)(nA + ntr * ntc), 320, 0, ctx->stream>>>(dA, n, nrows, lda, j0, d_info, d_arr + j0 / PO_NB, nA,
-                                                                                 ntc > 0 ? ntc : 1);
+        if (fused) {
+            // role B applies panel j-1 to the trailing matrix behind panel j: columns >= j0 + 32 (none on the first step)
+            const int ntc = (j0 > 0 && tc > 0) ? (int)((tc + 63) / 64) : 0;
+            const int ntr = (j0 > 0 && tc > 0) ? (int)((tr + 63) / 64) : 0;
+            potrf_step_kernel<<<(unsigned)(nA + ntr * ntc), 320, 0, ctx->stream>>>(dA, n, nrows, lda, j0, d_info, d_arr + j0 / PO_NB, nA,
+                                                                                     ntc > 0 ? ntc : 1, 1);
+        } else {
+            potrf_step_kernel<<<(unsigned)nA, 320, 0, ctx->stream>>>(dA, n, nrows, lda, j0, d_info, d_arr + j0 / PO_NB, nA, 1, 0);
+            if (tc > 0) {   // trailing update A22 -= L21 L21^T (lower tiles only), K = 32
+                const double* L21 = dA + (j0 + PO_NB) * lda + j0;
+                double* A22 = dA + (j0 + PO_NB) * lda + (j0 + PO_NB);
+                OAK_CHECK(gemm_nt(ctx, L21, L21, A22, tr, tc, PO_NB, lda, lda, lda, -1.0, 1.0, 1));
+            }
+        }
     }
     dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
     zero_upper_kernel<<<grid, 256, 0, ctx->stream>>>(dA, n, lda);

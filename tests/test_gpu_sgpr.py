@@ -273,3 +273,19 @@ def test_effective_L_of_get_model_sufficient_statistics(hip):
     K = o.oak_K(kernel_to_spec(mf.kernel), X[:80]) + float(mf.likelihood.variance.numpy()) * np.eye(80)
     np.testing.assert_allclose(np.asarray(L2), np.linalg.cholesky(K), rtol=1e-9, atol=1e-11)
     assert np.asarray(get_model_sufficient_statistics(mf, get_L=False)).shape == (80, 1)
+
+
+def test_gpr_beyond_the_fused_cholesky_size(hip):
+    """N = 6500 > 6144: the full-GP Cholesky takes the panel + GEMM path instead of the fused one-launch-per-panel path."""
+    N, D = 6500, 4
+    X, y, _ = o.synthetic_problem(N, D, 8, seed=21)
+    spec = o.make_spec(D, 2, lengthscales=[1.2, 0.9, 1.5, 1.0])
+    d = _capi.KernelDesc(spec)
+    hip.gpr_set_data(X, y)
+    lml = hip.gpr_log_marginal(d, 0.2)
+    ref = o.gpr_log_marginal_likelihood(spec, X, y, 0.2)
+    assert rel(lml, ref) <= 1e-10
+    Xs = np.random.default_rng(2).standard_normal((40, D))
+    m, v = hip.gpr_predict(d, Xs)
+    mr, vr = o.gpr_predict_f(spec, X, y, 0.2, Xs)
+    assert np.abs(m - mr[:, 0]).max() <= 1e-9 * max(1.0, np.abs(mr).max()) and np.abs(v - vr[:, 0]).max() <= 1e-9 * max(1.0, np.abs(vr).max())
