@@ -2,7 +2,8 @@
 // oak/utils.py:187-198: cholesky, triangular_solve, matmul).
 //
 //  * syrk_panel : Phi += P^T P for a row panel P [nrows x M] of Kfu, fp64 MFMA (v_mfma_f64_16x16x4),
-//                 128x128 tiles of the upper triangle x split-N, LDS-staged operands, partials reduced in fixed order.
+//                 64x64 blocks of the upper triangle, four per workgroup (descriptor table) x split-N, LDS-staged operands,
+//                 partials reduced in fixed order.
 //                 This is the dominant kernel of an ELBO evaluation: M(M+1)N flops.
 //  (Cholesky, triangular solves and the general MFMA GEMM live in factor.hip.)
 #include "oak_internal.h"

@@ -3,10 +3,13 @@
 //
 // The tail is latency-bound at M <= 2048, so the design goal is few, wide launches:
 //   * gemm_mfma  : C = beta*C + alpha*A*op(B), 64x64 tiles, v_mfma_f64_16x16x4, LDS pitches chosen conflict-free.
-//   * potrf_lower: right-looking, NB = 32.  The diagonal block is factored by ONE wave (lane = row, rows in
-//                  registers, finished entries mirrored to LDS for broadcast reads, no barriers); panel rows are
-//                  solved one per lane.  Every launch costs >= 5 us on this system, so the tail is launch-count bound.
-//   * trsm_rows  : NB = 128 blocked: small in-LDS leaf solves + MFMA GEMM updates.
+//   * potrf_lower: right-looking, NB = 32, ONE fused launch per panel (potrf_step_kernel): the diagonal block is factored
+//                  by one wave (lane = row, rows in registers, finished entries mirrored to LDS for broadcast reads, no
+//                  barriers) while the other waves apply the previous panel's pending update to their rows, which are then
+//                  solved one per lane; the remaining workgroups of the launch update the trailing matrix with MFMA
+//                  tiles.  Every launch costs >= 5 us on this system, so the tail is launch-count bound.
+//   * trsm_rows  : NB = 128 blocked: in-LDS leaf solves + MFMA GEMM updates; with >= 8192 right-hand sides left-looking,
+//                  the diagonal blocks inverted once and applied as GEMMs.
 #include "oak_internal.h"
 
 namespace oak {
