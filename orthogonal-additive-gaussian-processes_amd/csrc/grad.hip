@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(256) featurize_dx_kernel(DevDesc dd, DevMeasur
 }
 
 template <int R, int DMAX, int CPT, bool ALLRBF, bool UNITBV>
-__global__ void __launch_bounds__(256, (DMAX <= 16 ? 2 : 1))
+__global__ void __launch_bounds__(256, (DMAX <= 8 ? 2 : 1))      // 16 dims x 2 columns of accumulators: no spills at one wave per SIMD
 gram_bwd_z_kernel(const DevDesc dd, const double* __restrict__ tables, const double* __restrict__ Apack, int64_t a0, int64_t na,
                   const double* __restrict__ Bxs, const double* __restrict__ Bcn, const double* __restrict__ Bdz, int64_t b_ld,
                   int64_t nb, const double* __restrict__ G, int64_t ldg, const double* __restrict__ yA,
