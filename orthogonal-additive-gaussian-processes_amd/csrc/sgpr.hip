@@ -273,6 +273,34 @@ int sgpr_forward(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, doubl
     return rc;
 }
 
+// out[0] = sum log diag LB, out[1] = c^T c, out[2] = tr W, out[3..5] = (kappa, yy, nrows), out[6] = sum log diag L
+__global__ void __launch_bounds__(256) tail_scalars_kernel(const double* __restrict__ LB, const double* __restrict__ c,
+                                                           const double* __restrict__ W, const double* __restrict__ L, int64_t M,
+                                                           const double* __restrict__ kappa3, double* __restrict__ out) {
+    __shared__ double red[4][256];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int64_t i = threadIdx.x; i < M; i += 256) {
+        a0 += log(LB[i * M + i]);
+        a1 = __builtin_fma(c[i], c[i], a1);
+        a2 += W[i * M + i];
+        a3 += log(L[i * M + i]);
+    }
+    red[0][threadIdx.x] = a0; red[1][threadIdx.x] = a1; red[2][threadIdx.x] = a2; red[3][threadIdx.x] = a3;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[q][threadIdx.x] += red[q][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        out[0] = red[0][0]; out[1] = red[1][0]; out[2] = red[2][0];
+        out[3] = kappa3[0]; out[4] = kappa3[1]; out[5] = kappa3[2];
+        out[6] = red[3][0];
+    }
+}
+
 int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out,
               int l_state) {
     OAK_REQUIRE(ctx->have_stats, "SGPR tail: no sufficient statistics (call local_stats / set_stats first)");
@@ -338,12 +366,9 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
         OAK_CHECK(trsm_rows(ctx, dLB, M, M, dc, 1, M, 0));
     }
     OAK_CHECK(scale_vec(ctx, 1.0 / noise_var, dc, M));
-    // scalars
-    OAK_CHECK(reduce_sum(ctx, dLB, M, dscal + 0, 2, M + 1));    // sum log diag LB
-    OAK_CHECK(reduce_sum(ctx, dc, M, dscal + 1, 1, 1));         // c^T c
-    OAK_CHECK(reduce_sum(ctx, dT2, M, dscal + 2, 0, M + 1));    // tr W
-    OAK_CHECK(copy_d2d(ctx, dscal + 3, st.kappa, sizeof(double) * 3));   // kappa, yy, nrows
-    OAK_CHECK(reduce_sum(ctx, dL, M, dscal + 6, 2, M + 1));     // sum log diag L
+    // scalars: sum log diag LB, c^T c, tr W, (kappa, yy, nrows), sum log diag L -- one small kernel, fixed reduction trees
+    tail_scalars_kernel<<<1, 256, 0, ctx->stream>>>(dLB, dc, dT2, dL, M, st.kappa, dscal);
+    OAK_HIP_CHECK(hipGetLastError());
     double h[8] = {0};
     OAK_HIP_CHECK(hipMemcpyAsync(h, dscal, sizeof(double) * 7, hipMemcpyDeviceToHost, ctx->stream));
     if (l_state == 2) OAK_CHECK(potrf_check(ctx, 1, M));      // Kuu (side stream) first: it is the upstream failure
