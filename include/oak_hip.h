@@ -180,6 +180,28 @@ int oak_gpr_predict(oak_ctx* ctx, const oak_kernel_desc* desc,
 int oak_gpr_log_marginal_grad(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var,
                               double* out, double* grad_out);
 
+/* ---- SVGP, whitened, diagonal q, Bernoulli likelihood: the model the classification example puts on the OAK
+ *      kernel (examples/uci/uci_classification_train.py:108-116: gpflow.models.SVGP(kernel, Bernoulli(invlink),
+ *      Z, whiten=True, q_diag=True); its elbo/predict_f/predict_log_density, and the posterior pieces
+ *      oak/utils.py:174-179 reads).  Data and inducing inputs come from oak_sgpr_set_data (Y in {0,1}) and
+ *      oak_sgpr_set_inducing.  q_mu, q_sqrt [M].  (gh_x, gh_w) [n_gh <= 64] is numpy's hermgauss rule
+ *      (GPflow: 20 nodes); link 0: p = sigmoid(f)(1 - 2 eps) + eps (the example's inv_logit, eps = 1e-3),
+ *      link 1: p = Phi(f)(1 - 2 eps) + eps (GPflow's inv_probit). ------------------------------------- */
+/* elbo = sum_n E_q[log p(y_n | f_n)] - KL(q(v) || N(0, I)).  grad_out NULL: forward only; otherwise grad_out
+   [oak_grad_len, noise slot 0], grad_qmu [M], grad_qsqrt [M] receive d elbo / d (constrained parameter). */
+int oak_svgp_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, const double* q_mu, const double* q_sqrt,
+                       double jitter, const double* gh_x, const double* gh_w, int32_t n_gh, int32_t link,
+                       double link_eps, double* elbo_out, double* grad_out, double* grad_qmu, double* grad_qsqrt);
+/* predict_f: mean, var [Ns].  Ys/logdens non-NULL: also predict_log_density(Xs, Ys) [Ns] (needs the rule). */
+int oak_svgp_predict(oak_ctx* ctx, const oak_kernel_desc* desc, const double* q_mu, const double* q_sqrt,
+                     double jitter, const double* Xs, int64_t Ns, int32_t ldx, double* mean, double* var,
+                     const double* Ys, double* logdens, const double* gh_x, const double* gh_w, int32_t n_gh,
+                     int32_t link, double link_eps);
+/* posterior.alpha [M] and (L_out non-NULL) chol(inv(posterior.Qinv)) [M x M], oak/utils.py:174-179;
+   OAK_E_NOTPD when some q_sqrt >= 1 (the reference's Cholesky fails there). */
+int oak_svgp_posterior(oak_ctx* ctx, const oak_kernel_desc* desc, const double* q_mu, const double* q_sqrt,
+                       double jitter, double* alpha_out, double* L_out);
+
 /* ---- Sobol (replaces compute_sobol_oak, oak/utils.py:338-435, with compute_L :221-240,
  *      compute_L_binary_kernel :243-272, compute_L_categorical_kernel :275-309,
  *      compute_L_empirical_measure :312-335) ------------------------------------------------- */

@@ -649,12 +649,12 @@ __global__ void __launch_bounds__(256) reduce_gz_kernel(const double* __restrict
     gz[i] += s;
 }
 
-// Diagonal term: sum_n gconst * dKdiag_n / dtheta, one point per lane.
+// Diagonal term: sum_n gconst * (gvec ? gvec[n] : 1) * dKdiag_n / dtheta, one point per lane.
 template <int R>
 __global__ void __launch_bounds__(256)
 diag_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen, const double* __restrict__ Axs,
                 const double* __restrict__ Acn, const double* __restrict__ Adcn, int64_t a_ld, int64_t n, double gconst,
-                int64_t rows_per_wg, double* __restrict__ partial) {
+                const double* __restrict__ gvec, int64_t rows_per_wg, double* __restrict__ partial) {
     constexpr int RR = R > 0 ? R : 1;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int D = dd.D;
@@ -680,7 +680,7 @@ diag_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
         for (int t = 0; t < DT; ++t) {
             const int64_t i = i0 + t * 256 + tid;
             const bool ok = i < i_end;
-            g[t] = ok ? gconst : 0.0;
+            g[t] = ok ? (gvec != nullptr ? gconst * gvec[i] : gconst) : 0.0;
             ic[t] = ok ? i : i_begin;
 #pragma unroll
             for (int q = 0; q < RR; ++q) e[t][q] = 0.0;
@@ -770,11 +770,11 @@ __global__ void __launch_bounds__(256) reduce_records_kernel(const double* __res
     if (threadIdx.x == 0) out[j] += red[0];
 }
 
-static int64_t record_len(const PreparedKernel& pk) { return 2 * pk.dd.D + (pk.dd.R + 1) + (int64_t)pk.tables.size(); }
+int64_t record_len(const PreparedKernel& pk) { return 2 * pk.dd.D + (pk.dd.R + 1) + (int64_t)pk.tables.size(); }
 
 // d_rec[reclen] += contraction of G (na x nb block, + optional rank-1 yA avec^T) with dK/dtheta over pairs (A rows a0.., B)
 int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int64_t na, const Feat& B, const double* d_G,
-             int64_t ldg, double g_scale, const double* d_yA, const double* d_avec, double* d_rec, bool want_gk = true) {
+             int64_t ldg, double g_scale, const double* d_yA, const double* d_avec, double* d_rec, bool want_gk) {
     if (na <= 0 || B.n <= 0) return OAK_OK;
     OAK_REQUIRE(A.dcn != nullptr && B.dcn != nullptr, "gram_bwd: features were not prepared for the backward pass");
     const int D = pk.dd.D, R = pk.dd.R;
@@ -911,7 +911,7 @@ int gram_bwd_z(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0
     return OAK_OK;
 }
 
-int diag_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, double gconst, double* d_rec) {
+int diag_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, double gconst, double* d_rec, const double* d_gvec) {
     if (A.n <= 0) return OAK_OK;
     const int D = pk.dd.D, R = pk.dd.R;
     const int tablen = (int)pk.tables.size();
@@ -924,7 +924,7 @@ int diag_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, double gcons
     double* d_part = nullptr;
     OAK_CHECK(get_buf_t(ctx, "bwd_part_diag", (size_t)(nwg * reclen), &d_part));
     const size_t lds = sizeof(double) * ((size_t)8 * D + tablen + 4 * (R + 1) + 8);
-#define OAK_DB_CASE(RR) case RR: diag_bwd_kernel<RR><<<(unsigned)nwg, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen, A.xs, A.cn, A.dcn, A.ld, A.n, gconst, rows, d_part); break;
+#define OAK_DB_CASE(RR) case RR: diag_bwd_kernel<RR><<<(unsigned)nwg, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen, A.xs, A.cn, A.dcn, A.ld, A.n, gconst, d_gvec, rows, d_part); break;
     switch (R) {
         OAK_DB_CASE(0) OAK_DB_CASE(1) OAK_DB_CASE(2) OAK_DB_CASE(3) OAK_DB_CASE(4)
         OAK_DB_CASE(5) OAK_DB_CASE(6) OAK_DB_CASE(7) OAK_DB_CASE(8)
@@ -969,7 +969,7 @@ int set_identity(oak_ctx* ctx, double* dA, int64_t n) {
 
 // scatter a device record [gl | gk | gw | gtab] into the public gradient layout
 // [lengthscale (D) | base_var (D) | order_var (n_order_var) | noise | dTable (meas_data_len)]
-static void scatter_record(const oak_kernel_desc* desc, const PreparedKernel& pk, const std::vector<double>& rec, double dnoise,
+void scatter_record(const oak_kernel_desc* desc, const PreparedKernel& pk, const std::vector<double>& rec, double dnoise,
                            double* grad_out) {
     const int D = desc->num_dims, R = desc->max_depth;
     const int64_t glen = 2 * D + desc->n_order_var + 1 + desc->meas_data_len;

@@ -199,6 +199,16 @@ int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter,
 int sgpr_forward(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out);
 int sgpr_ensure_alpha(oak_ctx* ctx);
 
+// backward pieces shared with the SVGP path (grad.hip) ------------------------------------------------
+int64_t record_len(const PreparedKernel& pk);      // [d/d lengthscale' (D) | d/d log base_var (D) | d/d w (R+1) | d/d tables]
+// d_rec += contraction of the adjoint block G (na x nb, + optional rank-1 yA avec^T), scaled by g_scale, with dK/dtheta
+int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int64_t na, const Feat& B, const double* d_G,
+             int64_t ldg, double g_scale, const double* d_yA, const double* d_avec, double* d_rec, bool want_gk = true);
+// d_rec += sum_n gconst * (d_gvec ? d_gvec[n] : 1) * dKdiag_n/dtheta
+int diag_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, double gconst, double* d_rec, const double* d_gvec = nullptr);
+void scatter_record(const oak_kernel_desc* desc, const PreparedKernel& pk, const std::vector<double>& rec, double dnoise,
+                    double* grad_out);
+
 // collectives --------------------------------------------------------------------------------------
 int comm_allreduce_dev(oak_ctx* ctx, double* d_buf, int64_t n);
 

@@ -84,6 +84,10 @@ SIGNATURES = {
     "oak_sgpr_effective_L": (C.c_int, [_CTX, _D]),
     "oak_gpr_chol": (C.c_int, [_CTX, _D]),
     "oak_sgpr_elbo_grad_z": (C.c_int, [_CTX, _DESC, C.c_double, C.c_double, _D, _D, _D]),
+    "oak_svgp_elbo_grad": (C.c_int, [_CTX, _DESC, _D, _D, C.c_double, _D, _D, C.c_int32, C.c_int32, C.c_double, _D, _D, _D, _D]),
+    "oak_svgp_predict": (C.c_int, [_CTX, _DESC, _D, _D, C.c_double, _D, C.c_int64, C.c_int32, _D, _D, _D, _D, _D, _D, C.c_int32,
+                                   C.c_int32, C.c_double]),
+    "oak_svgp_posterior": (C.c_int, [_CTX, _DESC, _D, _D, C.c_double, _D, _D]),
     "oak_gpr_set_data": (C.c_int, [_CTX, _D, _D, C.c_int64, C.c_int32]),
     "oak_gpr_log_marginal": (C.c_int, [_CTX, _DESC, C.c_double, _D]),
     "oak_gpr_alpha": (C.c_int, [_CTX, _D]),
@@ -487,6 +491,57 @@ class HipContext:
         mean, var = np.empty(Xs.shape[0]), np.empty(Xs.shape[0])
         _check(self._lib.oak_gpr_predict(self._h, desc.ref, _dp(Xs), Xs.shape[0], Xs.shape[1], _dp(mean), _dp(var)))
         return mean, var
+
+    # -- SVGP (whitened, diagonal q, Bernoulli) -----------------------------------------------------
+    LINKS = {"logit": 0, "probit": 1}
+
+    @staticmethod
+    def _gh(n_gh: int):
+        x, w = np.polynomial.hermite.hermgauss(int(n_gh))
+        return np.ascontiguousarray(x, dtype=np.float64), np.ascontiguousarray(w, dtype=np.float64)
+
+    def svgp_elbo(self, desc: KernelDesc, q_mu, q_sqrt, link: str = "logit", link_eps: float = 1e-3, jitter: float = 1e-6,
+                  n_gh: int = 20, grad: bool = False):
+        """elbo, or with ``grad`` (elbo, grad [grad_len], d/d q_mu [M], d/d q_sqrt [M])."""
+        q_mu, q_sqrt = _f64(q_mu, 1), _f64(q_sqrt, 1)
+        x, w = self._gh(n_gh)
+        e = C.c_double()
+        if not grad:
+            _check(self._lib.oak_svgp_elbo_grad(self._h, desc.ref, _dp(q_mu), _dp(q_sqrt), float(jitter), _dp(x), _dp(w), len(x),
+                                                self.LINKS[link], float(link_eps), C.byref(e), None, None, None))
+            return e.value
+        g, gm, gs = np.zeros(self.grad_len(desc)), np.empty(q_mu.size), np.empty(q_mu.size)
+        _check(self._lib.oak_svgp_elbo_grad(self._h, desc.ref, _dp(q_mu), _dp(q_sqrt), float(jitter), _dp(x), _dp(w), len(x),
+                                            self.LINKS[link], float(link_eps), C.byref(e), _dp(g), _dp(gm), _dp(gs)))
+        return e.value, g, gm, gs
+
+    def svgp_predict(self, desc: KernelDesc, q_mu, q_sqrt, Xs, Ys=None, link: str = "logit", link_eps: float = 1e-3,
+                     jitter: float = 1e-6, n_gh: int = 20):
+        """(mean, var), or with ``Ys`` (mean, var, log predictive density)."""
+        q_mu, q_sqrt, Xs = _f64(q_mu, 1), _f64(q_sqrt, 1), _f64(Xs, 2)
+        mean, var = np.empty(Xs.shape[0]), np.empty(Xs.shape[0])
+        x, w = self._gh(n_gh)
+        if Ys is None:
+            _check(self._lib.oak_svgp_predict(self._h, desc.ref, _dp(q_mu), _dp(q_sqrt), float(jitter), _dp(Xs), Xs.shape[0],
+                                              Xs.shape[1], _dp(mean), _dp(var), None, None, _dp(x), _dp(w), len(x),
+                                              self.LINKS[link], float(link_eps)))
+            return mean, var
+        Ys = _f64(Ys, 1)
+        if Ys.size != Xs.shape[0]:
+            raise ValueError("Ys must hold one label per row of Xs")
+        ld = np.empty(Xs.shape[0])
+        _check(self._lib.oak_svgp_predict(self._h, desc.ref, _dp(q_mu), _dp(q_sqrt), float(jitter), _dp(Xs), Xs.shape[0],
+                                          Xs.shape[1], _dp(mean), _dp(var), _dp(Ys), _dp(ld), _dp(x), _dp(w), len(x),
+                                          self.LINKS[link], float(link_eps)))
+        return mean, var, ld
+
+    def svgp_posterior(self, desc: KernelDesc, q_mu, q_sqrt, jitter: float = 1e-6, get_L: bool = True):
+        q_mu, q_sqrt = _f64(q_mu, 1), _f64(q_sqrt, 1)
+        alpha = np.empty(q_mu.size)
+        L = np.empty((q_mu.size, q_mu.size)) if get_L else None
+        _check(self._lib.oak_svgp_posterior(self._h, desc.ref, _dp(q_mu), _dp(q_sqrt), float(jitter), _dp(alpha),
+                                            _dp(L) if get_L else None))
+        return (alpha, L) if get_L else alpha
 
     # -- Sobol / components -------------------------------------------------------------------
     @staticmethod
