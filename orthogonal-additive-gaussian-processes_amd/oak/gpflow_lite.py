@@ -361,8 +361,41 @@ class Gaussian(Module):
         return np.sum(-0.5 * (np.log(2 * np.pi) + np.log(var) + np.square(Fmu - np.asarray(Y)) / var), axis=-1)
 
 
+def inv_logit(x, jitter=1e-3):
+    """The classification example's link (examples/uci/uci_classification_train.py:43-45): sigmoid(x)(1 - 2 jitter) + jitter."""
+    x = np.asarray(x, dtype=np.float64)
+    return TensorLike(1.0 / (1.0 + np.exp(-x)) * (1 - 2 * jitter) + jitter)
+
+
+def inv_probit(x, jitter=1e-3):
+    """gpflow.likelihoods.utils.inv_probit: Phi(x)(1 - 2 jitter) + jitter."""
+    from scipy.special import erf
+    x = np.asarray(x, dtype=np.float64)
+    return TensorLike(0.5 * (1.0 + erf(x / np.sqrt(2.0))) * (1 - 2 * jitter) + jitter)
+
+
+inv_logit._oak_link = ("logit", 1e-3)
+inv_probit._oak_link = ("probit", 1e-3)
+
+
+class Bernoulli(Module):
+    """gpflow.likelihoods.Bernoulli(invlink): log p(y | f) = log(where(y == 1, p, 1 - p)), p = invlink(f); expectations
+    by 20-node Gauss-Hermite quadrature.  The quadrature runs inside the device kernels, which know two links:
+    :func:`inv_logit` (the reference's classification example) and :func:`inv_probit` (GPflow's default)."""
+
+    num_gauss_hermite_points = 20
+
+    def __init__(self, invlink=inv_probit):
+        link = getattr(invlink, "_oak_link", None)
+        if link is None:
+            raise NotImplementedError("Bernoulli: pass gpflow_lite.inv_logit or gpflow_lite.inv_probit as the inverse link")
+        self.invlink = invlink
+        self._link, self._link_eps = link
+
+
 class likelihoods:
     Gaussian = Gaussian
+    Bernoulli = Bernoulli
 
 
 class InducingPoints(Module):
@@ -564,9 +597,168 @@ class SGPR(GPModel):
         return obj, g, desc
 
 
+class _SVGPPosterior:
+    """The two members of gpflow's posterior object that oak/utils.py:174-179 reads."""
+
+    def __init__(self, model):
+        self._m = model
+
+    @property
+    def alpha(self):
+        return TensorLike(self._m._posterior(get_L=False)[:, None])
+
+    @property
+    def Qinv(self):
+        """[1, M, M]: Lm^-T (I - diag(q_sqrt^2)) Lm^-1, rebuilt from the factor the device returns (inv(Qinv) = L L^T)."""
+        _, L = self._m._posterior(get_L=True)
+        Linv = np.linalg.inv(L)
+        return TensorLike((Linv.T @ Linv)[None])
+
+
+class SVGP(Module):
+    """gpflow.models.SVGP as the classification example builds it (examples/uci/uci_classification_train.py:108-116):
+    ``whiten=True, q_diag=True``, one latent, Bernoulli likelihood, full-batch data handed to ``elbo`` /
+    ``training_loss_closure``.  Other configurations are not on the OAK path and raise NotImplementedError."""
+
+    def __init__(self, kernel, likelihood, inducing_variable, *, mean_function=None, num_latent_gps=1, q_diag=False,
+                 q_mu=None, q_sqrt=None, whiten=True, num_data=None):
+        if not (whiten and q_diag) or num_latent_gps != 1 or mean_function is not None:
+            raise NotImplementedError("SVGP: only whiten=True, q_diag=True, one latent, zero mean (the reference's use)")
+        if not isinstance(likelihood, Bernoulli):
+            raise NotImplementedError("SVGP: only the Bernoulli likelihood is on the OAK path")
+        if num_data is not None:
+            raise NotImplementedError("SVGP: minibatch scaling (num_data) is not used by the reference")
+        self.kernel = kernel
+        self.likelihood = likelihood
+        if not isinstance(inducing_variable, InducingPoints):
+            inducing_variable = InducingPoints(inducing_variable)
+        self.inducing_variable = inducing_variable
+        M = len(inducing_variable)
+        self.q_mu = Parameter(np.zeros((M, 1)) if q_mu is None else np.asarray(q_mu, dtype=np.float64).reshape(M, 1))
+        self.q_sqrt = Parameter(np.ones((M, 1)) if q_sqrt is None else np.asarray(q_sqrt, dtype=np.float64).reshape(M, 1),
+                                transform=positive())
+        self.data = None                 # the example assigns ``model.data`` before asking for Sobol indices (:150)
+        self._hip = _capi.HipContext(_capi.default_context().device)
+        self._z_sent = self._data_sent = None
+
+    # -- device state -----------------------------------------------------------------------------
+    def _spec(self):
+        from .oak_kernel import kernel_to_spec
+        return kernel_to_spec(self.kernel)
+
+    def _desc(self):
+        return _capi.KernelDesc(self._spec())
+
+    def _sync_Z(self):
+        Z = self.inducing_variable.Z.numpy()
+        if self._z_sent is None or self._z_sent.shape != Z.shape or not np.array_equal(self._z_sent, Z):
+            self._hip.sgpr_set_inducing(Z)
+            self._z_sent = Z.copy()
+
+    def _sync_data(self, data):
+        X = np.asarray(data[0], dtype=np.float64)
+        Y = np.asarray(data[1], dtype=np.float64).reshape(len(X), -1)
+        if Y.shape[1] != 1:
+            raise NotImplementedError("the HIP path supports a single output column")
+        key = self._data_sent
+        if key is None or key[0].shape != X.shape or not (np.array_equal(key[0], X) and np.array_equal(key[1], Y)):
+            self._hip.sgpr_set_data(X, Y)
+            self._data_sent = (X.copy(), Y.copy())
+            if self._z_sent is not None and self._z_sent.shape[1] != X.shape[1]:
+                self._z_sent = None          # the library drops inducing inputs of another column count
+
+    def _q(self):
+        return self.q_mu.numpy().reshape(-1), self.q_sqrt.numpy().reshape(-1)
+
+    def _lik(self):
+        return dict(link=self.likelihood._link, link_eps=self.likelihood._link_eps, jitter=default_jitter(),
+                    n_gh=self.likelihood.num_gauss_hermite_points)
+
+    # -- objective -----------------------------------------------------------------------------------
+    def prior_kl(self):
+        m, s = self._q()
+        return float(0.5 * (np.sum(m * m) - m.size - np.sum(np.log(s * s)) + np.sum(s * s)))
+
+    def elbo(self, data):
+        self._sync_data(data)
+        self._sync_Z()
+        return self._hip.svgp_elbo(self._desc(), *self._q(), **self._lik())
+
+    def maximum_log_likelihood_objective(self, data):
+        return self.elbo(data)
+
+    def log_prior_density(self):
+        return float(sum(p.log_prior_density() for p in self.trainable_parameters))
+
+    def training_loss(self, data):
+        return -(self.elbo(data) + self.log_prior_density())
+
+    def training_loss_closure(self, data, compile=True):
+        model = self
+
+        class _Closure:
+            def __call__(self):
+                return model.training_loss(data)
+
+            def value_and_grad(self, variables):
+                return model._training_loss_and_grad(data, variables)
+
+        return _Closure()
+
+    def _training_loss_and_grad(self, data, variables):
+        from .oak_kernel import scatter_gradient
+        self._sync_data(data)
+        self._sync_Z()
+        desc = self._desc()
+        obj, gvec, gm, gs = self._hip.svgp_elbo(desc, *self._q(), grad=True, **self._lik())
+        grads = scatter_gradient(self.kernel, self.likelihood, desc, gvec, variables)
+        extra = {id(self.q_mu): gm, id(self.q_sqrt): gs}
+        loss = -(obj + self.log_prior_density())
+        out = []
+        for p, g in zip(variables, grads):
+            g = extra.get(id(p), g)
+            if g is None:
+                raise NotImplementedError(f"no analytic gradient for parameter {p!r}")
+            g = np.asarray(g, dtype=np.float64).reshape(p.shape)
+            if p.prior is not None and hasattr(p.prior, "dlog_prob"):
+                g = g + p.prior.dlog_prob(p.numpy())
+            out.append(-(g * p.transform.dforward(p.unconstrained_variable)))
+        return loss, out
+
+    # -- predictions -----------------------------------------------------------------------------------
+    def predict_f(self, Xnew, full_cov=False, full_output_cov=False):
+        if full_cov:
+            raise NotImplementedError("full_cov=True is not on the OAK path")
+        self._sync_Z()
+        mean, var = self._hip.svgp_predict(self._desc(), *self._q(), np.asarray(Xnew, dtype=np.float64), jitter=default_jitter())
+        return TensorLike(mean[:, None]), TensorLike(var[:, None])
+
+    def predict_log_density(self, data, full_cov=False, full_output_cov=False):
+        X, Y = data
+        self._sync_Z()
+        _, _, ld = self._hip.svgp_predict(self._desc(), *self._q(), np.asarray(X, dtype=np.float64),
+                                          np.asarray(Y, dtype=np.float64).reshape(-1), **self._lik())
+        return TensorLike(ld)
+
+    def _posterior(self, get_L=True):
+        self._sync_Z()
+        return self._hip.svgp_posterior(self._desc(), *self._q(), jitter=default_jitter(), get_L=get_L)
+
+    def posterior(self, precompute_cache=None):
+        return _SVGPPosterior(self)
+
+    def alpha(self):
+        return TensorLike(self._posterior(get_L=False)[:, None])
+
+    def effective_L(self):
+        """chol(inv(posterior.Qinv[0])) of oak/utils.py:174-179."""
+        return self._posterior(get_L=True)[1]
+
+
 class models:
     GPR = GPR
     SGPR = SGPR
+    SVGP = SVGP
     GPModel = GPModel
     BayesianModel = GPModel
 

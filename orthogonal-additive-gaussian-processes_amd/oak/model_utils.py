@@ -29,8 +29,9 @@ def get_kmeans_centers(X: np.ndarray, K: int = 500) -> np.ndarray:
 
 
 def save_model(model: GPModel, filename: Path) -> None:
-    """npz with a single ``hyperparams`` entry listing the trainable parameter values (oak/model_utils.py:44-64)."""
-    values = [p.numpy() for p in model.trainable_parameters]
+    """npz with a single ``hyperparams`` entry listing the trainable parameter values -- every parameter for an SVGP model
+    (oak/model_utils.py:44-64)."""
+    values = [p.numpy() for p in (model.parameters if isinstance(model, gpflow.models.SVGP) else model.trainable_parameters)]
     filename = Path(filename)
     os.makedirs(filename.parents[0], exist_ok=True)
     arr = np.empty(len(values), dtype=object)

@@ -205,7 +205,7 @@ def scatter_gradient(kernel, likelihood, desc: _capi.KernelDesc, gvec: np.ndarra
     g_ov = gvec[2 * D:2 * D + n_ov]
     g_noise = gvec[2 * D + n_ov]
     g_tab = gvec[2 * D + n_ov + 1:]
-    lookup = {id(likelihood.variance): g_noise}
+    lookup = {id(likelihood.variance): g_noise} if hasattr(likelihood, "variance") else {}
     subs = kernel.kernels if isinstance(kernel, OAKKernel) else [kernel]
     if isinstance(kernel, OAKKernel):
         for r, v in enumerate(kernel.variances):

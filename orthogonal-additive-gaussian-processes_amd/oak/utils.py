@@ -87,7 +87,7 @@ def get_model_sufficient_statistics(m, get_L=True):
     """alpha such that the predictive mean is K(x*, Xc) alpha and, with ``get_L`` (the reference's default), the matrix L
     of oak/utils.py:168-218: the "effective" factor inv(L^-1 - LB^-1 L^-1) of a sparse model, chol(K + noise I) of a full
     one."""
-    if not isinstance(m, (gpflow.SGPR, gpflow.GPR)):
+    if not isinstance(m, (gpflow.SGPR, gpflow.GPR, gpflow.SVGP)):
         raise NotImplementedError
     alpha = m.alpha()
     if not get_L:
@@ -112,7 +112,7 @@ def compute_sobol_oak(model, delta: float, mu: float, share_var_across_orders: O
                 raise NotImplementedError
         elif not isinstance(k, (OrthogonalBinary, OrthogonalCategorical)):
             raise NotImplementedError
-    Xc = model.inducing_variable.Z.numpy() if isinstance(model, gpflow.SGPR) else model.data[0]
+    Xc = model.inducing_variable.Z.numpy() if isinstance(model, (gpflow.SGPR, gpflow.SVGP)) else model.data[0]
     alpha = get_model_sufficient_statistics(model, get_L=False)
     desc = _capi.KernelDesc(kernel_to_spec(model.kernel))
     sobol = _capi.default_context().sobol(desc, Xc, np.asarray(alpha).reshape(-1), subsets,

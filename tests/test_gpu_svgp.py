@@ -115,3 +115,116 @@ def test_argument_checks(hip):
         hip.svgp_elbo(d, q_mu, q_sqrt, n_gh=65)
     with pytest.raises(_capi.NotPositiveDefiniteError):
         hip.svgp_elbo(d, q_mu, q_sqrt, jitter=-10.0)
+
+
+# ---- model API: the flow of the reference's classification example -----------------------------------------------------
+def _classification_data(N, D, seed=4):
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(N, D))
+    f = 2.0 * np.sin(X[:, 0]) + 1.5 * X[:, 1] * X[:, 2]
+    y = (rng.uniform(size=N) < 1.0 / (1.0 + np.exp(-3 * f))).astype(float)[:, None]
+    return X, y, f
+
+
+def test_classification_example_flow(hip):
+    """examples/uci/uci_classification_train.py:99-183 on synthetic data: oak_model.fit(optimise=False) builds the kernel,
+    an SVGP with the same kernel is trained by BFGS on the analytic gradient, then predict_f / predict_log_density /
+    Sobol / per-term predictions."""
+    from oak import gpflow_lite as gpflow
+    from oak.gpflow_lite import inv_logit, set_trainable
+    from oak.model_utils import oak_model
+    from oak.utils import get_model_sufficient_statistics, get_prediction_component
+    X, y, _ = _classification_data(900, 4)
+    Xtr, ytr, Xte, yte = X[:700], y[:700], X[700:], y[700:]
+    oak = oak_model(max_interaction_depth=2, num_inducing=50, use_normalising_flow=False)
+    oak.fit(Xtr, ytr, optimise=False)
+    data = (np.asarray(oak.m.data[0]), ytr)
+    Z = data[0][:50].copy()
+    m = gpflow.models.SVGP(kernel=oak.m.kernel, likelihood=gpflow.likelihoods.Bernoulli(invlink=inv_logit), inducing_variable=Z,
+                           whiten=True, q_diag=True)
+    oak.m = m
+    set_trainable(m.inducing_variable, False)
+    assert all(v is not m.inducing_variable.Z for v in m.trainable_variables)
+    # initial point: q_mu = 0, q_sqrt = 1  =>  KL = 0, f ~ prior
+    assert m.prior_kl() == 0.0
+    e0 = m.elbo(data)
+    spec = m._spec()
+    assert abs(e0 - sv.svgp_elbo(spec, data[0], ytr, Z, np.zeros(50), np.ones(50))) <= 1e-10 * abs(e0)
+    res = gpflow.optimizers.Scipy().minimize(m.training_loss_closure(data), m.trainable_variables, method="BFGS",
+                                             options={"maxiter": 60})
+    assert np.isfinite(res.fun) and m.elbo(data) > e0 + 50.0
+    # parity of the trained model against the oracle, and the loss the optimiser saw
+    qm, qs = m.q_mu.numpy().reshape(-1), m.q_sqrt.numpy().reshape(-1)
+    spec = m._spec()
+    er = sv.svgp_elbo(spec, data[0], ytr, Z, qm, qs)
+    assert abs(m.elbo(data) - er) <= 1e-10 * abs(er)
+    assert abs(m.training_loss(data) + er + m.log_prior_density()) <= 1e-9 * abs(er)
+    XT = oak._transform_x(Xte)
+    mu, var = m.predict_f(XT)
+    assert mu.shape == (200, 1) and var.shape == (200, 1) and np.all(np.asarray(var) > 0)
+    prob = np.asarray(inv_logit(mu))
+    err = np.mean((prob > 0.5).astype(float) != yte)
+    assert err < 0.25                                           # labels are noisy draws; chance is 0.5
+    nll = -np.asarray(m.predict_log_density((XT, yte))).mean()
+    assert np.isfinite(nll) and nll < np.log(2.0)
+    np.testing.assert_allclose(np.asarray(m.predict_log_density((XT, yte))), sv.svgp_predict_log_density(spec, XT, yte, Z, qm, qs),
+                               rtol=1e-9, atol=1e-9)
+    # Sobol and the per-term decomposition of the latent mean (uci_classification_train.py:149-178)
+    oak.m.data = data
+    oak.get_sobol()
+    top = {tuple(int(i) for i in oak.tuple_of_indices[j]) for j in np.argsort(oak.normalised_sobols)[::-1][:2]}
+    assert top == {(0,), (1, 2)}
+    alpha = get_model_sufficient_statistics(m, get_L=False)
+    parts = get_prediction_component(m, alpha, XT)
+    const = np.asarray(alpha).sum() * m.kernel.variances[0].numpy()
+    np.testing.assert_allclose(const + np.sum([np.asarray(p) for p in parts], axis=0), np.asarray(mu)[:, 0], rtol=1e-7, atol=1e-7)
+    # posterior object surface read by oak/utils.py:174-179
+    post = m.posterior()
+    ar, _ = sv.svgp_posterior(spec, Z, qm, np.minimum(qs, 0.99))
+    np.testing.assert_allclose(np.asarray(post.alpha)[:, 0], ar, rtol=1e-6, atol=1e-6 * np.abs(ar).max())
+    if np.all(qs < 1.0):
+        a2, L = get_model_sufficient_statistics(m)
+        assert np.asarray(L).shape == (50, 50) and np.allclose(np.triu(np.asarray(L), 1), 0.0)
+
+
+def test_svgp_rejects_configurations_outside_the_reference_use(hip):
+    from oak import gpflow_lite as gpflow
+    from oak.gpflow_lite import inv_logit
+    k = gpflow.kernels.RBF()
+    Z = np.zeros((3, 1))
+    lik = gpflow.likelihoods.Bernoulli(invlink=inv_logit)
+    with pytest.raises(NotImplementedError):
+        gpflow.models.SVGP(k, lik, Z, whiten=False, q_diag=True)
+    with pytest.raises(NotImplementedError):
+        gpflow.models.SVGP(k, lik, Z, whiten=True, q_diag=False)
+    with pytest.raises(NotImplementedError):
+        gpflow.models.SVGP(k, gpflow.likelihoods.Gaussian(), Z, whiten=True, q_diag=True)
+    with pytest.raises(NotImplementedError):
+        gpflow.likelihoods.Bernoulli(invlink=lambda x: x)
+
+
+def test_svgp_save_and_load_all_parameters(hip, tmp_path):
+    """save_model stores every parameter of an SVGP model (oak/model_utils.py:53-56); load_model(load_all_parameters=True)
+    restores them positionally."""
+    from oak import gpflow_lite as gpflow
+    from oak.gpflow_lite import inv_probit
+    from oak.model_utils import load_model, save_model
+    from oak.oak_kernel import OAKKernel
+    rng = np.random.default_rng(0)
+    X = rng.normal(size=(120, 3))
+    y = (rng.uniform(size=(120, 1)) < 0.5).astype(float)
+
+    def build():
+        k = OAKKernel([gpflow.kernels.RBF] * 3, num_dims=3, max_interaction_depth=2, constrain_orthogonal=True)
+        return gpflow.models.SVGP(k, gpflow.likelihoods.Bernoulli(invlink=inv_probit), X[:10].copy(), whiten=True, q_diag=True)
+
+    a = build()
+    a.q_mu.assign(rng.normal(size=(10, 1)))
+    a.q_sqrt.assign(rng.uniform(0.3, 0.8, size=(10, 1)))
+    a.kernel.variances[1].assign(0.37)
+    save_model(a, tmp_path / "m" / "svgp.npz")
+    b = build()
+    load_model(b, tmp_path / "m" / "svgp.npz", load_all_parameters=True)
+    for pa, pb in zip(a.parameters, b.parameters):
+        np.testing.assert_array_equal(np.asarray(pa.numpy()), np.asarray(pb.numpy()))
+    assert a.elbo((X, y)) == b.elbo((X, y))
