@@ -741,6 +741,38 @@ int trsm_rows(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, double* dB
         }
     } else {
         const int64_t last = ((n - 1) / NB) * NB;
+        if (nrhs >= 8192) {
+            // Same formulation for the transposed solve (rows x with x L = b, i.e. L^T x^T = b^T; the N-sized adjoint solve of
+            // the SVGP reverse pass): blocks from the last to the first, left-looking.  Block j receives the finished
+            // later blocks in one GEMM  B[:, j] -= X[:, j+1:] L[j+1:, j]  -- against a transposed copy of L so that it is
+            // the NT form the 128 x 128 MFMA kernel takes -- then  X[:, j] = B[:, j] L_jj^-1.
+            double *dInvT = nullptr, *dTmp = nullptr, *dLT = nullptr;
+            const int64_t nfull = n / NB;
+            const int64_t ldt = (n + 1) & ~(int64_t)1;
+            OAK_CHECK(get_buf_t(ctx, "trsm_invT", (size_t)(nfull > 0 ? nfull : 1) * NB * NB, &dInvT));
+            OAK_CHECK(get_buf_t(ctx, "trsm_tmp", (size_t)nrhs * NB, &dTmp));
+            OAK_CHECK(get_buf_t(ctx, "trsm_LT", (size_t)n * ldt, &dLT));
+            OAK_CHECK(transpose(ctx, dL, n, n, ldl, dLT, ldt));
+            for (int64_t b = 0; b < nfull; ++b) {
+                double* it = dInvT + b * NB * NB;
+                OAK_CHECK(set_identity(ctx, it, NB));
+                OAK_CHECK(trsm_leaf(ctx, dL + (b * NB) * ldl + b * NB, NB, ldl, it, NB, NB, 0));   // the matrix L_bb^-T
+            }
+            for (int64_t j0 = last; j0 >= 0; j0 -= NB) {
+                const int64_t nbj = (n - j0 < NB) ? n - j0 : NB;
+                const int64_t rest = n - j0 - nbj;
+                if (rest > 0)
+                    OAK_CHECK(gemm_nt(ctx, dBT + j0 + nbj, dLT + j0 * ldt + j0 + nbj, dBT + j0, nrhs, nbj, rest, ldb, ldt, ldb, -1.0, 1.0, 0));
+                if (nbj == NB) {
+                    OAK_HIP_CHECK(hipMemcpy2DAsync(dTmp, sizeof(double) * NB, dBT + j0, sizeof(double) * (size_t)ldb, sizeof(double) * NB,
+                                                   (size_t)nrhs, hipMemcpyDeviceToDevice, ctx->stream));
+                    OAK_CHECK(gemm_nt(ctx, dTmp, dInvT + (j0 / NB) * NB * NB, dBT + j0, nrhs, NB, NB, NB, NB, ldb, 1.0, 0.0, 0));
+                } else {
+                    OAK_CHECK(trsm_leaf(ctx, dL + j0 * ldl + j0, nbj, ldl, dBT + j0, nrhs, ldb, 1));
+                }
+            }
+            return OAK_OK;
+        }
         for (int64_t j0 = last; j0 >= 0; j0 -= NB) {
             const int64_t nbj = (n - j0 < NB) ? n - j0 : NB;
             OAK_CHECK(trsm_leaf(ctx, dL + j0 * ldl + j0, nbj, ldl, dBT + j0, nrhs, ldb, 1));

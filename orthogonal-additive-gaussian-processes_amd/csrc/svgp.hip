@@ -94,29 +94,68 @@ __global__ void __launch_bounds__(256) svgp_rows_kernel(const double* __restrict
 }
 
 // Abar[n][j] = q_mu_j gmu_n + 2 (q_sqrt_j^2 - 1) A[n][j] gv_n     (adjoint of A, row layout)
-// BT[j][n]   = gv_n A[n][j]                                        (scaled and transposed, for W2 = A diag(gv) A^T)
+// P[n][j]    = sqrt(-gv_n) A[n][j] for rows with gv_n < 0, else 0   (panel of the weighted SYRK, see below)
+// upart[by][j] = sum over this block's rows of A[n][j] gmu_n       (u = A gmu, finished by svgp_usum_kernel)
+// W2 = A diag(gv) A^T is a SYRK with signed weights: rows are split by the sign of gv_n (negative for a log-concave
+// likelihood; the jittered links leave a few positive ones), each part runs through the MFMA SYRK of the SGPR path on a
+// panel scaled by sqrt|gv_n|, and W2 = P+^T P+ - P-^T P-.  (A plain M x M x N GEMM on a transposed copy ran at 16 TFLOP/s.)
+constexpr int SV_ROWS = 1024;     // rows per block: N / SV_ROWS partial rows of u
 __global__ void __launch_bounds__(256) svgp_adjoint_kernel(const double* __restrict__ AT, int64_t lda, int64_t N, int64_t M,
                                                            const double* __restrict__ qmu, const double* __restrict__ s2m1,
                                                            const double* __restrict__ gmu, const double* __restrict__ gv,
-                                                           double* __restrict__ Abar, double* __restrict__ BT, int64_t ldbt) {
-    __shared__ double tile[32][33];
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
-    const int64_t n0 = (int64_t)blockIdx.y * 32, j0 = (int64_t)blockIdx.x * 32;
-    for (int r = ty; r < 32; r += 8) {
-        const int64_t n = n0 + r, j = j0 + tx;
-        double b = 0.0;
-        if (n < N && j < M) {
-            const double x = AT[n * lda + j], g = gv[n];
-            Abar[n * lda + j] = __builtin_fma(qmu[j], gmu[n], 2.0 * s2m1[j] * x * g);
-            b = g * x;
+                                                           double* __restrict__ Abar, double* __restrict__ P,
+                                                           double* __restrict__ upart) {
+    __shared__ double red[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 columns x 8 rows per step
+    const int64_t jc = (int64_t)blockIdx.x * 32 + tx;            // < lda (grid covers the padded width)
+    const bool live = jc < M;
+    const double qm = live ? qmu[jc] : 0.0, sm = live ? s2m1[jc] : 0.0;
+    const int64_t n_begin = (int64_t)blockIdx.y * SV_ROWS;
+    const int64_t n_end = (n_begin + SV_ROWS < N) ? n_begin + SV_ROWS : N;
+    double cu = 0.0;
+    for (int64_t n = n_begin + ty; n < n_end; n += 8) {
+        const double g = gv[n], gm = gmu[n];
+        double pv = 0.0;
+        if (live) {
+            const double x = AT[n * lda + jc];
+            Abar[n * lda + jc] = __builtin_fma(qm, gm, 2.0 * sm * x * g);
+            cu = __builtin_fma(x, gm, cu);
+            pv = g < 0.0 ? sqrt(-g) * x : 0.0;
         }
-        tile[r][tx] = b;
+        P[n * lda + jc] = pv;
     }
+    red[ty][tx] = cu;
     __syncthreads();
-    for (int r = ty; r < 32; r += 8) {
-        const int64_t j = j0 + r, n = n0 + tx;
-        if (j < M && n < N) BT[j * ldbt + n] = tile[tx][r];
+    if (ty == 0 && live) {
+        double s = red[0][tx];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) s += red[r][tx];
+        upart[(int64_t)blockIdx.y * M + jc] = s;
     }
+}
+// the positive-weight panel (rare): P[n][j] = sqrt(gv_n) A[n][j] for rows with gv_n > 0, else 0
+__global__ void __launch_bounds__(256) svgp_pospanel_kernel(const double* __restrict__ AT, int64_t lda, int64_t N, int64_t M,
+                                                            const double* __restrict__ gv, double* __restrict__ P) {
+    const int64_t jc = (int64_t)blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
+    if (jc >= lda) return;
+    const double g = gv[n];
+    P[n * lda + jc] = (jc < M && g > 0.0) ? sqrt(g) * AT[n * lda + jc] : 0.0;
+}
+__global__ void svgp_usum_kernel(const double* __restrict__ upart, int64_t nby, int64_t M, double* __restrict__ u) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= M) return;
+    double s = 0.0;
+    for (int64_t b = 0; b < nby; ++b) s += upart[b * M + j];
+    u[j] = s;
+}
+__global__ void svgp_anypos_kernel(const double* __restrict__ gv, int64_t N, int* __restrict__ flag) {
+    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (n < N && gv[n] > 0.0) atomicOr(flag, 1);
+}
+// W2 = Wpos - Wneg (Wpos may be NULL)
+__global__ void svgp_w2_kernel(const double* __restrict__ Wpos, const double* __restrict__ Wneg, int64_t len, double* __restrict__ W2) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < len) W2[i] = (Wpos ? Wpos[i] : 0.0) - Wneg[i];
 }
 
 // Q = q_mu u^T + 2 diag(q_sqrt^2 - 1) W2
@@ -239,9 +278,9 @@ int oak_svgp_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, const double* 
         return OAK_OK;
     }
     // ---- reverse pass ----------------------------------------------------------------------------------------
-    double *dAbar, *dBT, *du, *dW2, *dQ, *dT, *dLinvT, *dLT, *dP, *dGuu, *dw2d;
+    double *dAbar, *dP, *du, *dW2, *dQ, *dT, *dLinvT, *dLT, *dPm, *dGuu, *dw2d;
     OAK_CHECK(get_buf_t(ctx, "gpanel", (size_t)N * Mp, &dAbar));
-    OAK_CHECK(get_buf_t(ctx, "svBT", (size_t)M * N, &dBT));
+    OAK_CHECK(get_buf_t(ctx, "svP", (size_t)N * Mp, &dP));
     OAK_CHECK(get_buf_t(ctx, "svu", (size_t)2 * M, &du));
     dw2d = du + M;
     OAK_CHECK(get_buf_t(ctx, "svW2", (size_t)M * M, &dW2));
@@ -249,15 +288,41 @@ int oak_svgp_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, const double* 
     OAK_CHECK(get_buf_t(ctx, "svT", (size_t)M * M, &dT));
     OAK_CHECK(get_buf_t(ctx, "svLinvT", (size_t)M * M, &dLinvT));
     OAK_CHECK(get_buf_t(ctx, "svLT", (size_t)M * M, &dLT));
-    OAK_CHECK(get_buf_t(ctx, "svP", (size_t)M * M, &dP));
+    OAK_CHECK(get_buf_t(ctx, "svPm", (size_t)M * M, &dPm));
     OAK_CHECK(get_buf_t(ctx, "svGuu", (size_t)M * M, &dGuu));
     {
-        dim3 grid((unsigned)((M + 31) / 32), (unsigned)((N + 31) / 32));
-        svgp_adjoint_kernel<<<grid, 256, 0, ctx->stream>>>(dAT, Mp, N, M, dqmu, ds2m1, dgmu, dgv, dAbar, dBT, N);
+        const int64_t nby = (N + SV_ROWS - 1) / SV_ROWS;
+        double *dup = nullptr, *dPart = nullptr, *dWn = nullptr, *dWp = nullptr;
+        int* dflag = nullptr;
+        OAK_CHECK(get_buf_t(ctx, "svupart", (size_t)nby * M, &dup));
+        OAK_CHECK(get_buf_t(ctx, "svflag", 1, &dflag));
+        OAK_HIP_CHECK(hipMemsetAsync(dflag, 0, sizeof(int), ctx->stream));
+        svgp_anypos_kernel<<<(unsigned)((N + 255) / 256), 256, 0, ctx->stream>>>(dgv, N, dflag);
+        OAK_HIP_CHECK(hipGetLastError());
+        int any_pos = 0;
+        OAK_HIP_CHECK(hipMemcpyAsync(&any_pos, dflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        dim3 grid((unsigned)(Mp / 32), (unsigned)nby);
+        svgp_adjoint_kernel<<<grid, 256, 0, ctx->stream>>>(dAT, Mp, N, M, dqmu, ds2m1, dgmu, dgv, dAbar, dP, dup);
+        OAK_HIP_CHECK(hipGetLastError());
+        svgp_usum_kernel<<<(unsigned)((M + 255) / 256), 256, 0, ctx->stream>>>(dup, nby, M, du);   // u = A gmu
+        OAK_HIP_CHECK(hipGetLastError());
+        const int nsplit = syrk_plan_splits(ctx, M, N);
+        OAK_CHECK(get_buf_t(ctx, "syrk_part", (size_t)nsplit * Mp * Mp, &dPart));
+        OAK_CHECK(get_buf_t(ctx, "svWn", (size_t)M * M, &dWn));
+        OAK_CHECK(syrk_panel(ctx, dP, Mp, N, M, dPart, nsplit, false));
+        OAK_CHECK(syrk_reduce(ctx, dPart, nsplit, M, dWn, false));
+        OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));                        // any_pos (and sum_ve) have landed
+        if (any_pos) {
+            OAK_CHECK(get_buf_t(ctx, "svWp", (size_t)M * M, &dWp));
+            dim3 gp((unsigned)((Mp + 255) / 256), (unsigned)N);
+            svgp_pospanel_kernel<<<gp, 256, 0, ctx->stream>>>(dAT, Mp, N, M, dgv, dP);
+            OAK_HIP_CHECK(hipGetLastError());
+            OAK_CHECK(syrk_panel(ctx, dP, Mp, N, M, dPart, nsplit, false));
+            OAK_CHECK(syrk_reduce(ctx, dPart, nsplit, M, dWp, false));
+        }
+        svgp_w2_kernel<<<(unsigned)((M * M + 255) / 256), 256, 0, ctx->stream>>>(dWp, dWn, M * M, dW2);   // W2 = A diag(gv) A^T
         OAK_HIP_CHECK(hipGetLastError());
     }
-    OAK_CHECK(gemm_nn(ctx, dgmu, dAT, du, 1, M, N, N, Mp, M, 1.0, 0.0));        // u = A gmu
-    OAK_CHECK(gemm_nn(ctx, dBT, dAT, dW2, M, M, N, N, Mp, M, 1.0, 0.0));        // W2 = A diag(gv) A^T
     const dim3 gm((unsigned)((M + 255) / 256), (unsigned)M);
     svgp_diag_kernel<<<(unsigned)((M + 255) / 256), 256, 0, ctx->stream>>>(dW2, M, dw2d);
     OAK_HIP_CHECK(hipGetLastError());
@@ -266,15 +331,15 @@ int oak_svgp_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, const double* 
     OAK_CHECK(set_identity(ctx, dLinvT, M));
     OAK_CHECK(trsm_rows(ctx, dL, M, M, dLinvT, M, M, 0));                        // rows = columns of Lm^-1: the matrix Lm^-T
     OAK_CHECK(gemm_nn(ctx, dLinvT, dQ, dT, M, M, M, M, M, M, 1.0, 0.0));         // Lm^-T Q
-    svgp_tri_kernel<<<gm, 256, 0, ctx->stream>>>(dT, M, 0, dP);                  // Lbar = -tril(Lm^-T Q)
+    svgp_tri_kernel<<<gm, 256, 0, ctx->stream>>>(dT, M, 0, dPm);                  // Lbar = -tril(Lm^-T Q)
     OAK_HIP_CHECK(hipGetLastError());
     OAK_CHECK(transpose(ctx, dL, M, M, M, dLT, M));
-    OAK_CHECK(gemm_nn(ctx, dLT, dP, dT, M, M, M, M, M, M, 1.0, 0.0));            // Lm^T Lbar
-    svgp_tri_kernel<<<gm, 256, 0, ctx->stream>>>(dT, M, 1, dP);                  // Phi(.)
+    OAK_CHECK(gemm_nn(ctx, dLT, dPm, dT, M, M, M, M, M, M, 1.0, 0.0));            // Lm^T Lbar
+    svgp_tri_kernel<<<gm, 256, 0, ctx->stream>>>(dT, M, 1, dPm);                  // Phi(.)
     OAK_HIP_CHECK(hipGetLastError());
-    OAK_CHECK(gemm_nn(ctx, dLinvT, dP, dT, M, M, M, M, M, M, 1.0, 0.0));         // Lm^-T Phi
-    OAK_CHECK(gemm_nt(ctx, dT, dLinvT, dP, M, M, M, M, M, M, 1.0, 0.0, 0));      // ... Lm^-1
-    svgp_tri_kernel<<<gm, 256, 0, ctx->stream>>>(dP, M, 2, dGuu);                // adjoint of Kuu, symmetrised
+    OAK_CHECK(gemm_nn(ctx, dLinvT, dPm, dT, M, M, M, M, M, M, 1.0, 0.0));         // Lm^-T Phi
+    OAK_CHECK(gemm_nt(ctx, dT, dLinvT, dPm, M, M, M, M, M, M, 1.0, 0.0, 0));      // ... Lm^-1
+    svgp_tri_kernel<<<gm, 256, 0, ctx->stream>>>(dPm, M, 2, dGuu);                // adjoint of Kuu, symmetrised
     OAK_HIP_CHECK(hipGetLastError());
     OAK_CHECK(trsm_rows(ctx, dL, M, M, dAbar, N, Mp, 1));                        // rows = columns of Lm^-T Abar: adjoint of Kuf
     const int64_t reclen = record_len(pk);

@@ -104,6 +104,36 @@ def test_gradient_matches_central_differences_of_the_oracle(hip, link, N, D, M, 
     assert g[2 * D + R + 1] == 0.0                                   # noise slot: no Gaussian likelihood here
 
 
+@pytest.mark.parametrize("N,M", [(9000, 300), (8192, 384)])
+def test_large_batch_gradient_directional(hip, N, M):
+    """N >= 8192 rows take the blocked (by-inverse, MFMA) forms of both triangular solves and the signed weighted SYRK;
+    checked by a central difference of the oracle along one random direction in (q_mu, q_sqrt, lengthscales, variances)."""
+    import copy
+    D, R = 4, 2
+    spec, X, y, Z, q_mu, q_sqrt = problem(N, N, D, M, R)
+    d = _capi.KernelDesc(spec)
+    hip.sgpr_set_data(X, y.reshape(-1, 1))
+    hip.sgpr_set_inducing(Z)
+    e, g, gm, gs = hip.svgp_elbo(d, q_mu, q_sqrt, grad=True)
+    assert abs(e - sv.svgp_elbo(spec, X, y, Z, q_mu, q_sqrt)) <= 1e-10 * abs(e)
+    rng = np.random.default_rng(0)
+    dm, ds = rng.standard_normal(M) / np.sqrt(M), 0.1 * rng.standard_normal(M) / np.sqrt(M)
+    dl, dv = 0.1 * rng.standard_normal(D), 0.1 * rng.standard_normal(R + 1)
+    ls0 = np.array([dim["lengthscale"] for dim in spec["dims"]]); ov0 = np.array(spec["order_variances"])
+
+    def f(t):
+        sp = copy.deepcopy(spec)
+        for k, dim in enumerate(sp["dims"]):
+            dim["lengthscale"] = float(ls0[k] + t * dl[k])
+        sp["order_variances"] = list(ov0 + t * dv)
+        return sv.svgp_elbo(sp, X, y, Z, q_mu + t * dm, q_sqrt + t * ds)
+
+    h = 2e-4           # five-point stencil: the oracle's own rounding (~1e-10 |elbo| through cond(Kuu)) is divided by 12 h
+    fd = (8 * (f(h) - f(-h)) - (f(2 * h) - f(-2 * h))) / (12 * h)
+    an = gm @ dm + gs @ ds + g[:D] @ dl + g[2 * D:2 * D + R + 1] @ dv
+    assert abs(an - fd) <= 1e-6 * abs(fd), (an, fd)
+
+
 def test_argument_checks(hip):
     spec, X, y, Z, q_mu, q_sqrt = problem(9, 100, 3, 20, 2)
     d = _capi.KernelDesc(spec)
