@@ -148,9 +148,9 @@ __global__ void svgp_usum_kernel(const double* __restrict__ upart, int64_t nby, 
     for (int64_t b = 0; b < nby; ++b) s += upart[b * M + j];
     u[j] = s;
 }
-__global__ void svgp_anypos_kernel(const double* __restrict__ gv, int64_t N, int* __restrict__ flag) {
+__global__ void svgp_anypos_kernel(const double* __restrict__ gv, int64_t N, double* __restrict__ flag) {
     const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n < N && gv[n] > 0.0) atomicOr(flag, 1);
+    if (n < N && gv[n] > 0.0) *flag = 1.0;        // every writer stores the same value
 }
 // W2 = Wpos - Wneg (Wpos may be NULL)
 __global__ void svgp_w2_kernel(const double* __restrict__ Wpos, const double* __restrict__ Wneg, int64_t len, double* __restrict__ W2) {
@@ -237,7 +237,6 @@ int oak_svgp_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, const double* 
     OAK_CHECK(sv_guard(ctx));
     OAK_REQUIRE(desc && q_mu && q_sqrt && elbo_out, "oak_svgp_elbo_grad: bad arguments");
     OAK_REQUIRE(ctx->have_data && ctx->have_Z, "SVGP: oak_sgpr_set_data and oak_sgpr_set_inducing must be called first");
-    OAK_REQUIRE(ctx->comm == nullptr, "SVGP: the row-sharded (communicator) path is not available for this model");
     const bool want_grad = grad_out != nullptr;
     OAK_REQUIRE(!want_grad || (grad_qmu && grad_qsqrt), "oak_svgp_elbo_grad: grad_qmu / grad_qsqrt are required with grad_out");
     SvQuad quad;
@@ -262,9 +261,18 @@ int oak_svgp_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, const double* 
     svgp_rows_kernel<<<(unsigned)((N + 3) / 4), 256, 0, ctx->stream>>>(dAT, Mp, N, M, dqmu, ds2m1, dkd, (double*)peek_buf(ctx, "Y"),
                                                                       quad, 0, dmu, dvar, dve, dgmu, dgv);
     OAK_HIP_CHECK(hipGetLastError());
+    // Row shards (one rank per GPU): the sum of the expectations, the sign flag, u, the SYRK results and the gradient
+    // record are sums over rows and are all-reduced; K(Z), its factor and everything M-sized is replicated.
     OAK_CHECK(reduce_sum(ctx, dve, N, dsc, 0, 1));
-    double sum_ve = 0.0;
-    OAK_HIP_CHECK(hipMemcpyAsync(&sum_ve, dsc, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    OAK_CHECK(fill_zero(ctx, dsc + 1, sizeof(double)));
+    if (want_grad) {
+        svgp_anypos_kernel<<<(unsigned)((N + 255) / 256), 256, 0, ctx->stream>>>(dgv, N, dsc + 1);
+        OAK_HIP_CHECK(hipGetLastError());
+    }
+    OAK_CHECK(comm_allreduce_dev(ctx, dsc, 2));
+    double hsc[2] = {0.0, 0.0};
+    OAK_HIP_CHECK(hipMemcpyAsync(hsc, dsc, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
+    const double& sum_ve = hsc[0];
     double kl = 0.0;
     for (int64_t j = 0; j < M; ++j) {
         const double s2 = q_sqrt[j] * q_sqrt[j];
@@ -293,14 +301,7 @@ int oak_svgp_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, const double* 
     {
         const int64_t nby = (N + SV_ROWS - 1) / SV_ROWS;
         double *dup = nullptr, *dPart = nullptr, *dWn = nullptr, *dWp = nullptr;
-        int* dflag = nullptr;
         OAK_CHECK(get_buf_t(ctx, "svupart", (size_t)nby * M, &dup));
-        OAK_CHECK(get_buf_t(ctx, "svflag", 1, &dflag));
-        OAK_HIP_CHECK(hipMemsetAsync(dflag, 0, sizeof(int), ctx->stream));
-        svgp_anypos_kernel<<<(unsigned)((N + 255) / 256), 256, 0, ctx->stream>>>(dgv, N, dflag);
-        OAK_HIP_CHECK(hipGetLastError());
-        int any_pos = 0;
-        OAK_HIP_CHECK(hipMemcpyAsync(&any_pos, dflag, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         dim3 grid((unsigned)(Mp / 32), (unsigned)nby);
         svgp_adjoint_kernel<<<grid, 256, 0, ctx->stream>>>(dAT, Mp, N, M, dqmu, ds2m1, dgmu, dgv, dAbar, dP, dup);
         OAK_HIP_CHECK(hipGetLastError());
@@ -311,14 +312,17 @@ int oak_svgp_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, const double* 
         OAK_CHECK(get_buf_t(ctx, "svWn", (size_t)M * M, &dWn));
         OAK_CHECK(syrk_panel(ctx, dP, Mp, N, M, dPart, nsplit, false));
         OAK_CHECK(syrk_reduce(ctx, dPart, nsplit, M, dWn, false));
-        OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));                        // any_pos (and sum_ve) have landed
-        if (any_pos) {
+        OAK_CHECK(comm_allreduce_dev(ctx, du, M));
+        OAK_CHECK(comm_allreduce_dev(ctx, dWn, M * M));
+        OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));                        // the sign flag (and sum_ve) have landed
+        if (hsc[1] > 0.0) {
             OAK_CHECK(get_buf_t(ctx, "svWp", (size_t)M * M, &dWp));
             dim3 gp((unsigned)((Mp + 255) / 256), (unsigned)N);
             svgp_pospanel_kernel<<<gp, 256, 0, ctx->stream>>>(dAT, Mp, N, M, dgv, dP);
             OAK_HIP_CHECK(hipGetLastError());
             OAK_CHECK(syrk_panel(ctx, dP, Mp, N, M, dPart, nsplit, false));
             OAK_CHECK(syrk_reduce(ctx, dPart, nsplit, M, dWp, false));
+            OAK_CHECK(comm_allreduce_dev(ctx, dWp, M * M));
         }
         svgp_w2_kernel<<<(unsigned)((M * M + 255) / 256), 256, 0, ctx->stream>>>(dWp, dWn, M * M, dW2);   // W2 = A diag(gv) A^T
         OAK_HIP_CHECK(hipGetLastError());
@@ -348,8 +352,10 @@ int oak_svgp_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, const double* 
     OAK_CHECK(fill_zero(ctx, d_rec, sizeof(double) * (size_t)reclen));
     const bool want_gk = desc->grad_base_var != 0;
     OAK_CHECK(gram_bwd(ctx, pk, FX, 0, N, FZ, dAbar, Mp, 1.0, nullptr, nullptr, d_rec, want_gk));
-    OAK_CHECK(gram_bwd(ctx, pk, FZ, 0, M, FZ, dGuu, M, 1.0, nullptr, nullptr, d_rec, want_gk));
+    // <adjoint of Kuu, dKuu> is replicated on every rank: each contributes 1/nranks, the all-reduce restores it once
+    OAK_CHECK(gram_bwd(ctx, pk, FZ, 0, M, FZ, dGuu, M, 1.0 / (double)(ctx->comm ? ctx->nranks : 1), nullptr, nullptr, d_rec, want_gk));
     OAK_CHECK(diag_bwd(ctx, pk, FX, 1.0, d_rec, dgv));
+    OAK_CHECK(comm_allreduce_dev(ctx, d_rec, reclen));
     std::vector<double> rec((size_t)reclen), hu((size_t)2 * M);
     OAK_HIP_CHECK(hipMemcpyAsync(rec.data(), d_rec, sizeof(double) * (size_t)reclen, hipMemcpyDeviceToHost, ctx->stream));
     OAK_HIP_CHECK(hipMemcpyAsync(hu.data(), du, sizeof(double) * (size_t)2 * M, hipMemcpyDeviceToHost, ctx->stream));

@@ -258,3 +258,27 @@ def test_svgp_save_and_load_all_parameters(hip, tmp_path):
     for pa, pb in zip(a.parameters, b.parameters):
         np.testing.assert_array_equal(np.asarray(pa.numpy()), np.asarray(pb.numpy()))
     assert a.elbo((X, y)) == b.elbo((X, y))
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_loopback_ranks_equal_stacked_rows(world):
+    """Row-sharded SVGP arithmetic on one GPU: under the loopback communicator (`world` ranks holding the same rows, every
+    all-reduce multiplies by `world`) ELBO and every gradient block equal a single-rank run on the rows stacked `world`
+    times -- all-reduce placement of sum(ve), the sign flag, u, the weighted SYRKs, the gradient record, and the 1/nranks
+    scaling of the replicated Kuu term."""
+    spec, X, y, Z, q_mu, q_sqrt = problem(77, 1200, 4, 48, 2, ("gaussian", "binary"))
+    d = _capi.KernelDesc(spec)
+    ref = _capi.HipContext(0)
+    ref.sgpr_set_data(np.tile(X, (world, 1)), np.tile(y.reshape(-1, 1), (world, 1))); ref.sgpr_set_inducing(Z)
+    e_ref, g_ref, gm_ref, gs_ref = ref.svgp_elbo(d, q_mu, q_sqrt, grad=True)
+    ctx = _capi.HipContext(0)
+    ctx.sgpr_set_data(X, y.reshape(-1, 1)); ctx.sgpr_set_inducing(Z)
+    ctx.comm_init_loopback(world)
+    e0 = ctx.svgp_elbo(d, q_mu, q_sqrt)
+    e, g, gm, gs = ctx.svgp_elbo(d, q_mu, q_sqrt, grad=True)
+    assert abs(e0 - e_ref) <= 1e-11 * abs(e_ref) and abs(e - e_ref) <= 1e-11 * abs(e_ref)
+    for a, b in ((g, g_ref), (gm, gm_ref), (gs, gs_ref)):
+        np.testing.assert_allclose(a, b, rtol=1e-9, atol=1e-9 * np.abs(b).max())
+    ctx.comm_destroy()
+    assert abs(ctx.svgp_elbo(d, q_mu, q_sqrt) - e_ref) > 1e-3 * abs(e_ref)
+    ctx.close(); ref.close()
