@@ -124,21 +124,27 @@ def main():
     exchange_note = "none" if world == 1 else args.exchange
     if world > 1 and not host_exchange:
         import torch
+        # ncclCommInitRank is collective: a rank that cannot even load librccl must not leave the others waiting inside it.
+        # Every rank first proves it can load the library (a unique id is generated locally), the ranks agree (MIN), and only
+        # then is rank 0's id broadcast and the communicator created.
         ok = 1
         try:
-            ids = [_capi.HipContext.comm_unique_id() if rank == 0 else None]
-        except Exception as e:                                   # librccl missing / not loadable on rank 0
-            ids, ok = [None], 0
-            print(f"[bench] rank {rank}: RCCL unique id failed: {e}", file=sys.stderr)
-        dist.broadcast_object_list(ids, src=0)
-        if ids[0] is None:
-            ok = 0
-        else:
+            my_id = _capi.HipContext.comm_unique_id()
+        except Exception as e:
+            my_id, ok = None, 0
+            print(f"[bench] rank {rank}: RCCL not usable: {e}", file=sys.stderr)
+        pre = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(pre, op=dist.ReduceOp.MIN)
+        if int(pre.item()) == 1:
+            ids = [my_id if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
             try:
                 ctx.comm_init(ids[0], world, rank)
             except Exception as e:
                 ok = 0
                 print(f"[bench] rank {rank}: RCCL communicator init failed: {e}", file=sys.stderr)
+        else:
+            ok = 0
         flag = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)              # every rank takes the same path
         if int(flag.item()) == 0:
