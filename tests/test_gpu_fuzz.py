@@ -3,6 +3,7 @@ variances, lengthscales and base variances over several decades, ragged sizes) a
 combination of the oracle's per-dimension matrices -- independent of both the HIP recurrence and the reference's
 Newton-Girard power sums (whose cancellation error the oracle inherits when the k_d differ by many orders of magnitude)."""
 import itertools
+import os
 
 import numpy as np
 import pytest
@@ -12,6 +13,7 @@ from oak import _capi
 from oracle import oak_oracle as o
 
 pytestmark = pytest.mark.gpu
+SEED0 = int(os.environ.get("OAK_FUZZ_SEED0", "0"))      # shift every stream: OAK_FUZZ_SEED0=100000 pytest ... for a fresh sweep
 KINDS = ("gaussian", "uniform", "mog", "none", "gauss2", "binary", "categorical")
 
 
@@ -37,7 +39,7 @@ def brute_force_K(spec, X, X2, diag=False):
 
 @pytest.mark.parametrize("seed", range(40))
 def test_random_kernels_against_brute_force(hip, seed):
-    rng = np.random.default_rng(1000 + seed)
+    rng = np.random.default_rng(SEED0 + 1000 + seed)
     D = int(rng.integers(1, 9))
     R = int(rng.integers(0, min(D, 4) + 1))
     share = bool(rng.integers(0, 2))
@@ -64,7 +66,7 @@ def test_random_kernels_gradient_against_forward_differences(hip, seed):
     differences of the HIP forward pass itself, parameter by parameter.  Relative steps of 1e-4: the forward value carries
     ~1e-13 |F| of rounding noise, which a 1e-6 step would turn into 1e-5-level noise in the difference quotient."""
     import copy
-    rng = np.random.default_rng(5000 + seed)
+    rng = np.random.default_rng(SEED0 + 5000 + seed)
     D = int(rng.integers(2, 8))
     R = int(rng.integers(1, min(D, 5) + 1))          # depth 5 exercises the generic two-pass backward kernel
     share = bool(rng.integers(0, 2))
@@ -109,7 +111,7 @@ def test_random_kernels_gradient_against_forward_differences(hip, seed):
 def test_random_kernels_sobol_and_components(hip, seed):
     """Sobol indices and per-component predictions of random kernels over the measure types that have a closed form
     (Gaussian N(0,1), binary, categorical), shared and separate variances, against the oracle (1e-9)."""
-    rng = np.random.default_rng(9000 + seed)
+    rng = np.random.default_rng(SEED0 + 9000 + seed)
     D = int(rng.integers(2, 7))
     R = int(rng.integers(1, min(D, 3) + 1))
     share = bool(rng.integers(0, 2))
@@ -125,3 +127,45 @@ def test_random_kernels_sobol_and_components(hip, seed):
     comp = hip.component_predict(_capi.KernelDesc(spec), Xs, Z, alpha[:, 0], subsets, use_order_var=share)
     refc = np.array(o.prediction_components(spec, Z, alpha, Xs, share_var_across_orders=share))
     np.testing.assert_allclose(comp, refc, rtol=1e-9, atol=1e-11)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_svgp_problems(hip, seed):
+    """SVGP ELBO, predictions and the q_mu / q_sqrt gradients of random kernels and variational parameters against the
+    oracle: ELBO 1e-10, mean / var / log density 1e-9, gradients 1e-6 of their largest entry vs central differences along
+    eight random directions."""
+    from oracle import svgp_oracle as sv
+    rng = np.random.default_rng(SEED0 + 13000 + seed)
+    D = int(rng.integers(1, 7))
+    R = int(rng.integers(1, min(D, 4) + 1))
+    kinds = tuple(rng.choice(("gaussian", "uniform", "mog", "binary", "categorical"), size=D))
+    spec = cases.random_spec(rng, D, R, kinds, share=True)
+    N, M = int(rng.integers(20, 600)), int(rng.integers(4, 90))
+    X, Z = cases.random_inputs(rng, spec, N), cases.random_inputs(rng, spec, M)
+    y = (rng.uniform(size=N) < 0.5).astype(float)
+    q_mu, q_sqrt = rng.standard_normal(M) * 10 ** rng.uniform(-1, 0.3), 10 ** rng.uniform(-1.5, 0.3, M)
+    link = ("logit", "probit")[seed % 2]
+    d = _capi.KernelDesc(spec)
+    ctx = _capi.HipContext(0)
+    try:
+        ctx.sgpr_set_data(X, y.reshape(-1, 1)); ctx.sgpr_set_inducing(Z)
+        e, g, gm, gs = ctx.svgp_elbo(d, q_mu, q_sqrt, link=link, grad=True)
+        er = sv.svgp_elbo(spec, X, y, Z, q_mu, q_sqrt, link=link)
+        assert abs(e - er) <= 1e-10 * abs(er), f"seed {seed}: {e} vs {er}"
+        Xs = cases.random_inputs(rng, spec, 40); ys = (rng.uniform(size=40) < 0.5).astype(float)
+        m, v, ld = ctx.svgp_predict(d, q_mu, q_sqrt, Xs, ys, link=link)
+        mr, vr = sv.conditional(spec, Xs, Z, q_mu, q_sqrt)
+        np.testing.assert_allclose(m, mr, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(v, vr, rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(ld, sv.predict_log_density_from_f(mr, vr, ys, link), rtol=1e-9, atol=1e-9)
+        scale = max(np.abs(gm).max(), np.abs(gs).max())
+        for _ in range(8):
+            dm, ds = rng.standard_normal(M), rng.standard_normal(M) * q_sqrt
+            nrm = np.sqrt(dm @ dm + ds @ ds); dm, ds = dm / nrm, ds / nrm
+            h = 1e-4 * min(1.0, q_sqrt.min() / np.abs(ds).max() * 0.1)
+            f = lambda t: sv.svgp_elbo(spec, X, y, Z, q_mu + t * dm, q_sqrt + t * ds, link=link)
+            fd = (8 * (f(h) - f(-h)) - (f(2 * h) - f(-2 * h))) / (12 * h)
+            an = gm @ dm + gs @ ds
+            assert abs(an - fd) <= 1e-6 * scale * np.sqrt(2 * M), f"seed {seed}: {an} vs {fd} (scale {scale})"
+    finally:
+        ctx.close()
