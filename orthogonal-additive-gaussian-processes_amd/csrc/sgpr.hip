@@ -22,6 +22,8 @@ __global__ void predict_var_kernel(const double* __restrict__ kdiag, const doubl
     if (i < n) var[i] = kdiag[i] + (s2 ? s2[i] : 0.0) - s1[i];
 }
 
+__global__ void set_double_kernel(double* p, double v) { *p = v; }
+
 static int guard(oak_ctx* ctx) {
     if (!ctx) { set_error("ctx is NULL"); return OAK_E_ARG; }
     OAK_HIP_CHECK(hipSetDevice(ctx->device));
@@ -155,9 +157,10 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
         OAK_CHECK(get_buf_t(ctx, "kdiag", (size_t)N, &dDiag));
         OAK_CHECK(gram_diag(ctx, pk, FX, dDiag, st.kappa));
         OAK_CHECK(reduce_sum(ctx, dY, N, st.yy, 1, 1));
-        const double nn = (double)N;
-        OAK_HIP_CHECK(hipMemcpyAsync(st.nrows, &nn, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // nn is a stack variable
+        // the row count goes in by kernel argument: no host buffer, so no host synchronisation here -- the tail's ~60
+        // launches are enqueued while the SYRK is still running
+        set_double_kernel<<<1, 1, 0, ctx->stream>>>(st.nrows, (double)N);
+        OAK_HIP_CHECK(hipGetLastError());
         t.stop();
     }
     ctx->have_stats = true;
@@ -309,9 +312,6 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     const int64_t M = ctx->M;
     Stats st;
     OAK_CHECK(stats_view(ctx, &st));
-    double* dZ = (double*)peek_buf(ctx, "Z");
-    Feat FZ;
-    OAK_CHECK(featurize(ctx, pk, dZ, M, ctx->ldx, "featZ", &FZ));
     double *dL, *dT1, *dT2, *dLB, *dv1, *dc, *dscal;
     OAK_CHECK(get_buf_t(ctx, "L", (size_t)M * M, &dL));
     OAK_CHECK(get_buf_t(ctx, "T1", (size_t)(M + 1) * M, &dT1));
@@ -325,6 +325,8 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     if (l_state == 2) {
         OAK_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev1, 0));    // join the side-stream factorisation (L, L^-1)
     } else if (l_state == 0) {
+        Feat FZ;
+        OAK_CHECK(featurize(ctx, pk, (double*)peek_buf(ctx, "Z"), M, ctx->ldx, "featZ", &FZ));
         OAK_CHECK(gram(ctx, pk, FZ, 0, M, FZ, dL, M, nullptr, nullptr, 0));
         OAK_CHECK(add_diag(ctx, dL, M, M, jitter));
         OAK_CHECK(potrf_lower(ctx, dL, M, M));
