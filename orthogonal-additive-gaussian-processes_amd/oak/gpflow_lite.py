@@ -639,7 +639,7 @@ class SVGP(Module):
                                 transform=positive())
         self.data = None                 # the example assigns ``model.data`` before asking for Sobol indices (:150)
         self._hip = _capi.HipContext(_capi.default_context().device)
-        self._z_sent = self._data_sent = None
+        self._z_sent = self._data_sent = self._data_obj = None
 
     # -- device state -----------------------------------------------------------------------------
     def _spec(self):
@@ -656,6 +656,9 @@ class SVGP(Module):
             self._z_sent = Z.copy()
 
     def _sync_data(self, data):
+        if self._data_obj is not None and data[0] is self._data_obj[0] and data[1] is self._data_obj[1]:
+            return                       # the closure hands over the same arrays at every evaluation (treated as immutable)
+        self._data_obj = (data[0], data[1])
         X = np.asarray(data[0], dtype=np.float64)
         Y = np.asarray(data[1], dtype=np.float64).reshape(len(X), -1)
         if Y.shape[1] != 1:
