@@ -282,3 +282,36 @@ def test_loopback_ranks_equal_stacked_rows(world):
     ctx.comm_destroy()
     assert abs(ctx.svgp_elbo(d, q_mu, q_sqrt) - e_ref) > 1e-3 * abs(e_ref)
     ctx.close(); ref.close()
+
+
+@pytest.mark.parametrize("N,D,M,R", [(166, 60, 166, 2), (280, 34, 200, 4)])
+def test_uci_classification_shapes(hip, N, D, M, R):
+    """The shapes of the reference's classification datasets with the most inputs (sonar: 60 inputs at depth 2, every
+    training row an inducing point; ionosphere: 34 inputs at depth 4): more than 32 dimensions take the generic
+    backward kernel.  ELBO 1e-10; gradient by a five-point directional difference of the oracle."""
+    import copy
+    spec, X, y, Z, q_mu, q_sqrt = problem(N + D, N, D, M, R)
+    if M == N:
+        Z = X.copy()
+    d = _capi.KernelDesc(spec)
+    hip.sgpr_set_data(X, y.reshape(-1, 1))
+    hip.sgpr_set_inducing(Z)
+    e, g, gm, gs = hip.svgp_elbo(d, q_mu, q_sqrt, grad=True)
+    er = sv.svgp_elbo(spec, X, y, Z, q_mu, q_sqrt)
+    assert abs(e - er) <= 1e-10 * abs(er)
+    rng = np.random.default_rng(1)
+    dm, ds = rng.standard_normal(M) / np.sqrt(M), 0.1 * rng.standard_normal(M) / np.sqrt(M)
+    dl, dv = 0.1 * rng.standard_normal(D) / np.sqrt(D), 0.1 * rng.standard_normal(R + 1)
+    ls0 = np.array([dim["lengthscale"] for dim in spec["dims"]]); ov0 = np.array(spec["order_variances"])
+
+    def f(t):
+        sp = copy.deepcopy(spec)
+        for k, dim in enumerate(sp["dims"]):
+            dim["lengthscale"] = float(ls0[k] + t * dl[k])
+        sp["order_variances"] = list(ov0 + t * dv)
+        return sv.svgp_elbo(sp, X, y, Z, q_mu + t * dm, q_sqrt + t * ds)
+
+    h = 2e-4
+    fd = (8 * (f(h) - f(-h)) - (f(2 * h) - f(-2 * h))) / (12 * h)
+    an = gm @ dm + gs @ ds + g[:D] @ dl + g[2 * D:2 * D + R + 1] @ dv
+    assert abs(an - fd) <= 2e-6 * abs(fd), (an, fd)
