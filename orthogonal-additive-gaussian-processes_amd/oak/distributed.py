@@ -88,3 +88,40 @@ class ShardedSGPR:
         self.ctx.sgpr_set_stats(total, whitened)
         e, _ = self.ctx.sgpr_tail(desc, noise_var, jitter)
         return e
+
+
+# ---- embarrassingly parallel pieces: no data-path collective, one gather of the results -------------------
+def torch_allgather(local: np.ndarray) -> list:
+    """Every rank's array, in rank order, over the default torch.distributed group (control plane, gloo)."""
+    import torch.distributed as dist
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, np.ascontiguousarray(local, dtype=np.float64))
+    return parts
+
+
+def sharded_sobol(ctx, desc, Xc, alpha, subsets, rank: int, world: int, gather: Callable[[np.ndarray], list] = torch_allgather,
+                  **kwargs) -> np.ndarray:
+    """Sobol terms are independent: rank g evaluates the contiguous block ``subsets[lo:hi]`` on its GPU (``ctx.sobol``),
+    the scalars are gathered.  Returns all len(subsets) values on every rank, in the order of ``subsets``."""
+    lo, hi = shard_bounds(len(subsets), rank, world)
+    local = np.asarray(ctx.sobol(desc, Xc, alpha, list(subsets[lo:hi]), **kwargs), dtype=np.float64) if hi > lo else np.empty(0)
+    out = np.concatenate([np.asarray(p, dtype=np.float64).reshape(-1) for p in gather(local)])
+    if out.size != len(subsets):
+        raise RuntimeError("sharded_sobol: gathered blocks do not tile the term list")
+    return out
+
+
+def sharded_predict(ctx, desc, Xs, rank: int, world: int, gather: Callable[[np.ndarray], list] = torch_allgather):
+    """Predictions are independent per test row: rank g predicts ``Xs[lo:hi]`` from its (replicated) posterior; mean and
+    variance are gathered.  The caller has run ``elbo`` on every rank first (that leaves the posterior in each context)."""
+    Xs = np.ascontiguousarray(Xs, dtype=np.float64)
+    lo, hi = shard_bounds(len(Xs), rank, world)
+    if hi > lo:
+        m, v = ctx.sgpr_predict(desc, Xs[lo:hi])
+        local = np.stack([m, v], axis=1)
+    else:
+        local = np.empty((0, 2))
+    out = np.concatenate([np.asarray(p, dtype=np.float64).reshape(-1, 2) for p in gather(local)], axis=0)
+    if out.shape[0] != len(Xs):
+        raise RuntimeError("sharded_predict: gathered blocks do not tile the test rows")
+    return out[:, 0].copy(), out[:, 1].copy()

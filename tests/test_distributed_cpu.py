@@ -71,6 +71,60 @@ def test_two_rank_sharded_elbo_matches_single_process(tmp_path):
     assert res[0][0] == res[1][0]    # every rank ends with the identical scalar
 
 
+class _OracleCtx:
+    """Stands in for HipContext in the CPU suite: the same call signatures, answers from the oracle."""
+
+    def __init__(self, o, spec, X, y, Z, s2):
+        self.o, self.spec, self.X, self.y, self.Z, self.s2 = o, spec, X, y, Z, s2
+
+    def sobol(self, desc, Xc, alpha, subsets, **kw):
+        all_subsets, vals = self.o.compute_sobol_oak(self.spec, Xc, np.asarray(alpha).reshape(-1, 1))
+        lookup = {tuple(s): v for s, v in zip(all_subsets, vals)}
+        return np.array([lookup[tuple(s)] for s in subsets])
+
+    def sgpr_predict(self, desc, Xs):
+        m, v = self.o.sgpr_predict_f(self.spec, self.X, self.y, self.Z, self.s2, Xs)
+        return np.asarray(m).reshape(-1), np.asarray(v).reshape(-1)
+
+
+def _worker_gather(rank, world, port, out_dir):
+    for p in (str(ROOT / "orthogonal-additive-gaussian-processes_amd"), str(ROOT), str(ROOT / "tests")):
+        sys.path.insert(0, p)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oak import distributed as D
+    from oracle import oak_oracle as o
+    import cases
+    spec, X, y, Z, s2 = cases.case_A()
+    ctx = _OracleCtx(o, spec, X, y, Z, s2)
+    alpha = o.sgpr_alpha(spec, X, y, Z, s2)
+    subsets, _ = o.compute_sobol_oak(spec, Z, alpha)
+    sob = D.sharded_sobol(ctx, None, Z, alpha, subsets, rank, world)
+    mean, var = D.sharded_predict(ctx, None, X[:37], rank, world)
+    np.savez(Path(out_dir) / f"g{rank}.npz", sob=sob, mean=mean, var=var)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_term_sharded_sobol_and_row_sharded_predict(tmp_path):
+    """The collective-free pieces of SURVEY 8e: Sobol terms shard over ranks, predictions over test rows; one gather each."""
+    world = 2
+    mp.spawn(_worker_gather, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    sys.path.insert(0, str(ROOT / "tests"))
+    import cases
+    from oracle import oak_oracle as o
+    spec, X, y, Z, s2 = cases.case_A()
+    alpha = o.sgpr_alpha(spec, X, y, Z, s2)
+    _, ref = o.compute_sobol_oak(spec, Z, alpha)
+    mr, vr = o.sgpr_predict_f(spec, X, y, Z, s2, X[:37])
+    for r in range(world):
+        got = np.load(tmp_path / f"g{r}.npz")
+        np.testing.assert_allclose(got["sob"], np.asarray(ref), rtol=1e-12)
+        np.testing.assert_allclose(got["mean"], np.asarray(mr).reshape(-1), rtol=1e-12)
+        np.testing.assert_allclose(got["var"], np.asarray(vr).reshape(-1), rtol=1e-12)
+
+
 def test_shard_bounds_and_packing():
     from oak import distributed as D
     for n, w in [(10, 3), (1048576, 8), (7, 8), (1, 1)]:

@@ -74,3 +74,37 @@ def test_loopback_ranks_equal_stacked_rows(world, route):
     ctx.comm_destroy()
     assert abs(ctx.sgpr_elbo(d, 0.05) - e_ref) > 1e-3 * abs(e_ref)       # without the communicator it is a different problem
     ctx.close(); ref_ctx.close()
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_term_sharded_sobol_and_row_sharded_predict(world):
+    """The collective-free pieces with the HIP kernels: each simulated rank evaluates its block of Sobol terms /
+    test rows on its own context; stitched together they equal the single-context answer bit for bit."""
+    from oak import distributed as D
+    X, y, Z = o.synthetic_problem(900, 5, 32, seed=3)
+    spec = o.make_spec(5, 3, lengthscales=[1.1, 0.8, 1.5, 1.0, 0.7], order_variances=[0.7, 1.2, 0.9, 0.4])
+    d = _capi.KernelDesc(spec)
+    ref = _capi.HipContext(0)
+    ref.sgpr_set_data(X, y); ref.sgpr_set_inducing(Z)
+    ref.sgpr_elbo(d, 0.05)
+    alpha = ref.sgpr_alpha(32)
+    subsets = [list(s) for r in range(1, 4) for s in __import__("itertools").combinations(range(5), r)]
+    sob_ref = ref.sobol(d, Z, alpha, subsets)
+    Xs = np.random.default_rng(0).standard_normal((101, 5))
+    m_ref, v_ref = ref.sgpr_predict(d, Xs)
+    blocks_s, blocks_p = {}, {}
+    ctxs = []
+    for rank in range(world):            # pass 1: every rank computes its block; the "gather" just records it
+        ctx = _capi.HipContext(0)
+        ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_elbo(d, 0.05)
+        ctxs.append(ctx)
+        lo, hi = D.shard_bounds(len(subsets), rank, world)
+        blocks_s[rank] = ctx.sobol(d, Z, alpha, subsets[lo:hi]) if hi > lo else np.empty(0)
+        lo, hi = D.shard_bounds(len(Xs), rank, world)
+        blocks_p[rank] = np.stack(ctx.sgpr_predict(d, Xs[lo:hi]), axis=1) if hi > lo else np.empty((0, 2))
+    for rank in range(world):            # pass 2: the library helpers with a gather that returns all recorded blocks
+        sob = D.sharded_sobol(ctxs[rank], d, Z, alpha, subsets, rank, world, gather=lambda local: [blocks_s[r] for r in range(world)])
+        mean, var = D.sharded_predict(ctxs[rank], d, Xs, rank, world, gather=lambda local: [blocks_p[r] for r in range(world)])
+        assert np.array_equal(sob, sob_ref) and np.array_equal(mean, m_ref) and np.array_equal(var, v_ref)
+    for c in ctxs + [ref]:
+        c.close()
