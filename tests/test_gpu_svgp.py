@@ -315,3 +315,32 @@ def test_uci_classification_shapes(hip, N, D, M, R):
     fd = (8 * (f(h) - f(-h)) - (f(2 * h) - f(-2 * h))) / (12 * h)
     an = gm @ dm + gs @ ds + g[:D] @ dl + g[2 * D:2 * D + R + 1] @ dv
     assert abs(an - fd) <= 2e-6 * abs(fd), (an, fd)
+
+
+def test_gradient_with_separate_base_variances(hip):
+    """share_var_across_orders=False: per-dimension base variances are trainable and only the constant term keeps an order
+    variance; their gradients come from the same backward contraction (base-variance slots of the record)."""
+    import copy
+    rng = np.random.default_rng(21)
+    N, D, M, R = 300, 4, 40, 3
+    spec = cases.random_spec(rng, D, R, kinds=("gaussian", "binary", "gaussian", "categorical"), share=False)
+    X = cases.random_inputs(rng, spec, N)
+    Z = X[:M].copy()
+    y = (rng.uniform(size=N) < 0.5).astype(float)
+    q_mu, q_sqrt = 0.5 * rng.standard_normal(M), rng.uniform(0.3, 1.2, M)
+    d = _capi.KernelDesc(spec)
+    hip.sgpr_set_data(X, y.reshape(-1, 1)); hip.sgpr_set_inducing(Z)
+    e, g, gm, gs = hip.svgp_elbo(d, q_mu, q_sqrt, grad=True)
+    assert abs(e - sv.svgp_elbo(spec, X, y, Z, q_mu, q_sqrt)) <= 1e-10 * abs(e)
+    h = 1e-4
+    for k in range(D):
+        def f(t):
+            sp = copy.deepcopy(spec); sp["dims"][k]["variance"] += t
+            return sv.svgp_elbo(sp, X, y, Z, q_mu, q_sqrt)
+        fd = (8 * (f(h) - f(-h)) - (f(2 * h) - f(-2 * h))) / (12 * h)
+        assert abs(g[D + k] - fd) <= 1e-6 * max(abs(fd), np.abs(g[D:2 * D]).max()), (k, g[D + k], fd)
+    def f0(t):
+        sp = copy.deepcopy(spec); sp["order_variances"][0] += t
+        return sv.svgp_elbo(sp, X, y, Z, q_mu, q_sqrt)
+    fd0 = (8 * (f0(h) - f0(-h)) - (f0(2 * h) - f0(-2 * h))) / (12 * h)
+    assert abs(g[2 * D] - fd0) <= 1e-6 * abs(fd0)
