@@ -121,6 +121,7 @@ def main():
     ctx.sgpr_set_inducing(Z)
     ctx.sgpr_set_route(args.route)
     host_exchange = world > 1 and args.exchange == "host"
+    abandoned_thread = False
     exchange_note = "none" if world == 1 else args.exchange
     if world > 1 and not host_exchange:
         import torch
@@ -138,17 +139,34 @@ def main():
         if int(pre.item()) == 1:
             ids = [my_id if rank == 0 else None]
             dist.broadcast_object_list(ids, src=0)
-            try:
-                ctx.comm_init(ids[0], world, rank)
-            except Exception as e:
+            # the collective init runs on a helper thread so that a rank stuck inside it (a fabric / IPC problem) is noticed:
+            # after OAK_BENCH_RCCL_TIMEOUT seconds the rank reports failure and every rank falls back to the host exchange
+            import threading
+            box = {}
+
+            def _init():
+                try:
+                    ctx.comm_init(ids[0], world, rank)
+                    box["ok"] = True
+                except Exception as e:                             # noqa: BLE001
+                    box["err"] = e
+
+            th = threading.Thread(target=_init, daemon=True)
+            th.start()
+            th.join(float(os.environ.get("OAK_BENCH_RCCL_TIMEOUT", "240")))
+            if th.is_alive():
+                ok, abandoned_thread = 0, True
+                print(f"[bench] rank {rank}: RCCL communicator init still running after the timeout; abandoning it", file=sys.stderr)
+            elif "err" in box:
                 ok = 0
-                print(f"[bench] rank {rank}: RCCL communicator init failed: {e}", file=sys.stderr)
+                print(f"[bench] rank {rank}: RCCL communicator init failed: {box['err']}", file=sys.stderr)
         else:
             ok = 0
         flag = torch.tensor([ok], dtype=torch.int32)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)              # every rank takes the same path
         if int(flag.item()) == 0:
-            ctx.comm_destroy()
+            if not abandoned_thread:
+                ctx.comm_destroy()
             host_exchange = True
             exchange_note = "host (RCCL init failed, statistics all-reduced over gloo)"
 
@@ -236,6 +254,8 @@ def main():
         if dist is not None:
             dist.barrier()
             dist.destroy_process_group()
+        if abandoned_thread:
+            os._exit(0)
         return
 
     n_local = hi - lo
@@ -314,10 +334,13 @@ def main():
             out["speedup_vs_cpu_baseline"] = value / out["cpu_baseline"]["value"]
         except Exception as ex:   # the baseline is a reported comparator, never the thing measured
             out["cpu_baseline"] = {"error": repr(ex)}
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if abandoned_thread:          # a helper thread is still inside ncclCommInitRank: do not wait for it at interpreter exit
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
