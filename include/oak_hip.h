@@ -188,7 +188,8 @@ int oak_gpr_log_marginal_grad(oak_ctx* ctx, const oak_kernel_desc* desc, double 
  *      (GPflow: 20 nodes); link 0: p = sigmoid(f)(1 - 2 eps) + eps (the example's inv_logit, eps = 1e-3),
  *      link 1: p = Phi(f)(1 - 2 eps) + eps (GPflow's inv_probit). ------------------------------------- */
 /* elbo = sum_n E_q[log p(y_n | f_n)] - KL(q(v) || N(0, I)).  grad_out NULL: forward only; otherwise grad_out
-   [oak_grad_len, noise slot 0], grad_qmu [M], grad_qsqrt [M] receive d elbo / d (constrained parameter). */
+   [oak_grad_len, noise slot 0], grad_qmu [M], grad_qsqrt [M] receive d elbo / d (constrained parameter).
+   Under a communicator (oak_comm_init) the rows are one rank's shard: the row sums are all-reduced inside. */
 int oak_svgp_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, const double* q_mu, const double* q_sqrt,
                        double jitter, const double* gh_x, const double* gh_w, int32_t n_gh, int32_t link,
                        double link_eps, double* elbo_out, double* grad_out, double* grad_qmu, double* grad_qsqrt);
