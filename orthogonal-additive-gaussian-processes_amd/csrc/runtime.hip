@@ -88,6 +88,87 @@ int fill_zero(oak_ctx* ctx, void* dst, size_t bytes) {
 // ---------------------------------------------------------------------------------------------
 // featurize kernels
 // ---------------------------------------------------------------------------------------------
+// one point, one dimension: vx = scaled input (category index for discrete dims), vc = cov_X_s / sqrt(var_s),
+// vd = its lengthscale derivative in the pair kernels' units
+__device__ __forceinline__ void featurize_point(const DevDesc& dd, const DevMeasure& dm, const double* __restrict__ meas, int d,
+                                                double x, double& vx, double& vc, double& vd) {
+    vx = 0.0; vc = 0.0; vd = 0.0;
+    if (dd.type[d] == OAK_DIM_RBF) {
+        vx = x * dd.scale[d];
+        const double l = dm.ls[d], bv = dd.bv[d];
+        double c = 0.0, dc = 0.0;     // cov_X_s(x) and its lengthscale derivative
+        switch (dm.kind[d]) {
+            case OAK_MEAS_GAUSSIAN: {   // oak/ortho_rbf_kernel.py:82-92
+                const double mu = dm.p0[d], var = dm.p1[d];
+                const double s = l * l + var;
+                const double u2 = (x - mu) * (x - mu);
+                c = bv * l / sqrt(s) * exp(-0.5 * u2 / s);
+                dc = c * (1.0 / l - l / s + u2 * l / (s * s));
+            } break;
+            case OAK_MEAS_UNIFORM: {    // oak/ortho_rbf_kernel.py:49-63
+                const double a = dm.p0[d], b = dm.p1[d];
+                const double r2l = 1.0 / (1.4142135623730951 * l);
+                const double zb = (b - x) * r2l, za = (a - x) * r2l;
+                const double pre = bv * l / (b - a) * 1.2533141373155001;
+                c = pre * (erf(zb) - erf(za));
+                dc = c / l + pre * 1.1283791670955126 * (-zb * exp(-zb * zb) + za * exp(-za * za)) / l;
+            } break;
+            case OAK_MEAS_EMPIRICAL: {  // oak/ortho_rbf_kernel.py:101-107
+                const int K = dm.k[d];
+                const double* loc = meas + dm.off[d];
+                const double* w = loc + K;
+                const double il2 = 0.5 / (l * l);
+                double acc = 0.0, dacc = 0.0;
+                for (int k = 0; k < K; ++k) {
+                    const double u = x - loc[k];
+                    const double e = w[k] * exp(-u * u * il2);
+                    acc += e; dacc += e * u * u;
+                }
+                c = bv * acc;
+                dc = bv * dacc / (l * l * l);
+            } break;
+            case OAK_MEAS_MOG: {        // oak/ortho_rbf_kernel.py:124-136
+                const int K = dm.k[d];
+                const double* mu = meas + dm.off[d];
+                const double* var = mu + K;
+                const double* w = var + K;
+                double acc = 0.0, dacc = 0.0;
+                for (int k = 0; k < K; ++k) {
+                    const double s = l * l + var[k];
+                    const double u = x - mu[k];
+                    const double e = w[k] * exp(-0.5 * u * u / s) / sqrt(s);
+                    acc += e; dacc += e * (-l / s + u * u * l / (s * s));
+                }
+                c = bv * l * acc;
+                dc = c / l + bv * l * dacc;
+            } break;
+            default: c = 0.0; dc = 0.0;
+        }
+        vc = c * dm.inv_sqrt_v[d];
+        // d/dl [ c / sqrt(v) ], pre-divided by 2 ln2 / l: the pair kernels form dk/dl in units of that factor (see grad.hip)
+        vd = (dc - 0.5 * c * dm.dlogv[d]) * dm.inv_sqrt_v[d] * (l / 1.3862943611198906);
+    } else {
+        // tf.cast(float64 -> int32) truncates toward zero (ortho_binary_kernel.py:47); clamp keeps lookups in range
+        double t = trunc(x);
+        const double hi = (double)(dd.ncat[d] - 1);
+        t = t < 0.0 ? 0.0 : (t > hi ? hi : t);
+        vx = t; vc = 0.0;
+    }
+}
+
+__device__ __forceinline__ void featurize_store(const DevDesc& dd, int d, int64_t idx, double vx, double vc, double vd,
+                                                double* __restrict__ xs, double* __restrict__ cn, double* __restrict__ dcn,
+                                                double* __restrict__ xs32, double* __restrict__ dcs) {
+    xs[idx] = vx;
+    cn[idx] = vc;
+    if (dcn != nullptr) {
+        dcn[idx] = vd;
+        xs32[idx] = dd.type[d] == OAK_DIM_RBF ? vx * 0.03125 : vx;
+        dcs[idx] = vd * 0.0009765625;
+    }
+}
+
+// generic form: one thread per (point, dimension); the strided reads of X cost a 128-byte line per 8 bytes used
 __global__ void __launch_bounds__(256) featurize_kernel(DevDesc dd, DevMeasure dm, const double* __restrict__ meas,
                                                         const double* __restrict__ X, int64_t n, int ldx, int64_t ld,
                                                         double* __restrict__ xs, double* __restrict__ cn, double* __restrict__ dcn,
@@ -96,76 +177,33 @@ __global__ void __launch_bounds__(256) featurize_kernel(DevDesc dd, DevMeasure d
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ld) return;
     double vx = 0.0, vc = 0.0, vd = 0.0;
-    if (i < n) {
-        const double x = X[i * ldx + dd.col[d]];
-        if (dd.type[d] == OAK_DIM_RBF) {
-            vx = x * dd.scale[d];
-            const double l = dm.ls[d], bv = dd.bv[d];
-            double c = 0.0, dc = 0.0;     // cov_X_s(x) and its lengthscale derivative
-            switch (dm.kind[d]) {
-                case OAK_MEAS_GAUSSIAN: {   // oak/ortho_rbf_kernel.py:82-92
-                    const double mu = dm.p0[d], var = dm.p1[d];
-                    const double s = l * l + var;
-                    const double u2 = (x - mu) * (x - mu);
-                    c = bv * l / sqrt(s) * exp(-0.5 * u2 / s);
-                    dc = c * (1.0 / l - l / s + u2 * l / (s * s));
-                } break;
-                case OAK_MEAS_UNIFORM: {    // oak/ortho_rbf_kernel.py:49-63
-                    const double a = dm.p0[d], b = dm.p1[d];
-                    const double r2l = 1.0 / (1.4142135623730951 * l);
-                    const double zb = (b - x) * r2l, za = (a - x) * r2l;
-                    const double pre = bv * l / (b - a) * 1.2533141373155001;
-                    c = pre * (erf(zb) - erf(za));
-                    dc = c / l + pre * 1.1283791670955126 * (-zb * exp(-zb * zb) + za * exp(-za * za)) / l;
-                } break;
-                case OAK_MEAS_EMPIRICAL: {  // oak/ortho_rbf_kernel.py:101-107
-                    const int K = dm.k[d];
-                    const double* loc = meas + dm.off[d];
-                    const double* w = loc + K;
-                    const double il2 = 0.5 / (l * l);
-                    double acc = 0.0, dacc = 0.0;
-                    for (int k = 0; k < K; ++k) {
-                        const double u = x - loc[k];
-                        const double e = w[k] * exp(-u * u * il2);
-                        acc += e; dacc += e * u * u;
-                    }
-                    c = bv * acc;
-                    dc = bv * dacc / (l * l * l);
-                } break;
-                case OAK_MEAS_MOG: {        // oak/ortho_rbf_kernel.py:124-136
-                    const int K = dm.k[d];
-                    const double* mu = meas + dm.off[d];
-                    const double* var = mu + K;
-                    const double* w = var + K;
-                    double acc = 0.0, dacc = 0.0;
-                    for (int k = 0; k < K; ++k) {
-                        const double s = l * l + var[k];
-                        const double u = x - mu[k];
-                        const double e = w[k] * exp(-0.5 * u * u / s) / sqrt(s);
-                        acc += e; dacc += e * (-l / s + u * u * l / (s * s));
-                    }
-                    c = bv * l * acc;
-                    dc = c / l + bv * l * dacc;
-                } break;
-                default: c = 0.0; dc = 0.0;
-            }
-            vc = c * dm.inv_sqrt_v[d];
-            // d/dl [ c / sqrt(v) ], pre-divided by 2 ln2 / l: the pair kernels form dk/dl in units of that factor (see grad.hip)
-            vd = (dc - 0.5 * c * dm.dlogv[d]) * dm.inv_sqrt_v[d] * (l / 1.3862943611198906);
-        } else {
-            // tf.cast(float64 -> int32) truncates toward zero (ortho_binary_kernel.py:47); clamp keeps lookups in range
-            double t = trunc(x);
-            const double hi = (double)(dd.ncat[d] - 1);
-            t = t < 0.0 ? 0.0 : (t > hi ? hi : t);
-            vx = t; vc = 0.0;
-        }
+    if (i < n) featurize_point(dd, dm, meas, d, X[i * ldx + dd.col[d]], vx, vc, vd);
+    featurize_store(dd, d, (int64_t)d * ld + i, vx, vc, vd, xs, cn, dcn, xs32, dcs);
+}
+
+// narrow inputs (ldx <= 31 columns): a workgroup reads its 256 rows of X ONCE, contiguously, into LDS (odd pitch: the
+// column reads are conflict-free) and walks the dimensions; every output array is written dimension-major, coalesced.
+// HBM traffic = the algorithmic bytes (the generic form fetched 16x the input at ldx = 16).
+__global__ void __launch_bounds__(256) featurize_tile_kernel(DevDesc dd, DevMeasure dm, const double* __restrict__ meas,
+                                                             const double* __restrict__ X, int64_t n, int ldx, int64_t ld,
+                                                             double* __restrict__ xs, double* __restrict__ cn, double* __restrict__ dcn,
+                                                             double* __restrict__ xs32, double* __restrict__ dcs) {
+    extern __shared__ __attribute__((aligned(16))) double tile[];      // [256][pitch]
+    const int pitch = ldx | 1;
+    const int64_t i0 = (int64_t)blockIdx.x * 256;
+    const int64_t rows = (n - i0 < 256) ? (n - i0 > 0 ? n - i0 : 0) : 256;
+    const double* src = X + i0 * ldx;
+    for (int64_t e = threadIdx.x; e < rows * ldx; e += 256) {
+        const int r = (int)(e / ldx), c = (int)(e - (int64_t)r * ldx);
+        tile[r * pitch + c] = src[e];
     }
-    xs[(int64_t)d * ld + i] = vx;
-    cn[(int64_t)d * ld + i] = vc;
-    if (dcn != nullptr) {
-        dcn[(int64_t)d * ld + i] = vd;
-        xs32[(int64_t)d * ld + i] = dd.type[d] == OAK_DIM_RBF ? vx * 0.03125 : vx;
-        dcs[(int64_t)d * ld + i] = vd * 0.0009765625;
+    __syncthreads();
+    const int64_t i = i0 + threadIdx.x;
+    if (i >= ld) return;
+    for (int d = 0; d < dd.D; ++d) {
+        double vx = 0.0, vc = 0.0, vd = 0.0;
+        if (i < n) featurize_point(dd, dm, meas, d, tile[threadIdx.x * pitch + dd.col[d]], vx, vc, vd);
+        featurize_store(dd, d, (int64_t)d * ld + i, vx, vc, vd, xs, cn, dcn, xs32, dcs);
     }
 }
 
@@ -367,9 +405,15 @@ int featurize(oak_ctx* ctx, const PreparedKernel& pk, const double* dX, int64_t 
     out->dcn = with_grad ? base + (size_t)2 * D * ld : nullptr;
     out->xs32 = with_grad ? base + (size_t)3 * D * ld : nullptr;
     out->dcs = with_grad ? base + (size_t)4 * D * ld : nullptr;
-    dim3 grid((unsigned)((ld + 255) / 256), (unsigned)D);
-    featurize_kernel<<<grid, 256, 0, ctx->stream>>>(pk.dd, pk.dm, pk.d_meas, dX, n, ldx, ld, out->xs, out->cn, out->dcn, out->xs32,
-                                                     out->dcs);
+    if (ldx <= 31 && n >= 4096) {
+        const size_t lds = sizeof(double) * 256 * (size_t)(ldx | 1);
+        featurize_tile_kernel<<<(unsigned)((ld + 255) / 256), 256, lds, ctx->stream>>>(pk.dd, pk.dm, pk.d_meas, dX, n, ldx, ld, out->xs,
+                                                                                     out->cn, out->dcn, out->xs32, out->dcs);
+    } else {
+        dim3 grid((unsigned)((ld + 255) / 256), (unsigned)D);
+        featurize_kernel<<<grid, 256, 0, ctx->stream>>>(pk.dd, pk.dm, pk.d_meas, dX, n, ldx, ld, out->xs, out->cn, out->dcn, out->xs32,
+                                                         out->dcs);
+    }
     OAK_HIP_CHECK(hipGetLastError());
     return OAK_OK;
 }
