@@ -331,3 +331,32 @@ def test_independent_contexts_are_thread_safe():
         assert len(o_) == 1 and not isinstance(o_[0], Exception), o_
         for a, b in zip(s, o_[0]):
             assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
+def test_every_entry_point_rejects_a_null_context():
+    """Each ctx-taking function of include/oak_hip.h returns a negative status (never dereferences) for ctx = NULL with all
+    other arguments zero / NULL, and leaves a message in oak_last_error."""
+    import ctypes as C
+    lib = _capi.load_library()
+    skipped = []
+    for name, (restype, argtypes) in _capi.SIGNATURES.items():
+        if not argtypes or argtypes[0] is not C.c_void_p or name in ("oak_ctx_destroy",):
+            skipped.append(name)
+            continue
+        args = []
+        for t in argtypes:
+            if t in (C.c_int, C.c_int32, C.c_int64):
+                args.append(0)
+            elif t is C.c_double:
+                args.append(0.0)
+            else:
+                args.append(None)
+        rc = getattr(lib, name)(*args)
+        if restype is C.c_int64 or name == "oak_comm_destroy":   # a length (0 for no context) / destroying nothing is fine
+            assert rc == 0, name
+        else:
+            assert rc < 0, f"{name} accepted a NULL context (rc={rc})"
+            assert lib.oak_last_error(), name
+    assert lib.oak_ctx_destroy(None) == 0                      # destroying nothing is fine
+    assert set(skipped) <= {"oak_last_error", "oak_version", "oak_device_count", "oak_grad_len", "oak_comm_unique_id", "oak_ctx_create",
+                            "oak_ctx_destroy"}, skipped
