@@ -360,3 +360,25 @@ def test_every_entry_point_rejects_a_null_context():
     assert lib.oak_ctx_destroy(None) == 0                      # destroying nothing is fine
     assert set(skipped) <= {"oak_last_error", "oak_version", "oak_device_count", "oak_grad_len", "oak_comm_unique_id", "oak_ctx_create",
                             "oak_ctx_destroy"}, skipped
+
+
+@pytest.mark.parametrize("N,M,D,R", [(1, 1, 1, 1), (2, 1, 1, 0), (1, 2, 2, 2), (3, 3, 1, 1), (5, 2, 3, 3), (64, 1, 2, 1)])
+def test_degenerate_sizes(hip, N, M, D, R):
+    """One row, one inducing point, depth 0, more inducing points than rows: ELBO, gradient, predictions and the full-GP
+    marginal likelihood against the oracle."""
+    rng = np.random.default_rng(N * 100 + M)
+    X, Z, y = rng.standard_normal((N, D)), rng.standard_normal((M, D)), rng.standard_normal((N, 1))
+    spec = o.make_spec(D, R, lengthscales=list(rng.uniform(0.8, 1.5, D)), order_variances=list(rng.uniform(0.5, 1.5, R + 1)))
+    d = _capi.KernelDesc(spec)
+    er = o.sgpr_elbo(spec, X, y, Z, 0.1)
+    mr, vr = o.sgpr_predict_f(spec, X, y, Z, 0.1, X)
+    for route in ("phi", "whitened"):
+        setup(hip, X, y, Z, route)
+        assert rel(hip.sgpr_elbo(d, 0.1), er) <= 1e-12
+        e2, g = hip.sgpr_elbo_grad(d, 0.1)
+        assert rel(e2, er) <= 1e-12 and np.isfinite(g).all()
+        m, v = hip.sgpr_predict(d, X)
+        np.testing.assert_allclose(m, np.asarray(mr).ravel(), rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(v, np.asarray(vr).ravel(), rtol=1e-10, atol=1e-12)
+    hip.gpr_set_data(X, y)
+    assert rel(hip.gpr_log_marginal(d, 0.1), o.gpr_log_marginal_likelihood(spec, X, y, 0.1)) <= 1e-12
