@@ -221,3 +221,33 @@ def test_far_apart_pairs_with_non_unit_base_variance(hip, variances):
     sp["dims"][1]["variance"] += h; sm["dims"][1]["variance"] -= h
     fd = (o.sgpr_elbo(sp, X, y, Z, 0.3) - o.sgpr_elbo(sm, X, y, Z, 0.3)) / (2 * h)
     assert abs(g[D + 1] - fd) <= 1e-4 * max(abs(fd), 1e-8)
+
+
+@pytest.mark.parametrize("ls", [1e-3, 3e-2, 50.0, 1e3])
+def test_lengthscales_at_the_bounds_of_the_reference(hip, ls, monkeypatch):
+    """oak_model bounds the lengthscales to [1e-3, 1e3] (model_utils.py:199).  At the upper bound exp(.) and cn cn cancel to
+    ~1e-6; at the lower bound x / l reaches the thousands and the reference's squared distance in GPflow's
+    |x|^2 + |z|^2 - 2 x z form loses |x / l|^2 * eps ~ 1e-9 to cancellation on near-coincident pairs, where the HIP kernel
+    subtracts first.  So: HIP vs the oracle with the distance formed as (x - z)^2 <= 1e-12 of the largest entry at every
+    lengthscale; HIP vs the reference-form oracle within that form's own cancellation bound."""
+    rng = np.random.default_rng(int(ls * 1000) % 97)
+    D, R = 4, 2
+    spec = o.make_spec(D, R, lengthscales=[ls, ls * 1.5, 1.0, ls], order_variances=[0.8, 1.1, 0.6])
+    X, X2 = rng.standard_normal((150, D)), rng.standard_normal((70, D))
+    X2[:5] = X[:5] + 4e-4 * rng.standard_normal((5, D))      # near-coincident pairs: the worst case of the expanded form
+    d = _capi.KernelDesc(spec)
+    got, got_diag = hip.gram(d, X, X2), hip.gram_diag(d, X)
+    ref_form = o.oak_K(spec, X, X2)
+    bound = 16 * np.finfo(float).eps * max(1.0, float(np.abs(X / min(ls, 1.0)).max()) ** 2) * np.abs(ref_form).max()
+    assert np.abs(got - ref_form).max() <= max(bound, 1e-12 * np.abs(ref_form).max())
+
+    def rbf_direct(A, B, lengthscale, variance):
+        A = np.asarray(A, dtype=np.float64); B = A if B is None else np.asarray(B, dtype=np.float64)
+        r2 = (((A[:, None, :] - B[None, :, :]) / lengthscale) ** 2).sum(-1)
+        return variance * np.exp(-0.5 * r2)
+
+    monkeypatch.setattr(o, "rbf_K", rbf_direct)
+    ref = o.oak_K(spec, X, X2)
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+    ref_diag = o.oak_K_diag(spec, X)
+    assert np.abs(got_diag - ref_diag).max() <= 1e-12 * np.abs(ref_diag).max()
