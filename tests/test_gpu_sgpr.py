@@ -382,3 +382,21 @@ def test_degenerate_sizes(hip, N, M, D, R):
         np.testing.assert_allclose(v, np.asarray(vr).ravel(), rtol=1e-10, atol=1e-12)
     hip.gpr_set_data(X, y)
     assert rel(hip.gpr_log_marginal(d, 0.1), o.gpr_log_marginal_likelihood(spec, X, y, 0.1)) <= 1e-12
+
+
+@pytest.mark.parametrize("ov_scale", [1e-4, 1.0, 1e4])
+@pytest.mark.parametrize("s2", [1e-6, 1.0, 1e6])
+def test_noise_and_variance_extremes(hip, ov_scale, s2):
+    """Twelve decades of noise variance (the likelihood's lower bound 1e-6 upward) and eight of kernel variance: ELBO 1e-10,
+    predictions 1e-9 on both routes (cond(Kuu + jitter I) ~ 1e4 here)."""
+    X, y, Z = o.synthetic_problem(3000, 5, 100, seed=2)
+    spec = o.make_spec(5, 2, lengthscales=[1.0, 0.7, 1.3, 2.0, 0.9], order_variances=[0.8 * ov_scale, 1.1 * ov_scale, 0.6 * ov_scale])
+    d = _capi.KernelDesc(spec)
+    er = o.sgpr_elbo(spec, X, y, Z, s2)
+    mr, vr = o.sgpr_predict_f(spec, X, y, Z, s2, X[:200])
+    mr, vr = np.asarray(mr).ravel(), np.asarray(vr).ravel()
+    for route in ("phi", "whitened"):
+        setup(hip, X, y, Z, route)
+        assert rel(hip.sgpr_elbo(d, s2), er) <= 1e-10
+        m, v = hip.sgpr_predict(d, X[:200])
+        assert np.abs(m - mr).max() <= 1e-9 * max(1.0, np.abs(mr).max()) and np.abs(v - vr).max() <= 1e-9 * np.abs(vr).max()
