@@ -148,8 +148,9 @@ int prepare_component(oak_ctx* ctx, const oak_kernel_desc* desc, const int32_t* 
                       int32_t apply_order_var, PreparedKernel* pk);
 
 // featurize -------------------------------------------------------------------------------------
+// d_kdiag_sum != NULL: where the kernel form allows it, also write sum_i K_diag(x_i) there (*kdiag_done tells)
 int featurize(oak_ctx* ctx, const PreparedKernel& pk, const double* dX, int64_t n, int32_t ldx,
-              const char* bufname, Feat* out, bool with_grad = false);
+              const char* bufname, Feat* out, bool with_grad = false, double* d_kdiag_sum = nullptr, bool* kdiag_done = nullptr);
 
 // gram ------------------------------------------------------------------------------------------
 // out[i*ldo + j] = K(A_i, B_j).  If yA != nullptr also accumulates psi[j] += sum_i K(i,j) y_i into d_psi

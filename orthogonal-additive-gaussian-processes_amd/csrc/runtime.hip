@@ -187,7 +187,8 @@ __global__ void __launch_bounds__(256) featurize_kernel(DevDesc dd, DevMeasure d
 __global__ void __launch_bounds__(256) featurize_tile_kernel(DevDesc dd, DevMeasure dm, const double* __restrict__ meas,
                                                              const double* __restrict__ X, int64_t n, int ldx, int64_t ld,
                                                              double* __restrict__ xs, double* __restrict__ cn, double* __restrict__ dcn,
-                                                             double* __restrict__ xs32, double* __restrict__ dcs) {
+                                                             double* __restrict__ xs32, double* __restrict__ dcs,
+                                                             const double* __restrict__ tables, double* __restrict__ kpart) {
     extern __shared__ __attribute__((aligned(16))) double tile[];      // [256][pitch]
     const int pitch = ldx | 1;
     const int64_t i0 = (int64_t)blockIdx.x * 256;
@@ -199,12 +200,38 @@ __global__ void __launch_bounds__(256) featurize_tile_kernel(DevDesc dd, DevMeas
     }
     __syncthreads();
     const int64_t i = i0 + threadIdx.x;
-    if (i >= ld) return;
+    // kpart != NULL: the workgroup also leaves the sum of K_diag over its rows (kappa of the SGPR bound) -- every k_d(x, x)
+    // is at hand here, so the separate pass over the features (gram_diag + its reduction) drops off the critical path
+    double e[OAK_MAX_DEPTH];
+#pragma unroll
+    for (int q = 0; q < OAK_MAX_DEPTH; ++q) e[q] = 0.0;
+    const int R = dd.R;
     for (int d = 0; d < dd.D; ++d) {
         double vx = 0.0, vc = 0.0, vd = 0.0;
         if (i < n) featurize_point(dd, dm, meas, d, tile[threadIdx.x * pitch + dd.col[d]], vx, vc, vd);
-        featurize_store(dd, d, (int64_t)d * ld + i, vx, vc, vd, xs, cn, dcn, xs32, dcs);
+        if (i < ld) featurize_store(dd, d, (int64_t)d * ld + i, vx, vc, vd, xs, cn, dcn, xs32, dcs);
+        if (kpart != nullptr) {
+            const double k = dd.type[d] == OAK_DIM_RBF ? __builtin_fma(-vc, vc, dd.bv[d])
+                                                       : tables[dd.tab_off[d] + dd.ncat[d] * dd.ncat[d] + (int)vx];
+#pragma unroll
+            for (int q = OAK_MAX_DEPTH - 1; q >= 1; --q)
+                if (q < R) e[q] = __builtin_fma(k, e[q - 1], e[q]);
+            e[0] += k;
+        }
     }
+    if (kpart == nullptr) return;
+    double kd = dd.w[0];
+#pragma unroll
+    for (int q = 0; q < OAK_MAX_DEPTH; ++q)
+        if (q < R) kd = __builtin_fma(dd.w[q + 1], e[q], kd);
+    __syncthreads();                                   // the X tile is no longer needed: reuse it for the reduction
+    tile[threadIdx.x] = (i < n) ? kd : 0.0;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) tile[threadIdx.x] += tile[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) kpart[blockIdx.x] = tile[0];
 }
 
 // tmp[k] = w_k * sum_l w_l * bv * exp(-(loc_k-loc_l)^2 / (2 l^2))   (var_s of the empirical measure, :109-120)
@@ -396,7 +423,8 @@ int prepare_component(oak_ctx* ctx, const oak_kernel_desc* desc, const int32_t* 
 }
 
 int featurize(oak_ctx* ctx, const PreparedKernel& pk, const double* dX, int64_t n, int32_t ldx, const char* bufname, Feat* out,
-              bool with_grad) {
+              bool with_grad, double* d_kdiag_sum, bool* kdiag_done) {
+    if (kdiag_done) *kdiag_done = false;
     const int D = pk.dd.D;
     const int64_t ld = ((n + 63) / 64) * 64 + 64;   // padded so tile loads never run past the array
     double* base = nullptr;
@@ -407,8 +435,16 @@ int featurize(oak_ctx* ctx, const PreparedKernel& pk, const double* dX, int64_t 
     out->dcs = with_grad ? base + (size_t)4 * D * ld : nullptr;
     if (ldx <= 31 && n >= 4096) {
         const size_t lds = sizeof(double) * 256 * (size_t)(ldx | 1);
-        featurize_tile_kernel<<<(unsigned)((ld + 255) / 256), 256, lds, ctx->stream>>>(pk.dd, pk.dm, pk.d_meas, dX, n, ldx, ld, out->xs,
-                                                                                     out->cn, out->dcn, out->xs32, out->dcs);
+        const unsigned nblk = (unsigned)((ld + 255) / 256);
+        double* d_kpart = nullptr;
+        if (d_kdiag_sum != nullptr) OAK_CHECK(get_buf_t(ctx, "feat_kpart", (size_t)nblk, &d_kpart));
+        featurize_tile_kernel<<<nblk, 256, lds, ctx->stream>>>(pk.dd, pk.dm, pk.d_meas, dX, n, ldx, ld, out->xs, out->cn, out->dcn,
+                                                             out->xs32, out->dcs, pk.d_tables, d_kpart);
+        if (d_kdiag_sum != nullptr) {
+            OAK_HIP_CHECK(hipGetLastError());
+            OAK_CHECK(reduce_sum(ctx, d_kpart, nblk, d_kdiag_sum, 0, 1));      // fixed-order tree over the workgroup sums
+            if (kdiag_done) *kdiag_done = true;
+        }
     } else {
         dim3 grid((unsigned)((ld + 255) / 256), (unsigned)D);
         featurize_kernel<<<grid, 256, 0, ctx->stream>>>(pk.dd, pk.dm, pk.d_meas, dX, n, ldx, ld, out->xs, out->cn, out->dcn, out->xs32,

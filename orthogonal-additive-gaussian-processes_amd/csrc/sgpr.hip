@@ -89,10 +89,11 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     OAK_CHECK(stats_view(ctx, &st));
     OAK_CHECK(fill_zero(ctx, st.phi, sizeof(double) * (size_t)st.len));
     Feat FX, FZ;
+    bool kappa_done = false;       // kappa = sum K_diag comes out of the featurize pass when its tiled form runs
     {
         PhaseTimer t(ctx, "featurize");
         OAK_CHECK(featurize(ctx, pk, dZ, M, ctx->ldx, "featZ", &FZ));
-        OAK_CHECK(featurize(ctx, pk, dX, N, ctx->ldx, "featX", &FX));
+        OAK_CHECK(featurize(ctx, pk, dX, N, ctx->ldx, "featX", &FX, false, st.kappa, &kappa_done));
         t.stop();
     }
     int64_t rows = ctx->panel_rows > 0 ? ctx->panel_rows : (int64_t)(((size_t)16 << 30) / (sizeof(double) * (size_t)Mp));
@@ -153,10 +154,12 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     {
         PhaseTimer t(ctx, "reduce");
         OAK_CHECK(syrk_reduce(ctx, dPart, nsplit, M, st.phi, false));
-        double* dDiag = nullptr;
-        OAK_CHECK(get_buf_t(ctx, "kdiag", (size_t)N, &dDiag));
-        OAK_CHECK(gram_diag(ctx, pk, FX, dDiag, st.kappa));
-        OAK_CHECK(reduce_sum(ctx, dY, N, st.yy, 1, 1));
+        if (!kappa_done) {
+            double* dDiag = nullptr;
+            OAK_CHECK(get_buf_t(ctx, "kdiag", (size_t)N, &dDiag));
+            OAK_CHECK(gram_diag(ctx, pk, FX, dDiag, st.kappa));
+        }
+        OAK_CHECK(copy_d2d(ctx, st.yy, peek_buf(ctx, "yy_const"), sizeof(double)));      // y^T y: computed once in set_data
         // the row count goes in by kernel argument: no host buffer, so no host synchronisation here -- the tail's ~60
         // launches are enqueued while the SYRK is still running
         set_double_kernel<<<1, 1, 0, ctx->stream>>>(st.nrows, (double)N);
@@ -463,6 +466,9 @@ int oak_sgpr_set_data(oak_ctx* ctx, const double* X, const double* Y, int64_t N,
     double *dX, *dY;
     OAK_CHECK(HostUpload::run(ctx, "X", X, (size_t)N * ldx, &dX));
     OAK_CHECK(HostUpload::run(ctx, "Y", Y, (size_t)N, &dY));
+    double* dyy = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "yy_const", 1, &dyy));
+    OAK_CHECK(reduce_sum(ctx, dY, N, dyy, 1, 1));              // y^T y does not change between evaluations
     OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ctx->N = N; ctx->ldx = ldx; ctx->have_data = true; ctx->have_stats = false; ctx->have_post = false;
     return OAK_OK;
