@@ -13,8 +13,9 @@
  *     thread-local message retrievable with oak_last_error();
  *   - all host buffers are caller-owned, C-contiguous, row-major, float64 (int32 where stated);
  *   - the library owns all device memory behind an opaque oak_ctx (one per device; a main HIP
- *     stream plus a side stream for work that overlaps it); a ctx is not thread-safe, distinct
- *     ctxs are independent;
+ *     stream plus a side stream for work that overlaps it); a ctx is not thread-safe; distinct
+ *     ctxs share no mutable library state (the reference is single-threaded, and the package
+ *     drives each ctx from one thread; tools/dev_threads.py is the multi-thread stress);
  *   - there is NO CPU fallback: without a usable HIP device every compute call fails with
  *     OAK_E_HIP.
  */
