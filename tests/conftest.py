@@ -23,6 +23,21 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a HIP device (MI355X); deselected by -m 'not gpu'")
 
 
+# Watchdog: a test that makes no progress for WATCHDOG_S seconds (a wedged device call cannot be interrupted from Python)
+# dumps every thread's stack and ends the process with a failure instead of hanging the run.
+WATCHDOG_S = 900
+
+
+@pytest.hookimpl(hookwrapper=True)
+def pytest_runtest_protocol(item, nextitem):
+    import faulthandler
+    faulthandler.dump_traceback_later(WATCHDOG_S, exit=True)
+    try:
+        yield
+    finally:
+        faulthandler.cancel_dump_traceback_later()
+
+
 @pytest.fixture
 def concrete_normalised_10_rows_data():
     """10 rows x 7 columns of normalised UCI-concrete inputs + targets: the data fixture of the reference's
