@@ -1015,7 +1015,10 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
     PhaseTimer ttot(ctx, "total");
     // ---- forward ------------------------------------------------------------------------------------------
     double elbo = 0.0, terms[8];
-    OAK_CHECK(sgpr_forward(ctx, pk, noise_var, jitter, &elbo, terms));
+    ctx->keep_kfu = true;                                   // a whitening forward keeps the raw Kfu panel for the loop below
+    const int frc = sgpr_forward(ctx, pk, noise_var, jitter, &elbo, terms);
+    ctx->keep_kfu = false;
+    OAK_CHECK(frc);
     OAK_CHECK(sgpr_ensure_alpha(ctx));
     const int64_t N = ctx->N, M = ctx->M, Mp = ((M + 127) / 128) * 128;
     const double s2 = noise_var;
@@ -1096,7 +1099,7 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
     double *dPanel = nullptr, *dG = nullptr;
     OAK_CHECK(get_buf_t(ctx, "panel", (size_t)rows * Mp, &dPanel));
     OAK_CHECK(get_buf_t(ctx, "gpanel", (size_t)rows * Mp, &dG));
-    const bool reuse_panel = (rows >= N) && !ctx->stats_whitened;    // forward left the raw Kfu panel in place
+    const bool reuse_panel = (rows >= N) && (!ctx->stats_whitened || ctx->kfu_kept);    // forward left the raw Kfu panel in place
     for (int64_t a0 = 0; a0 < N; a0 += rows) {
         const int64_t na = (a0 + rows <= N) ? rows : N - a0;
         if (!reuse_panel) {

@@ -122,6 +122,8 @@ struct oak_ctx {
     int num_cu = 256;
     int64_t flow_n = 0;              // length of the resident normalising-flow sample "flow_g"
     int syrk_desc_ntile = -1;        // ntile the device descriptor table "syrk_desc" was built for
+    bool keep_kfu = false;           // set by the gradient entry points: a whitening forward works on a COPY of the Kfu panel
+    bool kfu_kept = false;           // ... and reports here that "panel" still holds the raw Kfu rows of the whole data set
 };
 
 namespace oak {
