@@ -124,7 +124,7 @@ constexpr int G2_RPL = 64 / G2_LPR;          // rows per wave-load
 constexpr int G2_NQ = G2_T / (4 * G2_RPL);   // loads per thread per matrix
 
 __global__ void __launch_bounds__(256, 2)
-gemm128_nt_kernel(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, int64_t m, int64_t n,
+gemm128_nt_kernel(const double* A, const double* __restrict__ B, double* C /* may alias A: trsm_rows runs the diagonal-block product in place */, int64_t m, int64_t n,
                   int64_t k, int64_t lda, int64_t ldb, int64_t ldc, double alpha, double beta, int ntn) {
     __shared__ __attribute__((aligned(16))) double As[G2_T * G2_P];
     __shared__ __attribute__((aligned(16))) double Bs[G2_T * G2_P];
@@ -213,10 +213,14 @@ int gemm_nn(oak_ctx* ctx, const double* dA, const double* dB, double* dC, int64_
             int64_t ldb, int64_t ldc, double alpha, double beta) {
     return gemm_launch(ctx, 0, dA, dB, dC, m, n, k, lda, ldb, ldc, alpha, beta, 0);
 }
+// true when gemm_nt takes the 128 x 128 kernel (one workgroup per output tile, every operand read before the tile is stored)
+static bool gemm128_eligible(const double* dA, const double* dB, int64_t m, int64_t n, int64_t k, int64_t lda, int64_t ldb, int lower_only) {
+    const bool aligned = ((lda | ldb) & 1) == 0 && (((uintptr_t)dA | (uintptr_t)dB) & 15) == 0 && k >= 2 && (k & 1) == 0;
+    return !lower_only && aligned && m >= 2048 && n >= 128 && m > 0 && n > 0;
+}
 int gemm_nt(oak_ctx* ctx, const double* dA, const double* dB, double* dC, int64_t m, int64_t n, int64_t k, int64_t lda,
             int64_t ldb, int64_t ldc, double alpha, double beta, int lower_only) {
-    const bool aligned = ((lda | ldb) & 1) == 0 && (((uintptr_t)dA | (uintptr_t)dB) & 15) == 0 && k >= 2 && (k & 1) == 0;
-    if (!lower_only && aligned && m >= 2048 && n >= 128 && m > 0 && n > 0) {
+    if (gemm128_eligible(dA, dB, m, n, k, lda, ldb, lower_only)) {
         const int ntn = (int)((n + G2_T - 1) / G2_T);
         const int64_t nrb = (m + G2_T - 1) / G2_T;
         const int64_t ngrp = (nrb + 7) / 8;
@@ -723,9 +727,16 @@ int trsm_rows(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, double* dB
                 if (j0 > 0)     // B[:, j] -= X[:, 0:j0] L[j, 0:j0]^T
                     OAK_CHECK(gemm_nt(ctx, dBT, dL + j0 * ldl, dBT + j0, nrhs, nbj, j0, ldb, ldl, ldb, -1.0, 1.0, 0));
                 if (nbj == NB) {
-                    OAK_HIP_CHECK(hipMemcpy2DAsync(dTmp, sizeof(double) * NB, dBT + j0, sizeof(double) * (size_t)ldb, sizeof(double) * NB,
-                                                   (size_t)nrhs, hipMemcpyDeviceToDevice, ctx->stream));
-                    OAK_CHECK(gemm_nt(ctx, dTmp, dInv + (j0 / NB) * NB * NB, dBT + j0, nrhs, NB, NB, NB, NB, ldb, 1.0, 0.0, 0));
+                    const double* inv = dInv + (j0 / NB) * NB * NB;
+                    if (gemm128_eligible(dBT + j0, inv, nrhs, NB, NB, ldb, NB, 0)) {
+                        // IN PLACE: with one 128-column tile per row block, the workgroup that stores rows r..r+127 of block j is
+                        // the only one that reads them, and it has read all of them (its whole K loop) before its epilogue
+                        OAK_CHECK(gemm_nt(ctx, dBT + j0, inv, dBT + j0, nrhs, NB, NB, ldb, NB, ldb, 1.0, 0.0, 0));
+                    } else {
+                        OAK_HIP_CHECK(hipMemcpy2DAsync(dTmp, sizeof(double) * NB, dBT + j0, sizeof(double) * (size_t)ldb, sizeof(double) * NB,
+                                                       (size_t)nrhs, hipMemcpyDeviceToDevice, ctx->stream));
+                        OAK_CHECK(gemm_nt(ctx, dTmp, inv, dBT + j0, nrhs, NB, NB, NB, NB, ldb, 1.0, 0.0, 0));
+                    }
                 } else {
                     OAK_CHECK(trsm_leaf(ctx, dL + j0 * ldl + j0, nbj, ldl, dBT + j0, nrhs, ldb, 0));
                 }
@@ -764,9 +775,14 @@ int trsm_rows(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, double* dB
                 if (rest > 0)
                     OAK_CHECK(gemm_nt(ctx, dBT + j0 + nbj, dLT + j0 * ldt + j0 + nbj, dBT + j0, nrhs, nbj, rest, ldb, ldt, ldb, -1.0, 1.0, 0));
                 if (nbj == NB) {
-                    OAK_HIP_CHECK(hipMemcpy2DAsync(dTmp, sizeof(double) * NB, dBT + j0, sizeof(double) * (size_t)ldb, sizeof(double) * NB,
-                                                   (size_t)nrhs, hipMemcpyDeviceToDevice, ctx->stream));
-                    OAK_CHECK(gemm_nt(ctx, dTmp, dInvT + (j0 / NB) * NB * NB, dBT + j0, nrhs, NB, NB, NB, NB, ldb, 1.0, 0.0, 0));
+                    const double* invt = dInvT + (j0 / NB) * NB * NB;
+                    if (gemm128_eligible(dBT + j0, invt, nrhs, NB, NB, ldb, NB, 0)) {
+                        OAK_CHECK(gemm_nt(ctx, dBT + j0, invt, dBT + j0, nrhs, NB, NB, ldb, NB, ldb, 1.0, 0.0, 0));   // in place, as above
+                    } else {
+                        OAK_HIP_CHECK(hipMemcpy2DAsync(dTmp, sizeof(double) * NB, dBT + j0, sizeof(double) * (size_t)ldb, sizeof(double) * NB,
+                                                       (size_t)nrhs, hipMemcpyDeviceToDevice, ctx->stream));
+                        OAK_CHECK(gemm_nt(ctx, dTmp, invt, dBT + j0, nrhs, NB, NB, NB, NB, ldb, 1.0, 0.0, 0));
+                    }
                 } else {
                     OAK_CHECK(trsm_leaf(ctx, dL + j0 * ldl + j0, nbj, ldl, dBT + j0, nrhs, ldb, 1));
                 }
