@@ -82,6 +82,9 @@ def main():
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "host"],
                     help="N>1: 'rccl' = reduce-scatter + all-gather over xGMI inside liboak_hip (default); 'host' = debug path that "
                          "sums the packed statistics through the gloo control plane (lets several ranks share one GPU)")
+    ap.add_argument("--allow-host-exchange", action="store_true",
+                    help="N>1 with --exchange rccl: if the RCCL communicator cannot be created, fall back to the host exchange and "
+                         "still print a (degraded) line; without this flag such a run exits non-zero")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-rows", type=int, default=262144)
     args = ap.parse_args()
@@ -120,8 +123,10 @@ def main():
     ctx.sgpr_set_data(Xl, yl)
     ctx.sgpr_set_inducing(Z)
     ctx.sgpr_set_route(args.route)
+    ctx.sgpr_set_global_rows(N)            # the auto route's size rule is about the whole problem, not this rank's shard
     host_exchange = world > 1 and args.exchange == "host"
     abandoned_thread = False
+    degraded = False                       # True when the RCCL design could not run and the number comes from the host exchange
     exchange_note = "none" if world == 1 else args.exchange
     if world > 1 and not host_exchange:
         import torch
@@ -168,7 +173,17 @@ def main():
             if not abandoned_thread:
                 ctx.comm_destroy()
             host_exchange = True
+            degraded = True
             exchange_note = "host (RCCL init failed, statistics all-reduced over gloo)"
+            if not args.allow_host_exchange:
+                # a scaling number that silently is not the RCCL design is worse than no number
+                print(f"[bench] rank {rank}: RCCL exchange unavailable and --allow-host-exchange not given: failing the run",
+                      file=sys.stderr, flush=True)
+                dist.barrier()
+                if abandoned_thread:
+                    sys.stdout.flush(); sys.stderr.flush()
+                    os._exit(3)
+                raise SystemExit(3)
 
     spec = make_spec(D, R, mixed=cfg.get("mixed", False))
 
@@ -179,7 +194,8 @@ def main():
             ctx.sgpr_local_stats(desc, jitter)
             t = torch.from_numpy(ctx.sgpr_get_stats())
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            ctx.sgpr_set_stats(t.numpy(), False)
+            tot = t.numpy()
+            ctx.sgpr_set_stats(tot, bool(tot[-2] > 0))      # the summed vector says whether its shards were whitened
             elbo, _ = ctx.sgpr_tail(desc, noise, jitter)
         elif args.grad:
             elbo, g = ctx.sgpr_elbo_grad(desc, noise, jitter)
@@ -255,8 +271,8 @@ def main():
             dist.barrier()
             dist.destroy_process_group()
         if abandoned_thread:
-            os._exit(0)
-        return
+            os._exit(3 if degraded else 0)
+        return 3 if degraded else 0
 
     n_local = hi - lo
     ms_per_step = dt / args.steps * 1e3
@@ -293,7 +309,7 @@ def main():
         "metric": "ELBO steps/sec" + (" (forward+gradient)" if args.grad else " (forward)"),
         "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
+        "dtype": "f64", "data": "synthetic", "degraded": degraded,
         "config": {"workload": f"{args.config}: SGPR ELBO, N={N} D={D} M={M} order={R}, Gaussian-measure ortho-RBF, "
                                f"Z=X[:M], noise=0.01, jitter=1e-6, route={args.route}",
                    "N": N, "D": D, "M": M, "order": R, "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}",
@@ -340,8 +356,9 @@ def main():
         dist.destroy_process_group()
     if abandoned_thread:          # a helper thread is still inside ncclCommInitRank: do not wait for it at interpreter exit
         sys.stdout.flush(); sys.stderr.flush()
-        os._exit(0)
+        os._exit(3 if degraded else 0)
+    return 3 if degraded else 0       # a degraded (host-exchange fallback) run never exits 0, even when it was allowed to print
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -124,8 +124,10 @@ int oak_sgpr_set_inducing(oak_ctx* ctx, const double* Z, int64_t M, int32_t ldx)
 /* Row budget of the N x M Kuf panel kept in HBM per pass (0 = library default). */
 int oak_sgpr_set_panel_rows(oak_ctx* ctx, int64_t rows);
 /* Sufficient statistics of the local rows, left on the device in the packed layout
-   [Phi (M*M) | psi (M) | kappa | yy | n_rows], Phi = Kuf Kuf^T, psi = Kuf y,
-   kappa = sum K_diag(X), yy = y^T y. */
+   [Phi (M*M) | psi (M) | kappa | yy | n_rows | n_whitened | n_parts], Phi = Kuf Kuf^T, psi = Kuf y,
+   kappa = sum K_diag(X), yy = y^T y; n_parts = 1 and n_whitened = 1 if this shard took the whitened route, so that
+   a SUM of packed vectors carries how many of its shards whitened: the tail (and oak_sgpr_set_stats) fail with
+   OAK_E_STATE unless n_whitened is 0 or n_parts. */
 int oak_sgpr_local_stats(oak_ctx* ctx, const oak_kernel_desc* desc, double jitter);
 /* Solve route.  1 = "phi": accumulate Phi = Kuf Kuf^T (M^2 N flops) and whiten the M x M result in the
    tail; deviation from GPflow's op order grows like cond(Kuu)*eps.  2 = "whitened": apply L^-1 to each
@@ -133,12 +135,19 @@ int oak_sgpr_local_stats(oak_ctx* ctx, const oak_kernel_desc* desc, double jitte
    then holds W = L^-1 Phi L^-T.  0 = auto: whitened while N*M <= 2^24; above that oak_sgpr_elbo and
    oak_sgpr_elbo_grad whiten only when chol(Kuu) looks ill-conditioned, (max diag L / min diag L)^2 > 1e3,
    which keeps the result within ~1e-10 of the literal route (the stand-alone oak_sgpr_local_stats uses the
-   size rule alone).  Every rank sees the same Kuu, so all ranks take the same route. */
+   size rule alone).  Under a communicator N is the row count over ALL ranks (one scalar all-reduce the first time a
+   (data, communicator) pair is evaluated -- collective, so every rank must call oak_sgpr_set_data / oak_comm_init the
+   same number of times -- or whatever oak_sgpr_set_global_rows declared), and the conditioning decision is rank 0's,
+   shared with the other ranks; so all ranks take the same route even when their shards differ in size. */
 int oak_sgpr_set_route(oak_ctx* ctx, int32_t route);
+/* Rows over all shards when this ctx holds one shard and the statistics are exchanged outside the library
+   (oak_sgpr_get_stats / oak_sgpr_set_stats): the auto route's size rule uses it.  0 = unknown (default). */
+int oak_sgpr_set_global_rows(oak_ctx* ctx, int64_t n_total);
 int oak_sgpr_stats_whitened(oak_ctx* ctx, int32_t* flag);
-int64_t oak_sgpr_stats_len(oak_ctx* ctx);                    /* M*M + M + 3 */
+int64_t oak_sgpr_stats_len(oak_ctx* ctx);                    /* M*M + M + 5 */
 int oak_sgpr_get_stats(oak_ctx* ctx, double* packed_out);    /* D2H copy of the packed buffer */
-int oak_sgpr_set_stats(oak_ctx* ctx, const double* packed, int32_t whitened);  /* H2D (externally reduced stats) */
+/* H2D (externally reduced stats); `whitened` must agree with the counts the packed vector carries */
+int oak_sgpr_set_stats(oak_ctx* ctx, const double* packed, int32_t whitened);
 /* Replicated O(M^3) tail on the packed stats: L=chol(Kuu+jitter I), AAT, LB, c, alpha, ELBO
    (gpflow SGPR.elbo; op order of oak/utils.py:187-198).  terms_out (may be NULL) receives
    [sum log diag LB, c^T c, tr(AAT), kappa, yy, n_rows, log det Kuu, 0]. */
@@ -147,6 +156,9 @@ int oak_sgpr_tail(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, d
 /* Convenience: local_stats + (all-reduce when a communicator is attached) + tail. */
 int oak_sgpr_elbo(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, double jitter,
                   double* elbo_out);
+/* The terms_out vector of the most recent successful tail, whichever entry point ran it (oak_sgpr_elbo and
+   oak_sgpr_elbo_grad included): the kernel-dependent pieces of the bound, for term-by-term parity checks. */
+int oak_sgpr_last_terms(oak_ctx* ctx, double* terms_out);
 /* alpha [M] of oak/utils.py:197-198; valid after a successful tail/elbo call. */
 int oak_sgpr_alpha(oak_ctx* ctx, double* alpha_out);
 /* The "effective L" that get_model_sufficient_statistics(m, get_L=True) returns for a sparse model

@@ -133,5 +133,9 @@ def sgpr_elbo_chunked(spec, X, Y, Z, noise_variance, jitter=o.JITTER, chunk=8192
     bound += -0.5 * kdiag_sum / noise_variance
     bound += 0.5 * np.trace(AAT)
     if return_parts:
-        return float(bound), dict(L=L, LB=LB, c=c, AAT=AAT)
+        # the kernel-dependent pieces of the bound one by one (same names as HipContext.sgpr_last_terms)
+        terms = dict(sum_log_diag_LB=float(np.sum(np.log(np.diag(LB)))), cTc=float(np.sum(np.square(c))),
+                     tr_AAT=float(np.trace(AAT)), kappa=float(kdiag_sum), yy=float(np.sum(np.square(Y))), n_rows=float(N),
+                     logdet_Kuu=float(2.0 * np.sum(np.log(np.diag(L)))))
+        return float(bound), dict(L=L, LB=LB, c=c, AAT=AAT, terms=terms)
     return float(bound)

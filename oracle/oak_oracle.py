@@ -320,6 +320,16 @@ def sgpr_elbo(spec, X, Y, Z, noise_variance, jitter=JITTER):
     return float(bound)
 
 
+def sgpr_elbo_terms(spec, X, Y, Z, noise_variance, jitter=JITTER):
+    """The kernel-dependent pieces of the bound above, one by one (P = 1), named as HipContext.sgpr_last_terms names
+    them: a relative bound on the total is dominated by the data-only terms at large N, these are not."""
+    cc = sgpr_common(spec, X, Y, Z, noise_variance, jitter)
+    return dict(sum_log_diag_LB=float(np.sum(np.log(np.diag(cc["LB"])))), cTc=float(np.sum(np.square(cc["c"]))),
+                tr_AAT=float(np.sum(np.diag(cc["AAT"]))), kappa=float(np.sum(oak_K_diag(spec, X))),
+                yy=float(np.sum(np.square(cc["err"]))), n_rows=float(cc["err"].shape[0]),
+                logdet_Kuu=float(2.0 * np.sum(np.log(np.diag(cc["L"])))))
+
+
 def sgpr_alpha(spec, X, Y, Z, noise_variance, jitter=JITTER):
     """oak/utils.py:197-198."""
     cc = sgpr_common(spec, X, Y, Z, noise_variance, jitter)

@@ -58,21 +58,48 @@ static int load_rccl() {
 static char g_loopback_tag;
 static inline bool is_loopback(const oak_ctx* ctx) { return ctx->comm == (void*)&g_loopback_tag; }
 
-int comm_allreduce_dev(oak_ctx* ctx, double* d_buf, int64_t n) {
-    if (ctx->comm == nullptr || ctx->nranks <= 1) return OAK_OK;
-    if (is_loopback(ctx)) return scale_vec(ctx, (double)ctx->nranks, d_buf, n);
-    OAK_CHECK(load_rccl());
+int comm_allreduce_dev(oak_ctx* ctx, double* d_buf, int64_t n, const char* stage) {
+    if (ctx->comm == nullptr || ctx->nranks <= 1 || n <= 0) return OAK_OK;
     const int64_t P = ctx->nranks;
     const int64_t slice = (n + P - 1) / P;
     double* d_stage = nullptr;
-    OAK_CHECK(get_buf_t(ctx, "comm_stage", (size_t)(slice * P), &d_stage));
-    OAK_CHECK(fill_zero(ctx, d_stage + n, sizeof(double) * (size_t)(slice * P - n)));
+    OAK_CHECK(get_buf_t(ctx, stage, (size_t)(slice * P), &d_stage));
+    if (slice * P > n) OAK_CHECK(fill_zero(ctx, d_stage + n, sizeof(double) * (size_t)(slice * P - n)));
     OAK_CHECK(copy_d2d(ctx, d_stage, d_buf, sizeof(double) * (size_t)n));
-    ncclComm_t comm = (ncclComm_t)ctx->comm;
-    OAK_NCCL_CHECK(g_rccl.ReduceScatter(d_stage, d_stage + ctx->rank * slice, (size_t)slice, ncclFloat64, ncclSum, comm, ctx->stream));
-    OAK_NCCL_CHECK(g_rccl.AllGather(d_stage + ctx->rank * slice, d_stage, (size_t)slice, ncclFloat64, comm, ctx->stream));
+    if (is_loopback(ctx)) {
+        // the same slicing as the real exchange: slice r is what rank r's reduce-scatter would hold (every rank has the same
+        // local vector, so the sum is nranks * local), and the all-gather is the identity on the staging buffer
+        for (int64_t r = 0; r < P; ++r) OAK_CHECK(scale_vec(ctx, (double)P, d_stage + r * slice, slice));
+    } else {
+        OAK_CHECK(load_rccl());
+        ncclComm_t comm = (ncclComm_t)ctx->comm;
+        OAK_NCCL_CHECK(g_rccl.ReduceScatter(d_stage, d_stage + ctx->rank * slice, (size_t)slice, ncclFloat64, ncclSum, comm, ctx->stream));
+        OAK_NCCL_CHECK(g_rccl.AllGather(d_stage + ctx->rank * slice, d_stage, (size_t)slice, ncclFloat64, comm, ctx->stream));
+    }
     OAK_CHECK(copy_d2d(ctx, d_buf, d_stage, sizeof(double) * (size_t)n));
     return OAK_OK;
+}
+
+__global__ void set_scalar_kernel(double* p, double v) { *p = v; }
+
+// Control-plane collective: every rank contributes one scalar, every rank gets the sum.  Runs on the side stream with
+// its own staging buffer so that it neither waits for nor disturbs what the main stream has queued.
+int comm_allreduce_scalar_side(oak_ctx* ctx, double* value) {
+    if (ctx->comm == nullptr || ctx->nranks <= 1) return OAK_OK;
+    double* d = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "comm_ctl", 1, &d));
+    hipStream_t main_stream = ctx->stream;
+    ctx->stream = ctx->side;
+    int rc = [&]() -> int {
+        set_scalar_kernel<<<1, 1, 0, ctx->stream>>>(d, *value);
+        OAK_HIP_CHECK(hipGetLastError());
+        OAK_CHECK(comm_allreduce_dev(ctx, d, 1, "comm_ctl_stage"));
+        OAK_HIP_CHECK(hipMemcpyAsync(value, d, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        return OAK_OK;
+    }();
+    ctx->stream = main_stream;
+    return rc;
 }
 
 }  // namespace oak
@@ -101,7 +128,7 @@ int oak_comm_init(oak_ctx* ctx, const char* id_128, int32_t nranks, int32_t rank
     memcpy(&id, id_128, 128);
     ncclComm_t comm = nullptr;
     OAK_NCCL_CHECK(g_rccl.CommInitRank(&comm, nranks, id, rank));
-    ctx->comm = (void*)comm; ctx->nranks = nranks; ctx->rank = rank;
+    ctx->comm = (void*)comm; ctx->nranks = nranks; ctx->rank = rank; ctx->n_global_comm = 0;
     return OAK_OK;
 }
 
@@ -109,14 +136,14 @@ int oak_comm_init_loopback(oak_ctx* ctx, int32_t nranks) {
     if (!ctx) { set_error("ctx is NULL"); return OAK_E_ARG; }
     OAK_REQUIRE(nranks >= 1, "nranks %d invalid", nranks);
     if (ctx->comm) oak_comm_destroy(ctx);
-    ctx->comm = (void*)&g_loopback_tag; ctx->nranks = nranks; ctx->rank = 0;
+    ctx->comm = (void*)&g_loopback_tag; ctx->nranks = nranks; ctx->rank = 0; ctx->n_global_comm = 0;
     return OAK_OK;
 }
 
 int oak_comm_destroy(oak_ctx* ctx) {
     if (!ctx || !ctx->comm) return OAK_OK;
     if (!is_loopback(ctx) && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)ctx->comm);
-    ctx->comm = nullptr; ctx->nranks = 1; ctx->rank = 0;
+    ctx->comm = nullptr; ctx->nranks = 1; ctx->rank = 0; ctx->n_global_comm = 0;
     return OAK_OK;
 }
 
@@ -127,7 +154,8 @@ int oak_comm_allreduce_stats(oak_ctx* ctx) {
     if (ctx->comm == nullptr || ctx->nranks <= 1) return OAK_OK;
     double* d_stats = (double*)peek_buf(ctx, "stats");
     PhaseTimer t(ctx, "allreduce");
-    OAK_CHECK(comm_allreduce_dev(ctx, d_stats, ctx->M * ctx->M + ctx->M + 3));
+    // the two trailing slots (shards that whitened, shards summed) ride along: the tail rejects a mixed sum
+    OAK_CHECK(comm_allreduce_dev(ctx, d_stats, oak_sgpr_stats_len(ctx)));
     t.stop();
     return OAK_OK;
 }

@@ -115,10 +115,13 @@ struct oak_ctx {
     double cond_mm[2] = {1.0, 1.0};  // min / max of diag chol(Kuu), written by the side stream
     hipEvent_t ev2 = nullptr;        // side stream: conditioning estimate ready
     double noise_var = 0, jitter = 0;
+    double last_terms[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // terms of the most recent tail (oak_sgpr_last_terms)
     // GPR state
     int64_t gN = 0; int32_t gldx = 0; bool g_have_data = false, g_have_post = false; double g_noise = 0;
     // communicator (RCCL, dlopen'ed)
     void* comm = nullptr; int nranks = 1, rank = 0;
+    int64_t n_global_user = 0;       // rows over ALL shards as told by oak_sgpr_set_global_rows (0: not told)
+    int64_t n_global_comm = 0;       // ... as summed over the communicator (0: not yet; reset by set_data / comm init / destroy)
     int num_cu = 256;
     int64_t flow_n = 0;              // length of the resident normalising-flow sample "flow_g"
     int syrk_desc_ntile = -1;        // ntile the device descriptor table "syrk_desc" was built for
@@ -213,6 +216,9 @@ void scatter_record(const oak_kernel_desc* desc, const PreparedKernel& pk, const
                     double* grad_out);
 
 // collectives --------------------------------------------------------------------------------------
-int comm_allreduce_dev(oak_ctx* ctx, double* d_buf, int64_t n);
+int comm_allreduce_dev(oak_ctx* ctx, double* d_buf, int64_t n, const char* stage = "comm_stage");
+// sum over ranks of one host scalar, on the SIDE stream (so it can run underneath main-stream kernels); synchronises the side stream
+int comm_allreduce_scalar_side(oak_ctx* ctx, double* value);
+int64_t sgpr_route_rows(const oak_ctx* ctx);     // rows the auto route is decided on: global when known, else local
 
 }  // namespace oak

@@ -22,7 +22,7 @@ __global__ void predict_var_kernel(const double* __restrict__ kdiag, const doubl
     if (i < n) var[i] = kdiag[i] + (s2 ? s2[i] : 0.0) - s1[i];
 }
 
-__global__ void set_double_kernel(double* p, double v) { *p = v; }
+__global__ void set_triple_kernel(double* p, double v0, double v1, double v2) { p[0] = v0; p[1] = v1; p[2] = v2; }
 
 static int guard(oak_ctx* ctx) {
     if (!ctx) { set_error("ctx is NULL"); return OAK_E_ARG; }
@@ -69,13 +69,30 @@ static int gram_diag_to_host(oak_ctx* ctx, const PreparedKernel& pk, const doubl
 }
 
 // packed statistics buffer accessors
-struct Stats { double *phi, *psi, *kappa, *yy, *nrows; int64_t len; };
+// [Phi | psi | kappa | yy | n_rows | n_whitened | n_parts]: the last two count the shards summed into the vector that
+// whitened their rows / in total, so that a sum of mixed-route shards is detected wherever it was formed
+struct Stats { double *phi, *psi, *kappa, *yy, *nrows, *nwhite, *nparts; int64_t len; };
+static constexpr int STATS_SCALARS = 5;
 static int stats_view(oak_ctx* ctx, Stats* s) {
     const int64_t M = ctx->M;
     double* base = nullptr;
-    s->len = M * M + M + 3;
+    s->len = M * M + M + STATS_SCALARS;
     OAK_CHECK(get_buf_t(ctx, "stats", (size_t)s->len, &base));
     s->phi = base; s->psi = base + M * M; s->kappa = s->psi + M; s->yy = s->kappa + 1; s->nrows = s->yy + 1;
+    s->nwhite = s->nrows + 1; s->nparts = s->nwhite + 1;
+    return OAK_OK;
+}
+static int check_route_counts(double nwhite, double nparts, bool expect_whitened) {
+    if (!(nparts >= 1.0) || !(nwhite == 0.0 || nwhite == nparts)) {
+        set_error("SGPR statistics mix solve routes: %g of %g summed shards were whitened (all ranks must take the same route)",
+                  nwhite, nparts);
+        return OAK_E_STATE;
+    }
+    if ((nwhite > 0.0) != expect_whitened) {
+        set_error("SGPR statistics were %s but are flagged as %s", nwhite > 0.0 ? "whitened" : "not whitened",
+                  expect_whitened ? "whitened" : "not whitened");
+        return OAK_E_STATE;
+    }
     return OAK_OK;
 }
 
@@ -132,6 +149,13 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
             OAK_HIP_CHECK(hipEventSynchronize(ctx->ev2));
             const double ratio = ctx->cond_mm[1] / ctx->cond_mm[0];
             ctx->auto_whiten = (ratio * ratio > AUTO_WHITEN_DIAG_RATIO2) ? 1 : 0;
+            if (ctx->comm != nullptr && ctx->nranks > 1) {
+                // every rank factors the same Kuu, but "the same bits on every GPU" is not something to stake the all-reduce
+                // on: rank 0's decision is the one all ranks take (sum of [rank 0: flag, others: 0])
+                double flag = (ctx->rank == 0) ? (double)ctx->auto_whiten : 0.0;
+                OAK_CHECK(comm_allreduce_scalar_side(ctx, &flag));
+                ctx->auto_whiten = flag > 0.5 ? 1 : 0;
+            }
             ctx->auto_pending = false;
             whiten = ctx->auto_whiten > 0;
             if (whiten) {
@@ -172,7 +196,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
         OAK_CHECK(copy_d2d(ctx, st.yy, peek_buf(ctx, "yy_const"), sizeof(double)));      // y^T y: computed once in set_data
         // the row count goes in by kernel argument: no host buffer, so no host synchronisation here -- the tail's ~60
         // launches are enqueued while the SYRK is still running
-        set_double_kernel<<<1, 1, 0, ctx->stream>>>(st.nrows, (double)N);
+        set_triple_kernel<<<1, 1, 0, ctx->stream>>>(st.nrows, (double)N, whiten ? 1.0 : 0.0, 1.0);
         OAK_HIP_CHECK(hipGetLastError());
         t.stop();
     }
@@ -187,10 +211,17 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
 // conditioning of Kuu first -- the phi route's deviation from GPflow's op order grows like 4e-16 * cond(Kuu) -- and
 // whiten when (max diag L / min diag L)^2 > 1e3.  That ratio UNDER-estimates cond(Kuu + jitter I) by 20-600x on the
 // problems measured (tests/dev), so the switch keeps the ELBO within ~1e-10 of the literal route.
+// The size rule looks at the rows of ALL shards (sgpr_route_rows): ranks whose shards differ by a row must not land on
+// opposite sides of the threshold.
+int64_t sgpr_route_rows(const oak_ctx* ctx) {
+    if (ctx->n_global_user > 0) return ctx->n_global_user;
+    if (ctx->comm != nullptr && ctx->nranks > 1 && ctx->n_global_comm > 0) return ctx->n_global_comm;
+    return ctx->N;
+}
 bool sgpr_route_whitened(const oak_ctx* ctx) {
     if (ctx->route == 2) return true;
     if (ctx->route == 1) return false;
-    if (ctx->N * ctx->M <= ((int64_t)1 << 24)) return true;
+    if (sgpr_route_rows(ctx) * ctx->M <= ((int64_t)1 << 24)) return true;
     return ctx->auto_whiten > 0;
 }
 
@@ -271,7 +302,14 @@ int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter,
 int sgpr_forward(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out) {
     int l_state = 1;                                    // whitened route: local_stats leaves L in place
     ctx->auto_whiten = -1;
-    const bool auto_big = ctx->route == 0 && ctx->N * ctx->M > ((int64_t)1 << 24);
+    if (ctx->route == 0 && ctx->comm != nullptr && ctx->nranks > 1 && ctx->n_global_user <= 0 && ctx->n_global_comm <= 0) {
+        // auto route under a communicator: the size rule needs the global row count.  One scalar all-reduce, once per
+        // (data, communicator) pair -- collective, like the evaluation it belongs to.
+        double n = (double)ctx->N;
+        OAK_CHECK(comm_allreduce_scalar_side(ctx, &n));
+        ctx->n_global_comm = (int64_t)llround(n);
+    }
+    const bool auto_big = ctx->route == 0 && sgpr_route_rows(ctx) * ctx->M > ((int64_t)1 << 24);
     ctx->auto_pending = false;
     if (auto_big || !sgpr_route_whitened(ctx)) {
         // auto on a large problem: the side stream also reports min / max of diag L; local_stats decides under its first
@@ -289,7 +327,8 @@ int sgpr_forward(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, doubl
     return rc;
 }
 
-// out[0] = sum log diag LB, out[1] = c^T c, out[2] = tr W, out[3..5] = (kappa, yy, nrows), out[6] = sum log diag L
+// out[0] = sum log diag LB, out[1] = c^T c, out[2] = tr W, out[3..5] = (kappa, yy, nrows), out[6] = sum log diag L,
+// out[7..8] = (n_whitened, n_parts)
 __global__ void __launch_bounds__(256) tail_scalars_kernel(const double* __restrict__ LB, const double* __restrict__ c,
                                                            const double* __restrict__ W, const double* __restrict__ L, int64_t M,
                                                            const double* __restrict__ kappa3, double* __restrict__ out) {
@@ -314,6 +353,7 @@ __global__ void __launch_bounds__(256) tail_scalars_kernel(const double* __restr
         out[0] = red[0][0]; out[1] = red[1][0]; out[2] = red[2][0];
         out[3] = kappa3[0]; out[4] = kappa3[1]; out[5] = kappa3[2];
         out[6] = red[3][0];
+        out[7] = kappa3[3]; out[8] = kappa3[4];          // shards that whitened / shards summed
     }
 }
 
@@ -332,7 +372,7 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     OAK_CHECK(get_buf_t(ctx, "LB", (size_t)(M + 1) * M, &dLB));
     OAK_CHECK(get_buf_t(ctx, "v1", (size_t)M, &dv1));
     OAK_CHECK(get_buf_t(ctx, "c", (size_t)M, &dc));
-    OAK_CHECK(get_buf_t(ctx, "scal", 8, &dscal));
+    OAK_CHECK(get_buf_t(ctx, "scal", 16, &dscal));
     const bool aug = !ctx->stats_whitened && (M % 32) == 0;     // phi route: explicit L^-1, right-hand side rides in the Cholesky
     // Kuu + jitter I -> L   (oak/utils.py:185,188)
     if (l_state == 2) {
@@ -384,10 +424,12 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     // scalars: sum log diag LB, c^T c, tr W, (kappa, yy, nrows), sum log diag L -- one small kernel, fixed reduction trees
     tail_scalars_kernel<<<1, 256, 0, ctx->stream>>>(dLB, dc, dT2, dL, M, st.kappa, dscal);
     OAK_HIP_CHECK(hipGetLastError());
-    double h[8] = {0};
-    OAK_HIP_CHECK(hipMemcpyAsync(h, dscal, sizeof(double) * 7, hipMemcpyDeviceToHost, ctx->stream));
+    double h[9] = {0};
+    OAK_HIP_CHECK(hipMemcpyAsync(h, dscal, sizeof(double) * 9, hipMemcpyDeviceToHost, ctx->stream));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    OAK_CHECK(check_route_counts(h[7], h[8], ctx->stats_whitened));   // a mixed-route sum explains any failure below: report it first
     if (l_state == 2) OAK_CHECK(potrf_check(ctx, 1, M));      // Kuu (side stream) first: it is the upstream failure
-    OAK_CHECK(potrf_check(ctx, 0, M));                        // then B; both synchronise the main stream
+    OAK_CHECK(potrf_check(ctx, 0, M));                        // then B
     t.stop();
     const double sumlogLB = h[0], cTc = h[1], trAAT = h[2] / noise_var, kappa = h[3], yy = h[4], nrows = h[5];
     // gpflow SGPR.elbo, P = 1
@@ -399,10 +441,8 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     bound += -0.5 * kappa / noise_var;
     bound += 0.5 * trAAT;
     if (elbo_out) *elbo_out = bound;
-    if (terms_out) {
-        terms_out[0] = sumlogLB; terms_out[1] = cTc; terms_out[2] = trAAT; terms_out[3] = kappa;
-        terms_out[4] = yy; terms_out[5] = nrows; terms_out[6] = 2.0 * h[6]; terms_out[7] = 0.0;
-    }
+    const double terms[8] = {sumlogLB, cTc, trAAT, kappa, yy, nrows, 2.0 * h[6], 0.0};
+    for (int i = 0; i < 8; ++i) { ctx->last_terms[i] = terms[i]; if (terms_out) terms_out[i] = terms[i]; }
     ctx->noise_var = noise_var; ctx->jitter = jitter;
     ctx->have_post = true;
     ctx->have_alpha = false;
@@ -481,6 +521,14 @@ int oak_sgpr_set_data(oak_ctx* ctx, const double* X, const double* Y, int64_t N,
     OAK_CHECK(reduce_sum(ctx, dY, N, dyy, 1, 1));              // y^T y does not change between evaluations
     OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ctx->N = N; ctx->ldx = ldx; ctx->have_data = true; ctx->have_stats = false; ctx->have_post = false;
+    ctx->n_global_comm = 0;                                    // the rows changed: the communicator-wide count is stale
+    return OAK_OK;
+}
+
+int oak_sgpr_set_global_rows(oak_ctx* ctx, int64_t n_total) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(n_total >= 0, "global row count must be >= 0 (0 = unknown)");
+    ctx->n_global_user = n_total;
     return OAK_OK;
 }
 
@@ -524,7 +572,7 @@ int oak_sgpr_stats_whitened(oak_ctx* ctx, int32_t* flag) {
     return OAK_OK;
 }
 
-int64_t oak_sgpr_stats_len(oak_ctx* ctx) { return ctx ? ctx->M * ctx->M + ctx->M + 3 : 0; }
+int64_t oak_sgpr_stats_len(oak_ctx* ctx) { return ctx ? ctx->M * ctx->M + ctx->M + STATS_SCALARS : 0; }
 
 int oak_sgpr_get_stats(oak_ctx* ctx, double* packed_out) {
     OAK_CHECK(guard(ctx));
@@ -541,6 +589,7 @@ int oak_sgpr_set_stats(oak_ctx* ctx, const double* packed, int32_t whitened) {
     OAK_REQUIRE(ctx->have_Z && packed, "set_inducing must precede set_stats");
     Stats st;
     OAK_CHECK(stats_view(ctx, &st));
+    OAK_CHECK(check_route_counts(packed[st.len - 2], packed[st.len - 1], whitened != 0));
     OAK_HIP_CHECK(hipMemcpyAsync(st.phi, packed, sizeof(double) * (size_t)st.len, hipMemcpyHostToDevice, ctx->stream));
     OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ctx->have_stats = true; ctx->stats_whitened = whitened != 0; ctx->have_post = false;
@@ -561,6 +610,14 @@ int oak_sgpr_elbo(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, d
     PhaseTimer t(ctx, "total");
     OAK_CHECK(sgpr_forward(ctx, pk, noise_var, jitter, elbo_out, nullptr));
     t.stop();
+    return OAK_OK;
+}
+
+int oak_sgpr_last_terms(oak_ctx* ctx, double* terms_out) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(terms_out != nullptr, "terms_out is NULL");
+    if (!ctx->have_post) { set_error("SGPR posterior not available: call oak_sgpr_elbo/oak_sgpr_tail first"); return OAK_E_STATE; }
+    for (int i = 0; i < 8; ++i) terms_out[i] = ctx->last_terms[i];
     return OAK_OK;
 }
 

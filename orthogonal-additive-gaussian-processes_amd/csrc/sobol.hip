@@ -53,7 +53,11 @@ __global__ void __launch_bounds__(256) sobol_L_categorical_kernel(const double* 
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t i = blockIdx.y;
     if (k >= n) return;
-    const int xi = (int)x[i], xk = (int)x[k];
+    // category indices clamped to [0, C-1] exactly as the Gram / featurize path does (an inducing point moved by k-means or by
+    // zfixed=False can carry an unseen code)
+    int xi = (int)x[i], xk = (int)x[k];
+    xi = xi < 0 ? 0 : (xi > C - 1 ? C - 1 : xi);
+    xk = xk < 0 ? 0 : (xk > C - 1 ? C - 1 : xk);
     double acc = 0.0;
     for (int c = 0; c < C; ++c) acc += (B[c * C + xi] * bscale) * ((B[c * C + xk] * bscale) * p[c]);
     L[i * n + k] = acc;

@@ -71,6 +71,7 @@ SIGNATURES = {
     "oak_sgpr_set_panel_rows": (C.c_int, [_CTX, C.c_int64]),
     "oak_sgpr_local_stats": (C.c_int, [_CTX, _DESC, C.c_double]),
     "oak_sgpr_set_route": (C.c_int, [_CTX, C.c_int32]),
+    "oak_sgpr_set_global_rows": (C.c_int, [_CTX, C.c_int64]),
     "oak_sgpr_stats_whitened": (C.c_int, [_CTX, _I]),
     "oak_sgpr_stats_len": (C.c_int64, [_CTX]),
     "oak_sgpr_get_stats": (C.c_int, [_CTX, _D]),
@@ -78,6 +79,7 @@ SIGNATURES = {
     "oak_sgpr_tail": (C.c_int, [_CTX, _DESC, C.c_double, C.c_double, _D, _D]),
     "oak_sgpr_elbo": (C.c_int, [_CTX, _DESC, C.c_double, C.c_double, _D]),
     "oak_sgpr_alpha": (C.c_int, [_CTX, _D]),
+    "oak_sgpr_last_terms": (C.c_int, [_CTX, _D]),
     "oak_sgpr_predict": (C.c_int, [_CTX, _DESC, _D, C.c_int64, C.c_int32, _D, _D]),
     "oak_grad_len": (C.c_int64, [_DESC]),
     "oak_sgpr_elbo_grad": (C.c_int, [_CTX, _DESC, C.c_double, C.c_double, _D, _D]),
@@ -261,7 +263,8 @@ class KernelDesc:
         s.meas_off = _ip(self.meas_off)
         s.meas_data = _dp(self.meas_data)
         s.meas_data_len = int(off)
-        s.grad_base_var = int(bool(spec.get("base_var_grad", not share)))
+        # default: base variances are differentiated unless every one of them is the constant 1 of a shared-variance kernel
+        s.grad_base_var = int(bool(spec.get("base_var_grad", (not share) or bool(np.any(self.base_var != 1.0)))))
         self.struct = s
         self.D, self.R, self.share = D, R, share
         self.min_cols = int(self.active_col.max()) + 1
@@ -395,6 +398,10 @@ class HipContext:
     def sgpr_set_route(self, route):
         _check(self._lib.oak_sgpr_set_route(self._h, self.ROUTES.get(route, route)))
 
+    def sgpr_set_global_rows(self, n_total: int):
+        """Rows over all shards (0 = unknown): what the auto route's size rule looks at when this context holds one shard."""
+        _check(self._lib.oak_sgpr_set_global_rows(self._h, int(n_total)))
+
     def sgpr_stats_whitened(self) -> bool:
         f = C.c_int32()
         _check(self._lib.oak_sgpr_stats_whitened(self._h, C.byref(f)))
@@ -424,6 +431,14 @@ class HipContext:
         e = C.c_double()
         _check(self._lib.oak_sgpr_elbo(self._h, desc.ref, float(noise_var), float(jitter), C.byref(e)))
         return e.value
+
+    TERM_NAMES = ("sum_log_diag_LB", "cTc", "tr_AAT", "kappa", "yy", "n_rows", "logdet_Kuu")
+
+    def sgpr_last_terms(self) -> dict:
+        """Named pieces of the bound from the most recent tail (any entry point)."""
+        t = np.zeros(8)
+        _check(self._lib.oak_sgpr_last_terms(self._h, _dp(t)))
+        return dict(zip(self.TERM_NAMES, t[:7].tolist()))
 
     def sgpr_alpha(self, M: int) -> np.ndarray:
         out = np.empty(M)

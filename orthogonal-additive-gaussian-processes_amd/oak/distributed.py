@@ -1,7 +1,8 @@
 """Row-sharded SGPR across the GPUs of one node (new; the reference is single-process).
 
 Every N-dependent quantity of the collapsed bound is a sum over rows, so rank g reduces its contiguous block
-``X[lo:hi]`` to the packed statistics ``[Phi | psi | kappa | yy | n]`` (M^2 + M + 3 doubles) on its own GPU and the
+``X[lo:hi]`` to the packed statistics ``[Phi | psi | kappa | yy | n | n_whitened | n_parts]`` (M^2 + M + 5 doubles; the
+last two count the shards summed in that whitened their rows / in total, so a sum of mixed-route shards is rejected) on its own GPU and the
 only exchange is one sum-all-reduce of that vector -- RCCL reduce-scatter + all-gather over xGMI inside
 ``liboak_hip`` (``oak_comm_allreduce_stats``).  The O(M^3) tail is then replicated.  This module holds the
 process-level plumbing: shard arithmetic, the packed layout, the communicator bootstrap (unique id broadcast over
@@ -22,24 +23,33 @@ def shard_bounds(n_rows: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def stats_len(M: int) -> int:
-    return M * M + M + 3
+    return M * M + M + 5
 
 
-def pack_stats(Phi: np.ndarray, psi: np.ndarray, kappa: float, yy: float, n_rows: float) -> np.ndarray:
+def pack_stats(Phi: np.ndarray, psi: np.ndarray, kappa: float, yy: float, n_rows: float, whitened: bool = False) -> np.ndarray:
+    """One shard's packed vector (the layout of ``oak_sgpr_get_stats``)."""
     M = Phi.shape[0]
     out = np.empty(stats_len(M))
     out[:M * M] = np.asarray(Phi, dtype=np.float64).reshape(-1)
     out[M * M:M * M + M] = np.asarray(psi, dtype=np.float64).reshape(-1)
-    out[M * M + M:] = (kappa, yy, n_rows)
+    out[M * M + M:] = (kappa, yy, n_rows, 1.0 if whitened else 0.0, 1.0)
     return out
 
 
 def unpack_stats(packed: np.ndarray, M: int):
+    """(Phi, psi, kappa, yy, n_rows) of a (summed) packed vector; raises if the sum mixes whitened and raw shards."""
     packed = np.asarray(packed, dtype=np.float64)
     if packed.size != stats_len(M):
         raise ValueError("packed statistics have the wrong length")
+    n_white, n_parts = float(packed[-2]), float(packed[-1])
+    if n_parts < 1 or n_white not in (0.0, n_parts):
+        raise ValueError(f"packed statistics mix solve routes: {n_white:g} of {n_parts:g} shards whitened")
     return (packed[:M * M].reshape(M, M), packed[M * M:M * M + M].copy(), float(packed[M * M + M]),
             float(packed[M * M + M + 1]), float(packed[M * M + M + 2]))
+
+
+def stats_whitened(packed: np.ndarray) -> bool:
+    return float(np.asarray(packed)[-2]) > 0.0
 
 
 def torch_allreduce(packed: np.ndarray) -> np.ndarray:
@@ -71,6 +81,7 @@ class ShardedSGPR:
         self.n_total = int(n_total)
         ctx.sgpr_set_data(X_local, y_local)
         ctx.sgpr_set_inducing(Z)
+        ctx.sgpr_set_global_rows(self.n_total)       # the library's own auto rule then also sees the global size
         ctx.sgpr_set_route(route or choose_route(self.n_total, self.M))
 
     @staticmethod
@@ -83,9 +94,8 @@ class ShardedSGPR:
         if self.reducer is None:
             return self.ctx.sgpr_elbo(desc, noise_var, jitter)       # local stats + RCCL all-reduce + tail
         self.ctx.sgpr_local_stats(desc, jitter)
-        whitened = self.ctx.sgpr_stats_whitened()
         total = self.reducer(self.ctx.sgpr_get_stats())
-        self.ctx.sgpr_set_stats(total, whitened)
+        self.ctx.sgpr_set_stats(total, stats_whitened(total))    # set_stats rejects a sum of mixed-route shards
         e, _ = self.ctx.sgpr_tail(desc, noise_var, jitter)
         return e
 

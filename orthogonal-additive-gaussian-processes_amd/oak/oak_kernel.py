@@ -30,7 +30,18 @@ def _first_col(k) -> int:
     dims = k.active_dims
     if isinstance(dims, slice):
         return 0
-    return int(np.asarray(dims).reshape(-1)[0])
+    cols = np.asarray(dims).reshape(-1)
+    if cols.size != 1:
+        # the reference evaluates a grouped sub-kernel (active_dims=[[0, 1], ...]) as a multi-column base kernel
+        # (oak_kernel.py:74-82); the fused HIP kernel is built from one-column sub-kernels only
+        raise NotImplementedError(f"sub-kernel with {cols.size} active columns {cols.tolist()}: the HIP path "
+                                  "supports one column per sub-kernel")
+    return int(cols[0])
+
+
+def _has_trainable_base_variance(k) -> bool:
+    base = getattr(k, "base_kernel", k)
+    return isinstance(getattr(base, "variance", None), Parameter)
 
 
 def _sub_kernel_spec(k, col: int) -> dict:
@@ -46,9 +57,14 @@ def kernel_to_spec(kernel) -> dict:
     """Plain-data description (see _capi.KernelDesc) of an OAKKernel or of a single constrained sub-kernel."""
     if isinstance(kernel, OAKKernel):
         dims = [_sub_kernel_spec(k, _first_col(k)) for k in kernel.kernels]
+        # OAKKernel pins the base variance to a constant 1 only for Gaussian-measure / binary / categorical dims under
+        # share_var_across_orders (oak_kernel.py:163-166,179,187); empirical- and MOG-measure dims keep a trainable
+        # base_kernel.variance, whose gradient needs the pair-kernel contribution (grad_base_var)
         return dict(dims=dims, order_variances=[float(np.asarray(_as_value(v)).reshape(-1)[0]) for v in kernel.variances],
                     max_interaction_depth=int(kernel.max_interaction_depth),
-                    share_var_across_orders=bool(kernel.share_var_across_orders))
+                    share_var_across_orders=bool(kernel.share_var_across_orders),
+                    base_var_grad=(not kernel.share_var_across_orders)
+                    or any(_has_trainable_base_variance(k) for k in kernel.kernels))
     if isinstance(kernel, (OrthogonalRBFKernel, OrthogonalBinary, OrthogonalCategorical, gpflow.RBF)):
         if isinstance(kernel, gpflow.RBF) and not isinstance(kernel.active_dims, slice) and len(kernel.active_dims) != 1:
             raise NotImplementedError("multi-column stand-alone RBF inside a model is not on the OAK path")

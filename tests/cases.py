@@ -71,3 +71,14 @@ def random_inputs(rng, spec, n):
         elif dim["type"] == "categorical":
             X[:, d] = rng.integers(0, len(dim["p"]), n)
     return X
+
+
+TERMS = ("sum_log_diag_LB", "cTc", "tr_AAT", "kappa", "yy", "n_rows", "logdet_Kuu")
+
+
+def assert_terms_match(got: dict, ref: dict, rtol=1e-10, what=""):
+    """Term-by-term parity of the bound's kernel-dependent pieces (each RELATIVE to its own size; logdet Kuu, which can
+    pass through 0, relative to max(|ref|, M-ish scale 1))."""
+    for k in TERMS:
+        scale = max(abs(ref[k]), 1.0) if k == "logdet_Kuu" else abs(ref[k])
+        assert abs(got[k] - ref[k]) <= rtol * scale, f"{what} term {k}: {got[k]!r} vs {ref[k]!r} (rel {abs(got[k] - ref[k]) / max(scale, 1e-300):.2e})"

@@ -35,7 +35,7 @@ def _oracle_elbo_from_stats(o, spec, Z, Phi, psi, kappa, yy, n, s2):
             + 0.5 * c @ c - 0.5 * kappa / s2 + 0.5 * np.trace(W) / s2)
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, uneven=False):
     for p in (str(ROOT / "orthogonal-additive-gaussian-processes_amd"), str(ROOT), str(ROOT / "tests")):
         sys.path.insert(0, p)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
@@ -46,18 +46,31 @@ def _worker(rank, world, port, out_dir):
     import cases
     spec, X, y, Z, s2 = cases.case_A()
     lo, hi = D.shard_bounds(len(X), rank, world)
+    if uneven:                                   # user-chosen shards of very different sizes: 101 rows | the rest
+        lo, hi = (0, 101) if rank == 0 else (101, len(X))
     local = D.pack_stats(*_oracle_local_stats(o, spec, X[lo:hi], y[lo:hi], Z))
     total = D.torch_allreduce(local)
     Phi, psi, kappa, yy, n = D.unpack_stats(total, len(Z))
+    assert total[-1] == world and total[-2] == 0
     elbo = _oracle_elbo_from_stats(o, spec, Z, Phi, psi, kappa, yy, n, s2)
-    np.save(Path(out_dir) / f"r{rank}.npy", np.array([elbo, n, lo, hi]))
+    # ranks that decided differently (one whitened its shard, one did not) must be caught after the all-reduce
+    mixed = D.torch_allreduce(D.pack_stats(Phi, psi, kappa, yy, n, whitened=(rank == 0)))
+    try:
+        D.unpack_stats(mixed, len(Z))
+        caught = 0.0
+    except ValueError:
+        caught = 1.0
+    # the route every rank derives from the GLOBAL size is the same although the local sizes differ
+    route_code = float(D.choose_route(int(n), len(Z)) == "whitened")
+    np.save(Path(out_dir) / f"r{rank}.npy", np.array([elbo, n, lo, hi, caught, route_code]))
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_elbo_matches_single_process(tmp_path):
+@pytest.mark.parametrize("uneven", [False, True])
+def test_two_rank_sharded_elbo_matches_single_process(tmp_path, uneven):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), uneven), nprocs=world, join=True)
     sys.path.insert(0, str(ROOT / "tests"))
     import cases
     from oracle import oak_oracle as o
@@ -66,7 +79,7 @@ def test_two_rank_sharded_elbo_matches_single_process(tmp_path):
     res = [np.load(tmp_path / f"r{r}.npy") for r in range(world)]
     assert res[0][3] == res[1][2] and res[0][2] == 0 and res[1][3] == len(X)      # blocks tile the rows
     for r in res:
-        assert r[1] == len(X)
+        assert r[1] == len(X) and r[4] == 1.0 and r[5] == res[0][5]
         np.testing.assert_allclose(r[0], ref, rtol=1e-9)
     assert res[0][0] == res[1][0]    # every rank ends with the identical scalar
 
@@ -140,3 +153,10 @@ def test_shard_bounds_and_packing():
     P2, s2, k, yy, n = D.unpack_stats(p, 5)
     np.testing.assert_array_equal(P2, Phi); np.testing.assert_array_equal(s2, psi); assert (k, yy, n) == (1.5, 2.5, 77.0)
     assert D.choose_route(1 << 20, 1024) == "phi" and D.choose_route(4096, 128) == "whitened"
+    # sums of shards carry their route counts: two raw shards unpack, a raw + a whitened shard is rejected
+    q = D.pack_stats(Phi, psi, 1.0, 1.0, 3)
+    assert D.unpack_stats(p + q, 5)[4] == 80.0 and not D.stats_whitened(p + q)
+    w = D.pack_stats(Phi, psi, 1.0, 1.0, 3, whitened=True)
+    assert D.stats_whitened(w + w)
+    with pytest.raises(ValueError):
+        D.unpack_stats(p + w, 5)

@@ -108,3 +108,76 @@ def test_term_sharded_sobol_and_row_sharded_predict(world):
         assert np.array_equal(sob, sob_ref) and np.array_equal(mean, m_ref) and np.array_equal(var, v_ref)
     for c in ctxs + [ref]:
         c.close()
+
+
+def test_auto_route_is_decided_on_global_rows_under_a_communicator():
+    """Shard size and global size on opposite sides of the auto rule's threshold (N*M = 2^24): the local count alone would
+    whiten (and so would one rank of a pair whose shards differ by a row, while its peer would not); the library must
+    decide on the communicator-wide row count, here 2 x 100 000 rows x 128 inducing points, where the well-conditioned Kuu
+    keeps the phi route -- and the result must equal the single-rank run on the stacked rows."""
+    n_local, M, world = 100_000, 128, 2
+    assert n_local * M <= (1 << 24) < world * n_local * M
+    X, y, Z = o.synthetic_problem(n_local, 12, M, seed=4)
+    spec = o.make_spec(12, 2)
+    d = _capi.KernelDesc(spec)
+    ref = _capi.HipContext(0)
+    ref.sgpr_set_data(np.tile(X, (world, 1)), np.tile(y, (world, 1))); ref.sgpr_set_inducing(Z); ref.sgpr_set_route("auto")
+    e_ref = ref.sgpr_elbo(d, 0.05)
+    assert not ref.sgpr_stats_whitened()
+    ctx = _capi.HipContext(0)
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("auto")
+    ctx.sgpr_elbo(d, 0.05)
+    assert ctx.sgpr_stats_whitened()                 # alone, this shard is a small problem: whitened
+    ctx.comm_init_loopback(world)
+    e = ctx.sgpr_elbo(d, 0.05)
+    assert not ctx.sgpr_stats_whitened()             # under the communicator the global size decides
+    assert abs(e - e_ref) <= 1e-11 * abs(e_ref)
+    eg, g = ctx.sgpr_elbo_grad(d, 0.05)
+    assert not ctx.sgpr_stats_whitened() and abs(eg - e_ref) <= 1e-11 * abs(e_ref)
+    ctx.comm_destroy()
+    # host-exchange users declare the global size instead
+    ctx.sgpr_set_global_rows(world * n_local)
+    ctx.sgpr_local_stats(d)
+    assert not ctx.sgpr_stats_whitened()
+    ctx.sgpr_set_global_rows(0)
+    ctx.sgpr_local_stats(d)
+    assert ctx.sgpr_stats_whitened()
+    ctx.close(); ref.close()
+
+
+def test_mixed_route_statistics_are_rejected():
+    """A sum of one whitened and one raw shard (what two ranks deciding differently would all-reduce) must fail loudly, both
+    when it is handed back through set_stats and when the flag passed with it contradicts the vector."""
+    X, y, Z = o.synthetic_problem(3000, 5, 64, seed=2)
+    spec = o.make_spec(5, 2)
+    d = _capi.KernelDesc(spec)
+    ctx = _capi.HipContext(0)
+    ctx.sgpr_set_data(X[:1500], y[:1500]); ctx.sgpr_set_inducing(Z)
+    ctx.sgpr_set_route("phi"); ctx.sgpr_local_stats(d); raw = ctx.sgpr_get_stats()
+    ctx.sgpr_set_data(X[1500:], y[1500:])
+    ctx.sgpr_set_route("whitened"); ctx.sgpr_local_stats(d); white = ctx.sgpr_get_stats()
+    assert raw[-2:].tolist() == [0.0, 1.0] and white[-2:].tolist() == [1.0, 1.0]
+    for flag in (False, True):
+        with pytest.raises(_capi.OakHipError, match="mix"):
+            ctx.sgpr_set_stats(raw + white, flag)
+    with pytest.raises(_capi.OakHipError, match="flagged"):
+        ctx.sgpr_set_stats(raw + raw, True)
+    with pytest.raises(ValueError):
+        D.unpack_stats(raw + white, 64)
+    ctx.sgpr_set_stats(white + white, True)          # consistent sums pass
+    ctx.sgpr_set_stats(raw + raw, False)
+    ctx.close()
+
+
+@pytest.mark.parametrize("n", [1, 5, 8, 13, 1027])
+def test_allreduce_slices_and_padding_for_lengths_not_divisible_by_the_world(n):
+    """comm_allreduce_dev splits the vector into equal slices padded in a staging buffer (reduce-scatter + all-gather): for
+    every length, divisible by the world size or not, a 1-rank RCCL communicator must return the vector unchanged and the
+    loopback communicator (world 8) 8 x the vector, with nothing written past its end."""
+    ctx = _capi.HipContext(0)
+    v = np.arange(1.0, n + 1)
+    ctx.comm_init(_capi.HipContext.comm_unique_id(), 1, 0)
+    np.testing.assert_array_equal(ctx.comm_allreduce_host(v.copy()), v)
+    ctx.comm_init_loopback(8)
+    np.testing.assert_array_equal(ctx.comm_allreduce_host(v.copy()), 8 * v)
+    ctx.close()

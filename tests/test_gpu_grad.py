@@ -262,3 +262,70 @@ def test_trainable_inducing_inputs_through_the_model_api():
     gpflow.optimizers.Scipy().minimize(model.training_loss_closure(), variables, method="BFGS", options=dict(maxiter=5))
     assert model.training_loss() < before
     assert np.abs(model.inducing_variable.Z.numpy() - Z0).max() > 1e-6
+
+
+def _shared_spec_with_trainable_base_variances():
+    """share_var_across_orders=True with empirical- and MOG-measure dims: the reference pins the base variance to 1 only
+    for Gaussian-measure / binary / categorical dims (oak_kernel.py:163-166,179,187), the other RBF dims keep a trainable
+    base_kernel.variance."""
+    spec, X, y, Z, s2 = cases.case_B()
+    spec = copy.deepcopy(spec)
+    spec["dims"][2]["variance"] = 0.8      # MOG measure
+    spec["dims"][5]["variance"] = 1.3      # empirical measure
+    spec["dims"][1]["variance"] = 1.15     # uniform measure
+    spec["base_var_grad"] = True
+    return spec, X, y, Z, s2
+
+
+@pytest.mark.parametrize("route", ["phi", "whitened"])
+def test_sgpr_base_variance_gradient_under_shared_order_variances(hip, route):
+    spec, X, y, Z, s2 = _shared_spec_with_trainable_base_variances()
+    D = len(spec["dims"])
+    hip.sgpr_set_data(X, y); hip.sgpr_set_inducing(Z); hip.sgpr_set_route(route)
+    e, g = hip.sgpr_elbo_grad(_capi.KernelDesc(spec), s2)
+    np.testing.assert_allclose(e, o.sgpr_elbo(spec, X, y, Z, s2), rtol=1e-9)
+    for d in (1, 2, 5):
+        def f(h, d=d):
+            s = copy.deepcopy(spec); s["dims"][d]["variance"] += h
+            return o.sgpr_elbo(s, X, y, Z, s2)
+        check(g[D + d], fd(f), rtol=5e-5)
+    # without the flag the library is told the base variances are constants: it must not be what the model layer passes
+    nograd = copy.deepcopy(spec); nograd["base_var_grad"] = False
+    _, g0 = hip.sgpr_elbo_grad(_capi.KernelDesc(nograd), s2)
+    np.testing.assert_allclose(g0[:D], g[:D], rtol=1e-10)          # every other block is unaffected
+    np.testing.assert_allclose(g0[2 * D:], g[2 * D:], rtol=1e-10, atol=1e-12 * np.abs(g).max())
+
+
+@pytest.mark.parametrize("sparse", [True, False])
+def test_model_gradient_with_empirical_and_gmm_measures(sparse):
+    """oak_model(empirical_measure=..., gmm_measure=...) keeps base_kernel.variance trainable for those dims; the loss
+    gradient handed to BFGS must match central differences of the loss in EVERY trainable variable (the pair
+    contribution to d/d variance was dropped when share_var_across_orders=True)."""
+    from oak.model_utils import oak_model
+    from oak.oak_kernel import kernel_to_spec
+    rng = np.random.default_rng(17)
+    N = 260
+    X = rng.standard_normal((N, 4))
+    X[:, 3] = rng.integers(0, 2, N)
+    y = (np.sin(X[:, 0]) + 0.6 * X[:, 1] * X[:, 2] + 0.4 * X[:, 3] + 0.1 * rng.standard_normal(N)).reshape(-1, 1)
+    oak = oak_model(max_interaction_depth=2, num_inducing=30, sparse=sparse, binary_feature=[3], empirical_measure=[1],
+                    gmm_measure=[0, 0, 2, 0], use_normalising_flow=True)   # GMM dims need the flow branch (model_utils.py:305-317,350-353)
+    oak.fit(X, y, optimise=False)
+    model = oak.m
+    spec = kernel_to_spec(model.kernel)
+    assert spec["base_var_grad"] is True
+    variables = model.trainable_variables
+    n_var = sum(isinstance(getattr(getattr(k, "base_kernel", k), "variance", None), gpflow.Parameter) for k in model.kernel.kernels)
+    assert n_var == 2                                            # the empirical and the GMM dim
+    for k in model.kernel.kernels:                               # move off the initial values
+        base = getattr(k, "base_kernel", k)
+        if isinstance(getattr(base, "variance", None), gpflow.Parameter):
+            base.variance.assign(float(rng.uniform(0.6, 1.6)))
+    loss, grads = model._training_loss_and_grad(variables)
+    for p, g in zip(variables, grads):
+        u0 = p.unconstrained_variable.copy()
+        h = 1e-5
+        p._u = u0 + h; lp = model.training_loss()
+        p._u = u0 - h; lm = model.training_loss()
+        p._u = u0
+        np.testing.assert_allclose(float(np.asarray(g).reshape(-1)[0]), (lp - lm) / (2 * h), rtol=2e-4, atol=1e-6)

@@ -35,6 +35,10 @@ def test_elbo_alpha_predict_match_oracle(hip, route, N, D, M, R):
     er = o.sgpr_elbo(spec, X, y, Z, 0.01)
     tol = 1e-10 if (route == "whitened" or cond < 1e5) else 1e-16 * cond * 100
     assert rel(e, er) <= tol, f"route={route} cond={cond:.2e} rel={rel(e, er):.2e}"
+    # every kernel-dependent term of the bound on its own (the total is dominated by the data-only terms); the phi route's
+    # terms carry cond(Kuu)*eps
+    cases.assert_terms_match(hip.sgpr_last_terms(), o.sgpr_elbo_terms(spec, X, y, Z, 0.01),
+                             rtol=1e-10 if route == "whitened" else max(1e-10, 1e-16 * cond * 100), what=f"{route} cond={cond:.1e}:")
     Xs = rng.standard_normal((257, D))
     m, v = hip.sgpr_predict(d, Xs)
     mr, vr = o.sgpr_predict_f(spec, X, y, Z, 0.01, Xs)
@@ -103,7 +107,8 @@ def test_stats_are_additive_over_row_shards(hip):
         hip.sgpr_set_data(X[lo:hi], y[lo:hi])
         hip.sgpr_local_stats(d)
         acc += hip.sgpr_get_stats()
-    np.testing.assert_allclose(acc, full, rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(acc[:-2], full[:-2], rtol=1e-12, atol=1e-9)
+    assert full[-2:].tolist() == [0.0, 1.0] and acc[-2:].tolist() == [0.0, 3.0]       # raw shards, one / three of them
     hip.sgpr_set_stats(acc, False)
     e, terms = hip.sgpr_tail(d, 0.01)
     assert rel(e, o.sgpr_elbo(spec, X, y, Z, 0.01)) <= 1e-10 and terms[5] == 5000
@@ -126,10 +131,11 @@ def test_c2_scale_against_the_multicore_oracle(hip):
     X, y, Z = o.synthetic_problem(65536, 8, 512)
     spec = o.make_spec(8, 2)
     d = _capi.KernelDesc(spec)
-    er = c_oracle.sgpr_elbo_chunked(spec, X, y, Z, 0.01, chunk=8192)
+    er, parts = c_oracle.sgpr_elbo_chunked(spec, X, y, Z, 0.01, chunk=8192, return_parts=True)
     for route in ("phi", "whitened"):
         setup(hip, X, y, Z, route)
         assert rel(hip.sgpr_elbo(d, 0.01), er) <= 1e-10, route
+        cases.assert_terms_match(hip.sgpr_last_terms(), parts["terms"], rtol=1e-10 if route == "whitened" else 1e-9, what=f"C2 {route}:")
 
 
 def test_non_positive_definite_and_state_errors(hip):

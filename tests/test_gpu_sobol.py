@@ -53,3 +53,19 @@ def test_component_predictions(hip):
     got = hip.component_predict(_capi.KernelDesc(spec), X[:70], Z, alpha[:, 0], subsets)
     ref = o.prediction_components(spec, Z, alpha, X[:70])
     np.testing.assert_allclose(got, np.array(ref), rtol=1e-9, atol=1e-11)
+
+
+def test_categorical_L_clamps_codes_outside_the_table(hip):
+    """A categorical code outside [0, C-1] (an unseen code at an inducing point) is clamped exactly as the Gram path clamps
+    it, never read past the C x C table."""
+    rng = np.random.default_rng(3)
+    p = np.array([0.2, 0.5, 0.3]).reshape(-1, 1)
+    W, kappa = rng.uniform(size=(3, 2)), np.array([1.0, 0.5, 2.0])
+    dc = _capi.KernelDesc(dict(dims=[dict(type="categorical", p=p, W=W, kappa=kappa, variance=1.0)], order_variances=[0.0, 1.0],
+                               max_interaction_depth=1, share_var_across_orders=True))
+    Xc = rng.integers(0, 3, (30, 1)).astype(float)
+    Xbad = Xc.copy()
+    Xbad[Xc[:, 0] == 2] = 7.0          # beyond the table -> C-1
+    Xbad[Xc[:, 0] == 0] = -4.0         # below it -> 0
+    np.testing.assert_array_equal(hip.sobol_L(dc, 0, 1.3, 1.0, 0.0, Xbad), hip.sobol_L(dc, 0, 1.3, 1.0, 0.0, Xc))
+    np.testing.assert_array_equal(hip.gram(dc, Xbad), hip.gram(dc, Xc))

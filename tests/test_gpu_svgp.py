@@ -344,3 +344,30 @@ def test_gradient_with_separate_base_variances(hip):
         return sv.svgp_elbo(sp, X, y, Z, q_mu, q_sqrt)
     fd0 = (8 * (f0(h) - f0(-h)) - (f0(2 * h) - f0(-2 * h))) / (12 * h)
     assert abs(g[2 * D] - fd0) <= 1e-6 * abs(fd0)
+
+
+def test_gradient_of_trainable_base_variances_under_shared_order_variances(hip):
+    """share_var_across_orders=True with MOG / uniform-measure dims whose base variance stays trainable (as the reference's
+    OAKKernel leaves it for empirical- and MOG-measure dims): the pair contribution to d/d variance must be present."""
+    import copy
+    rng = np.random.default_rng(33)
+    N, D, M, R = 280, 4, 36, 2
+    spec = cases.random_spec(rng, D, R, kinds=("gaussian", "mog", "uniform", "binary"), share=True)
+    spec["dims"][1]["variance"] = 0.75
+    spec["dims"][2]["variance"] = 1.4
+    spec["base_var_grad"] = True
+    X = cases.random_inputs(rng, spec, N)
+    Z = X[:M].copy()
+    y = (rng.uniform(size=N) < 0.5).astype(float)
+    q_mu, q_sqrt = 0.5 * rng.standard_normal(M), rng.uniform(0.3, 1.2, M)
+    d = _capi.KernelDesc(spec)
+    hip.sgpr_set_data(X, y.reshape(-1, 1)); hip.sgpr_set_inducing(Z)
+    e, g, gm, gs = hip.svgp_elbo(d, q_mu, q_sqrt, grad=True)
+    assert abs(e - sv.svgp_elbo(spec, X, y, Z, q_mu, q_sqrt)) <= 1e-10 * abs(e)
+    h = 1e-4
+    for k in (1, 2):
+        def f(t):
+            sp = copy.deepcopy(spec); sp["dims"][k]["variance"] += t
+            return sv.svgp_elbo(sp, X, y, Z, q_mu, q_sqrt)
+        fd = (8 * (f(h) - f(-h)) - (f(2 * h) - f(-2 * h))) / (12 * h)
+        assert abs(g[D + k] - fd) <= 1e-6 * max(abs(fd), np.abs(g[D:2 * D]).max()), (k, g[D + k], fd)

@@ -177,3 +177,24 @@ def test_normalising_flow_transforms():
         orc = flow_oracle.kl_objective(m._g, m.bijector.log, float(m.scale.numpy()), float(m.shift.numpy()),
                                        float(m.skewness.numpy()), float(m.tailweight.numpy()))
         np.testing.assert_allclose(orc, direct, rtol=1e-12)
+
+
+def test_grouped_active_dims_are_rejected_not_silently_truncated():
+    """OAKKernel(active_dims=[[0, 1], [2]]) builds (as in the reference, oak_kernel.py:74-82), but a sub-kernel spanning two
+    columns has no description in the one-column-per-sub-kernel HIP path: describing it must raise, not evaluate a 1-D
+    kernel on the first column."""
+    from oak import gpflow_lite as gpflow
+    from oak.oak_kernel import OAKKernel, kernel_to_spec
+    k = OAKKernel([gpflow.kernels.RBF, gpflow.kernels.RBF], num_dims=3, max_interaction_depth=2, active_dims=[[0, 1], [2]],
+                  constrain_orthogonal=False)
+    with pytest.raises(NotImplementedError, match="active columns"):
+        kernel_to_spec(k)
+    ok = OAKKernel([gpflow.kernels.RBF, gpflow.kernels.RBF], num_dims=3, max_interaction_depth=2, active_dims=[[1], [2]],
+                   constrain_orthogonal=True)
+    spec = kernel_to_spec(ok)
+    assert [d["active_dim"] for d in spec["dims"]] == [1, 2] and spec["base_var_grad"] is False
+    # empirical-measure dims keep a trainable base variance under share_var_across_orders=True: the description says so
+    emp = OAKKernel([gpflow.kernels.RBF, gpflow.kernels.RBF], num_dims=2, max_interaction_depth=2, constrain_orthogonal=True,
+                    empirical_locations=[None, np.linspace(-1, 1, 5).reshape(-1, 1)],
+                    empirical_weights=[None, np.full((5, 1), 0.2)])
+    assert kernel_to_spec(emp)["base_var_grad"] is True
