@@ -299,6 +299,10 @@ int oak_kmeans_plusplus(oak_ctx* ctx, const double* X, int64_t N, int32_t D, int
 /* Explicit Kuf panel for the rows set with oak_sgpr_set_data, written to a device buffer and not
    copied back: the "Gram GB/s" workload.  bytes_out = algorithmic bytes 8*(N*M + N*D + M*D). */
 int oak_bench_gram_resident(oak_ctx* ctx, const oak_kernel_desc* desc, double* bytes_out);
+/* The Cholesky of the O(M^3) tail alone (tf.linalg.cholesky at oak/utils.py:188,193): factors an n x n SPD test matrix
+   (exponential kernel + 1e-3 I, built on the device) `reps` times; *ms_out = mean GPU time per factorisation (HIP events),
+   *logdet_out (may be NULL) = log det from the factor, for checking against a host Cholesky of the same matrix. */
+int oak_bench_potrf(oak_ctx* ctx, int64_t n, int32_t reps, double* ms_out, double* logdet_out);
 
 #ifdef __cplusplus
 }

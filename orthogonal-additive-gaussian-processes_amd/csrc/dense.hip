@@ -228,15 +228,24 @@ int syrk_plan_splits(oak_ctx* ctx, int64_t M, int64_t nrows) {
         return nsplit;
     }
     if (const char* e = getenv("OAK_SYRK_NSPLIT")) { int v = atoi(e); if (v >= 8 && v <= 256 && v % 8 == 0) return v; }   // tuning knob
-    const int slots = (ctx->num_cu / 8) * per_cu;
+    // Cost model fitted to sweeps on MI355X (tools/dev_syrk_sweep.py, profiles/r02_syrk_split_sweeps.txt).  Two workgroups
+    // that share a CU share its one DP pipe, so an XCD retires its s * npairs workgroups in ceil(s * npairs / CUs per XCD)
+    // rounds of one workgroup per CU; a round costs the rows a workgroup streams plus ~120 row-equivalents of prologue /
+    // epilogue, and every split adds one M x M partial to the fixed-order reduction (~100 row-equivalents per 8 splits at
+    // M = 1024).  The old rule (>= 2048 rows per split, fill 2 slots per CU) left C2 at 36 workgroups on 32 CUs: two rounds
+    // at 56 % occupancy, 30 TFLOP/s where 7 splits per XCD reach 50.
+    (void)per_cu;
+    const int cus_per_xcd = ctx->num_cu / 8 > 0 ? ctx->num_cu / 8 : 1;
+    const double red = 100.0 * ((double)ntile * SY_T / 1024.0) * ((double)ntile * SY_T / 1024.0);
     int best_s = 1;
-    double best_eff = 0.0;
-    for (int sp = 1; sp <= 16; ++sp) {
-        if (sp > 1 && nrows / (8 * sp) < 2048) break;
-        const int total = sp * npairs;
-        const int rounds = (total + slots - 1) / slots;
-        const double eff = (double)total / ((double)rounds * slots);
-        if (eff > best_eff + 0.005) { best_eff = eff; best_s = sp; }
+    double best_cost = 0.0;
+    const double part_bytes = 8.0 * 8.0 * (double)ntile * SY_T * (double)ntile * SY_T;     // partials of 8 splits
+    for (int sp = 1; sp <= 32; ++sp) {
+        const int64_t rps = (nrows + 8 * sp - 1) / (8 * sp);
+        if (sp > 1 && (rps < 256 || part_bytes * sp > 4.0 * 1024 * 1024 * 1024)) break;   // <= 4 GiB of partials
+        const int rounds = (sp * npairs + cus_per_xcd - 1) / cus_per_xcd;
+        const double cost = (double)rounds * ((double)rps + 120.0) + red * sp;
+        if (sp == 1 || cost < best_cost) { best_cost = cost; best_s = sp; }
     }
     return 8 * best_s;
 }

@@ -11,6 +11,7 @@
 //   * trsm_rows  : NB = 128 blocked: in-LDS leaf solves + MFMA GEMM updates; with >= 8192 right-hand sides left-looking,
 //                  the diagonal blocks inverted once and applied as GEMMs.
 #include "oak_internal.h"
+#include <cstdlib>
 
 namespace oak {
 
@@ -30,10 +31,18 @@ __device__ __forceinline__ double readlane_f64(double v, int lane) {
 // ---------------------------------------------------------------------------------------------
 constexpr int GM_T = 64, GM_K = 32, GM_PA = GM_K + 2, GM_PB = GM_T + 16;
 
+// tri (bit mask) declares triangular operands so that a tile only walks the k range where both are non-zero:
+//   1: A lower triangular (k < r0 + 64)   2: A upper triangular (k >= r0)
+//   4: B lower triangular (k < c0 + 64)   8: B upper triangular (k >= c0)      (B bits for BT = 1, B indexed [n][k])
+// nsplitk > 1: gridDim.z slices of each tile's k range write raw partial tiles to part[z][m][n]; gemm_splitk_reduce sums
+// them in a fixed order (the O(M^3) tail multiplies M x M matrices: 64 to 256 tiles cannot fill 256 CUs on their own).
+constexpr int GM_TRI_A_LOWER = 1, GM_TRI_A_UPPER = 2, GM_TRI_B_LOWER = 4, GM_TRI_B_UPPER = 8;
+
 template <int BT>
 __global__ void __launch_bounds__(256) gemm_mfma_kernel(const double* __restrict__ A, const double* __restrict__ B,
                                                         double* __restrict__ C, int64_t m, int64_t n, int64_t k, int64_t lda,
-                                                        int64_t ldb, int64_t ldc, double alpha, double beta, int lower_only) {
+                                                        int64_t ldb, int64_t ldc, double alpha, double beta, int lower_only,
+                                                        int tri, int nsplitk, double* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) double As[GM_T * GM_PA];
     __shared__ __attribute__((aligned(16))) double Bs[(BT ? GM_T * GM_PA : GM_K * GM_PB)];
     if (lower_only && blockIdx.x > blockIdx.y) return;
@@ -41,6 +50,18 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(const double* __restrict
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
     const int64_t r0 = (int64_t)blockIdx.y * GM_T, c0 = (int64_t)blockIdx.x * GM_T;
+    // k range of this tile, then of this split
+    int64_t kb = 0, ke = k;
+    if (tri & GM_TRI_A_LOWER) ke = (r0 + GM_T < ke) ? r0 + GM_T : ke;
+    if (tri & GM_TRI_A_UPPER) kb = (r0 > kb) ? r0 : kb;
+    if (tri & GM_TRI_B_LOWER) ke = (c0 + GM_T < ke) ? c0 + GM_T : ke;
+    if (tri & GM_TRI_B_UPPER) kb = (c0 > kb) ? c0 : kb;
+    if (nsplitk > 1) {
+        int64_t chunk = (ke - kb + nsplitk - 1) / nsplitk;
+        chunk = ((chunk + GM_K - 1) / GM_K) * GM_K;
+        kb += (int64_t)blockIdx.z * chunk;
+        ke = (kb + chunk < ke) ? kb + chunk : ke;
+    }
     const int fi = lane & 15, fk = lane >> 4;
     double4_t acc[2][2];
 #pragma unroll
@@ -53,26 +74,26 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(const double* __restrict
     const int64_t arow = (r0 + ar < m) ? r0 + ar : m - 1;
     const int64_t brow = BT ? ((c0 + ar < n) ? c0 + ar : n - 1) : 0;
     double va[8], vb[8];
-    // branch-free (clamped) loads so that all 16 stay in flight; values outside the matrix are zeroed by selects
+    // branch-free (clamped) loads so that all 16 stay in flight; values outside the matrix / k range are zeroed by selects
     auto load_stage = [&](int64_t k0) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int64_t kk = k0 + ak + q;
             const int64_t kc = kk < k ? kk : k - 1;
             const double x = A[arow * lda + kc];
-            va[q] = (kk < k && r0 + ar < m) ? x : 0.0;
+            va[q] = (kk < ke && r0 + ar < m) ? x : 0.0;
             if (BT) {
                 const double y = B[brow * ldb + kc];
-                vb[q] = (kk < k && c0 + ar < n) ? y : 0.0;
+                vb[q] = (kk < ke && c0 + ar < n) ? y : 0.0;
             } else {
                 const int64_t kr = k0 + bk, nc = c0 + bn + q;
                 const double y = B[(kr < k ? kr : k - 1) * ldb + (nc < n ? nc : n - 1)];
-                vb[q] = (kr < k && nc < n) ? y : 0.0;
+                vb[q] = (kr < ke && nc < n) ? y : 0.0;
             }
         }
     };
-    load_stage(0);
-    for (int64_t k0 = 0; k0 < k; k0 += GM_K) {
+    if (kb < ke) load_stage(kb);
+    for (int64_t k0 = kb; k0 < ke; k0 += GM_K) {
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -81,7 +102,7 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(const double* __restrict
             else Bs[bk * GM_PB + bn + q] = vb[q];
         }
         __syncthreads();
-        if (k0 + GM_K < k) load_stage(k0 + GM_K);            // register prefetch of the next K chunk under the MFMAs
+        if (k0 + GM_K < ke) load_stage(k0 + GM_K);           // register prefetch of the next K chunk under the MFMAs
 #pragma unroll
         for (int ks = 0; ks < GM_K / 4; ++ks) {
             double a[2], b[2];
@@ -96,6 +117,8 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(const double* __restrict
                 for (int h = 0; h < 2; ++h) acc[g][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g], b[h], acc[g][h], 0, 0, 0);
         }
     }
+    double* Cz = (nsplitk > 1) ? part + (int64_t)blockIdx.z * m * n : C;
+    const int64_t ldz = (nsplitk > 1) ? n : ldc;
 #pragma unroll
     for (int g = 0; g < 2; ++g)
 #pragma unroll
@@ -104,11 +127,26 @@ __global__ void __launch_bounds__(256) gemm_mfma_kernel(const double* __restrict
             for (int reg = 0; reg < 4; ++reg) {
                 const int64_t row = r0 + wr * 32 + 16 * g + 4 * reg + fk, col = c0 + wc * 32 + 16 * h + fi;
                 if (row < m && col < n) {
-                    double* q = C + row * ldc + col;
+                    double* q = Cz + row * ldz + col;
+                    if (nsplitk > 1) { *q = acc[g][h][reg]; continue; }
                     const double v = alpha * acc[g][h][reg];
                     *q = (beta == 0.0) ? v : __builtin_fma(beta, *q, v);
                 }
             }
+}
+
+// C = beta*C + alpha * sum_z part[z]  (fixed order); lower_only: only the 64 x 64 tiles on or below the diagonal were written
+__global__ void __launch_bounds__(256) gemm_splitk_reduce_kernel(const double* __restrict__ part, int nsplitk, int64_t m, int64_t n,
+                                                                 double* __restrict__ C, int64_t ldc, double alpha, double beta, int lower_only) {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (j >= n) return;
+    if (lower_only && (j / GM_T) > (i / GM_T)) return;
+    double s = 0.0;
+    for (int z = 0; z < nsplitk; ++z) s += part[(int64_t)z * m * n + i * n + j];
+    double* q = C + i * ldc + j;
+    const double v = alpha * s;
+    *q = (beta == 0.0) ? v : __builtin_fma(beta, *q, v);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -123,9 +161,11 @@ constexpr int G2_LPR = G2_K / 2;            // lanes per row chunk (16 B each)
 constexpr int G2_RPL = 64 / G2_LPR;          // rows per wave-load
 constexpr int G2_NQ = G2_T / (4 * G2_RPL);   // loads per thread per matrix
 
+template <bool TAIL>     // TAIL: triangular k ranges + split-k partials (M x M products); false: the N-sized products, unchanged
 __global__ void __launch_bounds__(256, 2)
 gemm128_nt_kernel(const double* A, const double* __restrict__ B, double* C /* may alias A: trsm_rows runs the diagonal-block product in place */, int64_t m, int64_t n,
-                  int64_t k, int64_t lda, int64_t ldb, int64_t ldc, double alpha, double beta, int ntn) {
+                  int64_t k, int64_t lda, int64_t ldb, int64_t ldc, double alpha, double beta, int ntn,
+                  int tri /* GM_TRI_* */, int nsplitk /* gridDim.y slices of each tile's k range -> part[z][m][n] */, double* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) double As[G2_T * G2_P];
     __shared__ __attribute__((aligned(16))) double Bs[G2_T * G2_P];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -138,6 +178,20 @@ gemm128_nt_kernel(const double* A, const double* __restrict__ B, double* C /* ma
     const int64_t cb = within >> 3;
     const int64_t r0 = rb * G2_T, c0 = cb * G2_T;
     if (r0 >= m) return;
+    // k range of this tile (triangular operands), then of this split
+    int64_t kb = 0, ke = k;
+    if constexpr (TAIL) {
+        if (tri & GM_TRI_A_LOWER) ke = (r0 + G2_T < ke) ? r0 + G2_T : ke;
+        if (tri & GM_TRI_A_UPPER) kb = (r0 > kb) ? r0 : kb;
+        if (tri & GM_TRI_B_LOWER) ke = (c0 + G2_T < ke) ? c0 + G2_T : ke;
+        if (tri & GM_TRI_B_UPPER) kb = (c0 > kb) ? c0 : kb;
+        if (nsplitk > 1) {
+            int64_t chunk = (ke - kb + nsplitk - 1) / nsplitk;
+            chunk = ((chunk + G2_K - 1) / G2_K) * G2_K;
+            kb += (int64_t)blockIdx.y * chunk;
+            ke = (kb + chunk < ke) ? kb + chunk : ke;
+        }
+    }
     const int fi = lane & 15, fk = lane >> 4;
     double4_t acc[4][4];
 #pragma unroll
@@ -155,14 +209,14 @@ gemm128_nt_kernel(const double* A, const double* __restrict__ B, double* C /* ma
             const int64_t kc = (k0 + lc + 1 < k) ? k0 + lc : ((k >= 2) ? k - 2 : 0);
             const double2 va = *reinterpret_cast<const double2*>(A + ar * lda + kc);
             const double2 vb = *reinterpret_cast<const double2*>(B + br * ldb + kc);
-            const bool okk = k0 + lc + 1 < k;
+            const bool okk = k0 + lc + 1 < ke;
             const bool oka = okk && (r0 + row < m), okb = okk && (c0 + row < n);
             ra[q] = make_double2(oka ? va.x : 0.0, oka ? va.y : 0.0);
             rbv[q] = make_double2(okb ? vb.x : 0.0, okb ? vb.y : 0.0);
         }
     };
-    load_stage(0);
-    for (int64_t k0 = 0; k0 < k; k0 += G2_K) {
+    load_stage(kb < ke ? kb : 0);
+    for (int64_t k0 = kb; k0 < ke; k0 += G2_K) {
 #pragma unroll
         for (int q = 0; q < G2_NQ; ++q) {
             const int row = (wave * G2_NQ + q) * G2_RPL + lr;
@@ -170,7 +224,7 @@ gemm128_nt_kernel(const double* A, const double* __restrict__ B, double* C /* ma
             *reinterpret_cast<double2*>(&Bs[row * G2_P + lc]) = rbv[q];
         }
         __syncthreads();
-        load_stage((k0 + G2_K < k) ? k0 + G2_K : 0);
+        load_stage((k0 + G2_K < ke) ? k0 + G2_K : 0);
 #pragma unroll
         for (int ks = 0; ks < G2_K / 4; ++ks) {
             double a[4], b[4];
@@ -193,6 +247,9 @@ gemm128_nt_kernel(const double* A, const double* __restrict__ B, double* C /* ma
             for (int reg = 0; reg < 4; ++reg) {
                 const int64_t row = r0 + 64 * wr + 16 * g + 4 * reg + fk, col = c0 + 64 * wc + 16 * h + fi;
                 if (row < m && col < n) {
+                    if constexpr (TAIL) {
+                        if (nsplitk > 1) { part[(int64_t)blockIdx.y * m * n + row * n + col] = acc[g][h][reg]; continue; }
+                    }
                     double* q = C + row * ldc + col;
                     const double v = alpha * acc[g][h][reg];
                     *q = (beta == 0.0) ? v : __builtin_fma(beta, *q, v);
@@ -201,17 +258,64 @@ gemm128_nt_kernel(const double* A, const double* __restrict__ B, double* C /* ma
 }
 
 static int gemm_launch(oak_ctx* ctx, int bt, const double* dA, const double* dB, double* dC, int64_t m, int64_t n, int64_t k,
-                       int64_t lda, int64_t ldb, int64_t ldc, double alpha, double beta, int lower_only) {
+                       int64_t lda, int64_t ldb, int64_t ldc, double alpha, double beta, int lower_only, int tri = 0, bool allow_split = false) {
     if (m <= 0 || n <= 0) return OAK_OK;
-    dim3 grid((unsigned)((n + GM_T - 1) / GM_T), (unsigned)((m + GM_T - 1) / GM_T));
-    if (bt) gemm_mfma_kernel<1><<<grid, 256, 0, ctx->stream>>>(dA, dB, dC, m, n, k, lda, ldb, ldc, alpha, beta, lower_only);
-    else    gemm_mfma_kernel<0><<<grid, 256, 0, ctx->stream>>>(dA, dB, dC, m, n, k, lda, ldb, ldc, alpha, beta, lower_only);
+    const int64_t tiles = ((n + GM_T - 1) / GM_T) * ((m + GM_T - 1) / GM_T);
+    int nsplitk = 1;
+    if (allow_split) {                     // few tiles, long k: slice k until ~4 workgroups per CU, at least two stages per slice
+        nsplitk = (int)((4 * (int64_t)ctx->num_cu) / (tiles > 0 ? tiles : 1));
+        if (nsplitk > 8) nsplitk = 8;
+        while (nsplitk > 1 && k / nsplitk < 2 * GM_K) --nsplitk;
+        if (nsplitk < 1) nsplitk = 1;
+    }
+    double* d_part = nullptr;
+    if (nsplitk > 1) OAK_CHECK(get_buf_t(ctx, (ctx->side != nullptr && ctx->stream == ctx->side) ? "gemm_part_side" : "gemm_part",
+                                         (size_t)nsplitk * m * n, &d_part));
+    dim3 grid((unsigned)((n + GM_T - 1) / GM_T), (unsigned)((m + GM_T - 1) / GM_T), (unsigned)nsplitk);
+    if (bt) gemm_mfma_kernel<1><<<grid, 256, 0, ctx->stream>>>(dA, dB, dC, m, n, k, lda, ldb, ldc, alpha, beta, lower_only, tri, nsplitk, d_part);
+    else    gemm_mfma_kernel<0><<<grid, 256, 0, ctx->stream>>>(dA, dB, dC, m, n, k, lda, ldb, ldc, alpha, beta, lower_only, tri, nsplitk, d_part);
     OAK_HIP_CHECK(hipGetLastError());
+    if (nsplitk > 1) {
+        dim3 rg((unsigned)((n + 255) / 256), (unsigned)m);
+        gemm_splitk_reduce_kernel<<<rg, 256, 0, ctx->stream>>>(d_part, nsplitk, m, n, dC, ldc, alpha, beta, lower_only);
+        OAK_HIP_CHECK(hipGetLastError());
+    }
     return OAK_OK;
 }
 int gemm_nn(oak_ctx* ctx, const double* dA, const double* dB, double* dC, int64_t m, int64_t n, int64_t k, int64_t lda,
             int64_t ldb, int64_t ldc, double alpha, double beta) {
     return gemm_launch(ctx, 0, dA, dB, dC, m, n, k, lda, ldb, ldc, alpha, beta, 0);
+}
+// The M x M products of the O(M^3) tail: triangular operands declared (tri: GM_TRI_* bits as OAK_TRI_* in oak_internal.h),
+// k sliced over gridDim.z.  bt = 1: C = alpha A B^T + beta C; bt = 0: C = alpha A B + beta C (B bits then unsupported).
+int gemm_tail(oak_ctx* ctx, int bt, const double* dA, const double* dB, double* dC, int64_t m, int64_t n, int64_t k, int64_t lda,
+              int64_t ldb, int64_t ldc, double alpha, double beta, int tri) {
+    if (!bt && (tri & (GM_TRI_B_LOWER | GM_TRI_B_UPPER))) { set_error("gemm_tail: B triangle bits need the NT form"); return OAK_E_ARG; }
+    const bool aligned = ((lda | ldb) & 1) == 0 && (((uintptr_t)dA | (uintptr_t)dB) & 15) == 0 && k >= 2 && (k & 1) == 0;
+    if (bt && aligned && m >= G2_T && n >= G2_T && getenv("OAK_TAIL_GEMM64") == nullptr) {
+        // 128 x 128 tiles (16-byte operand loads, the kernel of the N-sized products) with k sliced over gridDim.y until
+        // every CU has a workgroup: 64 tiles at M = 1024, 16 at M = 512
+        const int ntn = (int)((n + G2_T - 1) / G2_T);
+        const int64_t nrb = (m + G2_T - 1) / G2_T;
+        const int64_t ngrp = (nrb + 7) / 8;
+        int nsplitk = (int)((2 * (int64_t)ctx->num_cu) / (nrb * ntn));
+        if (nsplitk > 16) nsplitk = 16;
+        while (nsplitk > 1 && k / nsplitk < 2 * G2_K) --nsplitk;
+        if (nsplitk < 1) nsplitk = 1;
+        double* d_part = nullptr;
+        if (nsplitk > 1) OAK_CHECK(get_buf_t(ctx, (ctx->side != nullptr && ctx->stream == ctx->side) ? "gemm_part_side" : "gemm_part",
+                                             (size_t)nsplitk * m * n, &d_part));
+        dim3 grid((unsigned)(ngrp * 8 * ntn), (unsigned)nsplitk);
+        gemm128_nt_kernel<true><<<grid, 256, 0, ctx->stream>>>(dA, dB, dC, m, n, k, lda, ldb, ldc, alpha, beta, ntn, tri, nsplitk, d_part);
+        OAK_HIP_CHECK(hipGetLastError());
+        if (nsplitk > 1) {
+            dim3 rg((unsigned)((n + 255) / 256), (unsigned)m);
+            gemm_splitk_reduce_kernel<<<rg, 256, 0, ctx->stream>>>(d_part, nsplitk, m, n, dC, ldc, alpha, beta, 0);
+            OAK_HIP_CHECK(hipGetLastError());
+        }
+        return OAK_OK;
+    }
+    return gemm_launch(ctx, bt, dA, dB, dC, m, n, k, lda, ldb, ldc, alpha, beta, 0, tri, true);
 }
 // true when gemm_nt takes the 128 x 128 kernel (one workgroup per output tile, every operand read before the tile is stored)
 static bool gemm128_eligible(const double* dA, const double* dB, int64_t m, int64_t n, int64_t k, int64_t lda, int64_t ldb, int lower_only) {
@@ -224,7 +328,7 @@ int gemm_nt(oak_ctx* ctx, const double* dA, const double* dB, double* dC, int64_
         const int ntn = (int)((n + G2_T - 1) / G2_T);
         const int64_t nrb = (m + G2_T - 1) / G2_T;
         const int64_t ngrp = (nrb + 7) / 8;
-        gemm128_nt_kernel<<<(unsigned)(ngrp * 8 * ntn), 256, 0, ctx->stream>>>(dA, dB, dC, m, n, k, lda, ldb, ldc, alpha, beta, ntn);
+        gemm128_nt_kernel<false><<<(unsigned)(ngrp * 8 * ntn), 256, 0, ctx->stream>>>(dA, dB, dC, m, n, k, lda, ldb, ldc, alpha, beta, ntn, 0, 1, nullptr);
         OAK_HIP_CHECK(hipGetLastError());
         return OAK_OK;
     }
@@ -245,40 +349,74 @@ __device__ __forceinline__ double rsqrt_newton(double d) {
 }
 
 constexpr int PO_P = PO_NB + 2;    // LDS pitch of the diagonal block (even: 16-byte aligned row starts)
+constexpr int PO_RPW = 64;         // rows per role-A workgroup of the fused step (4 lanes per row, 256 worker lanes)
 
-// One wave factors the NB x NB diagonal block (Cholesky-Crout, column by column).  Lane i owns row i in registers and
-// mirrors each finished entry into LDS, so row j is available to every lane as broadcast ds_read_b128s: no barriers,
-// no cross-lane register traffic except one v_readlane of the pivot per column.  invd[j] = 1 / L_jj is kept for the
-// panel solve.  Two partial sums halve the dependent FMA chain of each column.
-__device__ __forceinline__ void potf2_wave(double* Dg /*[NB][PO_P]*/, double* invd /*[NB]*/, int lane, int64_t j0, int* info) {
-    const int i = lane % PO_NB;                 // with NB = 32 lanes 32..63 shadow lanes 0..31 and write nothing
-    const bool writer = lane < PO_NB;
-    double a[PO_NB];
+// value of quad lane `o` (0..3) to the four lanes of each quad (DPP quad_perm broadcast: no LDS, no SGPR round trip)
+template <int O> __device__ __forceinline__ double quad_bcast_imm(double v) {
+    constexpr int ctrl = O | (O << 2) | (O << 4) | (O << 6);
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, ctrl, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, ctrl, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double quad_bcast_f64(double v, int o) {
+    switch (o & 3) {
+        case 0: return quad_bcast_imm<0>(v);
+        case 1: return quad_bcast_imm<1>(v);
+        case 2: return quad_bcast_imm<2>(v);
+        default: return quad_bcast_imm<3>(v);
+    }
+}
+
+// One wave factors the NB x NB diagonal block.  Lane i owns row i in registers, right-looking: a[c] always carries the
+// rank-1 updates of the finished columns.  The dependent chain of a column is
+//     pivot (v_readlane) -> 1/sqrt (estimate + 2 Newton steps) -> scale -> the ONE entry the next pivot needs
+//     (l_{j+1,j} by v_readlane) -> one FMA into a[j+1];
+// the rank-1 update of the other entries runs one column behind: column j's multipliers are read back (broadcast reads of a
+// column-major LDS copy) right after they are written and consumed only during column j+1, so neither their FMAs nor the
+// LDS round trip sit on the chain.  All stores are unconditional (lanes i < j write don't-care values above the diagonal,
+// the shadow lanes the same values to the same addresses) so that the 32 columns are ONE basic block: with a branch per
+// column the compiler sinks every deferred FMA into the block that consumes it and spills the multipliers.
+// Measured alone (tools/ubench/potf2_bench): see DESIGN.md.  invd[j] = 1 / L_jj is kept for the panel solve; Dg receives L
+// row-major, Lt is scratch.
+__device__ __forceinline__ void potf2_wave(double* Dg /*[NB][PO_P]*/, double* Lt /*[NB][PO_P]*/, double* invd /*[NB]*/, int lane,
+                                           int64_t j0, int* info) {
+    const int i = lane % PO_NB;                 // with NB = 32 lanes 32..63 shadow lanes 0..31
+    double a[PO_NB], mp[PO_NB], mc[PO_NB];
 #pragma unroll
-    for (int c = 0; c < PO_NB; ++c) a[c] = Dg[i * PO_P + c];
-    int bad_at = -1;
+    for (int c = 0; c < PO_NB; ++c) { a[c] = Dg[i * PO_P + c]; mp[c] = 0.0; mc[c] = 0.0; }
+    double lprev = 0.0;
 #pragma unroll
     for (int j = 0; j < PO_NB; ++j) {
-        double s0 = a[j], s1 = 0.0;
-#pragma unroll
-        for (int k = 0; k + 1 < j; k += 2) {
-            const double2 l2 = *reinterpret_cast<const double2*>(&Dg[j * PO_P + k]);
-            s0 = __builtin_fma(-a[k], l2.x, s0);
-            s1 = __builtin_fma(-a[k + 1], l2.y, s1);
-        }
-        if (j & 1) s0 = __builtin_fma(-a[j - 1], Dg[j * PO_P + j - 1], s0);
-        const double s = s0 + s1;
-        const double d = readlane_f64(s, j);
-        if (!(d > 0.0) && bad_at < 0) bad_at = j;
+        const double d = readlane_f64(a[j], j);                 // a[j] of lane j: all earlier columns applied
         const double r = rsqrt_newton(d);
-        a[j] = (i == j) ? d * r : s * r;
-        if (writer && i >= j) Dg[i * PO_P + j] = a[j];
-        if (lane == j) invd[j] = r;
-    }
+        const double l = a[j] * r;                              // column j of L (lanes i >= j; lane j: d / sqrt(d))
+        a[j] = l;
+        if (j + 1 < PO_NB) a[j + 1] = __builtin_fma(-l, readlane_f64(l, j + 1), a[j + 1]);   // what the next pivot waits for
+        Dg[i * PO_P + j] = l;
+        Lt[j * PO_P + i] = l;
+        invd[j] = r;
 #pragma unroll
-    for (int c = 0; c < PO_NB; ++c)
-        if (writer && c > i) Dg[i * PO_P + c] = 0.0;
-    if (bad_at >= 0 && lane == 0 && info != nullptr) atomicMin(info, (int)(j0 + bad_at + 1));
+        for (int c = j + 2; c < PO_NB; ++c) mc[c] = Lt[j * PO_P + c];                        // multipliers of column j, for the next column
+        if (j >= 1) {                                           // column j-1's update of the entries right of column j
+#pragma unroll
+            for (int c = j + 1; c < PO_NB; ++c) a[c] = __builtin_fma(-lprev, mp[c], a[c]);
+        }
+#pragma unroll
+        for (int c = j + 2; c < PO_NB; ++c) mp[c] = mc[c];
+        lprev = l;
+    }
+    // A pivot d <= 0 (or NaN) makes 1/sqrt(d) and with it L_jj = d / sqrt(d) non-finite: the first such diagonal entry is the
+    // failing leading minor.  Checked once here rather than per column: d is wave-uniform, so a per-column test compiles to a
+    // scalar branch and splits the block (see above).
+    const double ldiag = Dg[i * PO_P + i];
+    const unsigned long long badmask = __ballot(!(ldiag > 0.0 && ldiag < __builtin_inf()));
+    if (lane < PO_NB) {
+#pragma unroll
+        for (int c = 0; c < PO_NB; ++c)
+            if (c > i) Dg[i * PO_P + c] = 0.0;
+    }
+    if (badmask != 0ull && lane == 0 && info != nullptr) atomicMin(info, (int)(j0 + (__ffsll((long long)badmask) - 1) + 1));
 }
 
 // Every role-A workgroup re-factors the (tiny) diagonal block itself instead of waiting for one producer.  The factor must
@@ -295,8 +433,11 @@ __device__ __forceinline__ void potf2_wave(double* Dg /*[NB][PO_P]*/, double* in
 // chain of the factorisation is 32 launches of ~max(role A, role B) instead of 64 launches.
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(320) potrf_step_kernel(double* __restrict__ A, int64_t n, int64_t nrows, int64_t lda, int64_t j0,
-                                                         int* __restrict__ info, int* __restrict__ arrivals, int nA, int ntc, int pending) {
+                                                         int* __restrict__ info, int* __restrict__ arrivals, int nA, int ntc, int pending,
+                                                         long long* __restrict__ trace /* dev aid, normally NULL: 8 stamps per role */) {
+#define PO_STAMP(slot) do { if (trace != nullptr && do_stamp) trace[slot] = wall_clock64(); } while (0)
     __shared__ __attribute__((aligned(16))) double Dg[PO_NB * PO_P];
+    __shared__ __attribute__((aligned(16))) double Lt[PO_NB * PO_P];    // role A: column-major scratch of the one-wave factorisation
     __shared__ __attribute__((aligned(16))) double Pj[64 * PO_P];       // role A: rows j0.. of panel j-1 (32 used); role B: A-side tile
     __shared__ __attribute__((aligned(16))) double Pc[64 * PO_P];       // role B: B-side tile
     __shared__ double invd[PO_NB];
@@ -308,6 +449,8 @@ __global__ void __launch_bounds__(320) potrf_step_kernel(double* __restrict__ A,
         const int t = blockIdx.x - nA;
         const int by = t / ntc, bx = t - by * ntc;
         if (bx > by || tid >= 256) return;                              // the fifth wave only exists for role A
+        const bool do_stamp = tid == 0 && (t == 0 || blockIdx.x == gridDim.x - 1);
+        PO_STAMP(t == 0 ? 16 : 20);
         const int64_t s0 = j0 + PO_NB;
         const int64_t r0 = s0 + 64 * (int64_t)by, c0 = s0 + 64 * (int64_t)bx;
         {   // stage both 64 x 32 operand tiles (clamped rows; rows past the matrix contribute to outputs that are not stored)
@@ -349,35 +492,69 @@ __global__ void __launch_bounds__(320) potrf_step_kernel(double* __restrict__ A,
                     const int64_t row = r0 + wr * 32 + 16 * g + 4 * reg + fk, col = c0 + wc * 32 + 16 * h + fi;
                     if (row < nrows && col < n) A[row * lda + col] -= acc[g][h][reg];
                 }
+        PO_STAMP(t == 0 ? 17 : 21);
         return;
     }
     // ---------------- role A: panel j ----------------
-    // 320 threads: wave 0 factors the diagonal block while the 256 workers (waves 1..4, one row each) apply the pending
-    // update to their rows -- the two halves of the step's critical path overlap.
+    // 320 threads: wave 0 factors the diagonal block; the 256 workers (waves 1..4) own 64 rows below it, FOUR LANES PER ROW
+    // (lane q of a quad holds columns q, q+4, .., q+28 of its row).  One row per lane kept a single lane busy for 1024 + 512
+    // dependent-ish FMAs on 64 scattered 8-byte loads (measured: 8.7 us for the pending update, 4.7 us for solve + store,
+    // against 5-7 us for the one-wave factorisation they were meant to hide under); spread over a quad the update is 256
+    // FMAs per lane and the triangular solve runs right-looking with the finished entry passed round the quad by DPP.
     const int wid = tid - 64;                                           // worker id, < 0 for the factor wave
     const bool worker = wid >= 0;
+    const bool do_stamp = blockIdx.x == 0 && (tid == 0 || tid == 64);
+    const int sb = tid == 0 ? 0 : 8;
+    PO_STAMP(sb + 0);
     const int nb = (n - j0 < PO_NB) ? (int)(n - j0) : PO_NB;
     const bool pre = j0 > 0 && pending;                                 // pending = 0: the caller already applied panel j-1
+    const int q = wid & 3;
+    const int64_t row = j0 + nb + (int64_t)blockIdx.x * PO_RPW + (wid >> 2);
+    const bool has_row = worker && row < nrows && nb == PO_NB;
+    // every global load of the step is issued before the first barrier, in the order of use
+    constexpr int PER = PO_NB * PO_NB / 256;
+    double pjv[4], dv[PER];
+    const int pr_r = wid >> 3, pr_k4 = (wid & 7) * 4;
     if (pre && worker) {   // rows j0 .. j0+31 of panel j-1
-        const int r = wid >> 3, k4 = (wid & 7) * 4;
-        const int64_t rr = (j0 + r < n) ? j0 + r : n - 1;
-        double v[4];
+        const int64_t rr = (j0 + pr_r < n) ? j0 + pr_r : n - 1;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = A[rr * lda + p0 + k4 + q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Pj[r * PO_P + k4 + q] = (j0 + r < n) ? v[q] : 0.0;
+        for (int k = 0; k < 4; ++k) pjv[k] = A[rr * lda + p0 + pr_k4 + k];
     }
-    __syncthreads();
     if (worker) {
-        // NB*NB entries of the diagonal block, clamped addresses; identity padding beyond nb; pending update applied
-        constexpr int PER = PO_NB * PO_NB / 256;
-        double v[PER];
 #pragma unroll
-        for (int q = 0; q < PER; ++q) {
-            const int idx = wid + 256 * q;
+        for (int e = 0; e < PER; ++e) {
+            const int idx = wid + 256 * e;
             const int i = idx / PO_NB, j = idx % PO_NB;
             const int ic = i < nb ? i : nb - 1, jc = j < nb ? j : nb - 1;
-            double x = A[(j0 + ic) * lda + j0 + jc];
+            dv[e] = A[(j0 + ic) * lda + j0 + jc];
+        }
+    }
+    double x[PO_NB / 4], pr[PO_NB];
+    if (has_row) {
+        const double* ap = A + row * lda + j0 + q;
+#pragma unroll
+        for (int t = 0; t < PO_NB / 4; ++t) x[t] = ap[4 * t];
+        if (pre) {
+            const double* pp = A + row * lda + p0;
+#pragma unroll
+            for (int k = 0; k < PO_NB; ++k) pr[k] = pp[k];
+        }
+    }
+    if (pre && worker) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) Pj[pr_r * PO_P + pr_k4 + k] = (j0 + pr_r < n) ? pjv[k] : 0.0;
+    }
+    __syncthreads();
+    PO_STAMP(sb + 1);
+    if (worker) {
+        // NB*NB entries of the diagonal block, clamped addresses; identity padding beyond nb; pending update applied
+        double v[PER];
+#pragma unroll
+        for (int e = 0; e < PER; ++e) {
+            const int idx = wid + 256 * e;
+            const int i = idx / PO_NB, j = idx % PO_NB;
+            const int ic = i < nb ? i : nb - 1, jc = j < nb ? j : nb - 1;
+            double xx = dv[e];
             if (pre) {
                 double s = 0.0;
 #pragma unroll
@@ -387,60 +564,61 @@ __global__ void __launch_bounds__(320) potrf_step_kernel(double* __restrict__ A,
                     s = __builtin_fma(a2.x, b2.x, s);
                     s = __builtin_fma(a2.y, b2.y, s);
                 }
-                x -= s;
+                xx -= s;
             }
-            v[q] = (i < nb && j < nb) ? ((j <= i) ? x : 0.0) : ((i == j) ? 1.0 : 0.0);
+            v[e] = (i < nb && j < nb) ? ((j <= i) ? xx : 0.0) : ((i == j) ? 1.0 : 0.0);
         }
 #pragma unroll
-        for (int q = 0; q < PER; ++q) { const int idx = wid + 256 * q; Dg[(idx / PO_NB) * PO_P + (idx % PO_NB)] = v[q]; }
+        for (int e = 0; e < PER; ++e) { const int idx = wid + 256 * e; Dg[(idx / PO_NB) * PO_P + (idx % PO_NB)] = v[e]; }
     }
     __syncthreads();
+    PO_STAMP(sb + 2);
     if (tid == 319) last_loader = (atomicAdd(arrivals, 1) == nA - 1);
-    const int64_t row = j0 + nb + (int64_t)blockIdx.x * 256 + wid;
-    const bool has_row = worker && row < nrows && nb == PO_NB;
-    double x[PO_NB];
-    if (!worker) {
-        potf2_wave(Dg, invd, tid, j0, blockIdx.x == 0 ? info : nullptr);
-    } else if (has_row) {
-        // this row of panel j with the pending update of panel j-1 applied (reads its own row and LDS only)
-        const double* ap = A + row * lda + j0;
+    // wave-uniform split (scalar branch), each side with its own barrier: the workers' registers are not live across the
+    // factorisation's code and vice versa
+    if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
+        potf2_wave(Dg, Lt, invd, tid, j0, blockIdx.x == 0 ? info : nullptr);
+        PO_STAMP(sb + 3);
+        __syncthreads();
+        PO_STAMP(sb + 4);
+    } else {
+        if (has_row && pre) {
+            // this lane's eight entries of panel j with the pending update of panel j-1 applied
 #pragma unroll
-        for (int c = 0; c < PO_NB; ++c) x[c] = ap[c];
-        if (pre) {
-            double pr[PO_NB];
-            const double* pp = A + row * lda + p0;
-#pragma unroll
-            for (int k = 0; k < PO_NB; ++k) pr[k] = pp[k];
-#pragma unroll
-            for (int c = 0; c < PO_NB; ++c) {
+            for (int t = 0; t < PO_NB / 4; ++t) {
+                const double* pj = &Pj[(4 * t + q) * PO_P];
                 double s0 = 0.0, s1 = 0.0;
 #pragma unroll
                 for (int k = 0; k < PO_NB; k += 2) {
-                    const double2 l2 = *reinterpret_cast<const double2*>(&Pj[c * PO_P + k]);
+                    const double2 l2 = *reinterpret_cast<const double2*>(&pj[k]);
                     s0 = __builtin_fma(pr[k], l2.x, s0);
                     s1 = __builtin_fma(pr[k + 1], l2.y, s1);
                 }
-                x[c] -= s0 + s1;
+                x[t] -= s0 + s1;
             }
         }
-    }
-    __syncthreads();
-    if (has_row) {   // X * L_jj^T = A_panel, one row per lane
+        PO_STAMP(sb + 3);
+        __syncthreads();
+        PO_STAMP(sb + 4);
+        if (has_row) {
+            // X L_jj^T = A_panel, right-looking over the columns: the owner of column c finishes its entry, the quad receives it
+            // by DPP and every lane eliminates it from its own later columns
 #pragma unroll
-        for (int c = 0; c < PO_NB; ++c) {
-            double s0 = x[c], s1 = 0.0;
+            for (int c = 0; c < PO_NB; ++c) {
+                const int to = c >> 2, owner = c & 3;
+                const double xc = quad_bcast_f64(x[to] * invd[c], owner);
+                x[to] = (q == owner) ? xc : x[to];
 #pragma unroll
-            for (int p = 0; p + 1 < c; p += 2) {
-                const double2 l2 = *reinterpret_cast<const double2*>(&Dg[c * PO_P + p]);
-                s0 = __builtin_fma(-x[p], l2.x, s0);
-                s1 = __builtin_fma(-x[p + 1], l2.y, s1);
+                for (int t = to; t < PO_NB / 4; ++t) {
+                    const double l = Dg[(4 * t + q) * PO_P + c];
+                    const double m = (t > to || q > owner) ? l : 0.0;
+                    x[t] = __builtin_fma(-xc, m, x[t]);
+                }
             }
-            if (c & 1) s0 = __builtin_fma(-x[c - 1], Dg[c * PO_P + c - 1], s0);
-            x[c] = (s0 + s1) * invd[c];
-        }
-        double* ap = A + row * lda + j0;
+            double* ap = A + row * lda + j0 + q;
 #pragma unroll
-        for (int c = 0; c < PO_NB; ++c) ap[c] = x[c];
+            for (int t = 0; t < PO_NB / 4; ++t) ap[4 * t] = x[t];
+        }
     }
     if (last_loader && worker) {
         for (int idx = wid; idx < nb * nb; idx += 256) {
@@ -448,6 +626,8 @@ __global__ void __launch_bounds__(320) potrf_step_kernel(double* __restrict__ A,
             A[(j0 + i) * lda + j0 + j] = Dg[i * PO_P + j];
         }
     }
+    PO_STAMP(sb + 5);
+#undef PO_STAMP
 }
 
 __global__ void zero_upper_kernel(double* __restrict__ A, int64_t n, int64_t lda) {
@@ -487,18 +667,20 @@ int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, bool check, in
     // are HBM-bound and the pipelined 64 x 64 GEMM kernel moves them faster than the single-stage role-B tiles
     // (n = 16384: 253 ms fused vs 182 ms), so large factorisations fall back to panel + GEMM per step.
     const bool fused = n <= 6144;
+    long long* d_trace = (long long*)peek_buf(ctx, "potrf_trace");     // dev aid (oak_bench_potrf with OAK_POTRF_TRACE=1): 24 stamps per step
     for (int64_t j0 = 0; j0 < n; j0 += PO_NB) {
+        long long* trc = d_trace ? d_trace + 24 * (j0 / PO_NB) : nullptr;
         const int64_t below_rows = nrows - j0 - PO_NB;     // rows under the diagonal block (extra rows included)
-        const int nA = below_rows > 0 ? (int)((below_rows + 255) / 256) : 1;
+        const int nA = below_rows > 0 ? (int)((below_rows + PO_RPW - 1) / PO_RPW) : 1;
         const int64_t tc = n - j0 - PO_NB, tr = nrows - j0 - PO_NB;
         if (fused) {
             // role B applies panel j-1 to the trailing matrix behind panel j: columns >= j0 + 32 (none on the first step)
             const int ntc = (j0 > 0 && tc > 0) ? (int)((tc + 63) / 64) : 0;
             const int ntr = (j0 > 0 && tc > 0) ? (int)((tr + 63) / 64) : 0;
             potrf_step_kernel<<<(unsigned)(nA + ntr * ntc), 320, 0, ctx->stream>>>(dA, n, nrows, lda, j0, d_info, d_arr + j0 / PO_NB, nA,
-                                                                                     ntc > 0 ? ntc : 1, 1);
+                                                                                     ntc > 0 ? ntc : 1, 1, trc);
         } else {
-            potrf_step_kernel<<<(unsigned)nA, 320, 0, ctx->stream>>>(dA, n, nrows, lda, j0, d_info, d_arr + j0 / PO_NB, nA, 1, 0);
+            potrf_step_kernel<<<(unsigned)nA, 320, 0, ctx->stream>>>(dA, n, nrows, lda, j0, d_info, d_arr + j0 / PO_NB, nA, 1, 0, trc);
             if (tc > 0) {   // trailing update A22 -= L21 L21^T (lower tiles only), K = 32
                 const double* L21 = dA + (j0 + PO_NB) * lda + j0;
                 double* A22 = dA + (j0 + PO_NB) * lda + (j0 + PO_NB);

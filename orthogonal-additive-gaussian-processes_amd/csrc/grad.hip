@@ -1050,15 +1050,20 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
         }
         OAK_CHECK(copy_d2d(ctx, dPT, dLinvT, sizeof(double) * (size_t)M * M));
         OAK_CHECK(trsm_rows(ctx, dLB, M, M, dPT, M, M, 0));                         // rows = columns of LB^-1 L^-1
-        OAK_CHECK(gemm_nt(ctx, dLinvT, dLinvT, dKinv, M, M, M, M, M, M, 1.0, 0.0, 0));     // Kuu^-1
-        OAK_CHECK(gemm_nt(ctx, dPT, dPT, dSinv, M, M, M, M, M, M, 1.0, 0.0, 0));           // Sigma^-1
-        OAK_CHECK(gemm_nn(ctx, dLinvT, dW, dTmp, M, M, M, M, M, M, 1.0, 0.0));             // L^-T W
-        OAK_CHECK(gemm_nt(ctx, dTmp, dLinvT, dKWK, M, M, M, M, M, M, 1.0, 0.0, 0));        // Kuu^-1 Phi Kuu^-1
+        // LinvT (rows = columns of L^-1) and PT are upper triangular, L lower: the products below skip the zero k ranges and
+        // slice k over gridDim.z (gemm_tail)
+        const int UU = OAK_TRI_A_UPPER | OAK_TRI_B_UPPER;
+        OAK_CHECK(gemm_tail(ctx, 1, dLinvT, dLinvT, dKinv, M, M, M, M, M, M, 1.0, 0.0, UU));                 // Kuu^-1
+        OAK_CHECK(gemm_tail(ctx, 1, dPT, dPT, dSinv, M, M, M, M, M, M, 1.0, 0.0, UU));                       // Sigma^-1
+        // W is symmetric up to rounding (W_ij and W_ji are the same sum in a different order), so L^-T W is taken as the NT
+        // product L^-T W^T, the form the 128 x 128 kernel computes
+        OAK_CHECK(gemm_tail(ctx, 1, dLinvT, dW, dTmp, M, M, M, M, M, M, 1.0, 0.0, OAK_TRI_A_UPPER));         // L^-T W
+        OAK_CHECK(gemm_tail(ctx, 1, dTmp, dLinvT, dKWK, M, M, M, M, M, M, 1.0, 0.0, OAK_TRI_B_UPPER));       // Kuu^-1 Phi Kuu^-1
         dim3 grid((unsigned)((M + 255) / 256), (unsigned)M);
         combine_h_kernel<<<grid, 256, 0, ctx->stream>>>(dKinv, dSinv, da, dKWK, s2, M, dH, dGuu);
         OAK_HIP_CHECK(hipGetLastError());
         // Kuu (+ jitter) = L L^T, for tr(Sigma^-1 Kuu) and a^T Kuu a
-        OAK_CHECK(gemm_nt(ctx, dL, dL, dKuu, M, M, M, M, M, M, 1.0, 0.0, 0));
+        OAK_CHECK(gemm_tail(ctx, 1, dL, dL, dKuu, M, M, M, M, M, M, 1.0, 0.0, OAK_TRI_A_LOWER | OAK_TRI_B_LOWER));
         OAK_CHECK(dot(ctx, dSinv, dKuu, M * M, dsc + 0));                            // tr(Sigma^-1 Kuu)
         OAK_CHECK(gemv_rows(ctx, dKuu, M, M, M, da, dvec));
         OAK_CHECK(dot(ctx, dvec, da, M, dsc + 1));                                   // a^T Kuu a

@@ -2,6 +2,7 @@
 #include "oak_internal.h"
 #include <cmath>
 #include <cstdlib>
+#include <vector>
 
 namespace oak {
 
@@ -395,9 +396,11 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
         // S = L^-1 Phi (rows 0..M-1 of T1; Phi is symmetric, so gemm_nt against it is the plain product), row M = psi^T;
         // [W ; (L^-1 psi)^T] = T1 L^-T in one (M+1) x M x M GEMM
         double* dLinv = (double*)peek_buf(ctx, "Linv");
-        OAK_CHECK(gemm_nt(ctx, dLinv, st.phi, dT1, M, M, M, M, M, M, 1.0, 0.0, 0));
+        // L^-1 is lower triangular: each 64 x 64 tile walks only the k range where it is non-zero (half the flops), and k is
+        // sliced over gridDim.z (the (M/64)^2 tiles alone leave most CUs idle)
+        OAK_CHECK(gemm_tail(ctx, 1, dLinv, st.phi, dT1, M, M, M, M, M, M, 1.0, 0.0, OAK_TRI_A_LOWER));
         OAK_CHECK(copy_d2d(ctx, dT1 + M * M, st.psi, sizeof(double) * (size_t)M));
-        OAK_CHECK(gemm_nt(ctx, dT1, dLinv, dT2, M + 1, M, M, M, M, M, 1.0, 0.0, 0));
+        OAK_CHECK(gemm_tail(ctx, 1, dT1, dLinv, dT2, M + 1, M, M, M, M, M, 1.0, 0.0, OAK_TRI_B_LOWER));
         OAK_CHECK(copy_d2d(ctx, dv1, dT2 + M * M, sizeof(double) * (size_t)M));
     } else {
         // rows 0..M-1 of T1 = Phi (symmetric), row M = psi: one blocked solve gives (L^-1 Phi)^T and L^-1 psi together
@@ -811,7 +814,75 @@ int oak_gpr_predict(oak_ctx* ctx, const oak_kernel_desc* desc, const double* Xs,
     return OAK_OK;
 }
 
-// ---- device-resident benchmarking hook ------------------------------------------------------------
+// ---- device-resident benchmarking hooks -----------------------------------------------------------
+__global__ void bench_spd_fill_kernel(double* __restrict__ A, int64_t n) {
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    if (j < n) A[i * n + j] = exp(-0.02 * fabs((double)(i - j))) + (i == j ? 1e-3 : 0.0);    // exponential kernel: SPD
+}
+
+// keeps the stream busy for ~us microseconds so that the launches under test are enqueued ahead of their execution (as they
+// are behind the SYRK in a real evaluation) and the measurement is not bound by the host's launch rate
+__global__ void bench_delay_kernel(long long cycles) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < cycles) __builtin_amdgcn_s_sleep(32);
+}
+
+int oak_bench_potrf(oak_ctx* ctx, int64_t n, int32_t reps, double* ms_out, double* logdet_out) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(n >= 1 && n <= 16384 && reps >= 1 && ms_out != nullptr, "oak_bench_potrf: bad arguments");
+    double *dA = nullptr, *dsc = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "bench_potrf_A", (size_t)n * n, &dA));
+    OAK_CHECK(get_buf_t(ctx, "scal", 16, &dsc));
+    const bool trace = getenv("OAK_POTRF_TRACE") != nullptr;
+    const int64_t nsteps = (n + 31) / 32;
+    long long* d_trace = nullptr;
+    if (trace) {
+        OAK_CHECK(get_buf_t(ctx, "potrf_trace", (size_t)nsteps * 24, &d_trace));
+        OAK_CHECK(fill_zero(ctx, d_trace, sizeof(long long) * (size_t)nsteps * 24));
+    }
+    hipEvent_t e0, e1;
+    OAK_HIP_CHECK(hipEventCreate(&e0)); OAK_HIP_CHECK(hipEventCreate(&e1));
+    double total = 0.0;
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
+    for (int r = 0; r < reps + 1; ++r) {                       // first pass warms up (buffers, code objects)
+        bench_spd_fill_kernel<<<grid, 256, 0, ctx->stream>>>(dA, n);
+        bench_delay_kernel<<<1, 64, 0, ctx->stream>>>((long long)(100 * 1000) * (2 + n / 512));   // 100 MHz clock: 2+ ms
+        OAK_HIP_CHECK(hipEventRecord(e0, ctx->stream));
+        OAK_CHECK(potrf_lower(ctx, dA, n, n, false));
+        OAK_HIP_CHECK(hipEventRecord(e1, ctx->stream));
+        OAK_CHECK(potrf_check(ctx, 0, n));
+        float ms = 0.f;
+        OAK_HIP_CHECK(hipEventElapsedTime(&ms, e0, e1));
+        if (r > 0) total += ms;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_out = total / reps;
+    if (trace) {
+        // per-step timeline of the last factorisation (100 MHz counter -> us), relative to the first step's start:
+        // factor wave F0..F5, first worker W0..W5 (entry, Pj staged, block staged, own work done, joined, end), first / last role-B tile
+        std::vector<long long> h((size_t)nsteps * 24);
+        OAK_HIP_CHECK(hipMemcpy(h.data(), d_trace, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+        const long long t0 = h[0];
+        for (int64_t st = 0; st < nsteps; ++st) {
+            const long long* q = h.data() + 24 * st;
+            fprintf(stderr, "step %3lld  F:", (long long)st);
+            for (int k = 0; k < 6; ++k) fprintf(stderr, " %7.2f", (q[k] - t0) / 100.0);
+            fprintf(stderr, "  W:");
+            for (int k = 8; k < 14; ++k) fprintf(stderr, " %7.2f", (q[k] - t0) / 100.0);
+            fprintf(stderr, "  B0: %7.2f %7.2f  Blast: %7.2f %7.2f\n", q[16] ? (q[16] - t0) / 100.0 : 0.0, q[17] ? (q[17] - t0) / 100.0 : 0.0,
+                    q[20] ? (q[20] - t0) / 100.0 : 0.0, q[21] ? (q[21] - t0) / 100.0 : 0.0);
+        }
+    }
+    if (logdet_out) {
+        OAK_CHECK(reduce_sum(ctx, dA, n, dsc, 2, n + 1));
+        OAK_HIP_CHECK(hipMemcpyAsync(logdet_out, dsc, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        *logdet_out *= 2.0;
+    }
+    return OAK_OK;
+}
+
 int oak_bench_gram_resident(oak_ctx* ctx, const oak_kernel_desc* desc, double* bytes_out) {
     OAK_CHECK(guard(ctx));
     OAK_REQUIRE(ctx->have_data && ctx->have_Z, "set_data and set_inducing must be called first");

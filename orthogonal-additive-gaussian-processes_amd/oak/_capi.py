@@ -107,6 +107,7 @@ SIGNATURES = {
     "oak_comm_allreduce_stats": (C.c_int, [_CTX]),
     "oak_comm_allreduce_host": (C.c_int, [_CTX, _D, C.c_int64]),
     "oak_bench_gram_resident": (C.c_int, [_CTX, _DESC, _D]),
+    "oak_bench_potrf": (C.c_int, [_CTX, C.c_int64, C.c_int32, _D, _D]),
     "oak_flow_objective": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, _D, _D]),
     "oak_flow_forward": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32, C.c_int32, _I, _D, _D]),
     "oak_kmeans_plusplus": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64, _D, C.c_int32, _D,
@@ -691,6 +692,13 @@ class HipContext:
         b = C.c_double()
         _check(self._lib.oak_bench_gram_resident(self._h, desc.ref, C.byref(b)))
         return b.value
+
+
+    def bench_potrf(self, n: int, reps: int = 10):
+        """(mean ms per factorisation, log det) of the library's Cholesky on an n x n exponential-kernel test matrix."""
+        ms, ld = C.c_double(), C.c_double()
+        _check(self._lib.oak_bench_potrf(self._h, int(n), int(reps), C.byref(ms), C.byref(ld)))
+        return ms.value, ld.value
 
 
 _default_ctx: Optional[HipContext] = None
