@@ -13,9 +13,11 @@
  *     thread-local message retrievable with oak_last_error();
  *   - all host buffers are caller-owned, C-contiguous, row-major, float64 (int32 where stated);
  *   - the library owns all device memory behind an opaque oak_ctx (one per device; a main HIP
- *     stream plus a side stream for work that overlaps it); a ctx is not thread-safe; distinct
- *     ctxs share no mutable library state (the reference is single-threaded, and the package
- *     drives each ctx from one thread; tools/dev_threads.py is the multi-thread stress);
+ *     stream plus a side stream for work that overlaps it, both non-blocking: nothing runs on
+ *     the legacy NULL stream); a ctx is not thread-safe; distinct ctxs may be driven from
+ *     different host threads concurrently -- they share no mutable library state (per-kernel
+ *     attributes and the RCCL loader are initialised once under a lock; oak_sync waits for the
+ *     caller's ctx only) -- tests/test_gpu_sgpr.py::test_independent_contexts_are_thread_safe;
  *   - there is NO CPU fallback: without a usable HIP device every compute call fails with
  *     OAK_E_HIP.
  */
@@ -36,7 +38,7 @@ extern "C" {
 #define OAK_E_STATE  -5   /* call order violated (e.g. predict before posterior)  */
 
 #define OAK_MAX_DIMS   64  /* sub-kernels per OAK kernel                          */
-#define OAK_MAX_DEPTH   8  /* max_interaction_depth supported by the fused kernels */
+#define OAK_MAX_DEPTH  16  /* max_interaction_depth supported by the fused kernels (the reference's examples go to 13) */
 
 /* dim_type: which constrained base kernel a sub-kernel is */
 #define OAK_DIM_RBF          0  /* oak/ortho_rbf_kernel.py:20-177         */
@@ -143,6 +145,19 @@ int oak_sgpr_set_route(oak_ctx* ctx, int32_t route);
 /* Rows over all shards when this ctx holds one shard and the statistics are exchanged outside the library
    (oak_sgpr_get_stats / oak_sgpr_set_stats): the auto route's size rule uses it.  0 = unknown (default). */
 int oak_sgpr_set_global_rows(oak_ctx* ctx, int64_t n_total);
+/* Arithmetic of the N-sized statistics.  0 (default): fp64 throughout, the reference's precision (oak/oak_kernel.py:31-32
+   sets float64 globally).  1: "fp32 statistics" -- the Kfu panel is generated in fp32 (hardware v_exp_f32) and Phi's row-split
+   partials are formed by fp32 MFMA (fp32 accumulation within one split of a few thousand rows only), everything else --
+   featurisation, kappa, the cross-split sums, the O(M^3) tail, prediction, Sobol, every gradient -- stays fp64.  Applies to
+   forward evaluations through oak_sgpr_elbo on the phi route; the whitened route, oak_sgpr_elbo_grad and the stand-alone
+   oak_sgpr_local_stats ignore it.  An fp32 error in Phi reaches W = L^-1 Phi L^-T divided by lambda_min(Kuu), so the mode is
+   honoured only when chol(Kuu) looks well conditioned ((max diag L / min diag L)^2 <= 1e2 -- the auto route's estimate, which
+   under-reads cond(Kuu) by 20-600x);
+   otherwise that evaluation runs in fp64 -- oak_sgpr_stats_precision reports what the last statistics used.  Not the
+   reference's arithmetic: ELBO within ~1e-6 relative of the fp64 path on the benchmark problems (tests/test_gpu_fp32.py),
+   never used for `value`. */
+int oak_sgpr_set_precision(oak_ctx* ctx, int32_t mode);
+int oak_sgpr_stats_precision(oak_ctx* ctx, int32_t* mode);
 int oak_sgpr_stats_whitened(oak_ctx* ctx, int32_t* flag);
 int64_t oak_sgpr_stats_len(oak_ctx* ctx);                    /* M*M + M + 5 */
 int oak_sgpr_get_stats(oak_ctx* ctx, double* packed_out);    /* D2H copy of the packed buffer */
@@ -150,7 +165,8 @@ int oak_sgpr_get_stats(oak_ctx* ctx, double* packed_out);    /* D2H copy of the 
 int oak_sgpr_set_stats(oak_ctx* ctx, const double* packed, int32_t whitened);
 /* Replicated O(M^3) tail on the packed stats: L=chol(Kuu+jitter I), AAT, LB, c, alpha, ELBO
    (gpflow SGPR.elbo; op order of oak/utils.py:187-198).  terms_out (may be NULL) receives
-   [sum log diag LB, c^T c, tr(AAT), kappa, yy, n_rows, log det Kuu, 0]. */
+   [sum log diag LB, c^T c, tr(AAT), kappa, yy, n_rows, log det Kuu, (max diag L / min diag L)^2 when the evaluation
+   computed that conditioning estimate (auto route on a large problem, fp32 mode), else 0]. */
 int oak_sgpr_tail(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, double jitter,
                   double* elbo_out, double* terms_out);
 /* Convenience: local_stats + (all-reduce when a communicator is attached) + tail. */

@@ -5,6 +5,7 @@
 #include "oak_internal.h"
 #include <rccl/rccl.h>
 #include <dlfcn.h>
+#include <mutex>
 
 namespace oak {
 
@@ -21,6 +22,8 @@ struct Rccl {
 static Rccl g_rccl;
 
 static int load_rccl() {
+    static std::mutex mu;                    // contexts on different host threads may race to the first use
+    std::lock_guard<std::mutex> lock(mu);
     if (g_rccl.h) return OAK_OK;
     const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
     void* h = nullptr;
@@ -57,6 +60,8 @@ static int load_rccl() {
 // on ONE GPU: a loopback run on data X must equal a single-rank run on X stacked nranks times.
 static char g_loopback_tag;
 static inline bool is_loopback(const oak_ctx* ctx) { return ctx->comm == (void*)&g_loopback_tag; }
+
+bool comm_is_loopback(const oak_ctx* ctx) { return is_loopback(ctx); }
 
 int comm_allreduce_dev(oak_ctx* ctx, double* d_buf, int64_t n, const char* stage) {
     if (ctx->comm == nullptr || ctx->nranks <= 1 || n <= 0) return OAK_OK;

@@ -250,10 +250,8 @@ int syrk_plan_splits(oak_ctx* ctx, int64_t M, int64_t nrows) {
     return 8 * best_s;
 }
 
-int syrk_panel(oak_ctx* ctx, const double* d_panel, int64_t ldp, int64_t nrows, int64_t M, double* d_part, int nsplit, bool accumulate) {
-    const int ntile = (int)((M + SY_T - 1) / SY_T);
-    const int64_t Mp = (int64_t)ntile * SY_T;
-    OAK_REQUIRE(ldp == Mp, "syrk: panel stride %lld must equal padded M %lld", (long long)ldp, (long long)Mp);
+// device descriptor table of the SYRK kernels for `ntile` 128-tiles (rebuilt when ntile changes); shared with the fp32 variant
+int syrk_descriptor_table(oak_ctx* ctx, int ntile, int** d_desc_out, int* npairs_out) {
     const int npairs = syrk_wg_per_split(ntile);
     int* d_desc = nullptr;
     OAK_CHECK(get_buf_t(ctx, "syrk_desc", (size_t)npairs * SY_DESC, &d_desc));
@@ -264,6 +262,17 @@ int syrk_panel(oak_ctx* ctx, const double* d_panel, int64_t ldp, int64_t nrows, 
         OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         ctx->syrk_desc_ntile = ntile;
     }
+    *d_desc_out = d_desc; *npairs_out = npairs;
+    return OAK_OK;
+}
+
+int syrk_panel(oak_ctx* ctx, const double* d_panel, int64_t ldp, int64_t nrows, int64_t M, double* d_part, int nsplit, bool accumulate) {
+    const int ntile = (int)((M + SY_T - 1) / SY_T);
+    const int64_t Mp = (int64_t)ntile * SY_T;
+    OAK_REQUIRE(ldp == Mp, "syrk: panel stride %lld must equal padded M %lld", (long long)ldp, (long long)Mp);
+    int* d_desc = nullptr;
+    int npairs = 0;
+    OAK_CHECK(syrk_descriptor_table(ctx, ntile, &d_desc, &npairs));
     int kb = SY_KB_DEFAULT;
     if (const char* e = getenv("OAK_SYRK_KB")) { int v = atoi(e); if (v == 8 || v == 16 || v == 32) kb = v; }
     int64_t rps = (nrows + nsplit - 1) / nsplit;

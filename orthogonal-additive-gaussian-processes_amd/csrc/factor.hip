@@ -861,7 +861,7 @@ static int trsm_leaf(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, dou
         const size_t lds = sizeof(double) * ((size_t)8 * RPG * nblk * 32 + 32 * 33);
         const unsigned grid = (unsigned)((nrhs + 8 * RPG - 1) / (8 * RPG));
         auto kern = trsm_leaf_many_kernel<RPG>;
-        if (lds > 64 * 1024) OAK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        if (lds > 64 * 1024) OAK_CHECK(ensure_max_dynamic_lds((const void*)kern));
         kern<<<grid, 256, lds, ctx->stream>>>(dL, n, ldl, dBT, nrhs, ldb, nblk);
         OAK_HIP_CHECK(hipGetLastError());
         return OAK_OK;

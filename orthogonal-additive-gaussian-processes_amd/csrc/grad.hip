@@ -219,14 +219,17 @@ gram_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
         for (int q = 0; q <= R; ++q) red[ty * (R + 1) + q] = gw[q];
     }
     __syncthreads();
-    const int64_t reclen = 2 * D + (R + 1) + tablen;
+    // the record is laid out for the kernel's ACTUAL depth dd.R <= R (depths 9..16 run the R = 12 / 16 instantiations with
+    // zero weights above dd.R; the unused accumulators are simply not written)
+    const int RA = dd.R;
+    const int64_t reclen = 2 * D + (RA + 1) + tablen;
     double* rec = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * reclen;
     for (int idx = tid; idx < D; idx += 256) {
         rec[idx] = ((accL[idx] + accL[D + idx]) + accL[2 * D + idx]) + accL[3 * D + idx];
         rec[D + idx] = ((accK[idx] + accK[D + idx]) + accK[2 * D + idx]) + accK[3 * D + idx];
     }
-    if (tid <= R) rec[2 * D + tid] = ((red[tid] + red[(R + 1) + tid]) + red[2 * (R + 1) + tid]) + red[3 * (R + 1) + tid];
-    for (int idx = tid; idx < tablen; idx += 256) rec[2 * D + (R + 1) + idx] = accT[idx];
+    if (tid <= RA) rec[2 * D + tid] = ((red[tid] + red[(R + 1) + tid]) + red[2 * (R + 1) + tid]) + red[3 * (R + 1) + tid];
+    for (int idx = tid; idx < tablen; idx += 256) rec[2 * D + (RA + 1) + idx] = accT[idx];
 }
 
 // Row-major pack of the backward features of rows a0 .. a0+na-1:  out[i][q][d],  q = (xs32, cn, dcs),  d < DP;
@@ -399,12 +402,22 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
             gw[0] += g;
 #pragma unroll
             for (int q = 1; q <= R; ++q) gw[q] = __builtin_fma(g, e[q - 1], gw[q]);
+            // dK/dk_d = sum_q w_{q+1} e_q^{(-d)} with the leave-one-out polynomials e_q^{(-d)} = sum_{i<=q} (-k_d)^i e_{q-i}: a
+            // polynomial of degree R-1 in k_d whose coefficients belong to the PAIR.  They are formed once per pair (with g and
+            // the signs folded in), leaving R-1 FMAs per dimension (Horner) instead of the 2(R-1)+1 of the recurrence.
+            double cg[R];
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                double ci = dd.w[i + 1];                                      // q = i term: e_0 = 1
+#pragma unroll
+                for (int q = i + 1; q < R; ++q) ci = __builtin_fma(dd.w[q + 1], e[q - i - 1], ci);
+                cg[i] = (i & 1) ? -(g * ci) : g * ci;
+            }
 #pragma unroll
             for (int d = 0; d < DMAX; ++d) {
-                double f = 1.0, coef = dd.w[1];
+                double gc = cg[R - 1];
 #pragma unroll
-                for (int q = 1; q < R; ++q) { f = __builtin_fma(-k[d], f, e[q - 1]); coef = __builtin_fma(dd.w[q + 1], f, coef); }
-                const double gc = g * coef;
+                for (int i = R - 2; i >= 0; --i) gc = __builtin_fma(gc, k[d], cg[i]);
                 gl[d] = __builtin_fma(gc, dk[d], gl[d]);
                 if constexpr (WANT_GK) gk[d] = __builtin_fma(gc, k[d], gk[d]);
                 if constexpr (!ALLRBF) {
@@ -612,12 +625,20 @@ gram_bwd_z_kernel(const DevDesc dd, const double* __restrict__ tables, const dou
                 for (int q = R - 1; q >= 1; --q) e[q] = __builtin_fma(k[d], e[q - 1], e[q]);
                 e[0] += k[d];
             }
+            double cg[R];                                    // pair-level Horner coefficients of dK/dk_d (see gram_bwd_fast_kernel)
+#pragma unroll
+            for (int i = 0; i < R; ++i) {
+                double ci = dd.w[i + 1];
+#pragma unroll
+                for (int q = i + 1; q < R; ++q) ci = __builtin_fma(dd.w[q + 1], e[q - i - 1], ci);
+                cg[i] = (i & 1) ? -(g * ci) : g * ci;
+            }
 #pragma unroll
             for (int d = 0; d < DMAX; ++d) {
-                double f = 1.0, coef = dd.w[1];
+                double gc = cg[R - 1];
 #pragma unroll
-                for (int q = 1; q < R; ++q) { f = __builtin_fma(-k[d], f, e[q - 1]); coef = __builtin_fma(dd.w[q + 1], f, coef); }
-                gz[c][d] = __builtin_fma(g * coef, zc[d], gz[c][d]);
+                for (int i = R - 2; i >= 0; --i) gc = __builtin_fma(gc, k[d], cg[i]);
+                gz[c][d] = __builtin_fma(gc, zc[d], gz[c][d]);
             }
         }
     }
@@ -743,14 +764,15 @@ diag_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
         for (int q = 0; q <= R; ++q) red[ty * (R + 1) + q] = gw[q];
     }
     __syncthreads();
-    const int64_t reclen = 2 * D + (R + 1) + tablen;
+    const int RA = dd.R;                                  // actual depth <= R (see gram_bwd_kernel)
+    const int64_t reclen = 2 * D + (RA + 1) + tablen;
     double* rec = partial + (int64_t)blockIdx.x * reclen;
     for (int idx = tid; idx < D; idx += 256) {
         rec[idx] = ((accL[idx] + accL[D + idx]) + accL[2 * D + idx]) + accL[3 * D + idx];
         rec[D + idx] = ((accK[idx] + accK[D + idx]) + accK[2 * D + idx]) + accK[3 * D + idx];
     }
-    if (tid <= R) rec[2 * D + tid] = ((red[tid] + red[(R + 1) + tid]) + red[2 * (R + 1) + tid]) + red[3 * (R + 1) + tid];
-    for (int idx = tid; idx < tablen; idx += 256) rec[2 * D + (R + 1) + idx] = accT[idx];
+    if (tid <= RA) rec[2 * D + tid] = ((red[tid] + red[(R + 1) + tid]) + red[2 * (R + 1) + tid]) + red[3 * (R + 1) + tid];
+    for (int idx = tid; idx < tablen; idx += 256) rec[2 * D + (RA + 1) + idx] = accT[idx];
 }
 
 // out[j] += sum_w partial[w][j]: one workgroup per entry j, thread t adds records t, t + 256, ... in order, then a fixed
@@ -816,14 +838,14 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
 #define OAK_BWD_LAUNCH(RR, CP)                                                                                                   \
     {                                                                                                                            \
         auto kern = gram_bwd_kernel<RR, CP>;                                                                                     \
-        if (lds > 64 * 1024) OAK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        if (lds > 64 * 1024) OAK_CHECK(ensure_max_dynamic_lds((const void*)kern)); \
         kern<<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen, A.xs, A.cn, A.dcn, A.ld, a0, na, B.xs, B.cn, B.dcn,  \
                                               B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part);                     \
     }
 #define OAK_BWD_FAST_K(RR, DM, AR, GK, UB)                                                                                         \
     {                                                                                                                             \
         auto kern = gram_bwd_fast_kernel<RR, DM, (DM <= 16 ? 2 : 1), AR, GK, UB>;                                                 \
-        if (lds > 64 * 1024) OAK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        if (lds > 64 * 1024) OAK_CHECK(ensure_max_dynamic_lds((const void*)kern)); \
         kern<<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen, d_pack, a0, na, B.xs32, B.cn, B.dcs, B.ld, nb, d_G, ldg, \
                                               d_yA, d_avec, g_scale, (int)rows, d_part);                                          \
     }
@@ -841,9 +863,9 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
             case 332: OAK_BWD_FAST(3, 32) break;  case 432: OAK_BWD_FAST(4, 32) break;
         }
     } else
-    switch (R) {
+    switch (R <= 8 ? R : (R <= 12 ? 12 : 16)) {      // depths 9..16: the next larger instantiation, zero weights above R
         OAK_BWD_CASE(0) OAK_BWD_CASE(1) OAK_BWD_CASE(2) OAK_BWD_CASE(3) OAK_BWD_CASE(4)
-        OAK_BWD_CASE(5) OAK_BWD_CASE(6) OAK_BWD_CASE(7) OAK_BWD_CASE(8)
+        OAK_BWD_CASE(5) OAK_BWD_CASE(6) OAK_BWD_CASE(7) OAK_BWD_CASE(8) OAK_BWD_CASE(12) OAK_BWD_CASE(16)
         default: set_error("gram_bwd: unsupported depth %d", R); return OAK_E_ARG;
     }
 #undef OAK_BWD_CASE
@@ -923,11 +945,12 @@ int diag_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, double gcons
     nwg = (A.n + rows - 1) / rows;
     double* d_part = nullptr;
     OAK_CHECK(get_buf_t(ctx, "bwd_part_diag", (size_t)(nwg * reclen), &d_part));
-    const size_t lds = sizeof(double) * ((size_t)8 * D + tablen + 4 * (R + 1) + 8);
+    const int RTP = R <= 8 ? R : (R <= 12 ? 12 : 16);          // template depth the launch below instantiates
+    const size_t lds = sizeof(double) * ((size_t)8 * D + tablen + 4 * (RTP + 1) + 8);
 #define OAK_DB_CASE(RR) case RR: diag_bwd_kernel<RR><<<(unsigned)nwg, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen, A.xs, A.cn, A.dcn, A.ld, A.n, gconst, d_gvec, rows, d_part); break;
-    switch (R) {
+    switch (R <= 8 ? R : (R <= 12 ? 12 : 16)) {
         OAK_DB_CASE(0) OAK_DB_CASE(1) OAK_DB_CASE(2) OAK_DB_CASE(3) OAK_DB_CASE(4)
-        OAK_DB_CASE(5) OAK_DB_CASE(6) OAK_DB_CASE(7) OAK_DB_CASE(8)
+        OAK_DB_CASE(5) OAK_DB_CASE(6) OAK_DB_CASE(7) OAK_DB_CASE(8) OAK_DB_CASE(12) OAK_DB_CASE(16)
         default: set_error("diag_bwd: unsupported depth %d", R); return OAK_E_ARG;
     }
 #undef OAK_DB_CASE
@@ -1153,7 +1176,7 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
     scatter_record(desc, pk, rec, dnoise, grad_out);
     if (gradZ_out != nullptr) {
         std::vector<double> gz((size_t)M * zdmax);
-        OAK_HIP_CHECK(hipMemcpy(gz.data(), d_gz, sizeof(double) * gz.size(), hipMemcpyDeviceToHost));
+        OAK_CHECK(copy_sync(ctx, gz.data(), d_gz, sizeof(double) * gz.size(), hipMemcpyDeviceToHost));
         const int32_t ldz = ctx->ldx;
         for (int64_t i = 0; i < M * (int64_t)ldz; ++i) gradZ_out[i] = 0.0;
         for (int d = 0; d < pk.dd.D; ++d) {

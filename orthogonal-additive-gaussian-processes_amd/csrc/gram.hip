@@ -269,7 +269,7 @@ static int launch_gram_t(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, 
     bool all_rbf = true;
     for (int d = 0; d < D; ++d) all_rbf = all_rbf && pk.dd.type[d] == OAK_DIM_RBF;
     auto kern = all_rbf ? gram_kernel<R, RT, CPT, true> : gram_kernel<R, RT, CPT, false>;
-    if (lds > 64 * 1024) OAK_HIP_CHECK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    if (lds > 64 * 1024) OAK_CHECK(ensure_max_dynamic_lds((const void*)kern));
     dim3 grid((unsigned)ncb, (unsigned)nrb);
     kern<<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, A.xs, A.cn, A.ld, a0, na, B.xs, B.cn, B.ld, nb, d_out, ldo,
                                           (int)rows, d_yA, d_part, zero_pad_to);
@@ -311,6 +311,11 @@ int gram(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int6
         case 6: return launch_gram_r<6>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
         case 7: return launch_gram_r<7>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
         case 8: return launch_gram_r<8>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+        // Depths 9..16 (the reference's regression example runs max_interaction_depth = D, up to 13 on UCI housing,
+        // examples/uci/uci_regression_train.py:86): the next larger instantiation.  DevDesc::w is zero above R, so the extra
+        // elementary symmetric polynomials are formed and weighted by 0.
+        case 9: case 10: case 11: case 12: return launch_gram_r<12>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+        case 13: case 14: case 15: case 16: return launch_gram_r<16>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
     }
     set_error("gram: unsupported depth %d", pk.dd.R);
     return OAK_E_ARG;
@@ -321,9 +326,9 @@ int gram_diag(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, double* d_o
     if (n <= 0) return OAK_OK;
     const unsigned g = (unsigned)((n + 255) / 256);
 #define OAK_DIAG_CASE(RR) case RR: gram_diag_kernel<RR><<<g, 256, 0, ctx->stream>>>(pk.dd, pk.d_tables, A.xs, A.cn, A.ld, n, d_out); break;
-    switch (pk.dd.R) {
+    switch (pk.dd.R <= 8 ? pk.dd.R : (pk.dd.R <= 12 ? 12 : 16)) {
         OAK_DIAG_CASE(0) OAK_DIAG_CASE(1) OAK_DIAG_CASE(2) OAK_DIAG_CASE(3) OAK_DIAG_CASE(4)
-        OAK_DIAG_CASE(5) OAK_DIAG_CASE(6) OAK_DIAG_CASE(7) OAK_DIAG_CASE(8)
+        OAK_DIAG_CASE(5) OAK_DIAG_CASE(6) OAK_DIAG_CASE(7) OAK_DIAG_CASE(8) OAK_DIAG_CASE(12) OAK_DIAG_CASE(16)
         default: set_error("gram_diag: unsupported depth %d", pk.dd.R); return OAK_E_ARG;
     }
 #undef OAK_DIAG_CASE

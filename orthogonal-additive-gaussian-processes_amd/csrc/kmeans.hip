@@ -235,9 +235,9 @@ extern "C" int oak_kmeans(oak_ctx* ctx, const double* X, int64_t N, int32_t D, i
             std::vector<double> hMind((size_t)N);
             std::vector<int32_t> hLab((size_t)N);
             hSums.resize((size_t)K * dmax);
-            OAK_HIP_CHECK(hipMemcpy(hMind.data(), dMind, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost));
-            OAK_HIP_CHECK(hipMemcpy(hLab.data(), dLab[lab], sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
-            OAK_HIP_CHECK(hipMemcpy(hSums.data(), dSums, sizeof(double) * hSums.size(), hipMemcpyDeviceToHost));
+            OAK_CHECK(copy_sync(ctx, hMind.data(), dMind, sizeof(double) * (size_t)N, hipMemcpyDeviceToHost));
+            OAK_CHECK(copy_sync(ctx, hLab.data(), dLab[lab], sizeof(int32_t) * (size_t)N, hipMemcpyDeviceToHost));
+            OAK_CHECK(copy_sync(ctx, hSums.data(), dSums, sizeof(double) * hSums.size(), hipMemcpyDeviceToHost));
             std::vector<int64_t> order((size_t)N);
             for (int64_t i = 0; i < N; ++i) order[(size_t)i] = i;
             const size_t ne = empty.size();
@@ -254,8 +254,8 @@ extern "C" int oak_kmeans(oak_ctx* ctx, const double* X, int64_t N, int32_t D, i
                 hCnt[(size_t)target] = 1;
                 hCnt[(size_t)donor] -= 1;
             }
-            OAK_HIP_CHECK(hipMemcpy(dSums, hSums.data(), sizeof(double) * hSums.size(), hipMemcpyHostToDevice));
-            OAK_HIP_CHECK(hipMemcpy(dCnt, hCnt.data(), sizeof(int32_t) * (size_t)K, hipMemcpyHostToDevice));
+            OAK_CHECK(copy_sync(ctx, dSums, hSums.data(), sizeof(double) * hSums.size(), hipMemcpyHostToDevice));
+            OAK_CHECK(copy_sync(ctx, dCnt, hCnt.data(), sizeof(int32_t) * (size_t)K, hipMemcpyHostToDevice));
         }
         kmeans_finalize_kernel<<<(unsigned)((K + 255) / 256), 256, 0, ctx->stream>>>(dSums, dCnt, dC[cur], dC[cur ^ 1], dShift, K, dmax);
         OAK_HIP_CHECK(hipGetLastError());

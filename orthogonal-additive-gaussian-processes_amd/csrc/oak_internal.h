@@ -110,8 +110,12 @@ struct oak_ctx {
     bool have_data = false, have_Z = false, have_stats = false, have_post = false, stats_whitened = false, have_alpha = false;
     bool have_linv = false;          // buffers "Linv" / "LinvT" hold L^-1 and its transpose for the current L
     int route = 0;   // 0 auto, 1 phi, 2 whitened
+    int precision = 0;               // 0: fp64 throughout; 1: fp32 Kfu panel + fp32-MFMA Phi partials on the phi route (forward only)
     int auto_whiten = -1;            // decision of the conditioning check for this evaluation (-1: none, use the size rule)
     bool auto_pending = false;       // the check's result (cond_mm) is still in flight on the side stream
+    bool cond_requested = false;     // this evaluation's side-stream factorisation also reports cond_mm (auto route / fp32 mode)
+    bool cond_seen = false;          // ... and cond_mm holds it for the tail's report (oak_sgpr_last_terms slot 7)
+    bool stats_fp32 = false;         // the statistics in "stats" came from the fp32 panel path
     double cond_mm[2] = {1.0, 1.0};  // min / max of diag chol(Kuu), written by the side stream
     hipEvent_t ev2 = nullptr;        // side stream: conditioning estimate ready
     double noise_var = 0, jitter = 0;
@@ -169,6 +173,11 @@ int gram_diag(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, double* d_o
 int syrk_panel(oak_ctx* ctx, const double* d_panel, int64_t ldp, int64_t nrows, int64_t M, double* d_part,
                int nsplit, bool accumulate);
 int syrk_plan_splits(oak_ctx* ctx, int64_t M, int64_t nrows);
+int syrk_descriptor_table(oak_ctx* ctx, int ntile, int** d_desc_out, int* npairs_out);
+// fp32 statistics variant (gram32.hip): fp32 Kfu panel and fp32-MFMA partials, everything downstream fp64
+int gram_f32(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int64_t na, const Feat& B, float* d_out, int64_t ldo,
+             const double* d_yA, double* d_psi, int64_t zero_pad_to);
+int syrk_panel_f32(oak_ctx* ctx, const float* d_panel, int64_t ldp, int64_t nrows, int64_t M, double* d_part, int nsplit, bool accumulate);
 int syrk_reduce(oak_ctx* ctx, const double* d_part, int nsplit, int64_t M, double* d_phi /*[M*M]*/, bool accumulate);
 // in place; strict upper zeroed.  nrows > n carries nrows - n extra rows through the panel solves and trailing updates
 // (row r >= n ends up as  A[r, :n] L^-T,  i.e. the solution of L x = A[r, :n]^T: a right-hand side rides for free).
@@ -186,6 +195,13 @@ int dot(oak_ctx* ctx, const double* d_x, const double* d_y, int64_t n, double* d
 int gemv_rows(oak_ctx* ctx, const double* dA, int64_t rows, int64_t cols, int64_t lda, const double* d_x, double* d_y); // y = A x
 int row_sumsq(oak_ctx* ctx, const double* dA, int64_t rows, int64_t cols, int64_t lda, double* d_out);                  // out_i = sum_j A_ij^2
 int copy_d2d(oak_ctx* ctx, void* dst, const void* src, size_t bytes);
+// host <-> device copy ON THE CONTEXT'S STREAM followed by a wait on that stream only.  The library never uses the legacy
+// NULL stream: its implicit synchronisation with every blocking stream of the process would couple independent contexts
+// driven from different host threads.
+int copy_sync(oak_ctx* ctx, void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
+// raises the dynamic-LDS limit of a kernel to the hardware's 160 KiB, once per kernel and process (the attribute belongs to
+// the function, not to the launch: setting it to each launch's own size would race between contexts on different threads)
+int ensure_max_dynamic_lds(const void* kernel);
 int fill_zero(oak_ctx* ctx, void* dst, size_t bytes);
 int axpy(oak_ctx* ctx, double a, const double* x, double* y, int64_t n);  // y += a x
 int scale_vec(oak_ctx* ctx, double a, double* x, int64_t n);
@@ -224,6 +240,7 @@ void scatter_record(const oak_kernel_desc* desc, const PreparedKernel& pk, const
 int comm_allreduce_dev(oak_ctx* ctx, double* d_buf, int64_t n, const char* stage = "comm_stage");
 // sum over ranks of one host scalar, on the SIDE stream (so it can run underneath main-stream kernels); synchronises the side stream
 int comm_allreduce_scalar_side(oak_ctx* ctx, double* value);
+bool comm_is_loopback(const oak_ctx* ctx);
 int64_t sgpr_route_rows(const oak_ctx* ctx);     // rows the auto route is decided on: global when known, else local
 
 }  // namespace oak

@@ -1,5 +1,7 @@
 // Runtime: context, scratch buffers, error reporting, kernel-description preparation, featurize.
 #include "oak_internal.h"
+#include <mutex>
+#include <set>
 #include <cstdarg>
 #include <cmath>
 
@@ -459,6 +461,25 @@ int featurize(oak_ctx* ctx, const PreparedKernel& pk, const double* dX, int64_t 
 // ---------------------------------------------------------------------------------------------
 // C ABI: runtime
 // ---------------------------------------------------------------------------------------------
+namespace oak {
+int copy_sync(oak_ctx* ctx, void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+    if (bytes == 0) return OAK_OK;
+    OAK_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, kind, ctx->stream));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return OAK_OK;
+}
+
+int ensure_max_dynamic_lds(const void* kernel) {
+    static std::mutex mu;
+    static std::set<const void*> done;
+    std::lock_guard<std::mutex> lock(mu);
+    if (done.count(kernel)) return OAK_OK;
+    OAK_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done.insert(kernel);
+    return OAK_OK;
+}
+}  // namespace oak
+
 extern "C" {
 
 const char* oak_last_error(void) { return oak::g_err; }
@@ -499,7 +520,8 @@ int oak_ctx_create(int device, oak_ctx** out) {
     ctx->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
-    if (hipStreamCreate(&ctx->stream) != hipSuccess || oak::create_side_stream(&ctx->side) != hipSuccess ||
+    // both streams are non-blocking: no implicit coupling to the legacy NULL stream, hence none between contexts
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || oak::create_side_stream(&ctx->side) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev0, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev1, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev2, hipEventDisableTiming) != hipSuccess) {
@@ -529,7 +551,8 @@ int oak_ctx_destroy(oak_ctx* ctx) {
 int oak_sync(oak_ctx* ctx) {
     if (!ctx) { oak::set_error("ctx is NULL"); return OAK_E_ARG; }
     OAK_HIP_CHECK(hipSetDevice(ctx->device));
-    OAK_HIP_CHECK(hipDeviceSynchronize());
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->side));          // this context's work only: other contexts are not waited for
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return OAK_OK;
 }
 

@@ -8,6 +8,9 @@ namespace oak {
 
 static inline int64_t pad128(int64_t m) { return ((m + 127) / 128) * 128; }
 static constexpr double AUTO_WHITEN_DIAG_RATIO2 = 1e3;   // auto route: whiten when (max diag L / min diag L)^2 exceeds this
+// fp32 statistics mode: honoured only below this value of the same estimate.  Measured (tools/dev_fp32.py): estimate 24
+// (headline, cond(Kuu) = 2.3e3) -> ELBO 9e-7 from fp64; 545 (config 2, cond 9e4) -> 2.6e-5: the latter is refused.
+static constexpr double FP32_MAX_DIAG_RATIO2 = 1e2;
 
 struct HostUpload {   // host -> device copy into a named scratch buffer
     static int run(oak_ctx* ctx, const char* name, const double* h, size_t count, double** d) {
@@ -23,6 +26,8 @@ __global__ void predict_var_kernel(const double* __restrict__ kdiag, const doubl
     if (i < n) var[i] = kdiag[i] + (s2 ? s2[i] : 0.0) - s1[i];
 }
 
+// the loopback test communicator multiplies every all-reduce by nranks: undo it for control values that are not 0 / 1 flags
+static double is_loopback_scale(const oak_ctx* ctx) { return comm_is_loopback(ctx) ? (double)ctx->nranks : 1.0; }
 __global__ void set_triple_kernel(double* p, double v0, double v1, double v2) { p[0] = v0; p[1] = v1; p[2] = v2; }
 
 static int guard(oak_ctx* ctx) {
@@ -129,10 +134,40 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     // In the auto route of a large problem the decision is still in flight (sgpr_forward started chol(Kuu) and the
     // diagonal-ratio estimate on the side stream): the first Gram panel is needed either way, so it is launched first and
     // the host waits for the estimate underneath it.
+    // fp32 statistics mode (oak_sgpr_set_precision): forward evaluations on the phi route only; a gradient call (keep_kfu)
+    // and the whitened route stay fp64.  The auto route's pending conditioning decision is then awaited up front, because it
+    // selects the panel's type.
+    // It also needs a well-conditioned Kuu: an fp32 error delta in Phi reaches W = L^-1 Phi L^-T as delta / lambda_min(Kuu),
+    // so the mode is honoured only when the side stream's conditioning estimate (the auto route's: (max diag L / min diag L)^2
+    // <= 1e3, i.e. cond(Kuu) below ~1e4..1e5) allows it; otherwise this evaluation runs in fp64 (oak_sgpr_stats_precision tells).
+    // The estimate selects the panel's type, so it is awaited before the first Gram launch.
+    bool want32 = ctx->precision == 1 && !ctx->keep_kfu && ctx->cond_requested;
+    if (want32) {
+        OAK_HIP_CHECK(hipEventSynchronize(ctx->ev2));
+        const double ratio = ctx->cond_mm[1] / ctx->cond_mm[0];
+        // two thresholds on one estimate: above 1e2 no fp32, above 1e3 (auto route only) whiten; rank 0's reading decides
+        int level = (ratio * ratio > AUTO_WHITEN_DIAG_RATIO2) ? 2 : ((ratio * ratio > FP32_MAX_DIAG_RATIO2) ? 1 : 0);
+        if (ctx->comm != nullptr && ctx->nranks > 1) {
+            double flag = (ctx->rank == 0) ? (double)level : 0.0;
+            OAK_CHECK(comm_allreduce_scalar_side(ctx, &flag));
+            level = (int)(flag / (is_loopback_scale(ctx)) + 0.5);
+        }
+        if (ctx->auto_pending) {
+            ctx->auto_whiten = level >= 2 ? 1 : 0;
+            ctx->auto_pending = false;
+            if (level >= 2) OAK_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev1, 0));   // the side stream's L serves the whitening below
+        }
+        if (level >= 1) want32 = false;
+    }
     const bool lazy = ctx->auto_pending;
     bool whiten = lazy ? false : sgpr_route_whitened(ctx);
+    const bool use32 = want32 && !whiten;
+    float* dPanel32 = nullptr;
+    if (use32) OAK_CHECK(get_buf_t(ctx, "panel_f32", (size_t)rows * Mp, &dPanel32));
     double* dLw = nullptr;
-    if (whiten) {
+    if (whiten && ctx->auto_whiten > 0 && ctx->precision == 1 && !ctx->keep_kfu && ctx->cond_requested) {
+        dLw = (double*)peek_buf(ctx, "L");                       // factored on the side stream (joined above)
+    } else if (whiten) {
         OAK_CHECK(get_buf_t(ctx, "L", (size_t)M * M, &dLw));
         OAK_CHECK(gram(ctx, pk, FZ, 0, M, FZ, dLw, M, nullptr, nullptr, 0));
         OAK_CHECK(add_diag(ctx, dLw, M, M, jitter));
@@ -143,7 +178,8 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
         const int64_t na = (a0 + rows <= N) ? rows : N - a0;
         {
             PhaseTimer t(ctx, "gram");
-            OAK_CHECK(gram(ctx, pk, FX, a0, na, FZ, dPanel, Mp, dY, st.psi, Mp));
+            if (use32) OAK_CHECK(gram_f32(ctx, pk, FX, a0, na, FZ, dPanel32, Mp, dY, st.psi, Mp));
+            else OAK_CHECK(gram(ctx, pk, FX, a0, na, FZ, dPanel, Mp, dY, st.psi, Mp));
             t.stop();
         }
         if (ctx->auto_pending) {
@@ -182,7 +218,8 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
         }
         {
             PhaseTimer t(ctx, "syrk");
-            OAK_CHECK(syrk_panel(ctx, dSy, Mp, na, M, dPart, nsplit, chunk_idx > 0));
+            if (use32) OAK_CHECK(syrk_panel_f32(ctx, dPanel32, Mp, na, M, dPart, nsplit, chunk_idx > 0));
+            else OAK_CHECK(syrk_panel(ctx, dSy, Mp, na, M, dPart, nsplit, chunk_idx > 0));
             t.stop();
         }
     }
@@ -203,6 +240,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     }
     ctx->have_stats = true;
     ctx->stats_whitened = whiten;
+    ctx->stats_fp32 = use32;
     ctx->have_post = false;
     return OAK_OK;
 }
@@ -312,15 +350,21 @@ int sgpr_forward(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, doubl
     }
     const bool auto_big = ctx->route == 0 && sgpr_route_rows(ctx) * ctx->M > ((int64_t)1 << 24);
     ctx->auto_pending = false;
+    ctx->cond_requested = false;
+    ctx->cond_seen = false;
     if (auto_big || !sgpr_route_whitened(ctx)) {
         // auto on a large problem: the side stream also reports min / max of diag L; local_stats decides under its first
-        // Gram panel and, if it whitens, uses the side stream's L
-        OAK_CHECK(sgpr_factor_kuu_async(ctx, pk, jitter, auto_big ? ctx->cond_mm : nullptr));
+        // Gram panel and, if it whitens, uses the side stream's L.  The fp32 statistics mode asks for the same estimate.
+        const bool want_cond = auto_big || (ctx->precision == 1 && !ctx->keep_kfu);
+        OAK_CHECK(sgpr_factor_kuu_async(ctx, pk, jitter, want_cond ? ctx->cond_mm : nullptr));
         ctx->auto_pending = auto_big;
+        ctx->cond_requested = want_cond;
+        ctx->cond_seen = want_cond;
         l_state = 2;
     }
     int rc = sgpr_local_stats(ctx, pk, jitter);
     ctx->auto_pending = false;
+    ctx->cond_requested = false;
     if (rc == OAK_OK && ctx->comm != nullptr) rc = oak_comm_allreduce_stats(ctx);
     if (rc != OAK_OK) { if (l_state == 2) (void)hipStreamSynchronize(ctx->side); ctx->auto_whiten = -1; return rc; }
     rc = sgpr_tail(ctx, pk, noise_var, jitter, elbo_out, terms_out, l_state);
@@ -444,7 +488,10 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     bound += -0.5 * kappa / noise_var;
     bound += 0.5 * trAAT;
     if (elbo_out) *elbo_out = bound;
-    const double terms[8] = {sumlogLB, cTc, trAAT, kappa, yy, nrows, 2.0 * h[6], 0.0};
+    // slot 7: the conditioning estimate (max diag L / min diag L)^2 when this evaluation asked the side stream for it (auto
+    // route on a large problem, fp32 statistics mode), else 0
+    const double cond_est = ctx->cond_seen ? (ctx->cond_mm[1] / ctx->cond_mm[0]) * (ctx->cond_mm[1] / ctx->cond_mm[0]) : 0.0;
+    const double terms[8] = {sumlogLB, cTc, trAAT, kappa, yy, nrows, 2.0 * h[6], cond_est};
     for (int i = 0; i < 8; ++i) { ctx->last_terms[i] = terms[i]; if (terms_out) terms_out[i] = terms[i]; }
     ctx->noise_var = noise_var; ctx->jitter = jitter;
     ctx->have_post = true;
@@ -565,6 +612,20 @@ int oak_sgpr_set_route(oak_ctx* ctx, int32_t route) {
     OAK_CHECK(guard(ctx));
     OAK_REQUIRE(route >= 0 && route <= 2, "route must be 0 (auto), 1 (phi) or 2 (whitened)");
     ctx->route = route;
+    return OAK_OK;
+}
+
+int oak_sgpr_set_precision(oak_ctx* ctx, int32_t mode) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(mode == 0 || mode == 1, "precision must be 0 (fp64) or 1 (fp32 statistics)");
+    ctx->precision = mode;
+    return OAK_OK;
+}
+
+int oak_sgpr_stats_precision(oak_ctx* ctx, int32_t* mode) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(ctx->have_stats && mode, "no statistics available");
+    *mode = ctx->stats_fp32 ? 1 : 0;
     return OAK_OK;
 }
 
@@ -862,7 +923,7 @@ int oak_bench_potrf(oak_ctx* ctx, int64_t n, int32_t reps, double* ms_out, doubl
         // per-step timeline of the last factorisation (100 MHz counter -> us), relative to the first step's start:
         // factor wave F0..F5, first worker W0..W5 (entry, Pj staged, block staged, own work done, joined, end), first / last role-B tile
         std::vector<long long> h((size_t)nsteps * 24);
-        OAK_HIP_CHECK(hipMemcpy(h.data(), d_trace, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
+        OAK_CHECK(copy_sync(ctx, h.data(), d_trace, sizeof(long long) * h.size(), hipMemcpyDeviceToHost));
         const long long t0 = h[0];
         for (int64_t st = 0; st < nsteps; ++st) {
             const long long* q = h.data() + 24 * st;

@@ -16,7 +16,7 @@ import numpy as np
 OAK_OK, OAK_E_ARG, OAK_E_HIP, OAK_E_NOTPD, OAK_E_NCCL, OAK_E_STATE = 0, -1, -2, -3, -4, -5
 DIM_RBF, DIM_BINARY, DIM_CATEGORICAL = 0, 1, 2
 MEAS_NONE, MEAS_GAUSSIAN, MEAS_UNIFORM, MEAS_EMPIRICAL, MEAS_MOG = 0, 1, 2, 3, 4
-MAX_DIMS, MAX_DEPTH = 64, 8
+MAX_DIMS, MAX_DEPTH = 64, 16
 
 _PKG_ROOT = Path(__file__).resolve().parent.parent
 LIB_PATH = Path(os.environ.get("OAK_HIP_LIB", _PKG_ROOT / "lib" / "liboak_hip.so"))
@@ -72,6 +72,8 @@ SIGNATURES = {
     "oak_sgpr_local_stats": (C.c_int, [_CTX, _DESC, C.c_double]),
     "oak_sgpr_set_route": (C.c_int, [_CTX, C.c_int32]),
     "oak_sgpr_set_global_rows": (C.c_int, [_CTX, C.c_int64]),
+    "oak_sgpr_set_precision": (C.c_int, [_CTX, C.c_int32]),
+    "oak_sgpr_stats_precision": (C.c_int, [_CTX, _I]),
     "oak_sgpr_stats_whitened": (C.c_int, [_CTX, _I]),
     "oak_sgpr_stats_len": (C.c_int64, [_CTX]),
     "oak_sgpr_get_stats": (C.c_int, [_CTX, _D]),
@@ -399,6 +401,19 @@ class HipContext:
     def sgpr_set_route(self, route):
         _check(self._lib.oak_sgpr_set_route(self._h, self.ROUTES.get(route, route)))
 
+    PRECISIONS = {"fp64": 0, "fp32": 1}
+
+    def sgpr_set_precision(self, mode):
+        """'fp64' (default, the reference's arithmetic) or 'fp32' = fp32 Kfu panel + fp32-MFMA Phi partials (forward, phi route)."""
+        _check(self._lib.oak_sgpr_set_precision(self._h, self.PRECISIONS.get(mode, mode)))
+
+    def sgpr_stats_precision(self) -> str:
+        """'fp32' when the last statistics really came from the fp32 panel path (the mode falls back to fp64 on an
+        ill-conditioned Kuu, on the whitened route and for gradient calls)."""
+        f = C.c_int32()
+        _check(self._lib.oak_sgpr_stats_precision(self._h, C.byref(f)))
+        return "fp32" if f.value else "fp64"
+
     def sgpr_set_global_rows(self, n_total: int):
         """Rows over all shards (0 = unknown): what the auto route's size rule looks at when this context holds one shard."""
         _check(self._lib.oak_sgpr_set_global_rows(self._h, int(n_total)))
@@ -433,13 +448,13 @@ class HipContext:
         _check(self._lib.oak_sgpr_elbo(self._h, desc.ref, float(noise_var), float(jitter), C.byref(e)))
         return e.value
 
-    TERM_NAMES = ("sum_log_diag_LB", "cTc", "tr_AAT", "kappa", "yy", "n_rows", "logdet_Kuu")
+    TERM_NAMES = ("sum_log_diag_LB", "cTc", "tr_AAT", "kappa", "yy", "n_rows", "logdet_Kuu", "cond_estimate")
 
     def sgpr_last_terms(self) -> dict:
         """Named pieces of the bound from the most recent tail (any entry point)."""
         t = np.zeros(8)
         _check(self._lib.oak_sgpr_last_terms(self._h, _dp(t)))
-        return dict(zip(self.TERM_NAMES, t[:7].tolist()))
+        return dict(zip(self.TERM_NAMES, t[:8].tolist()))
 
     def sgpr_alpha(self, M: int) -> np.ndarray:
         out = np.empty(M)

@@ -18,6 +18,11 @@ for p in (str(ROOT / "orthogonal-additive-gaussian-processes_amd"), str(ROOT)):
 
 GOLDEN = Path(__file__).resolve().parent / "golden"
 
+# Single-node runs: RCCL's bootstrap needs no real network; pin it to loopback so that a box with an odd interface list cannot
+# stall communicator creation (the data path is xGMI / device memory either way).
+import os as _os0
+_os0.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a HIP device (MI355X); deselected by -m 'not gpu'")
@@ -25,7 +30,8 @@ def pytest_configure(config):
 
 # Watchdog: a test that makes no progress for WATCHDOG_S seconds (a wedged device call cannot be interrupted from Python)
 # dumps every thread's stack and ends the process with a failure instead of hanging the run.
-WATCHDOG_S = 900
+import os as _os
+WATCHDOG_S = int(_os.environ.get("OAK_TEST_WATCHDOG_S", "600"))
 
 
 @pytest.hookimpl(hookwrapper=True)

@@ -176,8 +176,54 @@ def test_allreduce_slices_and_padding_for_lengths_not_divisible_by_the_world(n):
     loopback communicator (world 8) 8 x the vector, with nothing written past its end."""
     ctx = _capi.HipContext(0)
     v = np.arange(1.0, n + 1)
-    ctx.comm_init(_capi.HipContext.comm_unique_id(), 1, 0)
-    np.testing.assert_array_equal(ctx.comm_allreduce_host(v.copy()), v)
-    ctx.comm_init_loopback(8)
-    np.testing.assert_array_equal(ctx.comm_allreduce_host(v.copy()), 8 * v)
+    if n == 13:                       # one real (1-rank) RCCL communicator is enough: its slicing is the identity case
+        ctx.comm_init(_capi.HipContext.comm_unique_id(), 1, 0)
+        np.testing.assert_array_equal(ctx.comm_allreduce_host(v.copy()), v)
+    for world in (2, 3, 8):
+        ctx.comm_init_loopback(world)
+        np.testing.assert_array_equal(ctx.comm_allreduce_host(v.copy()), world * v)
     ctx.close()
+
+
+def _run_bench(extra, env_extra=None):
+    import json, os, socket, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_PORT=str(port), MASTER_ADDR="127.0.0.1", OAK_BENCH_DEVICE="0")
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    env.update(env_extra or {})
+    cmd = [sys.executable, str(root / "bench.py"), "--config", "tiny", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"] + extra
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    return p.returncode, (json.loads(lines[-1]) if lines else None), p.stderr
+
+
+@pytest.mark.parametrize("route", ["phi", "auto"])
+def test_bench_two_ranks_on_one_gpu_through_the_host_exchange(route):
+    """bench.py --gpus 2 end to end on ONE GPU (both ranks on device 0, statistics all-reduced over gloo): the launcher, the
+    row sharding, the route carried by the summed statistics and the aggregation of the JSON line.  The loss of the two-rank
+    job must equal the one-rank loss (1e-10), rows_per_gpu must be half, and the line must not be flagged degraded (the host
+    exchange was ASKED for here; a fallback to it is what `degraded` marks)."""
+    rc1, one, err1 = _run_bench(["--gpus", "1", "--route", route])
+    assert rc1 == 0 and one is not None, err1[-2000:]
+    rc2, two, err2 = _run_bench(["--gpus", "2", "--exchange", "host", "--route", route])
+    assert rc2 == 0 and two is not None, err2[-2000:]
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["degraded"] is False
+    assert two["config"]["rows_per_gpu"] * 2 == one["config"]["rows_per_gpu"] == one["config"]["N"]
+    assert two["config"]["exchange"] == "host" and two["steps"] == 3 and two["warmup"] == 1
+    # two shards sum Phi in a different order; the phi route amplifies that by cond(Kuu) (measured 1.4e-10 here), auto whitens
+    assert abs(two["loss"] - one["loss"]) <= (2e-9 if route == "phi" else 1e-10) * abs(one["loss"]), (two["loss"], one["loss"])
+    assert two["value"] > 0 and two["unit"] == "steps/s" and two["scaling"] == "strong"
+
+
+def test_bench_fails_loudly_when_rccl_cannot_be_used():
+    """Two ranks on ONE device with the default RCCL exchange: the communicator cannot be created (duplicate device).  Without
+    --allow-host-exchange the run must exit non-zero and print no result line; with it, a line flagged `degraded` and still a
+    non-zero status."""
+    rc, line, err = _run_bench(["--gpus", "2"], {"OAK_BENCH_RCCL_TIMEOUT": "60"})
+    assert rc != 0 and line is None, (rc, line, err[-1500:])
+    rc, line, err = _run_bench(["--gpus", "2", "--allow-host-exchange"], {"OAK_BENCH_RCCL_TIMEOUT": "60"})
+    assert rc != 0 and line is not None and line["degraded"] is True and "host" in line["config"]["exchange"], (rc, line, err[-1500:])

@@ -329,3 +329,31 @@ def test_model_gradient_with_empirical_and_gmm_measures(sparse):
         p._u = u0 - h; lm = model.training_loss()
         p._u = u0
         np.testing.assert_allclose(float(np.asarray(g).reshape(-1)[0]), (lp - lm) / (2 * h), rtol=2e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("D,R", [(10, 10), (13, 13)])
+def test_sgpr_elbo_and_gradient_beyond_depth_eight(hip, D, R):
+    """Full-order models as the reference's regression example builds them (max_interaction_depth = D, D = 13 for UCI
+    housing): ELBO against the oracle, gradient against central differences of the oracle."""
+    rng = np.random.default_rng(D + R)
+    N, M = 220, 18
+    X, y, Z = o.synthetic_problem(N, D, M, seed=D)
+    spec = o.make_spec(D, R, lengthscales=list(rng.uniform(0.9, 1.8, D)), order_variances=list(rng.uniform(0.05, 0.6, R + 1)))
+    s2 = 0.1
+    hip.sgpr_set_data(X, y); hip.sgpr_set_inducing(Z); hip.sgpr_set_route("whitened")
+    e, g = hip.sgpr_elbo_grad(_capi.KernelDesc(spec), s2)
+    np.testing.assert_allclose(e, o.sgpr_elbo(spec, X, y, Z, s2), rtol=1e-9)
+    for d in (0, D // 2, D - 1):
+        def f(h, d=d):
+            s = copy.deepcopy(spec); s["dims"][d]["lengthscale"] += h
+            return o.sgpr_elbo(s, X, y, Z, s2)
+        check(g[d], fd(f), rtol=1e-4)
+    for r in (0, 1, R // 2, R):
+        def f(h, r=r):
+            s = copy.deepcopy(spec); s["order_variances"][r] += h
+            return o.sgpr_elbo(s, X, y, Z, s2)
+        check(g[2 * D + r], fd(f), rtol=1e-4)
+    check(g[2 * D + R + 1], fd(lambda h: o.sgpr_elbo(spec, X, y, Z, s2 + h), h=1e-6), rtol=1e-4)
+    m, v = hip.sgpr_predict(_capi.KernelDesc(spec), X[:40])
+    mr, vr = o.sgpr_predict_f(spec, X, y, Z, s2, X[:40])
+    assert np.abs(m - mr[:, 0]).max() <= 1e-8 and np.abs(v - vr[:, 0]).max() <= 1e-8

@@ -251,3 +251,29 @@ def test_lengthscales_at_the_bounds_of_the_reference(hip, ls, monkeypatch):
     assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
     ref_diag = o.oak_K_diag(spec, X)
     assert np.abs(got_diag - ref_diag).max() <= 1e-12 * np.abs(ref_diag).max()
+
+
+@pytest.mark.parametrize("D,R", [(9, 9), (13, 13), (12, 10), (20, 16), (60, 11), (7, 12)])
+def test_gram_beyond_depth_eight(hip, D, R):
+    """The reference's Newton-Girard loop takes any max_interaction_depth (oak_kernel.py:236-249) and its regression example
+    runs depth = D, 13 on UCI housing (examples/uci/uci_regression_train.py:86).  Depths 9..16 run the next larger
+    instantiation of the fused kernels with zero weights above R: K, K_diag and a component against the oracle; where the
+    subset count allows, also against the exact sum over subsets (Newton-Girard itself loses digits at high order)."""
+    import test_gpu_fuzz as fz
+    rng = np.random.default_rng(D * 31 + R)
+    spec = cases.random_spec(rng, D, R, ("gaussian", "uniform", "binary", "gaussian", "categorical"))
+    X, X2 = cases.random_inputs(rng, spec, 83), cases.random_inputs(rng, spec, 140)
+    d = _capi.KernelDesc(spec)
+    K, Kd = hip.gram(d, X, X2), hip.gram_diag(d, X)
+    if D <= 13:                                    # <= 8192 subsets: exact reference
+        Kb = fz.brute_force_K(spec, X, X2)
+        assert np.abs(K - Kb).max() <= 1e-12 * np.abs(Kb).max()
+        Kdb = fz.brute_force_K(spec, X, None, diag=True)
+        assert np.abs(Kd - Kdb).max() <= 1e-12 * np.abs(Kdb).max()
+    Kr = o.oak_K(spec, X, X2)
+    assert np.abs(K - Kr).max() <= 1e-9 * np.abs(Kr).max()          # the oracle's Newton-Girard carries the cancellation
+    assert np.abs(Kd - o.oak_K_diag(spec, X)).max() <= 1e-9 * np.abs(Kd).max()
+    sub = list(range(min(D, R)))[:9]
+    close(hip.gram_component(d, sub, True, X, X2), o.component_K(spec, sub, X, X2))
+    with pytest.raises(ValueError):
+        _capi.KernelDesc(dict(spec, max_interaction_depth=17, order_variances=[1.0] * 18))

@@ -297,6 +297,52 @@ def test_gpr_beyond_the_fused_cholesky_size(hip):
     assert np.abs(m - mr[:, 0]).max() <= 1e-9 * max(1.0, np.abs(mr).max()) and np.abs(v - vr[:, 0]).max() <= 1e-9 * max(1.0, np.abs(vr).max())
 
 
+def test_independent_contexts_are_thread_safe():
+    """include/oak_hip.h: a context is not thread-safe, independent contexts are.  Four host threads, each with its own
+    context (own non-blocking streams, own scratch) and its own problem, run ELBO + gradient + prediction + an explicit Gram
+    concurrently (ctypes releases the GIL inside the library); every result must equal the serial run bit for bit (the
+    reductions are fixed-order).  Eight rounds of create / use / destroy.  The library shares no mutable state between
+    contexts: nothing runs on the legacy NULL stream (whose implicit synchronisation would couple the contexts), per-kernel
+    attributes are set once per process under a lock, and oak_sync waits for the caller's context only."""
+    import threading
+    probs = []
+    for t in range(4):
+        X, y, Z = o.synthetic_problem(3000 + 517 * t, 3 + t, 64 + 32 * t, seed=40 + t)
+        spec = o.make_spec(3 + t, 2, lengthscales=list(np.linspace(0.8, 1.6, 3 + t)), order_variances=[0.9, 1.1, 0.6])
+        probs.append((X, y, Z, spec))
+
+    def run(p, out, reps):
+        X, y, Z, spec = p
+        ctx = _capi.HipContext(0)
+        try:
+            d = _capi.KernelDesc(spec)
+            ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("phi")
+            for _ in range(reps):
+                e, g = ctx.sgpr_elbo_grad(d, 0.02)
+                m, v = ctx.sgpr_predict(d, X[:300])
+                K = ctx.gram(d, X[:200], Z)
+            out.append((e, g, m, v, K))
+        except Exception as ex:          # surfaced by the assertion below
+            out.append(ex)
+        finally:
+            ctx.close()
+
+    serial = []
+    for p in probs:
+        run(p, serial, 1)
+    for _ in range(8):
+        outs = [[] for _ in probs]
+        threads = [threading.Thread(target=run, args=(p, o_, 6)) for p, o_ in zip(probs, outs)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join()
+        for s, o_ in zip(serial, outs):
+            assert len(o_) == 1 and not isinstance(o_[0], Exception), o_
+            for a, b in zip(s, o_[0]):
+                assert np.array_equal(np.asarray(a), np.asarray(b))
+
+
 def test_every_entry_point_rejects_a_null_context():
     """Each ctx-taking function of include/oak_hip.h returns a negative status (never dereferences) for ctx = NULL with all
     other arguments zero / NULL, and leaves a message in oak_last_error."""

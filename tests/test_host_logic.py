@@ -117,7 +117,9 @@ def test_kernel_desc_packs_every_measure():
     with pytest.raises(ValueError):
         _capi.KernelDesc(dict(dims=spec["dims"], order_variances=[1.0], max_interaction_depth=3, share_var_across_orders=True))
     with pytest.raises(ValueError):
-        _capi.KernelDesc(dict(dims=spec["dims"][:1], order_variances=[1.0] * 10, max_interaction_depth=9, share_var_across_orders=True))
+        _capi.KernelDesc(dict(dims=spec["dims"][:1], order_variances=[1.0] * 18, max_interaction_depth=17, share_var_across_orders=True))
+    assert _capi.KernelDesc(dict(dims=spec["dims"][:1], order_variances=[1.0] * 14, max_interaction_depth=13,
+                                 share_var_across_orders=True)).R == 13       # depths up to 16 (the reference's examples go to 13)
 
 
 def test_categorical_chain_rule_matches_finite_differences():
