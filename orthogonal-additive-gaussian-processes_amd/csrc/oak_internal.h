@@ -49,7 +49,7 @@ struct DevDesc {
     double bv[OAK_MAX_DIMS];       // base variance
     // pair-kernel exponent form (exp2w.h): log2(bv) = n - 1024 woff, n = max(ceil(log2 bv), 0)
     double woff[OAK_MAX_DIMS];     // (n - log2 bv) / 1024 >= 0
-    double magic[OAK_MAX_DIMS];    // 1.5 * 2^33 + n / 1024
+    double magic[OAK_MAX_DIMS];    // 1.5 * 2^32 + n / 1024 (EW_MAGIC + n/1024, exp2w.h)
 };
 
 // measure parameters used only by the featurize kernels

@@ -324,7 +324,7 @@ int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk
                 OAK_REQUIRE(std::fabs(dd.log2bv[d]) <= 900.0, "dim %d: base variance out of range", d);
                 const double n = std::fmax(std::ceil(dd.log2bv[d]), 0.0);
                 dd.woff[d] = (n - dd.log2bv[d]) / 1024.0;
-                dd.magic[d] = 12884901888.0 + n / 1024.0;       // EW_MAGIC (exp2w.h) + n/1024
+                dd.magic[d] = 6442450944.0 + n / 1024.0;        // EW_MAGIC (exp2w.h: 1.5 * 2^32) + n/1024
             }
             dd.ncat[d] = 0; dd.tab_off[d] = 0;
             const int kind = desc->measure[d];

@@ -38,7 +38,7 @@ def test_elbo_alpha_predict_match_oracle(hip, route, N, D, M, R):
     # every kernel-dependent term of the bound on its own (the total is dominated by the data-only terms); the phi route's
     # terms carry cond(Kuu)*eps
     cases.assert_terms_match(hip.sgpr_last_terms(), o.sgpr_elbo_terms(spec, X, y, Z, 0.01),
-                             rtol=1e-10 if route == "whitened" else max(1e-10, 1e-16 * cond * 100), what=f"{route} cond={cond:.1e}:")
+                             rtol=1e-10 if route == "whitened" else max(1e-10, 1e-15 * cond * 100), what=f"{route} cond={cond:.1e}:")
     Xs = rng.standard_normal((257, D))
     m, v = hip.sgpr_predict(d, Xs)
     mr, vr = o.sgpr_predict_f(spec, X, y, Z, 0.01, Xs)
