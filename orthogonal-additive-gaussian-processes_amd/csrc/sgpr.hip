@@ -168,7 +168,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     if (whiten && ctx->auto_whiten > 0 && ctx->precision == 1 && !ctx->keep_kfu && ctx->cond_requested) {
         dLw = (double*)peek_buf(ctx, "L");                       // factored on the side stream (joined above)
     } else if (whiten) {
-        OAK_CHECK(get_buf_t(ctx, "L", (size_t)M * M, &dLw));
+        OAK_CHECK(get_buf_t(ctx, "L", (size_t)2 * M * M, &dLw));   // second half: room for L^-T (chol_with_inverse)
         OAK_CHECK(gram(ctx, pk, FZ, 0, M, FZ, dLw, M, nullptr, nullptr, 0));
         OAK_CHECK(add_diag(ctx, dLw, M, M, jitter));
         OAK_CHECK(potrf_lower(ctx, dLw, M, M));
@@ -298,6 +298,22 @@ static int build_linv(oak_ctx* ctx, const double* dL, int64_t M) {
     return OAK_OK;
 }
 
+// Cholesky AND inverse factor in one chain of launches: dL is a 2M x M array whose first M rows hold Kuu + jitter I.  The
+// identity is placed in rows M..2M-1 and rides through the factorisation's panel solves as extra rows (potrf_lower: row
+// r >= n ends up as A[r, :n] L^-T), so when the factor is done those rows ARE L^-T -- the rows-TRSM of the identity that
+// build_linv runs as a second dependent chain (8 leaf solves + 7 GEMMs, ~560 us at M = 1024 against 372 us for the whole
+// factorisation) costs nothing on top.  M must be a multiple of 32 (the panel width); otherwise the caller uses build_linv.
+static int chol_with_inverse(oak_ctx* ctx, double* dL, int64_t M) {
+    double *dLinvT, *dLinv;
+    OAK_CHECK(get_buf_t(ctx, "LinvT", (size_t)M * M, &dLinvT));
+    OAK_CHECK(get_buf_t(ctx, "Linv", (size_t)M * M, &dLinv));
+    OAK_CHECK(set_identity(ctx, dL + M * M, M));
+    OAK_CHECK(potrf_lower(ctx, dL, M, M, false, 2 * M));
+    OAK_CHECK(copy_d2d(ctx, dLinvT, dL + M * M, sizeof(double) * (size_t)M * M));
+    OAK_CHECK(transpose(ctx, dLinvT, M, M, M, dLinv, M));
+    return OAK_OK;
+}
+
 // L = chol(Kuu + jitter I) on the side stream.  It depends only on Z and the hyperparameters, so it runs concurrently
 // with the N-sized gram / SYRK stages; the tail joins on ev1 and reads the deferred Cholesky status (slot 1).
 int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter, double* cond_out /* [2] min, max diag L; may be NULL */) {
@@ -306,7 +322,7 @@ int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter,
     double* dmm = nullptr;
     OAK_CHECK(get_buf_t(ctx, "L_minmax", 2, &dmm));
     double *dL = nullptr, *dtmp = nullptr;
-    OAK_CHECK(get_buf_t(ctx, "L", (size_t)M * M, &dL));
+    OAK_CHECK(get_buf_t(ctx, "L", (size_t)2 * M * M, &dL));
     OAK_CHECK(get_buf_t(ctx, "LinvT", (size_t)M * M, &dtmp));      // allocate on the host side of the fork
     OAK_CHECK(get_buf_t(ctx, "Linv", (size_t)M * M, &dtmp));
     int* d_info = nullptr;
@@ -321,14 +337,16 @@ int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter,
         OAK_CHECK(featurize(ctx, pk, dZ, M, ctx->ldx, "featZ_side", &FZ));
         OAK_CHECK(gram(ctx, pk, FZ, 0, M, FZ, dL, M, nullptr, nullptr, 0));
         OAK_CHECK(add_diag(ctx, dL, M, M, jitter));
-        OAK_CHECK(potrf_lower(ctx, dL, M, M, false));
+        const bool fused_inverse = (M % 32) == 0;
+        if (fused_inverse) OAK_CHECK(chol_with_inverse(ctx, dL, M));
+        else OAK_CHECK(potrf_lower(ctx, dL, M, M, false));
         if (want_cond) {
             diag_minmax_kernel<<<1, 256, 0, ctx->stream>>>(dL, M, dmm);
             OAK_HIP_CHECK(hipGetLastError());
             OAK_HIP_CHECK(hipMemcpyAsync(cond_out, dmm, 2 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
             OAK_HIP_CHECK(hipEventRecord(ctx->ev2, ctx->stream));
         }
-        OAK_CHECK(build_linv(ctx, dL, M));
+        if (!fused_inverse) OAK_CHECK(build_linv(ctx, dL, M));
         return OAK_OK;
     }();
     ctx->stream = main_stream;
@@ -411,7 +429,7 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     Stats st;
     OAK_CHECK(stats_view(ctx, &st));
     double *dL, *dT1, *dT2, *dLB, *dv1, *dc, *dscal;
-    OAK_CHECK(get_buf_t(ctx, "L", (size_t)M * M, &dL));
+    OAK_CHECK(get_buf_t(ctx, "L", (size_t)2 * M * M, &dL));
     OAK_CHECK(get_buf_t(ctx, "T1", (size_t)(M + 1) * M, &dT1));
     OAK_CHECK(get_buf_t(ctx, "T2", (size_t)(M + 1) * M, &dT2));
     OAK_CHECK(get_buf_t(ctx, "LB", (size_t)(M + 1) * M, &dLB));
@@ -427,8 +445,8 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
         OAK_CHECK(featurize(ctx, pk, (double*)peek_buf(ctx, "Z"), M, ctx->ldx, "featZ", &FZ));
         OAK_CHECK(gram(ctx, pk, FZ, 0, M, FZ, dL, M, nullptr, nullptr, 0));
         OAK_CHECK(add_diag(ctx, dL, M, M, jitter));
-        OAK_CHECK(potrf_lower(ctx, dL, M, M));
-        if (aug) OAK_CHECK(build_linv(ctx, dL, M));
+        if (aug) { OAK_CHECK(chol_with_inverse(ctx, dL, M)); OAK_CHECK(potrf_check(ctx, 0, M)); }    // aug implies M % 32 == 0
+        else OAK_CHECK(potrf_lower(ctx, dL, M, M));
     }
     ctx->have_linv = aug && l_state != 1;
     // W = L^-1 Phi L^-T  (= sigma^2 * A A^T, utils.py:189-190 without materialising A)
