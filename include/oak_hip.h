@@ -154,7 +154,7 @@ int oak_sgpr_set_global_rows(oak_ctx* ctx, int64_t n_total);
    honoured only when chol(Kuu) looks well conditioned ((max diag L / min diag L)^2 <= 1e2 -- the auto route's estimate, which
    under-reads cond(Kuu) by 20-600x);
    otherwise that evaluation runs in fp64 -- oak_sgpr_stats_precision reports what the last statistics used.  Not the
-   reference's arithmetic: ELBO within ~1e-6 relative of the fp64 path on the benchmark problems (tests/test_gpu_fp32.py),
+   reference's arithmetic: ELBO within 1e-5 relative of the fp64 path on the benchmark problems (7e-6 at the headline size, terms <= 2e-6) (tests/test_gpu_fp32.py),
    never used for `value`. */
 int oak_sgpr_set_precision(oak_ctx* ctx, int32_t mode);
 int oak_sgpr_stats_precision(oak_ctx* ctx, int32_t* mode);

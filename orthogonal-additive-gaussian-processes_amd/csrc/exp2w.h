@@ -29,10 +29,14 @@ static __device__ const double g_exp2_table1024[1024] = {
 constexpr int EW_BITS = 10;
 constexpr int EW_N = 1 << EW_BITS;                      // LDS table entries
 constexpr double EW_MAGIC = 6442450944.0;               // 1.5 * 2^32: ulp 2^-20 = the rounding step of w
+// The 512-entry variant (TB = 9: every other table entry, degree-4 Taylor polynomial, magic 1.5 * 2^33) is kept for the
+// shapes where the extra 4 KiB of LDS would cost the Gram kernel a workgroup per CU (D = 32 at 128 columns per workgroup).
+template <int TB> constexpr double ew_magic() { return TB == 10 ? 6442450944.0 : 12884901888.0; }
 
+template <int TB = EW_BITS>
 __device__ __forceinline__ double biased_table_entry(int j) {
-    const double t4 = 4.0 * g_exp2_table1024[j];
-    return __hiloint2double(__double2hiint(t4) - (j << (20 - EW_BITS)), __double2loint(t4));
+    const double t4 = 4.0 * g_exp2_table1024[j << (EW_BITS - TB)];
+    return __hiloint2double(__double2hiint(t4) - (j << (20 - TB)), __double2loint(t4));
 }
 
 __device__ __forceinline__ double fma_clamp01(double a, double b, double c) {
@@ -42,11 +46,17 @@ __device__ __forceinline__ double fma_clamp01(double a, double b, double c) {
 }
 
 // NV independent values at once, interleaved so the DP pipe always has independent work
-template <int NV>
+template <int NV, int TB = EW_BITS>
 __device__ __forceinline__ void exp2_w_vec(const double (&w)[NV], const double (&magic)[NV], double (&out)[NV],
                                            const double* __restrict__ tab) {
-    // 0.25 * 2^(-1024 rw) on |rw| <= 2^-21 (see the header): hexadecimal literals, exactly the fitted doubles
-    constexpr double C1 = -0x1.62e42fefa39f1p+7, C2 = 0x1.ebfbe039d53f0p+15, C3 = -0x1.c6b08cf0db226p+23;
+    // TB = 10: 0.25 * 2^(-1024 rw) on |rw| <= 2^-21 (see the header): hexadecimal literals, exactly the fitted doubles.
+    // TB = 9: the degree-4 Taylor polynomial on |rw| <= 2^-20.
+    constexpr double T1 = 6.931471805599453094e-01, T2 = 2.402265069591007123e-01, T3 = 5.550410866482157995e-02,
+                     T4 = 9.618129107628477162e-03, S = -1024.0;
+    constexpr double C1 = TB == 10 ? -0x1.62e42fefa39f1p+7 : 0.25 * T1 * S;
+    constexpr double C2 = TB == 10 ? 0x1.ebfbe039d53f0p+15 : 0.25 * T2 * S * S;
+    constexpr double C3 = TB == 10 ? -0x1.c6b08cf0db226p+23 : 0.25 * T3 * S * S * S;
+    constexpr double C4 = 0.25 * T4 * S * S * S * S;
     double a[NV], r[NV], p[NV], tv[NV];
     int ki[NV];
 #pragma unroll
@@ -54,18 +64,25 @@ __device__ __forceinline__ void exp2_w_vec(const double (&w)[NV], const double (
 #pragma unroll
     for (int v = 0; v < NV; ++v) ki[v] = __double2loint(a[v]);
 #pragma unroll
-    for (int v = 0; v < NV; ++v) tv[v] = tab[ki[v] & (EW_N - 1)];
+    for (int v = 0; v < NV; ++v) tv[v] = tab[ki[v] & ((1 << TB) - 1)];
 #pragma unroll
     for (int v = 0; v < NV; ++v) r[v] = w[v] + (a[v] - magic[v]);
+    if constexpr (TB == 10) {
 #pragma unroll
-    for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(C3, r[v], C2);
+        for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(C3, r[v], C2);
+    } else {
+#pragma unroll
+        for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(C4, r[v], C3);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(p[v], r[v], C2);
+    }
 #pragma unroll
     for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(p[v], r[v], C1);
 #pragma unroll
     for (int v = 0; v < NV; ++v) p[v] = __builtin_fma(p[v], r[v], 0.25);
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
-        const int hi = __double2hiint(tv[v]) + (ki[v] << (20 - EW_BITS));
+        const int hi = __double2hiint(tv[v]) + (ki[v] << (20 - TB));
         out[v] = __hiloint2double(hi, __double2loint(tv[v])) * p[v];
     }
 }

@@ -40,7 +40,7 @@ __device__ __forceinline__ double esp_combine(const double (&e)[R > 0 ? R : 1], 
 //   CPT == 2: columns jb + 2*tx + {0,1}
 // The B-side (column) features of all D dims stay in LDS for the whole workgroup; A-side (row) features are
 // restaged per row-step.  Dynamic LDS = (EW_N + D*TJ*2 + D*4*RT*2 + 4*RT) doubles.
-template <int R, int RT, int CPT, bool ALLRBF>
+template <int R, int RT, int CPT, bool ALLRBF, int TB>
 __global__ void __launch_bounds__(256)
 gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* __restrict__ Axs,
             const double* __restrict__ Acn, int64_t a_ld, int64_t a0, int64_t na, const double* __restrict__ Bxs,
@@ -50,8 +50,9 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
     constexpr int RS = 4 * RT;   // rows per row-step
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int D = dd.D;
-    double* Tab = smem;                // [EW_N] biased exp2 table (exp2w.h); first, so the lookups use a constant LDS base
-    double* Bx = Tab + EW_N;             // [D][TJ]   (RBF dims: x * scale_d / 32)
+    constexpr int TABN = 1 << TB;      // exp2 table entries: 1024, or 512 where the larger table would cost a workgroup per CU
+    double* Tab = smem;                // [TABN] biased exp2 table (exp2w.h); first, so the lookups use a constant LDS base
+    double* Bx = Tab + TABN;             // [D][TJ]   (RBF dims: x * scale_d / 32)
     double* Bc = Bx + D * TJ;          // [D][TJ]
     double* Ax = Bc + D * TJ;          // [D][RS]
     double* Ac = Ax + D * RS;          // [D][RS]
@@ -72,7 +73,7 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
         Bx[idx] = ok ? Bxs[(int64_t)d * b_ld + gj] * pre : 0.0;
         Bc[idx] = ok ? Bcn[(int64_t)d * b_ld + gj] : 0.0;
     }
-    for (int j = tid; j < EW_N; j += 256) Tab[j] = biased_table_entry(j);
+    for (int j = tid; j < TABN; j += 256) Tab[j] = biased_table_entry<TB>(j);
     double psi[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) psi[c] = 0.0;
@@ -117,7 +118,7 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
                 // these RT*CPT values cross the merge (not the RT*CPT*R accumulators, which cost a v_mov each per dimension)
                 double kk[RT][CPT];
                 if (ALLRBF || dd.type[d] == OAK_DIM_RBF) {
-                    const double woff = dd.woff[d], magic = dd.magic[d];
+                    const double woff = dd.woff[d], magic = (dd.magic[d] - EW_MAGIC) + ew_magic<TB>();   // exact: n/1024 + magic(TB)
 #pragma unroll
                     for (int r = 0; r < RT; ++r) {
                         double w[CPT], E[CPT];
@@ -129,7 +130,7 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
                         double mg[CPT];
 #pragma unroll
                         for (int c = 0; c < CPT; ++c) mg[c] = magic;
-                        exp2_w_vec<CPT>(w, mg, E, Tab);
+                        exp2_w_vec<CPT, TB>(w, mg, E, Tab);
 #pragma unroll
                         for (int c = 0; c < CPT; ++c) kk[r][c] = __builtin_fma(-ca[r], cb[c], E[c]);
                     }
@@ -246,7 +247,11 @@ static int launch_gram_t(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, 
     constexpr int TJ = 64 * CPT;
     constexpr int RS = 4 * RT;
     const int D = pk.dd.D;
-    size_t lds = sizeof(double) * ((size_t)D * TJ * 2 + (size_t)D * RS * 2 + RS + EW_N);
+    // 1024-entry exp2 table unless its extra 4 KiB would lower the number of workgroups a CU holds (D = 32 at TJ = 128)
+    const size_t lds_body = sizeof(double) * ((size_t)D * TJ * 2 + (size_t)D * RS * 2 + RS);
+    const size_t cu_lds = 160 * 1024;
+    const bool big_table = cu_lds / (lds_body + sizeof(double) * 1024) == cu_lds / (lds_body + sizeof(double) * 512);
+    size_t lds = lds_body + sizeof(double) * (big_table ? 1024 : 512);
     const size_t lds_red = sizeof(double) * 4 * TJ;
     if (lds < lds_red) lds = lds_red;
     if (lds > 160 * 1024) { set_error("gram: LDS request %zu exceeds 160 KiB (D=%d)", lds, D); return OAK_E_ARG; }
@@ -268,7 +273,8 @@ static int launch_gram_t(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, 
     if (d_yA != nullptr) OAK_CHECK(get_buf_t(ctx, "psi_part", (size_t)(nrb * nb), &d_part));
     bool all_rbf = true;
     for (int d = 0; d < D; ++d) all_rbf = all_rbf && pk.dd.type[d] == OAK_DIM_RBF;
-    auto kern = all_rbf ? gram_kernel<R, RT, CPT, true> : gram_kernel<R, RT, CPT, false>;
+    auto kern = big_table ? (all_rbf ? gram_kernel<R, RT, CPT, true, 10> : gram_kernel<R, RT, CPT, false, 10>)
+                          : (all_rbf ? gram_kernel<R, RT, CPT, true, 9> : gram_kernel<R, RT, CPT, false, 9>);
     if (lds > 64 * 1024) OAK_CHECK(ensure_max_dynamic_lds((const void*)kern));
     dim3 grid((unsigned)ncb, (unsigned)nrb);
     kern<<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, A.xs, A.cn, A.ld, a0, na, B.xs, B.cn, B.ld, nb, d_out, ldo,

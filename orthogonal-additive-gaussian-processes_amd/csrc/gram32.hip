@@ -218,7 +218,7 @@ int gram_f32(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
 // SYRK, fp32 operands: same decomposition as syrk_kernel (descriptor table of 64 x 64 blocks, four per workgroup, XCD-aware
 // split mapping); each wave's 64 x 64 block as 4 x 4 tiles of v_mfma_f32_16x16x4_f32.  Partials are written as fp64.
 // ---------------------------------------------------------------------------------------------
-constexpr int S32_T = 128, S32_KB = 32, S32_LD = S32_T + 16, S32_DESC = 16, S32_FLUSH = 8;
+constexpr int S32_T = 128, S32_KB = 32, S32_LD = S32_T + 16, S32_DESC = 16, S32_FLUSH = 32;
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 __global__ void __launch_bounds__(256, 2)
@@ -245,9 +245,10 @@ syrk32_kernel(const float* __restrict__ P, int64_t ldp, int64_t nrows, const int
     const int64_t r0 = (int64_t)split * rows_per_split;
     int64_t r1 = r0 + rows_per_split;
     if (r1 > nrows) r1 = nrows;
-    // fp32 accumulation only over S32_FLUSH stages (256 rows); then the tile is added into fp64 accumulators.  With fp32
+    // fp32 accumulation only over S32_FLUSH stages (1024 rows); then the tile is added into fp64 accumulators.  With fp32
     // accumulation over a whole split (8192 rows) the random-walk rounding of the sums (~sqrt(rows) * 6e-8) reached tr(AA^T)
-    // at 3.5e-5 relative on the headline problem (ELBO 1.5e-4); with 256-row chunks it is the panel's own rounding that is left.
+    // at 3.5e-5 relative on the headline problem (ELBO 1.5e-4); with 256-row chunks ELBO 9e-7 but the flush (cvt + fp64 add
+    // on the pipe the MFMAs use) cost 12 % of the kernel, with 1024-row chunks it is a quarter of that.
     float4_t acc[4][4];
     double4_t acc64[4][4];
 #pragma unroll
