@@ -134,13 +134,13 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     // In the auto route of a large problem the decision is still in flight (sgpr_forward started chol(Kuu) and the
     // diagonal-ratio estimate on the side stream): the first Gram panel is needed either way, so it is launched first and
     // the host waits for the estimate underneath it.
-    // fp32 statistics mode (oak_sgpr_set_precision): forward evaluations on the phi route only; a gradient call (keep_kfu)
-    // and the whitened route stay fp64.  The auto route's pending conditioning decision is then awaited up front, because it
-    // selects the panel's type.
-    // It also needs a well-conditioned Kuu: an fp32 error delta in Phi reaches W = L^-1 Phi L^-T as delta / lambda_min(Kuu),
-    // so the mode is honoured only when the side stream's conditioning estimate (the auto route's: (max diag L / min diag L)^2
-    // <= 1e3, i.e. cond(Kuu) below ~1e4..1e5) allows it; otherwise this evaluation runs in fp64 (oak_sgpr_stats_precision tells).
-    // The estimate selects the panel's type, so it is awaited before the first Gram launch.
+    // fp32 statistics mode (oak_sgpr_set_precision): forward evaluations of the fused entry points on the phi route only; a
+    // gradient call (keep_kfu), the whitened route and the stand-alone local_stats stay fp64.  It needs a well-conditioned
+    // Kuu -- an fp32 error delta in Phi reaches W = L^-1 Phi L^-T as delta / lambda_min(Kuu) -- so it is honoured only when the
+    // side stream's conditioning estimate (max diag L / min diag L)^2 is <= FP32_MAX_DIAG_RATIO2; otherwise this evaluation runs
+    // in fp64 (oak_sgpr_stats_precision tells).  The estimate selects the panel's TYPE, so it is awaited before the first Gram
+    // launch (the auto route's pending whitening decision is settled from the same reading).  Under a communicator every rank
+    // must have the same mode set: the decision below is a collective.
     bool want32 = ctx->precision == 1 && !ctx->keep_kfu && ctx->cond_requested;
     if (want32) {
         OAK_HIP_CHECK(hipEventSynchronize(ctx->ev2));
