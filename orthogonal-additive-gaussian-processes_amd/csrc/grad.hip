@@ -85,7 +85,7 @@ gram_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
     double* Tab = Av + TJ;              // [64]
     double* accL = Tab + 64;            // [4][D]
     double* accK = accL + 4 * D;        // [4][D]
-    double* accT = accK + 4 * D;        // [tablen]
+    double* accT = accK + 4 * D;        // [4][tablen]: one copy per wave (see accTw)
     const int tid = threadIdx.x, tx = tid & 63;
     const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t jb = (int64_t)blockIdx.x * TJ;
@@ -102,7 +102,12 @@ gram_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
     for (int j = tid; j < TJ; j += 256) Av[j] = (avec != nullptr && jb + j < nb) ? avec[jb + j] : 0.0;
     if (tid < 64) Tab[tid] = c_exp2_table_g[tid];
     for (int idx = tid; idx < 8 * D; idx += 256) accL[idx] = 0.0;     // accL and accK are contiguous
-    for (int idx = tid; idx < tablen; idx += 256) accT[idx] = 0.0;
+    for (int idx = tid; idx < 4 * tablen; idx += 256) accT[idx] = 0.0;
+    // Categorical-table sums go through LDS atomics.  Each wave adds into ITS OWN copy: within one ds_add instruction the LDS
+    // unit serialises colliding lanes in a fixed order, and a wave's instructions are ordered, so a copy's contents do not
+    // depend on timing; what used to vary from run to run was the interleaving of the four waves on one shared copy.  The
+    // copies are combined in a fixed order at the end (tests/test_gpu_grad.py::test_mixed_kernel_gradient_is_bitwise_repeatable).
+    double* accTw = accT + ty * tablen;
     double gw[R + 1];
 #pragma unroll
     for (int q = 0; q <= R; ++q) gw[q] = 0.0;
@@ -201,7 +206,7 @@ gram_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
                         const double gc = g[r][c] * coef;
                         cl = __builtin_fma(gc, dkl, cl);
                         ck = __builtin_fma(gc, k, ck);
-                        if (!rbf && dd.type[d] == OAK_DIM_CATEGORICAL && gc != 0.0) atomicAdd(&accT[tidx], gc);
+                        if (!rbf && dd.type[d] == OAK_DIM_CATEGORICAL && gc != 0.0) atomicAdd(&accTw[tidx], gc);
                     }
                 cl = wave_sum(cl);
                 ck = wave_sum(ck);
@@ -229,7 +234,8 @@ gram_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
         rec[D + idx] = ((accK[idx] + accK[D + idx]) + accK[2 * D + idx]) + accK[3 * D + idx];
     }
     if (tid <= RA) rec[2 * D + tid] = ((red[tid] + red[(R + 1) + tid]) + red[2 * (R + 1) + tid]) + red[3 * (R + 1) + tid];
-    for (int idx = tid; idx < tablen; idx += 256) rec[2 * D + (RA + 1) + idx] = accT[idx];
+    for (int idx = tid; idx < tablen; idx += 256)
+        rec[2 * D + (RA + 1) + idx] = ((accT[idx] + accT[tablen + idx]) + accT[2 * tablen + idx]) + accT[3 * tablen + idx];
 }
 
 // Row-major pack of the backward features of rows a0 .. a0+na-1:  out[i][q][d],  q = (xs32, cn, dcs),  d < DP;
@@ -283,8 +289,8 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
     double* Tab = Av + TJ;              // [EW_N] biased exp2 table
     double* Cw = Tab + EW_N;            // [DMAX] woff per dim    (not allocated when UNITBV)
     double* Cm = Cw + DMAX;             // [DMAX] magic per dim
-    double* accT = UNITBV ? Tab + EW_N : Cm + DMAX;     // [tablen]
-    int* meta = reinterpret_cast<int*>(accT + tablen);   // [2*DMAX] (tab_off, ncat) of the discrete dims: read from LDS
+    double* accT = UNITBV ? Tab + EW_N : Cm + DMAX;     // [4][tablen]: one copy per wave (deterministic sums, see gram_bwd_kernel)
+    int* meta = reinterpret_cast<int*>(accT + 4 * tablen);   // [2*DMAX] (tab_off, ncat) of the discrete dims: read from LDS
                                         // inside the rare branch instead of living in ~100 SGPRs (they spilled to VGPR lanes)
     double* red = Bx;                   // [4][2*DMAX + R + 1], aliases the column features once the row loop is done
                                         // (54 272 B at DMAX = 16 without discrete tables: three workgroups per CU)
@@ -310,7 +316,8 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
             Cm[tid] = rbf ? dd.magic[tid] : EW_MAGIC;
         }
     }
-    for (int idx = tid; idx < tablen; idx += 256) accT[idx] = 0.0;
+    for (int idx = tid; idx < 4 * tablen; idx += 256) accT[idx] = 0.0;
+    double* accTw = accT + ty * tablen;
     unsigned rbf_mask = 0xffffffffu, cat_mask = 0u;
     if constexpr (!ALLRBF) {
         if (tid < DMAX) { meta[2 * tid] = tid < D ? dd.tab_off[tid] : 0; meta[2 * tid + 1] = tid < D ? dd.ncat[tid] : 0; }
@@ -422,7 +429,7 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
                 if constexpr (WANT_GK) gk[d] = __builtin_fma(gc, k[d], gk[d]);
                 if constexpr (!ALLRBF) {
                     if (((cat_mask >> d) & 1u) && gc != 0.0)
-                        atomicAdd(&accT[meta[2 * d] + (int)prow[d] * meta[2 * d + 1] + (int)Bx[d * TJ + col]], gc);
+                        atomicAdd(&accTw[meta[2 * d] + (int)prow[d] * meta[2 * d + 1] + (int)Bx[d * TJ + col]], gc);
                 }
             }
         }
@@ -448,7 +455,8 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
     auto sum4 = [&](int j) { return ((red[j] + red[NACC + j]) + red[2 * NACC + j]) + red[3 * NACC + j]; };
     for (int d = tid; d < D; d += 256) { rec[d] = sum4(d) * 1024.0; rec[D + d] = sum4(DMAX + d); }
     if (tid <= R) rec[2 * D + tid] = sum4(2 * DMAX + tid);
-    for (int idx = tid; idx < tablen; idx += 256) rec[2 * D + (R + 1) + idx] = accT[idx];
+    for (int idx = tid; idx < tablen; idx += 256)
+        rec[2 * D + (R + 1) + idx] = ((accT[idx] + accT[tablen + idx]) + accT[2 * tablen + idx]) + accT[3 * tablen + idx];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -681,10 +689,10 @@ diag_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
     const int D = dd.D;
     double* accL = smem;             // [4][D]
     double* accK = accL + 4 * D;     // [4][D]
-    double* accT = accK + 4 * D;     // [tablen]
-    double* red = accT + tablen;     // [4][R+1]
+    double* accT = accK + 4 * D;     // [4][tablen]: one copy per wave
+    double* red = accT + 4 * tablen; // [4][R+1]
     const int tid = threadIdx.x, tx = tid & 63, ty = tid >> 6;
-    for (int idx = tid; idx < 8 * D + tablen; idx += 256) smem[idx] = 0.0;
+    for (int idx = tid; idx < 8 * D + 4 * tablen; idx += 256) smem[idx] = 0.0;
     __syncthreads();
     double gw[R + 1];
 #pragma unroll
@@ -750,7 +758,7 @@ diag_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
                     const double gc = g[t] * coef;
                     cl = __builtin_fma(gc, dkl, cl);
                     ck = __builtin_fma(gc, k, ck);
-                    if (!rbf && dd.type[d] == OAK_DIM_CATEGORICAL && gc != 0.0) atomicAdd(&accT[tidx], gc);
+                    if (!rbf && dd.type[d] == OAK_DIM_CATEGORICAL && gc != 0.0) atomicAdd(&accT[ty * tablen + tidx], gc);
                 }
                 cl = wave_sum(cl); ck = wave_sum(ck);
                 if (tx == 0) { accL[ty * D + d] += cl; accK[ty * D + d] += ck; }
@@ -772,7 +780,8 @@ diag_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
         rec[D + idx] = ((accK[idx] + accK[D + idx]) + accK[2 * D + idx]) + accK[3 * D + idx];
     }
     if (tid <= RA) rec[2 * D + tid] = ((red[tid] + red[(R + 1) + tid]) + red[2 * (R + 1) + tid]) + red[3 * (R + 1) + tid];
-    for (int idx = tid; idx < tablen; idx += 256) rec[2 * D + (RA + 1) + idx] = accT[idx];
+    for (int idx = tid; idx < tablen; idx += 256)
+        rec[2 * D + (RA + 1) + idx] = ((accT[idx] + accT[tablen + idx]) + accT[2 * tablen + idx]) + accT[3 * tablen + idx];
 }
 
 // out[j] += sum_w partial[w][j]: one workgroup per entry j, thread t adds records t, t + 256, ... in order, then a fixed
@@ -801,7 +810,7 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     OAK_REQUIRE(A.dcn != nullptr && B.dcn != nullptr, "gram_bwd: features were not prepared for the backward pass");
     const int D = pk.dd.D, R = pk.dd.R;
     const int tablen = (int)pk.tables.size();
-    OAK_REQUIRE(tablen <= 4096, "gradient: discrete tables too large (%d doubles)", tablen);
+    OAK_REQUIRE(tablen <= 1024, "gradient: discrete tables too large (%d doubles; four per-wave copies are kept in LDS)", tablen);
     const bool fast = (R >= 1 && R <= 4 && D <= 32 && getenv("OAK_BWD_GENERIC") == nullptr);
     bool allrbf = true;
     for (int d = 0; d < D; ++d) allrbf = allrbf && pk.dd.type[d] == OAK_DIM_RBF;
@@ -810,8 +819,8 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     const int TJ = 64 * cpt, RS = 8;
     bool unitbv = true;
     for (int d = 0; d < D; ++d) unitbv = unitbv && (pk.dd.type[d] != OAK_DIM_RBF || pk.dd.bv[d] == 1.0);
-    const size_t lds = fast ? sizeof(double) * ((size_t)3 * dmax * TJ + TJ + EW_N + (unitbv ? 0 : 2 * dmax) + tablen + (allrbf ? 0 : dmax))
-                            : sizeof(double) * ((size_t)3 * D * TJ + (size_t)3 * D * RS + RS + TJ + 64 + 8 * D + tablen + 64);
+    const size_t lds = fast ? sizeof(double) * ((size_t)3 * dmax * TJ + TJ + EW_N + (unitbv ? 0 : 2 * dmax) + 4 * tablen + (allrbf ? 0 : dmax))
+                            : sizeof(double) * ((size_t)3 * D * TJ + (size_t)3 * D * RS + RS + TJ + 64 + 8 * D + 4 * tablen + 64);
     OAK_REQUIRE(lds <= 160 * 1024, "gram_bwd: LDS request %zu exceeds 160 KiB", lds);
     const int64_t nb = B.n;
     const int64_t ncb = (nb + TJ - 1) / TJ;
@@ -946,7 +955,7 @@ int diag_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, double gcons
     double* d_part = nullptr;
     OAK_CHECK(get_buf_t(ctx, "bwd_part_diag", (size_t)(nwg * reclen), &d_part));
     const int RTP = R <= 8 ? R : (R <= 12 ? 12 : 16);          // template depth the launch below instantiates
-    const size_t lds = sizeof(double) * ((size_t)8 * D + tablen + 4 * (RTP + 1) + 8);
+    const size_t lds = sizeof(double) * ((size_t)8 * D + 4 * tablen + 4 * (RTP + 1) + 8);
 #define OAK_DB_CASE(RR) case RR: diag_bwd_kernel<RR><<<(unsigned)nwg, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen, A.xs, A.cn, A.dcn, A.ld, A.n, gconst, d_gvec, rows, d_part); break;
     switch (R <= 8 ? R : (R <= 12 ? 12 : 16)) {
         OAK_DB_CASE(0) OAK_DB_CASE(1) OAK_DB_CASE(2) OAK_DB_CASE(3) OAK_DB_CASE(4)
