@@ -101,3 +101,27 @@ def test_fp32_mode_falls_back_to_fp64_on_an_ill_conditioned_kuu():
     est = t32.pop("cond_estimate"); t64.pop("cond_estimate")           # only the fp32-mode evaluation asks for the estimate
     assert est > 1e2 and used == "fp64" and e32 == e64 and t32 == t64
     ctx.close()
+
+
+def test_fp32_mode_under_a_communicator():
+    """The mode's conditioning decision is a collective (rank 0's reading, shared): under the loopback communicator (two ranks
+    holding the same rows) the evaluation must run in fp32 on a well-conditioned problem, fall back on an ill-conditioned one,
+    and agree with the single-rank run on the rows stacked twice to the mode's own accuracy."""
+    X, y, Z = o.synthetic_problem(30000, 16, 256, seed=8)
+    spec = o.make_spec(16, 2)
+    d = _capi.KernelDesc(spec)
+    ref = _capi.HipContext(0)
+    ref.sgpr_set_data(np.tile(X, (2, 1)), np.tile(y, (2, 1))); ref.sgpr_set_inducing(Z); ref.sgpr_set_route("phi")
+    e64 = ref.sgpr_elbo(d, 0.05)
+    ctx = _capi.HipContext(0)
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("phi"); ctx.sgpr_set_precision("fp32")
+    ctx.comm_init_loopback(2)
+    e32 = ctx.sgpr_elbo(d, 0.05)
+    assert ctx.sgpr_stats_precision() == "fp32" and abs(e32 - e64) <= 1e-6 * abs(e64)
+    # ill-conditioned Kuu (config 2's shape): both "ranks" fall back together
+    X2, y2, Z2 = o.synthetic_problem(20000, 8, 512)
+    spec2 = o.make_spec(8, 2)
+    ctx.sgpr_set_data(X2, y2); ctx.sgpr_set_inducing(Z2)
+    ctx.sgpr_elbo(_capi.KernelDesc(spec2), 0.01)
+    assert ctx.sgpr_stats_precision() == "fp64"
+    ctx.close(); ref.close()
