@@ -31,7 +31,7 @@ def pytest_configure(config):
 # Watchdog: a test that makes no progress for WATCHDOG_S seconds (a wedged device call cannot be interrupted from Python)
 # dumps every thread's stack and ends the process with a failure instead of hanging the run.
 import os as _os
-WATCHDOG_S = int(_os.environ.get("OAK_TEST_WATCHDOG_S", "600"))
+WATCHDOG_S = int(_os.environ.get("OAK_TEST_WATCHDOG_S", "420"))
 
 
 @pytest.hookimpl(hookwrapper=True)
