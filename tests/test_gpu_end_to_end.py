@@ -4,6 +4,8 @@ predict -> Sobol recovers the generating structure.  Mirrors the flow of /root/r
 import numpy as np
 import pytest
 
+from oracle import oak_oracle as o
+
 pytestmark = pytest.mark.gpu
 
 
@@ -65,3 +67,37 @@ def test_minimize_linalg_error_modes(hip):
     assert np.isfinite(res.fun) and res.fun < loss0
     with pytest.raises(ValueError):
         gpflow.Scipy().minimize(oak.m.training_loss_closure(), oak.m.trainable_variables, on_linalg_error="ignore")
+
+
+@pytest.mark.parametrize("sparse", [False, True])
+def test_full_order_model_as_in_the_regression_example(sparse):
+    """examples/uci/uci_regression_train.py:86 builds oak_model(max_interaction_depth=X.shape[1]) -- every interaction order, 13
+    on UCI housing.  D = 10 here (depth 10 > the r01 cap of 8; 1023 additive terms): fit without optimisation, one loss +
+    gradient evaluation, prediction and the Sobol indices of all terms, the normalised indices against the oracle."""
+    from oak.model_utils import oak_model
+    from oak.oak_kernel import kernel_to_spec
+    rng = np.random.default_rng(5)
+    N, D = 300, 10
+    X = rng.standard_normal((N, D))
+    y = (np.sin(X[:, 0]) + X[:, 1] * X[:, 2] + 0.3 * X[:, 3] * X[:, 4] * X[:, 5] + 0.05 * rng.standard_normal(N)).reshape(-1, 1)
+    oak = oak_model(max_interaction_depth=D, num_inducing=40, sparse=sparse, use_normalising_flow=False)
+    oak.fit(X, y, optimise=False)
+    spec = kernel_to_spec(oak.m.kernel)
+    assert spec["max_interaction_depth"] == D and len(spec["order_variances"]) == D + 1
+    loss, grads = oak.m._training_loss_and_grad(oak.m.trainable_variables)
+    assert np.isfinite(loss) and all(np.all(np.isfinite(np.asarray(g))) for g in grads)
+    pred = oak.predict(X[:50])
+    assert pred.shape == (50,) and np.all(np.isfinite(pred))
+    sob = oak.get_sobol()
+    assert len(sob) == 2 ** D - 1 and abs(sob.sum() - 1.0) < 1e-9 and (sob >= -1e-12).all()
+    # against the oracle's Sobol indices of the same posterior
+    Xs = oak.X_scaled
+    if sparse:
+        Z = oak.m.inducing_variable.Z.numpy()
+        alpha = o.sgpr_alpha(spec, Xs, oak.Y_scaled, Z, float(oak.m.likelihood.variance.numpy()))
+        _, ref = o.compute_sobol_oak(spec, Z, alpha)
+    else:
+        alpha = o.gpr_alpha(spec, Xs, oak.Y_scaled, float(oak.m.likelihood.variance.numpy()))
+        _, ref = o.compute_sobol_oak(spec, Xs, alpha)
+    ref = np.asarray(ref)
+    np.testing.assert_allclose(sob, ref / ref.sum(), atol=1e-8)
