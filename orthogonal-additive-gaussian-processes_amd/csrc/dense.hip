@@ -334,11 +334,23 @@ int add_diag(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, double v) {
 __global__ void scale_add_eye_kernel(const double* __restrict__ W, int64_t n, double s, double* __restrict__ B) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t i = blockIdx.y;
-    if (j < n) B[i * n + j] = W[i * n + j] * s + (i == j ? 1.0 : 0.0);
+    if (j >= n) return;
+    if (i < n) B[i * n + j] = W[i * n + j] * s + (i == j ? 1.0 : 0.0);
+    else B[i * n + j] = W[i * n + j];               // rows past the square ride along unchanged (right-hand sides of the solve)
 }
-int scale_add_eye(oak_ctx* ctx, const double* dW, int64_t n, double s, double* dB) {
-    dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
+int scale_add_eye(oak_ctx* ctx, const double* dW, int64_t n, double s, double* dB, int extra_rows) {
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)(n + extra_rows));
     scale_add_eye_kernel<<<grid, 256, 0, ctx->stream>>>(dW, n, s, dB);
+    OAK_HIP_CHECK(hipGetLastError());
+    return OAK_OK;
+}
+__global__ void scaled_copy_kernel(double a, const double* __restrict__ src, double* __restrict__ dst, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = a * src[i];
+}
+int scaled_copy(oak_ctx* ctx, double a, const double* d_src, double* d_dst, int64_t n) {      // dst = a * src
+    if (n <= 0) return OAK_OK;
+    scaled_copy_kernel<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(a, d_src, d_dst, n);
     OAK_HIP_CHECK(hipGetLastError());
     return OAK_OK;
 }

@@ -637,7 +637,6 @@ __global__ void zero_upper_kernel(double* __restrict__ A, int64_t n, int64_t lda
 }
 
 static const int PO_BIG = 0x7fffffff;
-__global__ void set_int_kernel(int* p, int v) { *p = v; }
 
 int potrf_check(oak_ctx* ctx, int slot, int64_t n) {
     int* d_info = (int*)peek_buf(ctx, "potrf_info");
@@ -651,6 +650,12 @@ int potrf_check(oak_ctx* ctx, int slot, int64_t n) {
     return OAK_OK;
 }
 
+__global__ void potrf_reset_kernel(int* info, int info_value, int* arrivals, int npanel) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) *info = info_value;
+    if (i < npanel) arrivals[i] = 0;
+}
+
 int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, bool check, int64_t nrows) {
     if (nrows < n) nrows = n;
     if (nrows > n && (n % PO_NB) != 0) { set_error("potrf_lower: extra rows need n to be a multiple of %d", PO_NB); return OAK_E_ARG; }
@@ -658,11 +663,10 @@ int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, bool check, in
     OAK_CHECK(get_buf_t(ctx, "potrf_info", 2, &d_info));
     const int slot = (ctx->side != nullptr && ctx->stream == ctx->side) ? 1 : 0;
     d_info += slot;
-    set_int_kernel<<<1, 1, 0, ctx->stream>>>(d_info, PO_BIG);
     int* d_arr = nullptr;
     const size_t npanel = (size_t)((n + PO_NB - 1) / PO_NB);
     OAK_CHECK(get_buf_t(ctx, slot ? "potrf_arrivals_side" : "potrf_arrivals", npanel, &d_arr));
-    OAK_HIP_CHECK(hipMemsetAsync(d_arr, 0, sizeof(int) * npanel, ctx->stream));
+    potrf_reset_kernel<<<(unsigned)((npanel + 255) / 256), 256, 0, ctx->stream>>>(d_info, PO_BIG, d_arr, (int)npanel);   // status + arrival counters in one launch
     // Fused mode (one launch per panel) is launch-latency optimal and wins up to n ~ 6000; beyond that the trailing updates
     // are HBM-bound and the pipelined 64 x 64 GEMM kernel moves them faster than the single-stage role-B tiles
     // (n = 16384: 253 ms fused vs 182 ms), so large factorisations fall back to panel + GEMM per step.

@@ -156,8 +156,17 @@ __global__ void __launch_bounds__(256) colsum_accum32_kernel(const double* __res
     const int cx = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int64_t j = (int64_t)blockIdx.x * 32 + cx;
     double s = 0.0;
-    if (j < cols)
-        for (int64_t r = g; r < rows; r += 8) s += part[r * cols + j];
+    if (j < cols) {
+        int64_t r = g;
+        for (; r + 56 < rows; r += 64) {          // eight loads in flight (the loop is latency-bound), summed in the same order
+            double v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = part[(r + 8 * q) * cols + j];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += v[q];
+        }
+        for (; r < rows; r += 8) s += part[r * cols + j];
+    }
     red[g][cx] = s;
     __syncthreads();
     if (g == 0 && j < cols) {

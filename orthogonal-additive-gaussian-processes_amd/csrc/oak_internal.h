@@ -189,7 +189,8 @@ int potrf_check(oak_ctx* ctx, int slot, int64_t n);   // deferred status of a ch
 int trsm_rows(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, double* dBT, int64_t nrhs, int64_t ldb, int trans);
 int transpose(oak_ctx* ctx, const double* dA, int64_t rows, int64_t cols, int64_t lda, double* dB, int64_t ldb);
 int add_diag(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, double v);
-int scale_add_eye(oak_ctx* ctx, const double* dW, int64_t n, double s, double* dB);   // B = I + s*W
+int scale_add_eye(oak_ctx* ctx, const double* dW, int64_t n, double s, double* dB, int extra_rows = 0);   // B = I + s*W (+ rows copied as they are)
+int scaled_copy(oak_ctx* ctx, double a, const double* d_src, double* d_dst, int64_t n);               // dst = a * src
 int reduce_sum(oak_ctx* ctx, const double* d_x, int64_t n, double* d_out /*1*/, int mode /*0 sum,1 sumsq,2 sumlog*/, int64_t stride);
 int dot(oak_ctx* ctx, const double* d_x, const double* d_y, int64_t n, double* d_out);
 int gemv_rows(oak_ctx* ctx, const double* dA, int64_t rows, int64_t cols, int64_t lda, const double* d_x, double* d_y); // y = A x

@@ -463,7 +463,6 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
         OAK_CHECK(gemm_tail(ctx, 1, dLinv, st.phi, dT1, M, M, M, M, M, M, 1.0, 0.0, OAK_TRI_A_LOWER));
         OAK_CHECK(copy_d2d(ctx, dT1 + M * M, st.psi, sizeof(double) * (size_t)M));
         OAK_CHECK(gemm_tail(ctx, 1, dT1, dLinv, dT2, M + 1, M, M, M, M, M, 1.0, 0.0, OAK_TRI_B_LOWER));
-        OAK_CHECK(copy_d2d(ctx, dv1, dT2 + M * M, sizeof(double) * (size_t)M));
     } else {
         // rows 0..M-1 of T1 = Phi (symmetric), row M = psi: one blocked solve gives (L^-1 Phi)^T and L^-1 psi together
         OAK_CHECK(copy_d2d(ctx, dT1, st.phi, sizeof(double) * (size_t)(M * M + M)));
@@ -474,18 +473,18 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     }
     // B = I + W / sigma^2 ; LB = chol(B)   (utils.py:190-193);  c = LB^-1 L^-1 psi / sigma^2   (utils.py:194-195:
     // Aerr = L^-1 psi / sigma, c = LB^-1 Aerr / sigma).  Status is read with the scalars below: one host sync per tail.
-    OAK_CHECK(scale_add_eye(ctx, dT2, M, 1.0 / noise_var, dLB));
     if (aug) {
-        // row M of the (M+1) x M array = (L^-1 psi)^T: the panel solves turn it into (LB^-1 L^-1 psi)^T
-        OAK_CHECK(copy_d2d(ctx, dLB + M * M, dv1, sizeof(double) * (size_t)M));
+        // row M of the (M+1) x M arrays = (L^-1 psi)^T, carried over unscaled: the panel solves turn it into (LB^-1 L^-1 psi)^T
+        OAK_CHECK(scale_add_eye(ctx, dT2, M, 1.0 / noise_var, dLB, 1));
         OAK_CHECK(potrf_lower(ctx, dLB, M, M, false, M + 1));
-        OAK_CHECK(copy_d2d(ctx, dc, dLB + M * M, sizeof(double) * (size_t)M));
+        OAK_CHECK(scaled_copy(ctx, 1.0 / noise_var, dLB + M * M, dc, M));
     } else {
+        OAK_CHECK(scale_add_eye(ctx, dT2, M, 1.0 / noise_var, dLB));
         OAK_CHECK(potrf_lower(ctx, dLB, M, M, false));
         OAK_CHECK(copy_d2d(ctx, dc, dv1, sizeof(double) * (size_t)M));
         OAK_CHECK(trsm_rows(ctx, dLB, M, M, dc, 1, M, 0));
+        OAK_CHECK(scale_vec(ctx, 1.0 / noise_var, dc, M));
     }
-    OAK_CHECK(scale_vec(ctx, 1.0 / noise_var, dc, M));
     // scalars: sum log diag LB, c^T c, tr W, (kappa, yy, nrows), sum log diag L -- one small kernel, fixed reduction trees
     tail_scalars_kernel<<<1, 256, 0, ctx->stream>>>(dLB, dc, dT2, dL, M, st.kappa, dscal);
     OAK_HIP_CHECK(hipGetLastError());

@@ -14,7 +14,8 @@ X, y, Z = bench.synthetic(N, D, M)
 spec = bench.make_spec(D, R)
 ctx = _capi.default_context()
 PH = ["featurize", "gram", "syrk", "reduce", "tail", "total"]
-for g in (1, 2, 4, 8):
+GS = tuple(int(a) for a in sys.argv[1:]) or (1, 2, 4, 8)      # e.g. `dev_shard.py 8` under rocprofv3 for one shard size
+for g in GS:
     n = N // g
     ctx.sgpr_set_data(np.ascontiguousarray(X[:n]), np.ascontiguousarray(y[:n]))
     ctx.sgpr_set_inducing(Z)
