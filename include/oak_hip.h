@@ -319,6 +319,11 @@ int oak_bench_gram_resident(oak_ctx* ctx, const oak_kernel_desc* desc, double* b
    (exponential kernel + 1e-3 I, built on the device) `reps` times; *ms_out = mean GPU time per factorisation (HIP events),
    *logdet_out (may be NULL) = log det from the factor, for checking against a host Cholesky of the same matrix. */
 int oak_bench_potrf(oak_ctx* ctx, int64_t n, int32_t reps, double* ms_out, double* logdet_out);
+/* The many-right-hand-side triangular solve alone (tf.linalg.triangular_solve at oak/utils.py:189 and in predict_f): every row
+   b of B (host, nrhs x n row-major, overwritten) becomes the solution of L x = b (trans = 0) or L^T x = b (trans = 1) for the
+   lower-triangular host matrix L (n x n); *ms_out (may be NULL) = mean GPU time of `reps` solves.  For residual checks and
+   timing of the blocked solve the whitened route, the SVGP and large prediction batches run. */
+int oak_bench_trsm(oak_ctx* ctx, const double* L, int64_t n, double* B, int64_t nrhs, int32_t trans, int32_t reps, double* ms_out);
 
 #ifdef __cplusplus
 }

@@ -961,6 +961,42 @@ int oak_bench_potrf(oak_ctx* ctx, int64_t n, int32_t reps, double* ms_out, doubl
     return OAK_OK;
 }
 
+int oak_bench_trsm(oak_ctx* ctx, const double* L, int64_t n, double* B, int64_t nrhs, int32_t trans, int32_t reps, double* ms_out) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(L != nullptr && B != nullptr && n >= 1 && nrhs >= 1 && reps >= 1, "oak_bench_trsm: bad arguments");
+    const int64_t ldb = (n + 1) & ~(int64_t)1;                 // even row stride, as the panels of the library have
+    double *dL = nullptr, *dB0 = nullptr, *dB = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "bench_trsm_L", (size_t)n * n, &dL));
+    OAK_CHECK(get_buf_t(ctx, "bench_trsm_B0", (size_t)nrhs * n, &dB0));
+    OAK_CHECK(get_buf_t(ctx, "bench_trsm_B", (size_t)nrhs * ldb, &dB));
+    OAK_CHECK(copy_sync(ctx, dL, L, sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice));
+    OAK_CHECK(copy_sync(ctx, dB0, B, sizeof(double) * (size_t)nrhs * n, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1;
+    OAK_HIP_CHECK(hipEventCreate(&e0)); OAK_HIP_CHECK(hipEventCreate(&e1));
+    double total = 0.0;
+    int rc = OAK_OK;
+    for (int r = 0; r < reps + 1 && rc == OAK_OK; ++r) {       // first pass warms up
+        rc = (hipMemcpy2DAsync(dB, sizeof(double) * (size_t)ldb, dB0, sizeof(double) * (size_t)n, sizeof(double) * (size_t)n, (size_t)nrhs,
+                               hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess) ? OAK_OK : OAK_E_HIP;
+        if (rc != OAK_OK) break;
+        (void)hipEventRecord(e0, ctx->stream);
+        rc = trsm_rows(ctx, dL, n, n, dB, nrhs, ldb, trans ? 1 : 0);
+        (void)hipEventRecord(e1, ctx->stream);
+        if (rc != OAK_OK) break;
+        if (hipEventSynchronize(e1) != hipSuccess) { rc = OAK_E_HIP; break; }
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, e0, e1);
+        if (r > 0) total += ms;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (rc != OAK_OK) { if (rc == OAK_E_HIP) set_error("oak_bench_trsm: HIP error"); return rc; }
+    if (ms_out) *ms_out = total / reps;
+    OAK_HIP_CHECK(hipMemcpy2DAsync(B, sizeof(double) * (size_t)n, dB, sizeof(double) * (size_t)ldb, sizeof(double) * (size_t)n, (size_t)nrhs,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return OAK_OK;
+}
+
 int oak_bench_gram_resident(oak_ctx* ctx, const oak_kernel_desc* desc, double* bytes_out) {
     OAK_CHECK(guard(ctx));
     OAK_REQUIRE(ctx->have_data && ctx->have_Z, "set_data and set_inducing must be called first");

@@ -110,6 +110,7 @@ SIGNATURES = {
     "oak_comm_allreduce_host": (C.c_int, [_CTX, _D, C.c_int64]),
     "oak_bench_gram_resident": (C.c_int, [_CTX, _DESC, _D]),
     "oak_bench_potrf": (C.c_int, [_CTX, C.c_int64, C.c_int32, _D, _D]),
+    "oak_bench_trsm": (C.c_int, [_CTX, _D, C.c_int64, _D, C.c_int64, C.c_int32, C.c_int32, _D]),
     "oak_flow_objective": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, _D, _D]),
     "oak_flow_forward": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32, C.c_int32, _I, _D, _D]),
     "oak_kmeans_plusplus": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64, _D, C.c_int32, _D,
@@ -714,6 +715,16 @@ class HipContext:
         ms, ld = C.c_double(), C.c_double()
         _check(self._lib.oak_bench_potrf(self._h, int(n), int(reps), C.byref(ms), C.byref(ld)))
         return ms.value, ld.value
+
+    def bench_trsm(self, L: np.ndarray, B: np.ndarray, trans: bool = False, reps: int = 3):
+        """(X, mean ms): rows of X solve L x = b (or L^T x = b) for the rows b of B -- the library's many-row triangular solve."""
+        L = np.ascontiguousarray(L, dtype=np.float64); X = np.array(B, dtype=np.float64, order="C", copy=True)
+        n = L.shape[0]
+        if L.shape != (n, n) or X.ndim != 2 or X.shape[1] != n:
+            raise ValueError("L must be n x n and B nrhs x n")
+        ms = C.c_double()
+        _check(self._lib.oak_bench_trsm(self._h, _dp(L), n, _dp(X), X.shape[0], int(bool(trans)), int(reps), C.byref(ms)))
+        return X, ms.value
 
 
 _default_ctx: Optional[HipContext] = None

@@ -49,6 +49,29 @@ def test_elbo_alpha_predict_match_oracle(hip, route, N, D, M, R):
     np.testing.assert_allclose(o.oak_K(spec, Xs, Z) @ a, mr[:, 0], rtol=1e-6, atol=ptol * 10)
 
 
+@pytest.mark.parametrize("N,M", [(9000, 300), (8192, 384), (8300, 301), (8200, 640)])
+def test_whitened_route_many_row_solves(hip, N, M):
+    """>= 8192 panel rows take the blocked rows-solve with inverted diagonal blocks (left-looking update GEMM, then the
+    diagonal-block product in place): whole 128-blocks, a ragged last block, odd M (staged product).  Same for the two solves
+    of a large prediction batch."""
+    D, R = 4, 2
+    X, y, Z = o.synthetic_problem(N, D, M, seed=M)
+    spec = o.make_spec(D, R, lengthscales=[1.1, 0.8, 1.4, 0.9], order_variances=[0.7, 1.2, 0.9])
+    d = _capi.KernelDesc(spec)
+    setup(hip, X, y, Z, "whitened")
+    e = hip.sgpr_elbo(d, 0.01)
+    cond = np.linalg.cond(o.oak_K(spec, Z) + 1e-6 * np.eye(M))
+    tol = max(1e-10, 1e-16 * cond)                         # cond ~ 4e8 here: the oracle's own solves carry cond(Kuu) * eps
+    assert rel(e, o.sgpr_elbo(spec, X, y, Z, 0.01)) <= tol, f"cond={cond:.1e}"
+    cases.assert_terms_match(hip.sgpr_last_terms(), o.sgpr_elbo_terms(spec, X, y, Z, 0.01), rtol=tol, what=f"whitened M={M}:")
+    Xs = np.random.default_rng(1).standard_normal((8192 + 77, D))
+    m, v = hip.sgpr_predict(d, Xs)
+    mr, vr = o.sgpr_predict_f(spec, X, y, Z, 0.01, Xs)
+    ptol = max(1e-9, 1e-16 * cond * 100)
+    assert np.abs(m - mr[:, 0]).max() <= ptol * max(1.0, np.abs(mr).max()), f"cond={cond:.1e}"
+    assert np.abs(v - vr[:, 0]).max() <= ptol * max(1.0, np.abs(vr).max()), f"cond={cond:.1e}"
+
+
 def test_whitened_route_on_an_ill_conditioned_problem(hip):
     """cond(Kuu) ~ 1e6: the whitened (GPflow A-route) solve stays at 1e-10, the phi route degrades like cond*eps."""
     X, y, Z = o.synthetic_problem(1000, 3, 50)

@@ -104,7 +104,7 @@ def test_gradient_matches_central_differences_of_the_oracle(hip, link, N, D, M, 
     assert g[2 * D + R + 1] == 0.0                                   # noise slot: no Gaussian likelihood here
 
 
-@pytest.mark.parametrize("N,M", [(9000, 300), (8192, 384)])
+@pytest.mark.parametrize("N,M", [(9000, 300), (8192, 384), (8300, 301)])     # ragged, whole blocks, odd (two-step form)
 def test_large_batch_gradient_directional(hip, N, M):
     """N >= 8192 rows take the blocked (by-inverse, MFMA) forms of both triangular solves and the signed weighted SYRK;
     checked by a central difference of the oracle along one random direction in (q_mu, q_sqrt, lengthscales, variances)."""

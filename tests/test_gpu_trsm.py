@@ -1,0 +1,46 @@
+"""The many-row triangular solve on its own (oak_bench_trsm): GPflow's `tf.linalg.triangular_solve(L, Kuf)` (oak/utils.py:189)
+and the two solves of predict_f.  Checked against extended-precision substitution on sampled rows: the backward error
+(residual) must be a small multiple of eps whatever the conditioning, the forward error a small multiple of eps * cond."""
+import numpy as np
+import pytest
+
+from oak import _capi
+from oracle import oak_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def hip():
+    return _capi.default_context()
+
+
+def _factor(M, D=4):
+    X, y, Z = o.synthetic_problem(9000, D, M, seed=M)
+    spec = o.make_spec(D, 2, lengthscales=list(np.linspace(0.8, 1.5, D)))
+    Kuu = o.oak_K(spec, Z) + 1e-6 * np.eye(M)
+    return spec, X, Z, np.linalg.cholesky(Kuu), np.linalg.cond(Kuu)
+
+
+# n <= 256: substitution leaf; larger with >= 8192 rows: inverted 128-blocks + MFMA GEMMs (whole blocks 384, ragged 300,
+# odd 301 -> staged diagonal product); fewer rows: blocked substitution
+@pytest.mark.parametrize("trans", [False, True])
+@pytest.mark.parametrize("M,nrhs", [(200, 9000), (300, 9000), (301, 8200), (384, 8192), (640, 8300), (384, 500), (300, 3)])
+def test_rows_solve_against_extended_precision(hip, M, nrhs, trans):
+    spec, X, Z, L, cond = _factor(M)
+    rng = np.random.default_rng(M + nrhs)
+    B = o.oak_K(spec, X[:nrhs], Z) if not trans else rng.standard_normal((nrhs, M))
+    Xs, _ = hip.bench_trsm(L, B, trans=trans, reps=1)
+    rows = rng.choice(nrhs, min(nrhs, 48), replace=False)
+    Ll = L.astype(np.longdouble)
+    A = Ll if not trans else Ll.T                      # rows x solve A x = b
+    Bl = B[rows].astype(np.longdouble)
+    ref = np.zeros_like(Bl)
+    order = range(M) if not trans else range(M - 1, -1, -1)
+    for j in order:                                    # substitution in extended precision
+        ref[:, j] = (Bl[:, j] - ref @ A[j, :]) / A[j, j]
+    xs = Xs[rows].astype(np.longdouble)
+    resid = np.abs(xs @ A.T - Bl).max(axis=1) / np.maximum((np.abs(xs) @ np.abs(A.T)).max(axis=1), 1e-300)
+    fwd = np.abs(xs - ref).max(axis=1) / np.abs(ref).max(axis=1)
+    assert float(resid.max()) <= 1e-13, f"residual {float(resid.max()):.2e} (cond {cond:.1e})"
+    assert float(fwd.max()) <= max(1e-13, 1e-16 * np.sqrt(cond) * 1e3), f"forward error {float(fwd.max()):.2e} (cond(L) {np.sqrt(cond):.1e})"
