@@ -1,6 +1,6 @@
 // Multi-GPU exchange: one RCCL reduce-scatter + all-gather (= all-reduce) of the packed SGPR statistics over xGMI.
 // The reference has no distributed code; every N-dependent term of the ELBO is a sum over rows, so
-// each rank reduces its own row shard to [Phi | psi | kappa | yy | n] and only that M^2+M+3 vector is exchanged.
+// each rank reduces its own row shard to [Phi | psi | kappa | yy | n | n_whitened | n_parts] and only that M^2+M+5 vector is exchanged.
 // librccl.so is dlopen'ed on first use so single-GPU runs carry no RCCL dependency.
 #include "oak_internal.h"
 #include <rccl/rccl.h>

@@ -269,37 +269,49 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const double* __restrict
 // when the record is written).  Padding dimensions d >= D are staged as xa = -1, xb = +1 (w clamps to 1, E = 2^-1024).
 // UNITBV: every RBF dimension has base variance exactly 1 (OAK's share_var_across_orders default): woff = 0 and
 // magic = EW_MAGIC are compile-time constants, no per-dimension constant is read at all.
-template <int R, int DMAX, int CPT, bool ALLRBF, bool WANT_GK, bool UNITBV>
-__global__ void __launch_bounds__(256, (DMAX <= 16 ? 2 : 1))      // <= 16 dims: hold the register budget at two waves per SIMD
+// SPLIT = 2 (17..32 dimensions): a pair is shared by two ADJACENT LANES, each walking DMAX = 16 of the DT = 32 staged dimensions
+// with the register footprint of the 16-dimension kernel (two waves per SIMD, no AGPR spill traffic; the 32-registers-per-array
+// form ran one wave per SIMD at 38 instructions per pair-dimension).  The elementary symmetric polynomials of the two halves
+// are exchanged once per pair (R values, adjacent-lane swap) and convolved, e_r = sum_{i+j=r} e_i(A) e_j(B); the leave-one-out
+// identity behind the Horner coefficients holds for the TOTAL polynomials, so from there on each lane runs the unchanged
+// per-dimension code on its own half.  Row features are lane-dependent then (vector loads from the packed rows, L1-resident).
+template <int R, int DMAX, int CPT, bool ALLRBF, bool WANT_GK, bool UNITBV, int SPLIT = 1>
+__global__ void __launch_bounds__(256, (DMAX <= 16 ? 2 : 1))      // <= 16 dims per lane: hold the register budget at two waves per SIMD
 gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
                      const double* __restrict__ Apack, int64_t a0, int64_t na, const double* __restrict__ Bxs,
                      const double* __restrict__ Bcn, const double* __restrict__ Bdcn, int64_t b_ld, int64_t nb,
                      const double* __restrict__ G, int64_t ldg, const double* __restrict__ yA, const double* __restrict__ avec,
                      double g_scale, int rows_per_wg, double* __restrict__ partial) {
-    // Apack: row-major [na][3][DMAX] = (xs32 | cn | dcs) of rows a0.. (pack_rows_kernel; padding dims hold -1, 0, 0).
+    // Apack: row-major [na][3][DT] = (xs32 | cn | dcs) of rows a0.. (pack_rows_kernel; padding dims hold -1, 0, 0).
     // Bxs is the PRE-SCALED array Feat::xs32, Bdcn is Feat::dcs.
-    constexpr int TJ = 64 * CPT, RT = 2, RS = 4 * RT;       // CPT = 2 up to 16 dims, 1 at 32 (LDS: 3 * DMAX * TJ doubles)
+    constexpr int DT = DMAX * SPLIT;                        // staged dimensions
+    constexpr int CW = 64 / SPLIT;                          // columns a wave covers per pass
+    constexpr int TJ = CW * CPT, RT = 2, RS = 4 * RT;       // LDS: 3 * DT * TJ doubles
     constexpr int NGK = WANT_GK ? DMAX : 1;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int D = dd.D;
-    double* Bx = smem;                  // [DMAX][TJ]
-    double* Bc = Bx + DMAX * TJ;
-    double* Bd = Bc + DMAX * TJ;
-    double* Av = Bd + DMAX * TJ;        // [TJ]
+    double* Bx = smem;                  // [DT][TJ]
+    double* Bc = Bx + DT * TJ;
+    double* Bd = Bc + DT * TJ;
+    double* Av = Bd + DT * TJ;          // [TJ]
     double* Tab = Av + TJ;              // [EW_N] biased exp2 table
-    double* Cw = Tab + EW_N;            // [DMAX] woff per dim    (not allocated when UNITBV)
-    double* Cm = Cw + DMAX;             // [DMAX] magic per dim
-    double* accT = UNITBV ? Tab + EW_N : Cm + DMAX;     // [4][tablen]: one copy per wave (deterministic sums, see gram_bwd_kernel)
-    int* meta = reinterpret_cast<int*>(accT + 4 * tablen);   // [2*DMAX] (tab_off, ncat) of the discrete dims: read from LDS
+    double* Cw = Tab + EW_N;            // [DT] woff per dim    (not allocated when UNITBV)
+    double* Cm = Cw + DT;               // [DT] magic per dim
+    double* accT = UNITBV ? Tab + EW_N : Cm + DT;     // [4][tablen]: one copy per wave (deterministic sums, see gram_bwd_kernel)
+    double* Tbl = accT + 4 * tablen;    // [tablen] the discrete dimensions' kernel tables: a pair walks one lane at a time with one
+                                        // wave per SIMD at 32 dims, so a look-up's latency is fully exposed (LDS ~100 cycles, global ~800)
+    int* meta = reinterpret_cast<int*>(Tbl + tablen);        // [2*DT] (tab_off, ncat) of the discrete dims: read from LDS
                                         // inside the rare branch instead of living in ~100 SGPRs (they spilled to VGPR lanes)
-    double* red = Bx;                   // [4][2*DMAX + R + 1], aliases the column features once the row loop is done
+    double* red = Bx;                   // [4][2*DT + R + 1], aliases the column features once the row loop is done
                                         // (54 272 B at DMAX = 16 without discrete tables: three workgroups per CU)
     const int tid = threadIdx.x, tx = tid & 63;
+    const int cl = (SPLIT == 2) ? (tx >> 1) : tx;           // column of the wave's pass this lane works on
+    const int hoff = (SPLIT == 2) ? (tx & 1) * DMAX : 0;    // first staged dimension of this lane's half
     const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t jb = (int64_t)blockIdx.x * TJ;
     const int64_t ib = (int64_t)blockIdx.y * rows_per_wg;
     const int64_t iend = (ib + rows_per_wg < na) ? ib + rows_per_wg : na;
-    for (int idx = tid; idx < DMAX * TJ; idx += 256) {
+    for (int idx = tid; idx < DT * TJ; idx += 256) {
         const int d = idx / TJ, j = idx - d * TJ;
         const int64_t gj = jb + j;
         const bool ok = gj < nb && d < D;
@@ -310,22 +322,24 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
     for (int j = tid; j < TJ; j += 256) Av[j] = (avec != nullptr && jb + j < nb) ? avec[jb + j] : 0.0;
     for (int j = tid; j < EW_N; j += 256) Tab[j] = biased_table_entry(j);
     if constexpr (!UNITBV) {
-        if (tid < DMAX) {
+        if (tid < DT) {
             const bool rbf = tid < D && dd.type[tid] == OAK_DIM_RBF;
             Cw[tid] = rbf ? dd.woff[tid] : 0.0;
             Cm[tid] = rbf ? dd.magic[tid] : EW_MAGIC;
         }
     }
     for (int idx = tid; idx < 4 * tablen; idx += 256) accT[idx] = 0.0;
+    for (int idx = tid; idx < tablen; idx += 256) Tbl[idx] = tables[idx];
     double* accTw = accT + ty * tablen;
     unsigned rbf_mask = 0xffffffffu, cat_mask = 0u;
     if constexpr (!ALLRBF) {
-        if (tid < DMAX) { meta[2 * tid] = tid < D ? dd.tab_off[tid] : 0; meta[2 * tid + 1] = tid < D ? dd.ncat[tid] : 0; }
+        if (tid < DT) { meta[2 * tid] = tid < D ? dd.tab_off[tid] : 0; meta[2 * tid + 1] = tid < D ? dd.ncat[tid] : 0; }
         for (int d = 0; d < D; ++d) {
             if (dd.type[d] != OAK_DIM_RBF) rbf_mask &= ~(1u << d);
             if (dd.type[d] == OAK_DIM_CATEGORICAL) cat_mask |= 1u << d;
         }
     }
+    const unsigned my_rbf = rbf_mask >> hoff, my_cat = cat_mask >> hoff;      // this lane's half (lane-dependent when SPLIT = 2)
     double gl[DMAX], gk[NGK], gw[R + 1];
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) gl[d] = 0.0;
@@ -343,36 +357,43 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
     // The adjoint G of a pair is loaded one pair AHEAD (clamped address, no branch), so its HBM latency hides under the
     // ~400 DP instructions of the pair in flight instead of stalling every pair.
     auto g_addr = [&](int64_t i0n, int prn) -> const double* {
-        const int64_t gin = i0n + ty * RT + prn / CPT, gjn = jb + tx + 64 * (prn % CPT);
+        const int64_t gin = i0n + ty * RT + prn / CPT, gjn = jb + cl + CW * (prn % CPT);
         return G + (gin < iend ? gin : iend - 1) * ldg + (gjn < nb ? gjn : nb - 1);
     };
     double graw_next = ib < iend ? *g_addr(ib, 0) : 0.0;
+    auto fetch = [&](const double* __restrict__ prow, int col, int d0, Chunk& ch) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int d = d0 + v;
+            ch.xa[v] = prow[d]; ch.ca[v] = prow[DT + d]; ch.ad[v] = prow[2 * DT + d];
+            ch.xb[v] = Bx[(d + hoff) * TJ + col]; ch.cb[v] = Bc[(d + hoff) * TJ + col]; ch.bd[v] = Bd[(d + hoff) * TJ + col];
+            if constexpr (!UNITBV) { ch.cw[v] = Cw[d + hoff]; ch.cm[v] = Cm[d + hoff]; }
+        }
+    };
+    auto row_ptr = [&](int64_t i0n, int prn) -> const double* {
+        const int64_t gin = i0n + ty * RT + prn / CPT;
+        return Apack + (gin < iend ? gin : iend - 1) * (3 * DT) + hoff;
+    };
+    // The first four dimensions' features of a pair are fetched while the PREVIOUS pair is in its second phase (polynomial
+    // coefficients, Horner, accumulation: no feature is live there), so a pair does not start on an exposed load.
+    Chunk cur;
+    if (ib < iend) fetch(row_ptr(ib, 0), cl, 0, cur);
     for (int64_t i0 = ib; i0 < iend; i0 += RS) {
 #pragma unroll 1
         for (int pr = 0; pr < RT * CPT; ++pr) {      // one pair at a time: only one set of k[], dk[] is live
             const int r = pr / CPT, c = pr % CPT;
-            const int col = tx + 64 * c;                          // lanes own adjacent columns: conflict-free LDS reads
+            const int col = cl + CW * c;                          // lanes own adjacent columns: conflict-free LDS reads
             const int64_t gi = i0 + ty * RT + r, gj = jb + col;
             const int64_t gr = gi < iend ? gi : iend - 1;         // uniform; rows past the end contribute g = 0
-            const double* __restrict__ prow = Apack + gr * (3 * DMAX);
+            const double* __restrict__ prow = Apack + gr * (3 * DT) + hoff;
             const double yrow = yA != nullptr ? yA[a0 + gr] : 0.0;
             const double g = (gi < iend && gj < nb) ? __builtin_fma(g_scale, graw_next, yrow * Av[col]) : 0.0;
             graw_next = (pr + 1 < RT * CPT) ? *g_addr(i0, pr + 1) : *g_addr(i0 + RS, 0);
             double k[DMAX], dk[DMAX];
-            auto fetch = [&](int d0, Chunk& ch) {
-#pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int d = d0 + v;
-                    ch.xa[v] = prow[d]; ch.ca[v] = prow[DMAX + d]; ch.ad[v] = prow[2 * DMAX + d];
-                    ch.xb[v] = Bx[d * TJ + col]; ch.cb[v] = Bc[d * TJ + col]; ch.bd[v] = Bd[d * TJ + col];
-                    if constexpr (!UNITBV) { ch.cw[v] = Cw[d]; ch.cm[v] = Cm[d]; }
-                }
-            };
-            Chunk cur, nxt;
-            fetch(0, cur);
+            Chunk nxt;
 #pragma unroll
             for (int d0 = 0; d0 < DMAX; d0 += 4) {
-                if (d0 + 4 < DMAX) fetch(d0 + 4, nxt);      // software prefetch of the next 4 dimensions' features
+                if (d0 + 4 < DMAX) fetch(prow, col, d0 + 4, nxt);      // software prefetch of the next 4 dimensions' features
                 asm volatile("" ::: "memory");              // keep later chunks' loads below this point: bounds the live SGPRs
                 double w[4], u2[4], mg[4], E[4];
 #pragma unroll
@@ -391,11 +412,16 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
                     double kv = __builtin_fma(-cur.ca[v], cur.cb[v], E[v]);
                     double dv = __builtin_fma(E[v], u2[v], -__builtin_fma(cur.ad[v], cur.cb[v], cur.ca[v] * cur.bd[v]));
                     if constexpr (!ALLRBF) {
-                        if (!((rbf_mask >> d) & 1u)) { kv = tables[meta[2 * d] + (int)cur.xa[v] * meta[2 * d + 1] + (int)cur.xb[v]]; dv = 0.0; }
+                        if (!((my_rbf >> d) & 1u)) { kv = Tbl[meta[2 * (d + hoff)] + (int)cur.xa[v] * meta[2 * (d + hoff) + 1] + (int)cur.xb[v]]; dv = 0.0; }
                     }
                     k[d] = kv; dk[d] = dv;
                 }
                 if (d0 + 4 < DMAX) cur = nxt;
+            }
+            {   // next pair's first chunk (clamped addresses past the end: loaded, never used)
+                const bool same = pr + 1 < RT * CPT;
+                const int prn = same ? pr + 1 : 0;
+                fetch(row_ptr(same ? i0 : i0 + RS, prn), cl + CW * (prn % CPT), 0, cur);
             }
             double e[R];
 #pragma unroll
@@ -406,9 +432,25 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
                 for (int q = R - 1; q >= 1; --q) e[q] = __builtin_fma(k[d], e[q - 1], e[q]);
                 e[0] += k[d];
             }
-            gw[0] += g;
+            if constexpr (SPLIT == 2) {
+                // e holds this half's polynomials e_1..e_R; the partner lane holds the other half's.  Total: e_r = sum_{i+j=r} e_i e'_j
+                double eo[R], et[R];
 #pragma unroll
-            for (int q = 1; q <= R; ++q) gw[q] = __builtin_fma(g, e[q - 1], gw[q]);
+                for (int q = 0; q < R; ++q) eo[q] = __shfl_xor(e[q], 1, 64);
+#pragma unroll
+                for (int r = 1; r <= R; ++r) {
+                    double t = e[r - 1] + eo[r - 1];
+#pragma unroll
+                    for (int i = 1; i < r; ++i) t = __builtin_fma(e[i - 1], eo[r - i - 1], t);
+                    et[r - 1] = t;
+                }
+#pragma unroll
+                for (int q = 0; q < R; ++q) e[q] = et[q];
+            }
+            const double gq = (SPLIT == 2 && hoff != 0) ? 0.0 : g;      // the order-variance sums count a pair once
+            gw[0] += gq;
+#pragma unroll
+            for (int q = 1; q <= R; ++q) gw[q] = __builtin_fma(gq, e[q - 1], gw[q]);
             // dK/dk_d = sum_q w_{q+1} e_q^{(-d)} with the leave-one-out polynomials e_q^{(-d)} = sum_{i<=q} (-k_d)^i e_{q-i}: a
             // polynomial of degree R-1 in k_d whose coefficients belong to the PAIR.  They are formed once per pair (with g and
             // the signs folded in), leaving R-1 FMAs per dimension (Horner) instead of the 2(R-1)+1 of the recurrence.
@@ -428,33 +470,39 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
                 gl[d] = __builtin_fma(gc, dk[d], gl[d]);
                 if constexpr (WANT_GK) gk[d] = __builtin_fma(gc, k[d], gk[d]);
                 if constexpr (!ALLRBF) {
-                    if (((cat_mask >> d) & 1u) && gc != 0.0)
-                        atomicAdd(&accTw[meta[2 * d] + (int)prow[d] * meta[2 * d + 1] + (int)Bx[d * TJ + col]], gc);
+                    if (((my_cat >> d) & 1u) && gc != 0.0)
+                        atomicAdd(&accTw[meta[2 * (d + hoff)] + (int)prow[d] * meta[2 * (d + hoff) + 1] + (int)Bx[(d + hoff) * TJ + col]], gc);
                 }
             }
         }
     }
     // workgroup reduction of the register accumulators
-    constexpr int NACC = 2 * DMAX + R + 1;
+    constexpr int NACC = 2 * DT + R + 1;
+    auto class_sum = [](double v) {          // over the lanes of this lane's half (all lanes when SPLIT = 1)
+        for (int o = 32; o >= SPLIT; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
 #pragma unroll
-    for (int d = 0; d < DMAX; ++d) gl[d] = wave_sum(gl[d]);
+    for (int d = 0; d < DMAX; ++d) gl[d] = class_sum(gl[d]);
 #pragma unroll
-    for (int d = 0; d < NGK; ++d) gk[d] = wave_sum(gk[d]);
+    for (int d = 0; d < NGK; ++d) gk[d] = class_sum(gk[d]);
 #pragma unroll
-    for (int q = 0; q <= R; ++q) gw[q] = wave_sum(gw[q]);
+    for (int q = 0; q <= R; ++q) gw[q] = class_sum(gw[q]);
     __syncthreads();
-    if (tx == 0) {
+    if (tx < SPLIT) {
 #pragma unroll
-        for (int d = 0; d < DMAX; ++d) { red[ty * NACC + d] = gl[d]; red[ty * NACC + DMAX + d] = WANT_GK ? gk[WANT_GK ? d : 0] : 0.0; }
+        for (int d = 0; d < DMAX; ++d) { red[ty * NACC + hoff + d] = gl[d]; red[ty * NACC + DT + hoff + d] = WANT_GK ? gk[WANT_GK ? d : 0] : 0.0; }
+        if (tx == 0) {
 #pragma unroll
-        for (int q = 0; q <= R; ++q) red[ty * NACC + 2 * DMAX + q] = gw[q];
+            for (int q = 0; q <= R; ++q) red[ty * NACC + 2 * DT + q] = gw[q];
+        }
     }
     __syncthreads();
     const int64_t reclen = 2 * D + (R + 1) + tablen;
     double* rec = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * reclen;
     auto sum4 = [&](int j) { return ((red[j] + red[NACC + j]) + red[2 * NACC + j]) + red[3 * NACC + j]; };
-    for (int d = tid; d < D; d += 256) { rec[d] = sum4(d) * 1024.0; rec[D + d] = sum4(DMAX + d); }
-    if (tid <= R) rec[2 * D + tid] = sum4(2 * DMAX + tid);
+    for (int d = tid; d < D; d += 256) { rec[d] = sum4(d) * 1024.0; rec[D + d] = sum4(DT + d); }
+    if (tid <= R) rec[2 * D + tid] = sum4(2 * DT + tid);
     for (int idx = tid; idx < tablen; idx += 256)
         rec[2 * D + (R + 1) + idx] = ((accT[idx] + accT[tablen + idx]) + accT[2 * tablen + idx]) + accT[3 * tablen + idx];
 }
@@ -819,7 +867,7 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     const int TJ = 64 * cpt, RS = 8;
     bool unitbv = true;
     for (int d = 0; d < D; ++d) unitbv = unitbv && (pk.dd.type[d] != OAK_DIM_RBF || pk.dd.bv[d] == 1.0);
-    const size_t lds = fast ? sizeof(double) * ((size_t)3 * dmax * TJ + TJ + EW_N + (unitbv ? 0 : 2 * dmax) + 4 * tablen + (allrbf ? 0 : dmax))
+    const size_t lds = fast ? sizeof(double) * ((size_t)3 * dmax * TJ + TJ + EW_N + (unitbv ? 0 : 2 * dmax) + 5 * tablen + (allrbf ? 0 : dmax))
                             : sizeof(double) * ((size_t)3 * D * TJ + (size_t)3 * D * RS + RS + TJ + 64 + 8 * D + 4 * tablen + 64);
     OAK_REQUIRE(lds <= 160 * 1024, "gram_bwd: LDS request %zu exceeds 160 KiB", lds);
     const int64_t nb = B.n;
@@ -853,7 +901,7 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     }
 #define OAK_BWD_FAST_K(RR, DM, AR, GK, UB)                                                                                         \
     {                                                                                                                             \
-        auto kern = gram_bwd_fast_kernel<RR, DM, (DM <= 16 ? 2 : 1), AR, GK, UB>;                                                 \
+        auto kern = gram_bwd_fast_kernel<RR, (DM <= 16 ? DM : 16), 2, AR, GK, UB, (DM <= 16 ? 1 : 2)>;                            \
         if (lds > 64 * 1024) OAK_CHECK(ensure_max_dynamic_lds((const void*)kern)); \
         kern<<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen, d_pack, a0, na, B.xs32, B.cn, B.dcs, B.ld, nb, d_G, ldg, \
                                               d_yA, d_avec, g_scale, (int)rows, d_part);                                          \
