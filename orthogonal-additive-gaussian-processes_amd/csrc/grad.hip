@@ -300,13 +300,17 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
     double* accT = UNITBV ? Tab + EW_N : Cm + DT;     // [4][tablen]: one copy per wave (deterministic sums, see gram_bwd_kernel)
     double* Tbl = accT + 4 * tablen;    // [tablen] the discrete dimensions' kernel tables: a pair walks one lane at a time with one
                                         // wave per SIMD at 32 dims, so a look-up's latency is fully exposed (LDS ~100 cycles, global ~800)
-    int* meta = reinterpret_cast<int*>(Tbl + tablen);        // [2*DT] (tab_off, ncat) of the discrete dims: read from LDS
+    int* meta = reinterpret_cast<int*>(Tbl + tablen);        // [DT] tab_off | ncat << 16 of the discrete dims: read from LDS
                                         // inside the rare branch instead of living in ~100 SGPRs (they spilled to VGPR lanes)
     double* red = Bx;                   // [4][2*DT + R + 1], aliases the column features once the row loop is done
                                         // (54 272 B at DMAX = 16 without discrete tables: three workgroups per CU)
     const int tid = threadIdx.x, tx = tid & 63;
     const int cl = (SPLIT == 2) ? (tx >> 1) : tx;           // column of the wave's pass this lane works on
-    const int hoff = (SPLIT == 2) ? (tx & 1) * DMAX : 0;    // first staged dimension of this lane's half
+    const int half = (SPLIT == 2) ? (tx & 1) : 0;           // which of the pair's two lanes this is
+    // lane (half, step d) works on staged dimension SPLIT * d + half: with the usual ordering of a mixed kernel (continuous
+    // columns first) both lanes of a pair then meet the same kind of dimension at most steps, and whole chunks of four steps
+    // are all-RBF or all-discrete -- decided by wave-uniform tests on the dimension mask, not per lane
+#define OAK_SD(d) (SPLIT * (d) + half)
     const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t jb = (int64_t)blockIdx.x * TJ;
     const int64_t ib = (int64_t)blockIdx.y * rows_per_wg;
@@ -333,13 +337,18 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
     double* accTw = accT + ty * tablen;
     unsigned rbf_mask = 0xffffffffu, cat_mask = 0u;
     if constexpr (!ALLRBF) {
-        if (tid < DT) { meta[2 * tid] = tid < D ? dd.tab_off[tid] : 0; meta[2 * tid + 1] = tid < D ? dd.ncat[tid] : 0; }
+        if (tid < DT) meta[tid] = tid < D ? (dd.tab_off[tid] | (dd.ncat[tid] << 16)) : 0;      // tablen <= 1024
         for (int d = 0; d < D; ++d) {
             if (dd.type[d] != OAK_DIM_RBF) rbf_mask &= ~(1u << d);
             if (dd.type[d] == OAK_DIM_CATEGORICAL) cat_mask |= 1u << d;
         }
     }
-    const unsigned my_rbf = rbf_mask >> hoff, my_cat = cat_mask >> hoff;      // this lane's half (lane-dependent when SPLIT = 2)
+    unsigned my_rbf = 0u, my_cat = 0u;          // bit d: this lane's dimension at step d (lane-dependent when SPLIT = 2)
+#pragma unroll
+    for (int d = 0; d < DMAX; ++d) {
+        my_rbf |= ((rbf_mask >> OAK_SD(d)) & 1u) << d;
+        my_cat |= ((cat_mask >> OAK_SD(d)) & 1u) << d;
+    }
     double gl[DMAX], gk[NGK], gw[R + 1];
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) gl[d] = 0.0;
@@ -365,14 +374,14 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int d = d0 + v;
-            ch.xa[v] = prow[d]; ch.ca[v] = prow[DT + d]; ch.ad[v] = prow[2 * DT + d];
-            ch.xb[v] = Bx[(d + hoff) * TJ + col]; ch.cb[v] = Bc[(d + hoff) * TJ + col]; ch.bd[v] = Bd[(d + hoff) * TJ + col];
-            if constexpr (!UNITBV) { ch.cw[v] = Cw[d + hoff]; ch.cm[v] = Cm[d + hoff]; }
+            ch.xa[v] = prow[SPLIT * d]; ch.ca[v] = prow[DT + SPLIT * d]; ch.ad[v] = prow[2 * DT + SPLIT * d];
+            ch.xb[v] = Bx[OAK_SD(d) * TJ + col]; ch.cb[v] = Bc[OAK_SD(d) * TJ + col]; ch.bd[v] = Bd[OAK_SD(d) * TJ + col];
+            if constexpr (!UNITBV) { ch.cw[v] = Cw[OAK_SD(d)]; ch.cm[v] = Cm[OAK_SD(d)]; }
         }
     };
     auto row_ptr = [&](int64_t i0n, int prn) -> const double* {
         const int64_t gin = i0n + ty * RT + prn / CPT;
-        return Apack + (gin < iend ? gin : iend - 1) * (3 * DT) + hoff;
+        return Apack + (gin < iend ? gin : iend - 1) * (3 * DT) + half;
     };
     // The first four dimensions' features of a pair are fetched while the PREVIOUS pair is in its second phase (polynomial
     // coefficients, Horner, accumulation: no feature is live there), so a pair does not start on an exposed load.
@@ -385,7 +394,7 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
             const int col = cl + CW * c;                          // lanes own adjacent columns: conflict-free LDS reads
             const int64_t gi = i0 + ty * RT + r, gj = jb + col;
             const int64_t gr = gi < iend ? gi : iend - 1;         // uniform; rows past the end contribute g = 0
-            const double* __restrict__ prow = Apack + gr * (3 * DT) + hoff;
+            const double* __restrict__ prow = Apack + gr * (3 * DT) + half;
             const double yrow = yA != nullptr ? yA[a0 + gr] : 0.0;
             const double g = (gi < iend && gj < nb) ? __builtin_fma(g_scale, graw_next, yrow * Av[col]) : 0.0;
             graw_next = (pr + 1 < RT * CPT) ? *g_addr(i0, pr + 1) : *g_addr(i0 + RS, 0);
@@ -395,27 +404,44 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
             for (int d0 = 0; d0 < DMAX; d0 += 4) {
                 if (d0 + 4 < DMAX) fetch(prow, col, d0 + 4, nxt);      // software prefetch of the next 4 dimensions' features
                 asm volatile("" ::: "memory");              // keep later chunks' loads below this point: bounds the live SGPRs
-                double w[4], u2[4], mg[4], E[4];
+                // the staged dimensions SPLIT*d0 .. SPLIT*(d0+4)-1 of this chunk: wave-uniform view of their types
+                constexpr unsigned CM = (1u << (4 * SPLIT)) - 1u;
+                const unsigned cbits = ALLRBF ? CM : ((rbf_mask >> (SPLIT * d0)) & CM);
+                double kv4[4] = {0.0, 0.0, 0.0, 0.0}, dv4[4] = {0.0, 0.0, 0.0, 0.0};
+                if (ALLRBF || cbits != 0u) {                // some lane has an RBF dimension here: the exp2 path (all lanes)
+                    double w[4], u2[4], mg[4], E[4];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const double u = cur.xa[v] - cur.xb[v];
-                    if constexpr (UNITBV) {
-                        w[v] = fma_clamp01(u, u, 0.0); u2[v] = w[v]; mg[v] = EW_MAGIC;
-                    } else {
-                        w[v] = fma_clamp01(u, u, cur.cw[v]); u2[v] = w[v] - cur.cw[v]; mg[v] = cur.cm[v];
+                    for (int v = 0; v < 4; ++v) {
+                        const double u = cur.xa[v] - cur.xb[v];
+                        if constexpr (UNITBV) {
+                            w[v] = fma_clamp01(u, u, 0.0); u2[v] = w[v]; mg[v] = EW_MAGIC;
+                        } else {
+                            w[v] = fma_clamp01(u, u, cur.cw[v]); u2[v] = w[v] - cur.cw[v]; mg[v] = cur.cm[v];
+                        }
+                    }
+                    exp2_w_vec<4>(w, mg, E, Tab);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) {
+                        kv4[v] = __builtin_fma(-cur.ca[v], cur.cb[v], E[v]);
+                        dv4[v] = __builtin_fma(E[v], u2[v], -__builtin_fma(cur.ad[v], cur.cb[v], cur.ca[v] * cur.bd[v]));
                     }
                 }
-                exp2_w_vec<4>(w, mg, E, Tab);
+                if constexpr (!ALLRBF) {
+                    if (cbits != CM) {                      // some lane has a discrete dimension here: table value, no lengthscale
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const int d = d0 + v;
-                    double kv = __builtin_fma(-cur.ca[v], cur.cb[v], E[v]);
-                    double dv = __builtin_fma(E[v], u2[v], -__builtin_fma(cur.ad[v], cur.cb[v], cur.ca[v] * cur.bd[v]));
-                    if constexpr (!ALLRBF) {
-                        if (!((my_rbf >> d) & 1u)) { kv = Tbl[meta[2 * (d + hoff)] + (int)cur.xa[v] * meta[2 * (d + hoff) + 1] + (int)cur.xb[v]]; dv = 0.0; }
+                        for (int v = 0; v < 4; ++v) {
+                            const int d = d0 + v;
+                            const bool disc = !((my_rbf >> d) & 1u);
+                            const int mt = meta[OAK_SD(d)];
+                            const int idx = disc ? (mt & 0xffff) + (int)cur.xa[v] * (mt >> 16) + (int)cur.xb[v] : 0;
+                            const double tv = Tbl[idx];
+                            kv4[v] = disc ? tv : kv4[v];
+                            dv4[v] = disc ? 0.0 : dv4[v];
+                        }
                     }
-                    k[d] = kv; dk[d] = dv;
                 }
+#pragma unroll
+                for (int v = 0; v < 4; ++v) { k[d0 + v] = kv4[v]; dk[d0 + v] = dv4[v]; }
                 if (d0 + 4 < DMAX) cur = nxt;
             }
             {   // next pair's first chunk (clamped addresses past the end: loaded, never used)
@@ -447,7 +473,7 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
 #pragma unroll
                 for (int q = 0; q < R; ++q) e[q] = et[q];
             }
-            const double gq = (SPLIT == 2 && hoff != 0) ? 0.0 : g;      // the order-variance sums count a pair once
+            const double gq = (SPLIT == 2 && half != 0) ? 0.0 : g;      // the order-variance sums count a pair once
             gw[0] += gq;
 #pragma unroll
             for (int q = 1; q <= R; ++q) gw[q] = __builtin_fma(gq, e[q - 1], gw[q]);
@@ -470,8 +496,12 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
                 gl[d] = __builtin_fma(gc, dk[d], gl[d]);
                 if constexpr (WANT_GK) gk[d] = __builtin_fma(gc, k[d], gk[d]);
                 if constexpr (!ALLRBF) {
-                    if (((my_cat >> d) & 1u) && gc != 0.0)
-                        atomicAdd(&accTw[meta[2 * (d + hoff)] + (int)prow[d] * meta[2 * (d + hoff) + 1] + (int)Bx[(d + hoff) * TJ + col]], gc);
+                    if ((cat_mask >> (SPLIT * d)) & ((1u << SPLIT) - 1u)) {       // wave-uniform: a categorical dimension at this step
+                        if (((my_cat >> d) & 1u) && gc != 0.0) {
+                            const int mt = meta[OAK_SD(d)];
+                            atomicAdd(&accTw[(mt & 0xffff) + (int)prow[SPLIT * d] * (mt >> 16) + (int)Bx[OAK_SD(d) * TJ + col]], gc);
+                        }
+                    }
                 }
             }
         }
@@ -491,7 +521,7 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
     __syncthreads();
     if (tx < SPLIT) {
 #pragma unroll
-        for (int d = 0; d < DMAX; ++d) { red[ty * NACC + hoff + d] = gl[d]; red[ty * NACC + DT + hoff + d] = WANT_GK ? gk[WANT_GK ? d : 0] : 0.0; }
+        for (int d = 0; d < DMAX; ++d) { red[ty * NACC + OAK_SD(d)] = gl[d]; red[ty * NACC + DT + OAK_SD(d)] = WANT_GK ? gk[WANT_GK ? d : 0] : 0.0; }
         if (tx == 0) {
 #pragma unroll
             for (int q = 0; q <= R; ++q) red[ty * NACC + 2 * DT + q] = gw[q];
@@ -506,6 +536,7 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
     for (int idx = tid; idx < tablen; idx += 256)
         rec[2 * D + (R + 1) + idx] = ((accT[idx] + accT[tablen + idx]) + accT[2 * tablen + idx]) + accT[3 * tablen + idx];
 }
+#undef OAK_SD
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Gradient with respect to the INDUCING INPUTS (create_model_oak(zfixed=False), oak/model_utils.py:156-157; the reference
