@@ -120,6 +120,66 @@ def test_sgpr_gradient_all_kernel_types(hip):
         check(gk[i], fd(lambda h: perturbed(("kappa", i), h)), rtol=1e-4)
 
 
+@pytest.mark.parametrize("D,R,share", [(22, 3, False), (27, 2, True), (32, 4, False)])
+def test_sgpr_gradient_wide_mixed_kernels(hip, D, R, share):
+    """17..32 sub-kernels of mixed type: the backward pair kernel splits the dimensions of a pair over two adjacent lanes
+    (interleaved), with chunks of four steps that are all-RBF, all-discrete or mixed, padding dimensions when D < 32,
+    trainable base variances (share=False) and the categorical-table gradient."""
+    rng = np.random.default_rng(D)
+    N, M = 300, 24
+    # types in an order that produces every kind of chunk: a run of RBF, then alternating, then a discrete tail
+    kinds = ["rbf"] * 9 + ["bin", "rbf", "cat", "rbf", "bin", "rbf"] + ["bin", "cat", "bin", "cat", "bin", "bin", "cat"] + ["rbf"] * 10
+    kinds = kinds[:D]
+    C = 4
+    pc = np.array([0.1, 0.2, 0.3, 0.4])
+    X = rng.standard_normal((N, D))
+    for d, kd in enumerate(kinds):
+        if kd == "bin":
+            X[:, d] = (rng.uniform(size=N) < 0.35).astype(float)
+        elif kd == "cat":
+            X[:, d] = rng.choice(C, size=N, p=pc).astype(float)
+    y = (np.sin(X[:, 0]) + X[:, 9 % D] * 0.5 + 0.1 * rng.standard_normal(N)).reshape(-1, 1)
+    Z = X[:M].copy()
+    spec = o.make_spec(D, R, p0=[0.65 if kd == "bin" else None for kd in kinds], p=[pc if kd == "cat" else None for kd in kinds],
+                       lengthscales=list(rng.uniform(0.9, 1.8, D)), share_var_across_orders=share,
+                       order_variances=list(rng.uniform(0.3, 0.9, R + 1)) if share else [0.6],
+                       base_variances=None if share else list(rng.uniform(0.7, 1.3, D)),
+                       cat_W=[rng.uniform(size=(C, 2)) if kd == "cat" else None for kd in kinds],
+                       cat_kappa=[rng.uniform(0.5, 1.5, C) if kd == "cat" else None for kd in kinds])
+    s2 = 0.1
+    hip.sgpr_set_data(X, y); hip.sgpr_set_inducing(Z); hip.sgpr_set_route("whitened")
+    desc = _capi.KernelDesc(spec)
+    e, g = hip.sgpr_elbo_grad(desc, s2)
+    np.testing.assert_allclose(e, o.sgpr_elbo(spec, X, y, Z, s2), rtol=1e-10)
+    rbf_dims = [d for d, kd in enumerate(kinds) if kd == "rbf"]
+    for d in (rbf_dims[0], rbf_dims[len(rbf_dims) // 2], rbf_dims[-1]):       # lengthscales in the first, a middle and the last chunk
+        def f(h, d=d):
+            s = copy.deepcopy(spec); s["dims"][d]["lengthscale"] += h
+            return o.sgpr_elbo(s, X, y, Z, s2)
+        check(g[d], fd(f), rtol=5e-5)
+    if not share:
+        for d in (0, 9, 11, 16, D - 1):                                        # base variances of RBF, binary and categorical dims
+            def f(h, d=d):
+                s = copy.deepcopy(spec); s["dims"][d]["variance"] += h
+                return o.sgpr_elbo(s, X, y, Z, s2)
+            check(g[D + d], fd(f), rtol=5e-5)
+    nov = R + 1 if share else 1
+    for r in range(nov):
+        def f(h, r=r):
+            s = copy.deepcopy(spec); s["order_variances"][r] += h
+            return o.sgpr_elbo(s, X, y, Z, s2)
+        check(g[2 * D + r], fd(f), rtol=5e-5)
+    cat_d = [d for d, kd in enumerate(kinds) if kd == "cat"][-1]               # a categorical dimension's table -> kappa gradient
+    off, Cc = desc.cat_blocks[cat_d]
+    GB = g[2 * D + nov + 1:][off:off + Cc * Cc].reshape(Cc, Cc)
+    gW, gk = _categorical_chain(spec["dims"][cat_d]["W"], spec["dims"][cat_d]["kappa"], spec["dims"][cat_d]["p"], GB)
+    for i in (0, Cc - 1):
+        def f(h, i=i):
+            s = copy.deepcopy(spec); s["dims"][cat_d]["kappa"] = s["dims"][cat_d]["kappa"].copy(); s["dims"][cat_d]["kappa"][i] += h
+            return o.sgpr_elbo(s, X, y, Z, s2)
+        check(gk[i], fd(f), rtol=1e-4)
+
+
 def test_gpr_gradient(hip):
     X, y, _ = o.synthetic_problem(150, 3, 4, seed=9)
     spec = o.make_spec(3, 2, lengthscales=[0.9, 1.3, 1.1], order_variances=[0.7, 1.2, 0.9])
