@@ -240,9 +240,11 @@ gram_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
 
 // Row-major pack of the backward features of rows a0 .. a0+na-1:  out[i][q][d],  q = (xs32, cn, dcs),  d < DP;
 // padding dimensions d >= D hold (-1, 0, 0) so that against the column-side padding (+1) the pair clamps to E = 2^-1024.
+// split = 2 (the lane-pair form of the fast kernel, DP = 32): lane h of a pair walks dimensions 2*step + h; its features are laid out
+// [h][chunk of four steps][q][step in chunk], so that a chunk's 12 values are contiguous (wide vector loads).
 __global__ void __launch_bounds__(256) pack_rows_kernel(const double* __restrict__ xs32, const double* __restrict__ cn,
                                                         const double* __restrict__ dcs, int64_t ld, int64_t a0, int64_t na, int D,
-                                                        int DP, double* __restrict__ out) {
+                                                        int DP, double* __restrict__ out, int split) {
     __shared__ double tile[96][65];                               // 3 * DP <= 96
     const int64_t i0 = (int64_t)blockIdx.x * 64;
     const int W = 3 * DP;
@@ -257,7 +259,13 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const double* __restrict
     __syncthreads();
     for (int idx = threadIdx.x; idx < W * 64; idx += 256) {       // coalesced over the packed row
         const int r = idx / W, j = idx - r * W;
-        if (i0 + r < na) out[(i0 + r) * W + j] = tile[j][r];
+        int src = j;
+        if (split == 2) {                                         // j = ((h * nch + c) * 3 + q) * 4 + v  <-  tile row q * DP + d
+            const int v = j & 3, q = (j >> 2) % 3, hc = (j >> 2) / 3, nch = DP / 8;
+            const int h = hc / nch, c = hc - h * nch;
+            src = q * DP + 2 * (4 * c + v) + h;
+        }
+        if (i0 + r < na) out[(i0 + r) * W + j] = tile[src][r];
     }
 }
 
@@ -374,14 +382,18 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int d = d0 + v;
-            ch.xa[v] = prow[SPLIT * d]; ch.ca[v] = prow[DT + SPLIT * d]; ch.ad[v] = prow[2 * DT + SPLIT * d];
+            if constexpr (SPLIT == 2) {        // [half][chunk][q][v]: 12 contiguous values per chunk (prow already points at this half)
+                ch.xa[v] = prow[3 * d0 + v]; ch.ca[v] = prow[3 * d0 + 4 + v]; ch.ad[v] = prow[3 * d0 + 8 + v];
+            } else {
+                ch.xa[v] = prow[d]; ch.ca[v] = prow[DT + d]; ch.ad[v] = prow[2 * DT + d];
+            }
             ch.xb[v] = Bx[OAK_SD(d) * TJ + col]; ch.cb[v] = Bc[OAK_SD(d) * TJ + col]; ch.bd[v] = Bd[OAK_SD(d) * TJ + col];
             if constexpr (!UNITBV) { ch.cw[v] = Cw[OAK_SD(d)]; ch.cm[v] = Cm[OAK_SD(d)]; }
         }
     };
     auto row_ptr = [&](int64_t i0n, int prn) -> const double* {
         const int64_t gin = i0n + ty * RT + prn / CPT;
-        return Apack + (gin < iend ? gin : iend - 1) * (3 * DT) + half;
+        return Apack + (gin < iend ? gin : iend - 1) * (3 * DT) + half * (3 * DMAX);
     };
     // The first four dimensions' features of a pair are fetched while the PREVIOUS pair is in its second phase (polynomial
     // coefficients, Horner, accumulation: no feature is live there), so a pair does not start on an exposed load.
@@ -394,7 +406,7 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
             const int col = cl + CW * c;                          // lanes own adjacent columns: conflict-free LDS reads
             const int64_t gi = i0 + ty * RT + r, gj = jb + col;
             const int64_t gr = gi < iend ? gi : iend - 1;         // uniform; rows past the end contribute g = 0
-            const double* __restrict__ prow = Apack + gr * (3 * DT) + half;
+            const double* __restrict__ prow = Apack + gr * (3 * DT) + half * (3 * DMAX);
             const double yrow = yA != nullptr ? yA[a0 + gr] : 0.0;
             const double g = (gi < iend && gj < nb) ? __builtin_fma(g_scale, graw_next, yrow * Av[col]) : 0.0;
             graw_next = (pr + 1 < RT * CPT) ? *g_addr(i0, pr + 1) : *g_addr(i0 + RS, 0);
@@ -499,7 +511,7 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
                     if ((cat_mask >> (SPLIT * d)) & ((1u << SPLIT) - 1u)) {       // wave-uniform: a categorical dimension at this step
                         if (((my_cat >> d) & 1u) && gc != 0.0) {
                             const int mt = meta[OAK_SD(d)];
-                            atomicAdd(&accTw[(mt & 0xffff) + (int)prow[SPLIT * d] * (mt >> 16) + (int)Bx[OAK_SD(d) * TJ + col]], gc);
+                            atomicAdd(&accTw[(mt & 0xffff) + (int)prow[SPLIT == 2 ? 3 * (d & ~3) + (d & 3) : d] * (mt >> 16) + (int)Bx[OAK_SD(d) * TJ + col]], gc);
                         }
                     }
                 }
@@ -920,7 +932,7 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     if (fast) {
         OAK_REQUIRE(A.xs32 != nullptr && B.xs32 != nullptr, "gram_bwd: features were not prepared for the backward pass");
         OAK_CHECK(get_buf_t(ctx, "bwd_pack", (size_t)na * 3 * dmax, &d_pack));
-        pack_rows_kernel<<<(unsigned)((na + 63) / 64), 256, 0, ctx->stream>>>(A.xs32, A.cn, A.dcs, A.ld, a0, na, D, dmax, d_pack);
+        pack_rows_kernel<<<(unsigned)((na + 63) / 64), 256, 0, ctx->stream>>>(A.xs32, A.cn, A.dcs, A.ld, a0, na, D, dmax, d_pack, dmax > 16 ? 2 : 1);
         OAK_HIP_CHECK(hipGetLastError());
     }
 #define OAK_BWD_LAUNCH(RR, CP)                                                                                                   \
@@ -996,7 +1008,7 @@ int gram_bwd_z(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0
     double *d_pack = nullptr, *d_part = nullptr;
     OAK_CHECK(get_buf_t(ctx, "bwd_pack", (size_t)na * 3 * dmax, &d_pack));
     OAK_CHECK(get_buf_t(ctx, "bwdz_part", (size_t)nrb * nb * dmax, &d_part));
-    pack_rows_kernel<<<(unsigned)((na + 63) / 64), 256, 0, ctx->stream>>>(A.xs32, A.cn, A.dcs, A.ld, a0, na, D, dmax, d_pack);
+    pack_rows_kernel<<<(unsigned)((na + 63) / 64), 256, 0, ctx->stream>>>(A.xs32, A.cn, A.dcs, A.ld, a0, na, D, dmax, d_pack, 1);
     OAK_HIP_CHECK(hipGetLastError());
     dim3 grid((unsigned)ncb, (unsigned)nrb);
 #define OAK_BZ_K(RR, DM, AR, UB)                                                                                                  \
