@@ -282,7 +282,8 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const double* __restrict
 // form ran one wave per SIMD at 38 instructions per pair-dimension).  The elementary symmetric polynomials of the two halves
 // are exchanged once per pair (R values, adjacent-lane swap) and convolved, e_r = sum_{i+j=r} e_i(A) e_j(B); the leave-one-out
 // identity behind the Horner coefficients holds for the TOTAL polynomials, so from there on each lane runs the unchanged
-// per-dimension code on its own half.  Row features are lane-dependent then (vector loads from the packed rows, L1-resident).
+// per-dimension code on its own half.  Lane h of a pair takes the staged dimensions 2*step + h.  Row features are lane-dependent
+// then: vector loads (L1-resident) from rows packed [half][chunk of four steps][feature][step] by pack_rows_kernel(split = 2).
 template <int R, int DMAX, int CPT, bool ALLRBF, bool WANT_GK, bool UNITBV, int SPLIT = 1>
 __global__ void __launch_bounds__(256, (DMAX <= 16 ? 2 : 1))      // <= 16 dims per lane: hold the register budget at two waves per SIMD
 gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
@@ -290,7 +291,8 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
                      const double* __restrict__ Bcn, const double* __restrict__ Bdcn, int64_t b_ld, int64_t nb,
                      const double* __restrict__ G, int64_t ldg, const double* __restrict__ yA, const double* __restrict__ avec,
                      double g_scale, int rows_per_wg, double* __restrict__ partial) {
-    // Apack: row-major [na][3][DT] = (xs32 | cn | dcs) of rows a0.. (pack_rows_kernel; padding dims hold -1, 0, 0).
+    // Apack: row-major [na][3][DT] = (xs32 | cn | dcs) of rows a0.. (pack_rows_kernel; padding dims hold -1, 0, 0); SPLIT = 2: the
+    // same 3 * DT values per row in the [half][chunk][feature][step] order.
     // Bxs is the PRE-SCALED array Feat::xs32, Bdcn is Feat::dcs.
     constexpr int DT = DMAX * SPLIT;                        // staged dimensions
     constexpr int CW = 64 / SPLIT;                          // columns a wave covers per pass
