@@ -25,13 +25,112 @@ constexpr int SY_LD = SY_T + 16;   // LDS row stride (doubles): k-group rows lan
 // Work decomposition.  The output is handled in 64 x 64 blocks, four per workgroup (one per wave), drawn from at most four
 // staged 64-column panels Q0..Q3 of the Kuf panel:
 //   * an off-diagonal 128 x 128 tile (bi < bj) is the usual 2 x 2 arrangement: Q = {2bi, 2bi+1, 2bj, 2bj+1};
-//   * the diagonal tiles need only three blocks each -- (2I,2I), (2I,2I+1), (2I+1,2I+1) -- and a square 2 x 2 arrangement
-//     would spend a whole wave on the mirror block.  Their blocks are therefore packed four to a workgroup IN SEQUENCE
-//     (any four consecutive ones touch at most two tiles = four panels): 3*ntile blocks in ceil(3*ntile/4) workgroups
-//     instead of ntile (M = 1024: 34 workgroups per row split instead of 36, -5.6 % MFMA work).
+//   * the diagonal tiles need only three blocks each -- (2I,2I), (2I,2I+1), (2I+1,2I+1) -- and of the two diagonal 64-blocks
+//     only the upper 16 x 16 tiles (10 of 16).  Two diagonal tiles share a workgroup (panels p0..p3): wave w takes the 10 tiles
+//     of the diagonal block of p_w plus HALF of its tile's off-diagonal block (32 rows, 8 tiles) -- 18 MFMAs per k-step from the
+//     same eight LDS fragment reads an off-diagonal wave makes for 16 (syrk_diag_body).  M = 1024: 28 + 4 workgroups per row
+//     split; the older packing (full diagonal blocks, three per tile: 28 + 6, still used by the fp32 variant) did 5.9 % more MFMAs.
 // A descriptor table (built on the host per ntile, syrk_descriptors) gives each workgroup its panels and each wave its
 // two LDS panels and its output block; the inner loop only sees two wave-uniform LDS offsets.
-constexpr int SY_DESC = 16;        // ints per workgroup: c[4], then per wave {ia | ib << 2 | store << 4, row block, col block}
+constexpr int SY_DESC = 16;        // ints per workgroup: c[4], then per wave {ia | ib << 2 | store << 4 | diagonal-pair type << 5, row block, col block}
+
+// Workgroup of two diagonal 128-tiles (panels c[0..3]; see the decomposition above).  Same staging as the off-diagonal body.
+// DK = panel rows per stage of this body: 18 accumulator tiles (144 VGPRs) leave room for 16-row staging registers, not 32.
+template <int SY_KB, int DK>
+__device__ __forceinline__ void syrk_diag_body(const double* __restrict__ P, int64_t ldp, const int* __restrict__ dsc, int64_t r0, int64_t r1,
+                                               double* __restrict__ dst, int64_t Mp, int accumulate, double (&S)[2][SY_KB * SY_LD]) {
+    static_assert(DK <= SY_KB && DK % 4 == 0, "stage depth");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const double* own = S[wave >> 1] + 64 * (wave & 1);
+    const double* oth = S[wave >> 1] + 64 * ((wave & 1) ^ 1);
+    double4_t accD[10], accO[8];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) accD[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 8; ++q) accO[q] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    const int lrow = (2 * tid) >> 7;
+    const int lcol = (2 * tid) & 127;
+    const double* pa = P + (int64_t)dsc[lcol >> 6] * 64 + (lcol & 63);
+    const double* pb = P + (int64_t)dsc[2 + (lcol >> 6)] * 64 + (lcol & 63);
+    constexpr int NQ = DK / 4;
+    double2 ra[NQ], rb[NQ];
+    // raw loads (clamped row index) that stay in flight under the MFMAs of the current stage; rows past the end are zeroed when
+    // the registers are written to LDS, so nothing forces a wait on them earlier
+    int64_t nloaded = r0;
+    auto load_stage = [&](int64_t n0) {
+        nloaded = n0;
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const int64_t row = n0 + lrow + 4 * q;
+            const int64_t rc = row < r1 ? row : r1 - 1;
+            ra[q] = *reinterpret_cast<const double2*>(pa + rc * ldp);
+            rb[q] = *reinterpret_cast<const double2*>(pb + rc * ldp);
+        }
+    };
+    if (r0 < r1) load_stage(r0);
+    const int fr = lane & 15, fk = lane >> 4;
+    // The off-diagonal half-block: rows 16*(g0+g), g < 2, of the tile's EVEN panel against all four column tiles of its ODD panel.
+    // Even wave: rows from its own panel, columns from the other; odd wave: the reverse -- expressed through two wave-uniform
+    // LDS pointers so that both run the same instruction stream (ten fragment reads, 18 MFMAs per k-step).
+    const double* orow = (wave & 1) ? oth + 32 : own;
+    const double* ocol = (wave & 1) ? own : oth;
+    for (int64_t n0 = r0; n0 < r1; n0 += DK) {
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const bool ok = nloaded + lrow + 4 * q < r1;
+            *reinterpret_cast<double2*>(&S[0][(lrow + 4 * q) * SY_LD + lcol]) = make_double2(ok ? ra[q].x : 0.0, ok ? ra[q].y : 0.0);
+            *reinterpret_cast<double2*>(&S[1][(lrow + 4 * q) * SY_LD + lcol]) = make_double2(ok ? rb[q].x : 0.0, ok ? rb[q].y : 0.0);
+        }
+        __syncthreads();
+        load_stage((n0 + DK < r1) ? n0 + DK : r0);
+#pragma unroll
+        for (int kk = 0; kk < DK / 4; ++kk) {
+            double o[4], a[2], b[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) o[g] = own[(4 * kk + fk) * SY_LD + 16 * g + fr];
+#pragma unroll
+            for (int g = 0; g < 2; ++g) a[g] = orow[(4 * kk + fk) * SY_LD + 16 * g + fr];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) b[h] = ocol[(4 * kk + fk) * SY_LD + 16 * h + fr];
+            int q = 0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int h = g; h < 4; ++h, ++q) accD[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(o[g], o[h], accD[q], 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int h = 0; h < 4; ++h) accO[4 * g + h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g], b[h], accO[4 * g + h], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    if (!((dsc[4 + 3 * wave] >> 4) & 1)) return;          // second tile absent (odd tile count): padding waves
+    const int64_t pown = dsc[wave], prow = dsc[wave & 2], pcol = dsc[(wave & 2) + 1];
+    int q = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int h = g; h < 4; ++h, ++q)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                double* e = dst + (pown * 64 + 16 * g + 4 * reg + fk) * Mp + pown * 64 + 16 * h + fr;
+                const double v = accD[q][reg];
+                *e = accumulate ? (*e + v) : v;
+            }
+    const int g0 = 2 * (wave & 1);
+#pragma unroll
+    for (int g = 0; g < 2; ++g)
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                double* e = dst + (prow * 64 + 16 * (g0 + g) + 4 * reg + fk) * Mp + pcol * 64 + 16 * h + fr;
+                const double v = accO[4 * g + h][reg];
+                *e = accumulate ? (*e + v) : v;
+            }
+}
 
 template <int SY_KB>
 __global__ void __launch_bounds__(256, 2)
@@ -56,6 +155,12 @@ syrk_kernel(const double* __restrict__ P, int64_t ldp, int64_t nrows, const int*
         split = blockIdx.x - unit * nsplit;
     }
     const int* dsc = desc + unit * SY_DESC;
+    if ((dsc[4] >> 5) & 1) {            // workgroup-uniform: a pair of diagonal tiles
+        const int64_t q0 = (int64_t)split * rows_per_split;
+        const int64_t q1 = (q0 + rows_per_split < nrows) ? q0 + rows_per_split : nrows;
+        syrk_diag_body<SY_KB, SY_KB>(P, ldp, dsc, q0, q1, part + (int64_t)split * Mp * Mp, Mp, accumulate, S);
+        return;
+    }
     const int wcode = dsc[4 + 3 * wave], wrb = dsc[5 + 3 * wave], wcb = dsc[6 + 3 * wave];
     const int ia = wcode & 3, ib = (wcode >> 2) & 3, wstore = (wcode >> 4) & 1;
     const double* Sa = S[ia >> 1] + 64 * (ia & 1);
@@ -137,9 +242,9 @@ syrk_kernel(const double* __restrict__ P, int64_t ldp, int64_t nrows, const int*
             }
 }
 
-// Fixed-order sum of the split partials.  Only tiles of the upper block triangle were written (of a diagonal tile only
-// its upper 64-blocks); each thread sums one element of such a tile over the splits (coalesced reads) and stores it to
-// (i, j) and, off the diagonal tiles, to its mirror (j, i).
+// Fixed-order sum of the split partials.  Only tiles of the upper block triangle were written (of a diagonal 128-tile only
+// the 16 x 16 tiles on or above the diagonal are relied on); each thread sums one element of such a tile over the splits
+// (coalesced reads) and stores it to (i, j) and, off the diagonal tiles, to its mirror (j, i).
 __global__ void __launch_bounds__(256) syrk_reduce_kernel(const double* __restrict__ part, int nsplit, int64_t M, int64_t Mp,
                                                           int ntile, double* __restrict__ phi, int accumulate) {
     int bi = 0, rem = blockIdx.y;
@@ -148,7 +253,12 @@ __global__ void __launch_bounds__(256) syrk_reduce_kernel(const double* __restri
     const int e = blockIdx.x * 256 + threadIdx.x;          // element within the 128 x 128 tile
     const int64_t i = (int64_t)bi * SY_T + (e >> 7), j = (int64_t)bj * SY_T + (e & 127);
     if (i >= M || j >= M) return;
-    const int64_t src = (bi == bj && (i >> 6) > (j >> 6)) ? j * Mp + i : i * Mp + j;     // lower 64-block of a diagonal tile: mirror
+    // diagonal tile: only the 16 x 16 tiles on or above the diagonal were computed; an element below them is written as the
+    // mirror of (j, i) by the thread that owns that one, so every read of the partials is coalesced
+    const bool diag = bi == bj;
+    if (diag && (i >> 4) > (j >> 4)) return;
+    const bool mirror = !diag || (i >> 4) < (j >> 4);
+    const int64_t src = i * Mp + j;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int sp = 0;
     for (; sp + 4 <= nsplit; sp += 4) {                      // four independent chains, combined in a fixed order
@@ -161,10 +271,10 @@ __global__ void __launch_bounds__(256) syrk_reduce_kernel(const double* __restri
     const double s = (s0 + s1) + (s2 + s3);
     if (accumulate) {
         phi[i * M + j] += s;
-        if (bi != bj) phi[j * M + i] += s;
+        if (mirror) phi[j * M + i] += s;
     } else {
         phi[i * M + j] = s;
-        if (bi != bj) phi[j * M + i] = s;
+        if (mirror) phi[j * M + i] = s;
     }
 }
 
@@ -175,10 +285,12 @@ static bool syrk_xcd_mapping() {
 
 // Number of row splits.  XCD mode: 8*s splits, s per XCD, chosen so that s*npairs workgroups fill the XCD's resident slots
 // in (nearly) whole rounds while every workgroup still streams >= 2048 rows.
-static int syrk_wg_per_split(int ntile) { return ntile * (ntile - 1) / 2 + (3 * ntile + 3) / 4; }
+static int syrk_wg_per_split(int ntile, bool diag_pairs) {
+    return ntile * (ntile - 1) / 2 + (diag_pairs ? (ntile + 1) / 2 : (3 * ntile + 3) / 4);
+}
 
 // Descriptor table of syrk_kernel for ntile 128-tiles (see the kernel's header comment).
-static std::vector<int> syrk_descriptors(int ntile) {
+static std::vector<int> syrk_descriptors(int ntile, bool diag_pairs) {
     std::vector<int> d;
     auto emit = [&](const int (&c)[4], const int (&w)[4][4]) {      // w[k] = {ia, ib, row block, col block} or ia < 0 for padding
         for (int k = 0; k < 4; ++k) d.push_back(c[k]);
@@ -190,12 +302,25 @@ static std::vector<int> syrk_descriptors(int ntile) {
             d.push_back(src[3]);
         }
     };
+    // the diagonal pairs first: they run ~12 % longer than the others, so they should not be the last to start
+    if (diag_pairs) {                                               // two diagonal tiles per workgroup (syrk_diag_body)
+        for (int I = 0; I < ntile; I += 2) {
+            const bool two = I + 1 < ntile;
+            d.push_back(2 * I); d.push_back(2 * I + 1); d.push_back(two ? 2 * I + 2 : 2 * I + 1); d.push_back(two ? 2 * I + 3 : 2 * I + 1);
+            for (int k = 0; k < 4; ++k) {
+                const int store = (k < 2 || two) ? 1 : 0;
+                d.push_back((store << 4) | (1 << 5));
+                d.push_back(0); d.push_back(0);
+            }
+        }
+    }
     for (int bi = 0; bi < ntile; ++bi)
         for (int bj = bi + 1; bj < ntile; ++bj) {
             const int c[4] = {2 * bi, 2 * bi + 1, 2 * bj, 2 * bj + 1};
             const int w[4][4] = {{0, 2, 2 * bi, 2 * bj}, {0, 3, 2 * bi, 2 * bj + 1}, {1, 2, 2 * bi + 1, 2 * bj}, {1, 3, 2 * bi + 1, 2 * bj + 1}};
             emit(c, w);
         }
+    if (diag_pairs) return d;
     std::vector<std::pair<int, int>> blocks;                        // upper 64-blocks of the diagonal tiles, in sequence
     for (int I = 0; I < ntile; ++I) { blocks.push_back({2 * I, 2 * I}); blocks.push_back({2 * I, 2 * I + 1}); blocks.push_back({2 * I + 1, 2 * I + 1}); }
     for (size_t g0 = 0; g0 < blocks.size(); g0 += 4) {
@@ -218,7 +343,7 @@ static std::vector<int> syrk_descriptors(int ntile) {
 
 int syrk_plan_splits(oak_ctx* ctx, int64_t M, int64_t nrows) {
     const int ntile = (int)((M + SY_T - 1) / SY_T);
-    const int npairs = syrk_wg_per_split(ntile);
+    const int npairs = syrk_wg_per_split(ntile, true);
     int per_cu = 2;
     if (const char* e = getenv("OAK_SYRK_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 4) per_cu = v; }
     if (!syrk_xcd_mapping()) {
@@ -228,39 +353,43 @@ int syrk_plan_splits(oak_ctx* ctx, int64_t M, int64_t nrows) {
         return nsplit;
     }
     if (const char* e = getenv("OAK_SYRK_NSPLIT")) { int v = atoi(e); if (v >= 8 && v <= 256 && v % 8 == 0) return v; }   // tuning knob
-    // Cost model fitted to sweeps on MI355X (tools/dev_syrk_sweep.py, profiles/r02_syrk_split_sweeps.txt).  Two workgroups
-    // that share a CU share its one DP pipe, so an XCD retires its s * npairs workgroups in ceil(s * npairs / CUs per XCD)
-    // rounds of one workgroup per CU; a round costs the rows a workgroup streams plus ~120 row-equivalents of prologue /
-    // epilogue, and every split adds one M x M partial to the fixed-order reduction (~100 row-equivalents per 8 splits at
-    // M = 1024).  The old rule (>= 2048 rows per split, fill 2 slots per CU) left C2 at 36 workgroups on 32 CUs: two rounds
-    // at 56 % occupancy, 30 TFLOP/s where 7 splits per XCD reach 50.
+    // Cost model fitted to sweeps on MI355X (tools/dev_syrk_sweep.py, profiles/r02_syrk_split_sweeps.txt, r02_syrk_diagpair_sweeps.txt).
+    // A CU holds two workgroups, which share its one DP pipe: an XCD retires its W = s * npairs workgroups in batches of
+    // 2 * CUs, each batch taking two workgroup lengths (W <= CUs: one length).  A length costs the rows a workgroup streams plus
+    // ~120 row-equivalents of prologue / epilogue; ramp-up, the ragged end and workgroups that started together running in
+    // phase cost another ~1.7 lengths (with 28 + 4 workgroups per split at M = 1024 this term is what separates 8 splits,
+    // 34.6 ms, from 128-256, 17.4 ms); every 8 splits add M x M partials to the fixed-order reduction (~100 row-equivalents
+    // at M <= 1024, growing with M^2).
     (void)per_cu;
     const int cus_per_xcd = ctx->num_cu / 8 > 0 ? ctx->num_cu / 8 : 1;
-    const double red = 100.0 * ((double)ntile * SY_T / 1024.0) * ((double)ntile * SY_T / 1024.0);
+    const double red_m2 = 100.0 * ((double)ntile * SY_T / 1024.0) * ((double)ntile * SY_T / 1024.0);
+    const double red = red_m2 > 100.0 ? red_m2 : 100.0;
     int best_s = 1;
     double best_cost = 0.0;
     const double part_bytes = 8.0 * 8.0 * (double)ntile * SY_T * (double)ntile * SY_T;     // partials of 8 splits
-    for (int sp = 1; sp <= 32; ++sp) {
+    for (int sp = 1; sp <= 16; ++sp) {     // beyond 128 splits the SYRK gains < 1 % (17.69 / 17.65 / 17.51 ms at 128 / 192 / 256) and the reduction pays for it
         const int64_t rps = (nrows + 8 * sp - 1) / (8 * sp);
         if (sp > 1 && (rps < 256 || part_bytes * sp > 4.0 * 1024 * 1024 * 1024)) break;   // <= 4 GiB of partials
-        const int rounds = (sp * npairs + cus_per_xcd - 1) / cus_per_xcd;
-        const double cost = (double)rounds * ((double)rps + 120.0) + red * sp;
+        const int W = sp * npairs;
+        const int rounds = W <= cus_per_xcd ? 1 : 2 * ((W + 2 * cus_per_xcd - 1) / (2 * cus_per_xcd));
+        const double cost = ((double)rounds + 1.7) * (double)rps + 120.0 * rounds + red * sp;
         if (sp == 1 || cost < best_cost) { best_cost = cost; best_s = sp; }
     }
     return 8 * best_s;
 }
 
 // device descriptor table of the SYRK kernels for `ntile` 128-tiles (rebuilt when ntile changes); shared with the fp32 variant
-int syrk_descriptor_table(oak_ctx* ctx, int ntile, int** d_desc_out, int* npairs_out) {
-    const int npairs = syrk_wg_per_split(ntile);
+int syrk_descriptor_table(oak_ctx* ctx, int ntile, int** d_desc_out, int* npairs_out, bool diag_pairs) {
+    const int npairs = syrk_wg_per_split(ntile, diag_pairs);
     int* d_desc = nullptr;
-    OAK_CHECK(get_buf_t(ctx, "syrk_desc", (size_t)npairs * SY_DESC, &d_desc));
-    if (ctx->syrk_desc_ntile != ntile) {
-        const std::vector<int> h = syrk_descriptors(ntile);
+    OAK_CHECK(get_buf_t(ctx, diag_pairs ? "syrk_desc" : "syrk_desc_blocks", (size_t)npairs * SY_DESC, &d_desc));
+    int& cached = diag_pairs ? ctx->syrk_desc_ntile : ctx->syrk_desc_blocks_ntile;
+    if (cached != ntile) {
+        const std::vector<int> h = syrk_descriptors(ntile, diag_pairs);
         OAK_REQUIRE((int)h.size() == npairs * SY_DESC, "syrk: descriptor table size mismatch");
         OAK_HIP_CHECK(hipMemcpyAsync(d_desc, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice, ctx->stream));
         OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-        ctx->syrk_desc_ntile = ntile;
+        cached = ntile;
     }
     *d_desc_out = d_desc; *npairs_out = npairs;
     return OAK_OK;
@@ -272,7 +401,7 @@ int syrk_panel(oak_ctx* ctx, const double* d_panel, int64_t ldp, int64_t nrows, 
     OAK_REQUIRE(ldp == Mp, "syrk: panel stride %lld must equal padded M %lld", (long long)ldp, (long long)Mp);
     int* d_desc = nullptr;
     int npairs = 0;
-    OAK_CHECK(syrk_descriptor_table(ctx, ntile, &d_desc, &npairs));
+    OAK_CHECK(syrk_descriptor_table(ctx, ntile, &d_desc, &npairs, true));
     int kb = SY_KB_DEFAULT;
     if (const char* e = getenv("OAK_SYRK_KB")) { int v = atoi(e); if (v == 8 || v == 16 || v == 32) kb = v; }
     int64_t rps = (nrows + nsplit - 1) / nsplit;

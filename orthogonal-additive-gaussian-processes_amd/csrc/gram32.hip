@@ -348,7 +348,7 @@ int syrk_panel_f32(oak_ctx* ctx, const float* d_panel, int64_t ldp, int64_t nrow
     OAK_REQUIRE(ldp == Mp, "syrk32: panel stride %lld must equal padded M %lld", (long long)ldp, (long long)Mp);
     int* d_desc = nullptr;
     int npairs = 0;
-    OAK_CHECK(syrk_descriptor_table(ctx, ntile, &d_desc, &npairs));
+    OAK_CHECK(syrk_descriptor_table(ctx, ntile, &d_desc, &npairs, false));   // full diagonal 64-blocks (this kernel has no diagonal-pair body)
     int64_t rps = (nrows + nsplit - 1) / nsplit;
     rps = ((rps + S32_KB - 1) / S32_KB) * S32_KB;
     if (rps < S32_KB) rps = S32_KB;

@@ -129,6 +129,7 @@ struct oak_ctx {
     int num_cu = 256;
     int64_t flow_n = 0;              // length of the resident normalising-flow sample "flow_g"
     int syrk_desc_ntile = -1;        // ntile the device descriptor table "syrk_desc" was built for
+    int syrk_desc_blocks_ntile = -1; // same for "syrk_desc_blocks" (the fp32 variant's table: full diagonal 64-blocks)
     bool keep_kfu = false;           // set by the gradient entry points: a whitening forward works on a COPY of the Kfu panel
     bool kfu_kept = false;           // ... and reports here that "panel" still holds the raw Kfu rows of the whole data set
 };
@@ -173,7 +174,7 @@ int gram_diag(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, double* d_o
 int syrk_panel(oak_ctx* ctx, const double* d_panel, int64_t ldp, int64_t nrows, int64_t M, double* d_part,
                int nsplit, bool accumulate);
 int syrk_plan_splits(oak_ctx* ctx, int64_t M, int64_t nrows);
-int syrk_descriptor_table(oak_ctx* ctx, int ntile, int** d_desc_out, int* npairs_out);
+int syrk_descriptor_table(oak_ctx* ctx, int ntile, int** d_desc_out, int* npairs_out, bool diag_pairs);
 // fp32 statistics variant (gram32.hip): fp32 Kfu panel and fp32-MFMA partials, everything downstream fp64
 int gram_f32(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int64_t na, const Feat& B, float* d_out, int64_t ldo,
              const double* d_yA, double* d_psi, int64_t zero_pad_to);
