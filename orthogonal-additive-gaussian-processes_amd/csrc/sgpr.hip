@@ -379,7 +379,6 @@ int sgpr_forward(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, doubl
         ctx->cond_requested = want_cond;
         ctx->cond_seen = want_cond;
         l_state = 2;
-        if (getenv("OAK_SERIAL_CHAIN")) OAK_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev1, 0));   // EXPERIMENT
     }
     int rc = sgpr_local_stats(ctx, pk, jitter);
     ctx->auto_pending = false;
