@@ -85,14 +85,18 @@ def test_whitened_route_on_an_ill_conditioned_problem(hip):
     assert rel(hip.sgpr_elbo(d, 0.01), er) <= 1e-7
 
 
-def test_sufficient_statistics(hip):
-    X, y, Z = o.synthetic_problem(3001, 7, 200)
+# M = 200: two 128-tiles (one diagonal pair, ragged); 100: a single tile (half a pair); 640: five tiles (two pairs + a single);
+# 1100: nine tiles.  panel_rows: the statistics accumulated over several row panels (the SYRK's accumulate path)
+@pytest.mark.parametrize("M,panel_rows", [(200, 0), (100, 0), (640, 0), (1100, 0), (640, 1024)])
+def test_sufficient_statistics(hip, M, panel_rows):
+    X, y, Z = o.synthetic_problem(3001, 7, M)
     spec = o.make_spec(7, 2)
     d = _capi.KernelDesc(spec)
     setup(hip, X, y, Z, "phi")
+    hip.sgpr_set_panel_rows(panel_rows)
     hip.sgpr_local_stats(d)
     st = hip.sgpr_get_stats()
-    M = 200
+    hip.sgpr_set_panel_rows(0)
     kuf = o.oak_K(spec, Z, X)
     Phi = st[:M * M].reshape(M, M)
     np.testing.assert_allclose(Phi, kuf @ kuf.T, rtol=1e-12, atol=1e-9)
