@@ -29,4 +29,6 @@ for g in GS:
         ctx.sgpr_elbo(_capi.KernelDesc(spec), 0.01, 1e-6)
     ctx.sync(); dt = (time.perf_counter() - t0) / K
     ph = {k: round(ctx.timing(k)[0] / K, 3) for k in PH}
-    print(f"g={g} rows={n} wall={dt*1e3:.2f} ms  ideal={33.3/g:.2f}  {ph}")
+    if g == GS[0]:
+        base = dt * g                      # perfect strong scaling measured from the first (largest) shard of this run
+    print(f"g={g} rows={n} wall={dt*1e3:.2f} ms  linear={base*1e3/g:.2f}  {ph}")
