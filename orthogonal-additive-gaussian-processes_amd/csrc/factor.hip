@@ -890,6 +890,11 @@ int trsm_rows(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, double* dB
         // substitution on the vector pipe.  Invert each diagonal block once (substitution against I: exact to the block's
         // own conditioning) and apply it as an MFMA GEMM -- the usual blocked-TRSM formulation of GPU BLAS libraries; the
         // coupling between blocks is still eliminated block by block.
+        // whole column blocks: one launch over all of them (trsm_fused.hip), in place.  (Callers whose panels carry zero-padded
+        // columns up to the next multiple of 128 call trsm_rows_fused themselves.)
+        if (nrhs >= 4096 && n <= 4096 && (n % NB) == 0 && (ldb % 2) == 0 && ((uintptr_t)dBT & 15) == 0 &&
+            getenv("OAK_TRSM_UNFUSED") == nullptr)
+            return trsm_rows_fused(ctx, dL, n, ldl, nullptr, 0, nullptr, dBT, ldb, dBT, ldb, nrhs);
         const bool by_inverse = nrhs >= 8192;   // below this the substitution leaf wins (measured at nrhs = 2048..4096)
         double *dInvT = nullptr, *dInv = nullptr, *dTmp = nullptr;
         const int64_t nfull = n / NB;

@@ -113,6 +113,7 @@ struct oak_ctx {
     int precision = 0;               // 0: fp64 throughout; 1: fp32 Kfu panel + fp32-MFMA Phi partials on the phi route (forward only)
     int auto_whiten = -1;            // decision of the conditioning check for this evaluation (-1: none, use the size rule)
     bool auto_pending = false;       // the check's result (cond_mm) is still in flight on the side stream
+    bool kuu_async = false;          // sgpr_forward started chol(Kuu + jitter I) and L^-1 on the side stream (join on ev1)
     bool cond_requested = false;     // this evaluation's side-stream factorisation also reports cond_mm (auto route / fp32 mode)
     bool cond_seen = false;          // ... and cond_mm holds it for the tail's report (oak_sgpr_last_terms slot 7)
     bool stats_fp32 = false;         // the statistics in "stats" came from the fp32 panel path
@@ -188,6 +189,12 @@ int potrf_check(oak_ctx* ctx, int slot, int64_t n);   // deferred status of a ch
 // rows-trsm: each of the nrhs rows of BT (row stride ldb) is a right-hand side; solves L x = b (trans=0)
 // or L^T x = b (trans=1) in place.
 int trsm_rows(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, double* dBT, int64_t nrhs, int64_t ldb, int trans);
+// The same forward solve for MANY rows as one launch (trsm_fused.hip): out of place allowed (dBin != dXout keeps the right-hand
+// sides), n is padded to a multiple of 128 with the identity, so both panels must have pad128(n) columns (pad columns are
+// copied).  The inverses of the 128 x 128 diagonal blocks come either from a full inverse dLinv (row-major, leading
+// dimension ldinv: its diagonal blocks are those inverses) or from dInvBlocks = compact [n/128][128][128] block inverses.
+int trsm_rows_fused(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, const double* dLinv, int64_t ldinv,
+                    const double* dInvBlocks, const double* dBin, int64_t ldin, double* dXout, int64_t ldout, int64_t nrhs);
 int transpose(oak_ctx* ctx, const double* dA, int64_t rows, int64_t cols, int64_t lda, double* dB, int64_t ldb);
 int add_diag(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, double v);
 int scale_add_eye(oak_ctx* ctx, const double* dW, int64_t n, double s, double* dB, int extra_rows = 0);   // B = I + s*W (+ rows copied as they are)

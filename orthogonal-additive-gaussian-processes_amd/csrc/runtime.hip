@@ -471,11 +471,13 @@ int copy_sync(oak_ctx* ctx, void* dst, const void* src, size_t bytes, hipMemcpyK
 
 int ensure_max_dynamic_lds(const void* kernel) {
     static std::mutex mu;
-    static std::set<const void*> done;
+    static std::set<std::pair<int, const void*>> done;     // the attribute belongs to the current device's copy of the function
     std::lock_guard<std::mutex> lock(mu);
-    if (done.count(kernel)) return OAK_OK;
+    int dev = 0;
+    OAK_HIP_CHECK(hipGetDevice(&dev));
+    if (done.count({dev, kernel})) return OAK_OK;
     OAK_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    done.insert(kernel);
+    done.insert({dev, kernel});
     return OAK_OK;
 }
 }  // namespace oak

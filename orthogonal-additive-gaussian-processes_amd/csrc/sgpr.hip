@@ -142,6 +142,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     // launch (the auto route's pending whitening decision is settled from the same reading).  Under a communicator every rank
     // must have the same mode set: the decision below is a collective.
     bool want32 = ctx->precision == 1 && !ctx->keep_kfu && ctx->cond_requested;
+    const bool want32_asked = want32;
     if (want32) {
         OAK_HIP_CHECK(hipEventSynchronize(ctx->ev2));
         const double ratio = ctx->cond_mm[1] / ctx->cond_mm[0];
@@ -164,10 +165,12 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     const bool use32 = want32 && !whiten;
     float* dPanel32 = nullptr;
     if (use32) OAK_CHECK(get_buf_t(ctx, "panel_f32", (size_t)rows * Mp, &dPanel32));
-    double* dLw = nullptr;
-    if (whiten && ctx->auto_whiten > 0 && ctx->precision == 1 && !ctx->keep_kfu && ctx->cond_requested) {
-        dLw = (double*)peek_buf(ctx, "L");                       // factored on the side stream (joined above)
+    double *dLw = nullptr, *dLinvw = nullptr;      // whitened route: L and (when it exists) the explicit L^-1 whose diagonal blocks the solve applies
+    bool l_joined = false;                          // the main stream already waits for the side stream's factorisation
+    if (whiten && ctx->kuu_async) {
+        if (want32_asked && ctx->auto_whiten > 0) l_joined = true;        // joined above (fp32 mode settled the auto route early)
     } else if (whiten) {
+        // stand-alone statistics (oak_sgpr_local_stats): nobody started the factorisation, do it here
         OAK_CHECK(get_buf_t(ctx, "L", (size_t)2 * M * M, &dLw));   // second half: room for L^-T (chol_with_inverse)
         OAK_CHECK(gram(ctx, pk, FZ, 0, M, FZ, dLw, M, nullptr, nullptr, 0));
         OAK_CHECK(add_diag(ctx, dLw, M, M, jitter));
@@ -195,25 +198,33 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
             }
             ctx->auto_pending = false;
             whiten = ctx->auto_whiten > 0;
-            if (whiten) {
-                // the side stream's L serves: join it.  The solve stays GPflow's literal TRSM: applying the explicit L^-1 as a
-                // GEMM would be twice as fast but measured 6e-10 off on a cond ~1e8 problem -- the case this check exists for.
-                OAK_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev1, 0));
-                dLw = (double*)peek_buf(ctx, "L");
-            }
+        }
+        if (whiten && ctx->kuu_async && dLw == nullptr) {
+            // the side stream's L (and L^-1) serve; joined here, behind the first Gram panel, so that the factorisation chain ran
+            // underneath it.  The solve stays GPflow's literal TRSM: applying the explicit L^-1 as one GEMM would be faster but
+            // measured 6e-10 off on a cond ~1e8 problem -- the case the whitened route exists for.
+            if (!l_joined) OAK_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev1, 0));
+            dLw = (double*)peek_buf(ctx, "L");
+            dLinvw = (double*)peek_buf(ctx, "Linv");
         }
         double* dSy = dPanel;                                            // what the SYRK consumes
         if (whiten) {
             PhaseTimer t(ctx, "trsm");
+            const double* dIn = dPanel;
             if (ctx->keep_kfu && na == N) {
-                // a gradient follows and the whole data set is one panel: whiten a copy (in the buffer the backward pass
-                // fills with its adjoint panel later) so that the backward finds the raw Kfu rows still in place --
-                // a 3.5 ms copy instead of regenerating the 10.5 ms Gram
+                // a gradient follows and the whole data set is one panel: the whitened rows go to the buffer the backward pass
+                // fills with its adjoint panel later, so that the backward finds the raw Kfu rows still in place
                 OAK_CHECK(get_buf_t(ctx, "gpanel", (size_t)rows * Mp, &dSy));
-                OAK_CHECK(copy_d2d(ctx, dSy, dPanel, sizeof(double) * (size_t)na * Mp));
                 ctx->kfu_kept = true;
             }
-            OAK_CHECK(trsm_rows(ctx, dLw, M, M, dSy, na, Mp, 0));        // row n <- L^-1 K(Z, x_n)
+            // row n <- L^-1 K(Z, x_n)
+            if (dLinvw != nullptr && na >= 4096 && Mp <= 4096) {
+                // one launch, out of place where a gradient follows (trsm_fused.hip); M is padded to Mp with the identity
+                OAK_CHECK(trsm_rows_fused(ctx, dLw, M, M, dLinvw, M, nullptr, dIn, Mp, dSy, Mp, na));
+            } else {
+                if (dSy != dIn) OAK_CHECK(copy_d2d(ctx, dSy, dIn, sizeof(double) * (size_t)na * Mp));
+                OAK_CHECK(trsm_rows(ctx, dLw, M, M, dSy, na, Mp, 0));
+            }
             t.stop();
         }
         {
@@ -357,7 +368,7 @@ int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter,
 
 // forward pass shared by oak_sgpr_elbo and oak_sgpr_elbo_grad
 int sgpr_forward(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out) {
-    int l_state = 1;                                    // whitened route: local_stats leaves L in place
+    int l_state = 2;                                    // L = chol(Kuu + jitter I) and L^-1 come from the side stream on every route
     ctx->auto_whiten = -1;
     if (ctx->route == 0 && ctx->comm != nullptr && ctx->nranks > 1 && ctx->n_global_user <= 0 && ctx->n_global_comm <= 0) {
         // auto route under a communicator: the size rule needs the global row count.  One scalar all-reduce, once per
@@ -370,19 +381,22 @@ int sgpr_forward(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, doubl
     ctx->auto_pending = false;
     ctx->cond_requested = false;
     ctx->cond_seen = false;
-    if (auto_big || !sgpr_route_whitened(ctx)) {
+    {
+        // The factorisation depends only on Z and the hyperparameters: it runs on the side stream underneath the first Gram
+        // panel whatever the route (the whitened route joins it before its N-sized solve, the phi route in the tail).
         // auto on a large problem: the side stream also reports min / max of diag L; local_stats decides under its first
-        // Gram panel and, if it whitens, uses the side stream's L.  The fp32 statistics mode asks for the same estimate.
-        const bool want_cond = auto_big || (ctx->precision == 1 && !ctx->keep_kfu);
+        // Gram panel.  The fp32 statistics mode asks for the same estimate.
+        const bool want_cond = auto_big || (ctx->precision == 1 && !ctx->keep_kfu && !sgpr_route_whitened(ctx));
         OAK_CHECK(sgpr_factor_kuu_async(ctx, pk, jitter, want_cond ? ctx->cond_mm : nullptr));
         ctx->auto_pending = auto_big;
         ctx->cond_requested = want_cond;
         ctx->cond_seen = want_cond;
-        l_state = 2;
+        ctx->kuu_async = true;
     }
     int rc = sgpr_local_stats(ctx, pk, jitter);
     ctx->auto_pending = false;
     ctx->cond_requested = false;
+    ctx->kuu_async = false;
     if (rc == OAK_OK && ctx->comm != nullptr) rc = oak_comm_allreduce_stats(ctx);
     if (rc != OAK_OK) { if (l_state == 2) (void)hipStreamSynchronize(ctx->side); ctx->auto_whiten = -1; return rc; }
     rc = sgpr_tail(ctx, pk, noise_var, jitter, elbo_out, terms_out, l_state);
@@ -448,7 +462,7 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
         if (aug) { OAK_CHECK(chol_with_inverse(ctx, dL, M)); OAK_CHECK(potrf_check(ctx, 0, M)); }    // aug implies M % 32 == 0
         else OAK_CHECK(potrf_lower(ctx, dL, M, M));
     }
-    ctx->have_linv = aug && l_state != 1;
+    ctx->have_linv = l_state == 2 || (aug && l_state == 0);      // the side stream always leaves L^-1 / L^-T behind
     // W = L^-1 Phi L^-T  (= sigma^2 * A A^T, utils.py:189-190 without materialising A)
     if (ctx->stats_whitened) {
         OAK_CHECK(copy_d2d(ctx, dT2, st.phi, sizeof(double) * (size_t)M * M));   // statistics already hold W
@@ -964,7 +978,10 @@ int oak_bench_potrf(oak_ctx* ctx, int64_t n, int32_t reps, double* ms_out, doubl
 int oak_bench_trsm(oak_ctx* ctx, const double* L, int64_t n, double* B, int64_t nrhs, int32_t trans, int32_t reps, double* ms_out) {
     OAK_CHECK(guard(ctx));
     OAK_REQUIRE(L != nullptr && B != nullptr && n >= 1 && nrhs >= 1 && reps >= 1, "oak_bench_trsm: bad arguments");
-    const int64_t ldb = (n + 1) & ~(int64_t)1;                 // even row stride, as the panels of the library have
+    // row stride as the panels of the library have it: a multiple of 128 with zero padding (the one-launch solve of many rows
+    // works on whole 128-column blocks), an even stride for the small cases
+    const bool padded = !trans && n > 256 && nrhs >= 4096 && pad128(n) <= 4096;
+    const int64_t ldb = padded ? pad128(n) : ((n + 1) & ~(int64_t)1);
     double *dL = nullptr, *dB0 = nullptr, *dB = nullptr;
     OAK_CHECK(get_buf_t(ctx, "bench_trsm_L", (size_t)n * n, &dL));
     OAK_CHECK(get_buf_t(ctx, "bench_trsm_B0", (size_t)nrhs * n, &dB0));
@@ -976,11 +993,14 @@ int oak_bench_trsm(oak_ctx* ctx, const double* L, int64_t n, double* B, int64_t 
     double total = 0.0;
     int rc = OAK_OK;
     for (int r = 0; r < reps + 1 && rc == OAK_OK; ++r) {       // first pass warms up
+        if (padded && ldb != n) rc = fill_zero(ctx, dB, sizeof(double) * (size_t)nrhs * ldb);
+        if (rc != OAK_OK) break;
         rc = (hipMemcpy2DAsync(dB, sizeof(double) * (size_t)ldb, dB0, sizeof(double) * (size_t)n, sizeof(double) * (size_t)n, (size_t)nrhs,
                                hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess) ? OAK_OK : OAK_E_HIP;
         if (rc != OAK_OK) break;
         (void)hipEventRecord(e0, ctx->stream);
-        rc = trsm_rows(ctx, dL, n, n, dB, nrhs, ldb, trans ? 1 : 0);
+        if (padded && getenv("OAK_TRSM_UNFUSED") == nullptr) rc = trsm_rows_fused(ctx, dL, n, n, nullptr, 0, nullptr, dB, ldb, dB, ldb, nrhs);
+        else rc = trsm_rows(ctx, dL, n, n, dB, nrhs, ldb, trans ? 1 : 0);
         (void)hipEventRecord(e1, ctx->stream);
         if (rc != OAK_OK) break;
         if (hipEventSynchronize(e1) != hipSuccess) { rc = OAK_E_HIP; break; }

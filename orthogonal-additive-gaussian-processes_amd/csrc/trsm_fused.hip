@@ -1,0 +1,288 @@
+// Many-row forward triangular solve  X L^T = B  (row n of X = L^-1 K(Z, x_n): GPflow's  A = triangular_solve(L, Kuf),
+// oak/utils.py:189, and the two solves of predict_f) as ONE launch.
+//
+// A workgroup owns 64 rows of the panel from the first column block to the last (left-looking per row tile: no dependency
+// between workgroups, so no launch boundary per block and no read-modify-write of the block by separate kernels).  For column
+// block j (128 columns) it forms the residual  T = B_j - X_{<j} L_{j,<j}^T  with fp64 MFMAs and multiplies it by the inverse of
+// the 128 x 128 diagonal block -- the arithmetic of the blocked solve this replaces (the residual is cancelled first, only the
+// diagonal block is inverted, so the error stays that of a substitution with 128-wide pivots) -- but T never leaves the
+// registers: the products are formed TRANSPOSED (D = L_block X^T), and the fp64 MFMA's D layout (lane (fi, fk), register v
+// holds D[4v + fk][fi]) is exactly its B-operand layout for four consecutive k, so the residual feeds the diagonal product
+// and the finished block feeds the next block's update without any data movement.
+//
+// The triangular factor reaches the kernel as a PACK: per stage one 128 x 16 tile (16 KiB, the LDS image itself, XOR
+// swizzled for conflict-free ds_read_b64) in the order the kernel consumes them, negated / permuted / inverted by a small
+// builder kernel.  All workgroups stream the same pack (4.7 MB at M = 1024), so it stays in L2.
+// Stage order of block j:  8 tiles against the block finished last (X from registers), 8 (j-1) tiles against the older
+// columns (X re-read from the output, 32 B per lane), 8 tiles of the inverse of the diagonal block (lower triangular:
+// tile h only feeds the output tiles >= h).  MFMA count per 16 rows: M^2/128 + 9 M/8 = 8320 at M = 1024 against the
+// 8192 of an exact triangular count.
+#include "oak_internal.h"
+#include <cstdlib>
+
+namespace oak {
+
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+constexpr int TF_NB = 128;                  // column block
+constexpr int TF_KC = 16;                   // k per stage
+constexpr int TF_ROWS = 64;                 // panel rows per workgroup (16 per wave)
+constexpr int TF_TILE = TF_NB * TF_KC;      // doubles per stage tile
+
+__host__ __device__ inline int64_t tf_stages_before(int64_t j) { return 4 * j * (j + 1); }   // block j has 8 j + 8 stages
+
+// element (r, p) of a stage tile lives at r * 16 + (p ^ tf_swz(r)): the 16 rows of a fragment land on 16 different 8-byte
+// columns, conflict-free both for ds_read_b64 (32 lanes = 16 rows x 2 k over 64 banks) and for the ds_read2_b64 pairs the
+// compiler forms (16 lanes = 16 rows over 32 banks)
+__host__ __device__ inline int tf_swz(int r) { return r & 15; }
+
+// grid (8 * nb, nb): blockIdx.y = column block j, blockIdx.x = stage within the block (those beyond 8 j + 8 exit)
+__global__ void __launch_bounds__(256) trsm_pack_kernel(const double* __restrict__ L, int64_t n, int64_t ldl,
+                                                        const double* __restrict__ Inv, int64_t inv_bs, int64_t inv_ld,
+                                                        double* __restrict__ pack) {
+    const int j = blockIdx.y, t = blockIdx.x;
+    if (t >= 8 * j + 8) return;
+    double* tile = pack + (tf_stages_before(j) + t) * TF_TILE;
+    const int64_t j0 = (int64_t)j * TF_NB;
+    const bool diag = t >= 8 * j;
+    // update stages: first the block finished last (k0 = j0 - 128 ...), then the older columns from 0
+    const int64_t k0 = diag ? j0 + 16 * (t - 8 * j) : (t < 8 ? j0 - TF_NB + 16 * t : 16 * (int64_t)(t - 8));
+    for (int e = threadIdx.x; e < TF_TILE; e += 256) {
+        const int r = e >> 4, pp = e & 15;
+        const int p = pp ^ tf_swz(r);
+        const int kk = p;
+        const int64_t gi = j0 + r, gk = k0 + kk;
+        double v;
+        if (diag) {
+            if (gi < n && gk < n) v = (gk <= gi) ? Inv[(int64_t)j * inv_bs + (int64_t)r * inv_ld + (gk - j0)] : 0.0;
+            else v = (gi == gk) ? 1.0 : 0.0;        // identity padding up to the next multiple of 128
+        } else {
+            v = (gi < n && gk < n) ? -L[gi * ldl + gk] : 0.0;
+        }
+        tile[e] = v;
+    }
+}
+
+// Inverses of the 128 x 128 diagonal blocks of L (identity-padded past n) by forward substitution, one workgroup per block,
+// thread c owning column c of the inverse: x_i = (e_c[i] - sum_{c <= k < i} L_ik x_k) / L_ii.  The column's history lives in
+// LDS ([k][c]: conflict-free), L_ik is wave-uniform (scalar loads).  One launch instead of three per block.
+__global__ void __launch_bounds__(128) trsm_block_inverse_kernel(const double* __restrict__ L, int64_t n, int64_t ldl, double* __restrict__ inv) {
+    extern __shared__ __attribute__((aligned(16))) double xs[];     // [128][128]
+    const int c = threadIdx.x;
+    const int64_t b0 = (int64_t)blockIdx.x * TF_NB;
+    const int kmin = __builtin_amdgcn_readfirstlane(c) & ~63;        // first column of this wave: everything before it is zero
+    double* out = inv + (int64_t)blockIdx.x * TF_NB * TF_NB;
+    for (int i = 0; i < TF_NB; ++i) {
+        const int64_t gi = b0 + i;
+        double x;
+        if (gi < n) {
+            const double* Li = L + gi * ldl + b0;
+            double sum = (i == c) ? 1.0 : 0.0;
+            for (int k = kmin; k < i; ++k) sum = __builtin_fma(-Li[k], xs[k * TF_NB + c], sum);
+            x = (i >= c) ? sum / Li[i] : 0.0;
+        } else {
+            x = (i == c) ? 1.0 : 0.0;
+        }
+        xs[i * TF_NB + c] = x;
+        out[(int64_t)i * TF_NB + c] = x;           // row-major inverse: out[i][c]
+    }
+}
+
+// ---- hand-counted memory pipeline ------------------------------------------------------------------------------------
+// Both streams of a stage go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write pass), two
+// stages ahead, into rings of three slots: the pack tile (16 KiB, shared by the four waves) and the stage's 16 older X
+// columns (8 KiB; each wave fetches and reads only its own 16 rows).  vmcnt retires in order, so ONE counted wait at the
+// end of stage s -- "all but the operations issued during stage s" -- retires exactly what stage s + 1 consumes (issued in
+// stage s - 1) while everything issued in stage s stays in flight across the barrier.  The counts are exact because every
+// lane issues every operation (rows past the end are redirected to a scratch row instead of being masked), and nothing
+// asynchronous targets a register, so the compiler's own bookkeeping stays valid.
+template <int N> __device__ __forceinline__ void tf_wait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+
+constexpr int TF_XT = TF_ROWS * TF_KC;       // doubles per X stage tile
+constexpr int TF_NSLOT = 3;
+
+__global__ void __launch_bounds__(256, 2)
+trsm_fused_kernel(const double* __restrict__ pack, const double* Bin, double* Xout, double* scratch, int64_t nrhs, int64_t ldin,
+                  int64_t ldout, int nb) {
+    __shared__ __attribute__((aligned(16))) double Ls[TF_NSLOT * (TF_TILE + TF_XT)];     // 72 KiB: two workgroups per CU
+    double* const Xs = Ls + TF_NSLOT * TF_TILE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fi = lane & 15, fk = lane >> 4;
+    const int64_t row = (int64_t)blockIdx.x * TF_ROWS + 16 * wave + fi;
+    // B tile / X store: register v <-> column 16 ct + 4 v + fk
+    const double* bin = row < nrhs ? Bin + row * ldin + fk : scratch + fk;
+    double* xst = row < nrhs ? Xout + row * ldout + fk : scratch + fk;
+    // X fetch: lane l of piece i brings 16 bytes of row 8 i + l / 8; the 16-byte chunk it brings is the one that belongs
+    // at its (lane-linear) LDS position under the XOR swizzle  chunk' = chunk ^ ((row >> 1) & 7)
+    const double* xsrc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = 8 * i + (lane >> 3);
+        const int64_t grow = (int64_t)blockIdx.x * TF_ROWS + 16 * wave + r;
+        const int chunk = (lane & 7) ^ ((r >> 1) & 7);
+        xsrc[i] = (grow < nrhs ? Xout + grow * ldout : scratch) + 2 * chunk;
+    }
+    int off[4], xoff[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        off[v] = fi * 16 + ((4 * v + fk) ^ tf_swz(fi));
+        const int k = 4 * v + fk;
+        xoff[v] = wave * 256 + fi * 16 + 2 * ((k >> 1) ^ ((fi >> 1) & 7)) + (k & 1);
+    }
+    const int64_t nst = tf_stages_before(nb);
+    int64_t s = 0;
+    int slot = 0;                                   // s % 3
+    auto slot_of = [&](int ahead) { const int t = slot + ahead; return t >= TF_NSLOT ? t - TF_NSLOT : t; };
+    auto glds_pack = [&](int64_t t, int sl) {      // tile t (clamped) -> slot sl; four 1 KiB pieces per wave
+        const int64_t tc = t < nst ? t : nst - 1;
+        const double* src = pack + tc * TF_TILE + wave * 512 + lane * 2;
+        double* dst = Ls + sl * TF_TILE + wave * 512;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q * 128),
+                                             (__attribute__((address_space(3))) void*)(dst + q * 128), 16, 0, 0);
+    };
+    auto glds_x = [&](int64_t k0, int sl) {         // this wave's 16 rows x 16 columns from k0 -> its part of X slot sl
+        double* dst = Xs + sl * TF_XT + wave * 256;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(dst + i * 128), 16, 0, 0);
+    };
+    auto next_stage = [&]() { __builtin_amdgcn_s_barrier(); ++s; slot = slot_of(1); };
+
+    double4_t bnext[8], xprev[8];
+    glds_pack(0, 0);
+    glds_pack(1, 1);
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        xprev[h] = (double4_t){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int v = 0; v < 4; ++v) bnext[h][v] = bin[16 * h + 4 * v];      // right-hand sides of block 0
+    }
+    tf_wait<0>();
+    __builtin_amdgcn_s_barrier();
+
+    // Operation counts per stage (every stage starts with the 4 pack fetches, which the NEXT stage's end must retire; the
+    // "lazy" operations behind them -- stores, right-hand-side loads, X fetches -- may stay in flight one stage longer,
+    // because vmcnt retires in order and they are younger than the pack fetches of their stage):
+    //   wait at the end of stage s = vmcnt(4 + lazy(s) + lazy(s - 1))
+    //   update from registers, stage h : lazy = 4 stores of the previous block's tile h (+ 2 X fetches for h >= 6)
+    //   update from older columns      : lazy = 2 X fetches
+    //   diagonal product, stage h      : lazy = 8 right-hand-side loads of the next block for h < 4, else none
+    for (int j = 0; j < nb; ++j) {
+        const int64_t j0 = (int64_t)j * TF_NB;
+        // acc starts as B_j (loaded under the previous block's diagonal product); the pack holds -L, so the update stages add
+        double4_t acc[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) acc[h] = bnext[h];
+        if (j > 0) {
+            const int64_t kold = j0 - TF_NB;               // columns [0, kold) are re-read from the output
+            // the block finished last, straight from its registers -- and on its way to memory: tile h is stored under stage h
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                glds_pack(s + 2, slot_of(2));
+#pragma unroll
+                for (int v = 0; v < 4; ++v) xst[kold + 16 * h + 4 * v] = xprev[h][v];
+                if (h >= 6) glds_x((h == 7 && kold > TF_KC) ? TF_KC : 0, slot_of(2));    // X of the first two older-column stages
+                const double* Lt = Ls + slot * TF_TILE;
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int h2 = 0; h2 < 8; ++h2)
+                        acc[h2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[h2 * 256 + off[v]], xprev[h][v], acc[h2], 0, 0, 0);
+                if (h == 0) tf_wait<8>(); else if (h < 6) tf_wait<12>(); else if (h == 6) tf_wait<14>(); else tf_wait<16>();
+                next_stage();
+            }
+            for (int64_t k0 = 0; k0 < kold; k0 += TF_KC) {
+                glds_pack(s + 2, slot_of(2));
+                glds_x(k0 + 2 * TF_KC < kold ? k0 + 2 * TF_KC : kold - TF_KC, slot_of(2));   // (the last two fetch a tile nobody reads)
+                const double* Lt = Ls + slot * TF_TILE;
+                const double* Xt = Xs + slot * TF_XT;
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                    const double xv = Xt[xoff[v]];
+#pragma unroll
+                    for (int h2 = 0; h2 < 8; ++h2)
+                        acc[h2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[h2 * 256 + off[v]], xv, acc[h2], 0, 0, 0);
+                }
+                if (k0 == 0) tf_wait<12>(); else tf_wait<8>();
+                next_stage();
+            }
+        }
+        // acc = residual T = B_j - X_{<j} L_{j,<j}^T;  X_j = T inv(L_jj)^T  (the inverse is lower triangular: stage h feeds the
+        // tiles >= h).  The right-hand sides of the next block are fetched meanwhile (two tiles per stage under the first four
+        // stages; the last block re-reads its own columns and drops them)
+        double4_t out[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) out[h] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        const int64_t jn = (j + 1 < nb) ? j0 + TF_NB : j0;
+#pragma unroll
+        for (int h = 0; h < 8; ++h) {
+            glds_pack(s + 2, slot_of(2));
+            if (h < 4) {
+#pragma unroll
+                for (int t = 2 * h; t < 2 * h + 2; ++t)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) bnext[t][v] = bin[jn + 16 * t + 4 * v];
+            }
+            const double* Lt = Ls + slot * TF_TILE;
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+                for (int ct = h; ct < 8; ++ct)
+                    out[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[ct * 256 + off[v]], acc[h][v], out[ct], 0, 0, 0);
+            if (h == 0) { if (j == 0) tf_wait<12>(); else if (j == 1) tf_wait<18>(); else tf_wait<14>(); }
+            else if (h < 4) tf_wait<20>();
+            else if (h == 4) tf_wait<12>();
+            else tf_wait<4>();
+            next_stage();
+        }
+#pragma unroll
+        for (int h = 0; h < 8; ++h) xprev[h] = out[h];
+    }
+    const int64_t jl = (int64_t)(nb - 1) * TF_NB;
+#pragma unroll
+    for (int h = 0; h < 8; ++h)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) xst[jl + 16 * h + 4 * v] = xprev[h][v];
+}
+
+// dLinv != nullptr: a full row-major inverse of L (leading dimension ldinv; its diagonal blocks ARE the inverses of L's
+// diagonal blocks); else dInvBlocks: compact [nb][128][128] inverses of the diagonal blocks; neither: computed here.
+int trsm_rows_fused(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, const double* dLinv, int64_t ldinv,
+                    const double* dInvBlocks, const double* dBin, int64_t ldin, double* dXout, int64_t ldout, int64_t nrhs) {
+    if (n <= 0 || nrhs <= 0) return OAK_OK;
+    const int64_t npad = ((n + TF_NB - 1) / TF_NB) * TF_NB;
+    OAK_REQUIRE(ldin >= npad && ldout >= npad && (ldin % 2) == 0 && (ldout % 2) == 0 &&
+                    (((uintptr_t)dBin | (uintptr_t)dXout) & 15) == 0,
+                "trsm_rows_fused: the panels need %lld (padded) columns, even row strides and 16-byte alignment", (long long)npad);
+    const int nb = (int)(npad / TF_NB);
+    if (dLinv == nullptr && dInvBlocks == nullptr) {
+        double* dInv = nullptr;
+        OAK_CHECK(get_buf_t(ctx, "trsm_inv", (size_t)nb * TF_NB * TF_NB, &dInv));
+        const size_t lds = sizeof(double) * TF_NB * TF_NB;
+        OAK_CHECK(ensure_max_dynamic_lds((const void*)trsm_block_inverse_kernel));
+        trsm_block_inverse_kernel<<<(unsigned)nb, 128, lds, ctx->stream>>>(dL, n, ldl, dInv);
+        OAK_HIP_CHECK(hipGetLastError());
+        dInvBlocks = dInv;
+    }
+    double* dPack = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "trsm_pack", (size_t)tf_stages_before(nb) * TF_TILE, &dPack));
+    const double* inv = dLinv ? dLinv : dInvBlocks;
+    const int64_t inv_bs = dLinv ? TF_NB * ldinv + TF_NB : (int64_t)TF_NB * TF_NB;
+    const int64_t inv_ld = dLinv ? ldinv : TF_NB;
+    trsm_pack_kernel<<<dim3((unsigned)(8 * nb), (unsigned)nb), 256, 0, ctx->stream>>>(dL, n, ldl, inv, inv_bs, inv_ld, dPack);
+    OAK_HIP_CHECK(hipGetLastError());
+    const unsigned grid = (unsigned)((nrhs + TF_ROWS - 1) / TF_ROWS);
+    double* dScratch = nullptr;                       // where the lanes of rows past the end read and write
+    OAK_CHECK(get_buf_t(ctx, "trsm_scratch_row", (size_t)npad + 64, &dScratch));
+    OAK_CHECK(fill_zero(ctx, dScratch, sizeof(double) * ((size_t)npad + 64)));
+    trsm_fused_kernel<<<grid, 256, 0, ctx->stream>>>(dPack, dBin, dXout, dScratch, nrhs, ldin, ldout, nb);
+    OAK_HIP_CHECK(hipGetLastError());
+    return OAK_OK;
+}
+
+}  // namespace oak
