@@ -137,10 +137,10 @@ int oak_sgpr_local_stats(oak_ctx* ctx, const oak_kernel_desc* desc, double jitte
    then holds W = L^-1 Phi L^-T.  0 = auto: whitened while N*M <= 2^24; above that oak_sgpr_elbo and
    oak_sgpr_elbo_grad whiten only when chol(Kuu) looks ill-conditioned, (max diag L / min diag L)^2 > 1e3,
    which keeps the result within ~1e-10 of the literal route (the stand-alone oak_sgpr_local_stats uses the
-   size rule alone).  Under a communicator N is the row count over ALL ranks (one scalar all-reduce the first time a
-   (data, communicator) pair is evaluated -- collective, so every rank must call oak_sgpr_set_data / oak_comm_init the
-   same number of times -- or whatever oak_sgpr_set_global_rows declared), and the conditioning decision is rank 0's,
-   shared with the other ranks; so all ranks take the same route even when their shards differ in size. */
+   size rule alone).  Under a communicator N is the row count over ALL ranks: what oak_sgpr_set_global_rows declared
+   (either every rank declares it or none does), else one scalar all-reduce on EVERY auto-route evaluation (never a
+   per-rank cache: the sequence of collectives is then the same on all ranks whatever their history); the conditioning
+   decision is rank 0's, shared with the other ranks; so all ranks take the same route even when their shards differ. */
 int oak_sgpr_set_route(oak_ctx* ctx, int32_t route);
 /* Rows over all shards when this ctx holds one shard and the statistics are exchanged outside the library
    (oak_sgpr_get_stats / oak_sgpr_set_stats): the auto route's size rule uses it.  0 = unknown (default). */
@@ -266,9 +266,22 @@ int oak_comm_init(oak_ctx* ctx, const char* id_128, int32_t nranks, int32_t rank
    Runs the whole N > 1 code path on one GPU: the result must equal a single-rank run on the rows stacked nranks times
    (tests/test_gpu_distributed.py). */
 int oak_comm_init_loopback(oak_ctx* ctx, int32_t nranks);
+/* Host-exchange communicator: every sum over ranks the library needs (packed statistics, gradient records, route and
+   precision decisions) is delegated to `fn`, called on a HOST copy of the buffer: it must replace buf[0..n) by the sum over
+   all ranks and return 0, identically on every rank (a socket / MPI / gloo control plane of the host language).  The whole
+   N > 1 path then runs where RCCL cannot: several ranks on one GPU, no xGMI fabric.  oak/distributed.py uses it when the
+   exchange is set to "host". */
+typedef int (*oak_host_allreduce_fn)(double* buf, int64_t n, void* user);
+int oak_comm_init_host(oak_ctx* ctx, int32_t nranks, int32_t rank, oak_host_allreduce_fn fn, void* user);
+/* Which librccl.so was loaded ($ROCM_PATH/lib is preferred: the library that belongs to the header this was compiled
+   against), its ncclGetVersion and the header's NCCL_VERSION_CODE; a major-version mismatch is refused at load time. */
+int oak_comm_info(char* path_out, int64_t cap, int32_t* version_out, int32_t* header_version_out);
 int oak_comm_destroy(oak_ctx* ctx);
 int oak_comm_allreduce_stats(oak_ctx* ctx);                    /* in-place sum of packed stats */
 int oak_comm_allreduce_host(oak_ctx* ctx, double* buf, int64_t n); /* small host vector (gradients) */
+/* All-gather of variable-sized blocks of a host vector: buf has `total` doubles, this rank owns [offset, offset + count),
+   on return every rank holds all blocks (Sobol terms and predictions are sharded with no other exchange). */
+int oak_comm_allgatherv(oak_ctx* ctx, double* buf, int64_t total, int64_t offset, int64_t count);
 
 /* ---- input preprocessing ----------------------------------------------------------------------- */
 /* KL objective of the per-feature normalising flow and its gradient (oak/normalising_flow.py:79-85

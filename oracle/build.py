@@ -34,7 +34,7 @@ def build(force: bool = False) -> Path:
     # -O3 -march=native (vectorised where the op order allows), no -ffast-math: the CPU figure is a fair many-core number and
     # the arithmetic stays the reference's.  Built on the machine it runs on (build() is called again on the GPU box when the
     # shipped .so was built for another CPU: see c_oracle._load).
-    subprocess.run(["gcc", "-O3", "-march=native", "-fopenmp", "-shared", "-fPIC", str(src), "-o", str(OUT), "-lm"], check=True)
+    subprocess.run(["gcc", "-O3", "-march=native", "-fopenmp", "-shared", "-fPIC", str(src), "-o", str(OUT), "-lmvec", "-lm"], check=True)
     sig_file.write_text(sig)
     return OUT
 

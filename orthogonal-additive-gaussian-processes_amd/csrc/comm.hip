@@ -6,6 +6,9 @@
 #include <rccl/rccl.h>
 #include <dlfcn.h>
 #include <mutex>
+#include <cstdlib>
+#include <string>
+#include <vector>
 
 namespace oak {
 
@@ -21,13 +24,22 @@ struct Rccl {
 };
 static Rccl g_rccl;
 
+static std::string g_rccl_path;      // where the loaded librccl.so lives (dladdr on one of its symbols)
+static int g_rccl_version = 0;       // ncclGetVersion of the loaded library
+
 static int load_rccl() {
     static std::mutex mu;                    // contexts on different host threads may race to the first use
     std::lock_guard<std::mutex> lock(mu);
     if (g_rccl.h) return OAK_OK;
-    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    // The header this file compiles against is ROCm's (<rccl/rccl.h> under $ROCM_PATH/include): prefer the library that
+    // belongs to it over whatever librccl.so the loader would find first (PyTorch wheels ship their own copy).
+    std::vector<std::string> names;
+    if (const char* rp = getenv("ROCM_PATH")) names.push_back(std::string(rp) + "/lib/librccl.so");
+    names.push_back("/opt/rocm/lib/librccl.so");
+    names.push_back("librccl.so");
+    names.push_back("librccl.so.1");
     void* h = nullptr;
-    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    for (const auto& n : names) { h = dlopen(n.c_str(), RTLD_NOW | RTLD_GLOBAL); if (h) break; }
     if (!h) { set_error("cannot dlopen librccl.so: %s", dlerror()); return OAK_E_NCCL; }
 #define OAK_SYM(field, sym)                                                                  \
     g_rccl.field = (decltype(g_rccl.field))dlsym(h, sym);                                    \
@@ -40,6 +52,20 @@ static int load_rccl() {
     OAK_SYM(AllReduce, "ncclAllReduce")
     OAK_SYM(GetErrorString, "ncclGetErrorString")
 #undef OAK_SYM
+    auto get_version = (ncclResult_t(*)(int*))dlsym(h, "ncclGetVersion");
+    int v = 0;
+    if (!get_version || get_version(&v) != ncclSuccess) { set_error("librccl.so: ncclGetVersion unavailable"); return OAK_E_NCCL; }
+    // ncclGetVersion encodes major * 10000 + minor * 100 + patch (major * 1000 + ... before 2.9); the ABI of the calls used
+    // here is stable within a major version
+    const int major_loaded = v >= 10000 ? v / 10000 : v / 1000;
+    if (major_loaded != NCCL_MAJOR) {
+        set_error("librccl.so reports version %d (major %d) but liboak_hip was compiled against rccl.h %d.%d.%d", v, major_loaded,
+                  NCCL_MAJOR, NCCL_MINOR, NCCL_PATCH);
+        return OAK_E_NCCL;
+    }
+    Dl_info info;
+    if (dladdr((void*)g_rccl.CommInitRank, &info) && info.dli_fname) g_rccl_path = info.dli_fname;
+    g_rccl_version = v;
     g_rccl.h = h;
     return OAK_OK;
 }
@@ -58,13 +84,28 @@ static int load_rccl() {
 // Test communicator (oak_comm_init_loopback): every "rank" is assumed to hold the same local buffer, so the sum over ranks
 // is nranks * local.  It runs the complete N > 1 code path (scaling of the replicated terms, placement of the reductions)
 // on ONE GPU: a loopback run on data X must equal a single-rank run on X stacked nranks times.
-static char g_loopback_tag;
+static char g_loopback_tag, g_host_tag;
 static inline bool is_loopback(const oak_ctx* ctx) { return ctx->comm == (void*)&g_loopback_tag; }
+// Host-exchange communicator (oak_comm_init_host): the sum over ranks is delegated to a callback of the host language on a
+// host copy of the buffer (a socket / MPI / gloo control plane).  Every collective of the library -- statistics, gradient
+// records, route decisions -- goes through comm_allreduce_dev, so the whole N > 1 path runs unchanged with several ranks
+// sharing one GPU or with no xGMI fabric at all; it is also what the model API falls back to when RCCL cannot be used.
+static inline bool is_host(const oak_ctx* ctx) { return ctx->comm == (void*)&g_host_tag; }
 
 bool comm_is_loopback(const oak_ctx* ctx) { return is_loopback(ctx); }
 
 int comm_allreduce_dev(oak_ctx* ctx, double* d_buf, int64_t n, const char* stage) {
     if (ctx->comm == nullptr || ctx->nranks <= 1 || n <= 0) return OAK_OK;
+    if (is_host(ctx)) {
+        std::vector<double> h((size_t)n);
+        OAK_HIP_CHECK(hipMemcpyAsync(h.data(), d_buf, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        const int rc = ((oak_host_allreduce_fn)ctx->host_allreduce)(h.data(), n, ctx->host_user);
+        if (rc != 0) { set_error("host all-reduce callback failed with status %d", rc); return OAK_E_NCCL; }
+        OAK_HIP_CHECK(hipMemcpyAsync(d_buf, h.data(), sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+        OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));      // h goes out of scope
+        return OAK_OK;
+    }
     const int64_t P = ctx->nranks;
     const int64_t slice = (n + P - 1) / P;
     double* d_stage = nullptr;
@@ -145,9 +186,27 @@ int oak_comm_init_loopback(oak_ctx* ctx, int32_t nranks) {
     return OAK_OK;
 }
 
+int oak_comm_init_host(oak_ctx* ctx, int32_t nranks, int32_t rank, oak_host_allreduce_fn fn, void* user) {
+    if (!ctx || !fn) { set_error("bad argument"); return OAK_E_ARG; }
+    OAK_REQUIRE(nranks >= 1 && rank >= 0 && rank < nranks, "rank %d / nranks %d invalid", rank, nranks);
+    if (ctx->comm) oak_comm_destroy(ctx);
+    ctx->comm = (void*)&g_host_tag; ctx->nranks = nranks; ctx->rank = rank; ctx->n_global_comm = 0;
+    ctx->host_allreduce = (void*)fn; ctx->host_user = user;
+    return OAK_OK;
+}
+
+int oak_comm_info(char* path_out, int64_t cap, int32_t* version_out, int32_t* header_version_out) {
+    OAK_CHECK(load_rccl());
+    if (path_out && cap > 0) { strncpy(path_out, g_rccl_path.c_str(), (size_t)cap - 1); path_out[cap - 1] = 0; }
+    if (version_out) *version_out = g_rccl_version;
+    if (header_version_out) *header_version_out = NCCL_VERSION_CODE;
+    return OAK_OK;
+}
+
 int oak_comm_destroy(oak_ctx* ctx) {
     if (!ctx || !ctx->comm) return OAK_OK;
-    if (!is_loopback(ctx) && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)ctx->comm);
+    if (!is_loopback(ctx) && !is_host(ctx) && g_rccl.CommDestroy) g_rccl.CommDestroy((ncclComm_t)ctx->comm);
+    ctx->host_allreduce = nullptr; ctx->host_user = nullptr;
     ctx->comm = nullptr; ctx->nranks = 1; ctx->rank = 0; ctx->n_global_comm = 0;
     return OAK_OK;
 }
@@ -176,6 +235,16 @@ int oak_comm_allreduce_host(oak_ctx* ctx, double* buf, int64_t n) {
     OAK_HIP_CHECK(hipMemcpyAsync(buf, d, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return OAK_OK;
+}
+
+// All-gather of variable-sized host blocks: buf has `total` doubles, this rank's block sits at [offset, offset + count), the
+// rest is overwritten with the other ranks' blocks (sum of zero-padded copies: every block is owned by exactly one rank).
+int oak_comm_allgatherv(oak_ctx* ctx, double* buf, int64_t total, int64_t offset, int64_t count) {
+    if (!ctx || (!buf && total > 0) || total < 0 || offset < 0 || count < 0 || offset + count > total) { set_error("bad argument"); return OAK_E_ARG; }
+    if (ctx->comm == nullptr || ctx->nranks <= 1 || total == 0) return OAK_OK;
+    for (int64_t i = 0; i < offset; ++i) buf[i] = 0.0;
+    for (int64_t i = offset + count; i < total; ++i) buf[i] = 0.0;
+    return oak_comm_allreduce_host(ctx, buf, total);
 }
 
 }  // extern "C"

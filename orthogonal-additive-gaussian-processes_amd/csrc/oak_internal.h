@@ -125,6 +125,7 @@ struct oak_ctx {
     int64_t gN = 0; int32_t gldx = 0; bool g_have_data = false, g_have_post = false; double g_noise = 0;
     // communicator (RCCL, dlopen'ed)
     void* comm = nullptr; int nranks = 1, rank = 0;
+    void* host_allreduce = nullptr; void* host_user = nullptr;   // host-exchange communicator (oak_comm_init_host)
     int64_t n_global_user = 0;       // rows over ALL shards as told by oak_sgpr_set_global_rows (0: not told)
     int64_t n_global_comm = 0;       // ... as summed over the communicator (0: not yet; reset by set_data / comm init / destroy)
     int num_cu = 256;

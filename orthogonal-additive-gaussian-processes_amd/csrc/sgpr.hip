@@ -176,6 +176,13 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
         OAK_CHECK(add_diag(ctx, dLw, M, M, jitter));
         OAK_CHECK(potrf_lower(ctx, dLw, M, M));
     }
+    if (whiten && ctx->kuu_async && !l_joined) {
+        // Route known up front: the solve needs L before anything else can follow the Gram, and next to the Gram kernel the
+        // latency-bound factorisation chain both runs 4-5x slower and slows the Gram (shared DP pipe: 10.3 vs 9.6 ms at the
+        // headline size) -- let the 0.45 ms chain run first, alone.
+        OAK_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ctx->ev1, 0));
+        l_joined = true;
+    }
     int chunk_idx = 0;
     for (int64_t a0 = 0; a0 < N; a0 += rows, ++chunk_idx) {
         const int64_t na = (a0 + rows <= N) ? rows : N - a0;
@@ -370,9 +377,11 @@ int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter,
 int sgpr_forward(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out) {
     int l_state = 2;                                    // L = chol(Kuu + jitter I) and L^-1 come from the side stream on every route
     ctx->auto_whiten = -1;
-    if (ctx->route == 0 && ctx->comm != nullptr && ctx->nranks > 1 && ctx->n_global_user <= 0 && ctx->n_global_comm <= 0) {
-        // auto route under a communicator: the size rule needs the global row count.  One scalar all-reduce, once per
-        // (data, communicator) pair -- collective, like the evaluation it belongs to.
+    if (ctx->route == 0 && ctx->comm != nullptr && ctx->nranks > 1 && ctx->n_global_user <= 0) {
+        // auto route under a communicator: the size rule needs the global row count.  Ranks that did not declare it
+        // (oak_sgpr_set_global_rows: either every rank does or none) exchange it with one scalar all-reduce on EVERY such
+        // evaluation -- never from a per-rank cache, which a rank that reloaded its shard would not share with its peers, so
+        // that the sequence of collectives is the same on all ranks whatever their history.
         double n = (double)ctx->N;
         OAK_CHECK(comm_allreduce_scalar_side(ctx, &n));
         ctx->n_global_comm = (int64_t)llround(n);
@@ -464,10 +473,12 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     }
     ctx->have_linv = l_state == 2 || (aug && l_state == 0);      // the side stream always leaves L^-1 / L^-T behind
     // W = L^-1 Phi L^-T  (= sigma^2 * A A^T, utils.py:189-190 without materialising A)
+    const bool aug_b = (M % 32) == 0;       // L^-1 psi rides through chol(B) as an extra row (potrf_lower: nrows = M + 1)
     if (ctx->stats_whitened) {
         OAK_CHECK(copy_d2d(ctx, dT2, st.phi, sizeof(double) * (size_t)M * M));   // statistics already hold W
-        OAK_CHECK(copy_d2d(ctx, dv1, st.psi, sizeof(double) * (size_t)M));
-        OAK_CHECK(trsm_rows(ctx, dL, M, M, dv1, 1, M, 0));
+        double* dv = aug_b ? dT2 + M * M : dv1;
+        OAK_CHECK(copy_d2d(ctx, dv, st.psi, sizeof(double) * (size_t)M));
+        OAK_CHECK(trsm_rows(ctx, dL, M, M, dv, 1, M, 0));
     } else if (aug) {
         // S = L^-1 Phi (rows 0..M-1 of T1; Phi is symmetric, so gemm_nt against it is the plain product), row M = psi^T;
         // [W ; (L^-1 psi)^T] = T1 L^-T in one (M+1) x M x M GEMM
@@ -487,7 +498,7 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     }
     // B = I + W / sigma^2 ; LB = chol(B)   (utils.py:190-193);  c = LB^-1 L^-1 psi / sigma^2   (utils.py:194-195:
     // Aerr = L^-1 psi / sigma, c = LB^-1 Aerr / sigma).  Status is read with the scalars below: one host sync per tail.
-    if (aug) {
+    if (aug || (ctx->stats_whitened && aug_b)) {
         // row M of the (M+1) x M arrays = (L^-1 psi)^T, carried over unscaled: the panel solves turn it into (LB^-1 L^-1 psi)^T
         OAK_CHECK(scale_add_eye(ctx, dT2, M, 1.0 / noise_var, dLB, 1));
         OAK_CHECK(potrf_lower(ctx, dLB, M, M, false, M + 1));

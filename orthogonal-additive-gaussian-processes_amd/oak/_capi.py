@@ -49,6 +49,7 @@ class KernelDescStruct(C.Structure):
 _D = C.POINTER(C.c_double)
 _I = C.POINTER(C.c_int32)
 _CTX = C.c_void_p
+_HOST_ALLREDUCE = C.CFUNCTYPE(C.c_int, C.POINTER(C.c_double), C.c_int64, C.c_void_p)   # oak_host_allreduce_fn
 _DESC = C.POINTER(KernelDescStruct)
 
 # name -> (restype, argtypes); every symbol include/oak_hip.h declares
@@ -108,6 +109,9 @@ SIGNATURES = {
     "oak_comm_init_loopback": (C.c_int, [_CTX, C.c_int32]),
     "oak_comm_allreduce_stats": (C.c_int, [_CTX]),
     "oak_comm_allreduce_host": (C.c_int, [_CTX, _D, C.c_int64]),
+    "oak_comm_init_host": (C.c_int, [_CTX, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "oak_comm_info": (C.c_int, [C.c_char_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "oak_comm_allgatherv": (C.c_int, [_CTX, _D, C.c_int64, C.c_int64, C.c_int64]),
     "oak_bench_gram_resident": (C.c_int, [_CTX, _DESC, _D]),
     "oak_bench_potrf": (C.c_int, [_CTX, C.c_int64, C.c_int32, _D, _D]),
     "oak_bench_trsm": (C.c_int, [_CTX, _D, C.c_int64, _D, C.c_int64, C.c_int32, C.c_int32, _D]),
@@ -630,13 +634,54 @@ class HipContext:
 
     def comm_init(self, unique_id: bytes, nranks: int, rank: int):
         _check(self._lib.oak_comm_init(self._h, unique_id, int(nranks), int(rank)))
+        self._comm_rank = int(rank)
 
     def comm_init_loopback(self, nranks: int):
         """Test communicator: `nranks` identical ranks (every all-reduce multiplies by nranks)."""
         _check(self._lib.oak_comm_init_loopback(self._h, int(nranks)))
 
+    def comm_init_host(self, nranks: int, rank: int, allreduce):
+        """Host-exchange communicator: ``allreduce(a)`` must return the sum over all ranks of the 1-D float64 array ``a``
+        (same result on every rank).  Every collective of the library then goes through it on a host copy of the buffer."""
+        def _cb(buf, n, _user):
+            try:
+                a = np.ctypeslib.as_array(buf, shape=(int(n),))
+                a[:] = np.asarray(allreduce(a.copy()), dtype=np.float64).reshape(-1)
+                return 0
+            except Exception as ex:                                     # noqa: BLE001  (must not propagate into C)
+                self._host_comm_error = ex
+                return 1
+        self._host_cb = _HOST_ALLREDUCE(_cb)                            # keep the trampoline alive as long as the context
+        _check(self._lib.oak_comm_init_host(self._h, int(nranks), int(rank), C.cast(self._host_cb, C.c_void_p), None))
+        self._comm_rank = int(rank)
+
+    @staticmethod
+    def comm_info() -> dict:
+        """Path and version of the librccl.so the library loaded, and the version of the header it was compiled against."""
+        path = C.create_string_buffer(1024)
+        v, hv = C.c_int32(), C.c_int32()
+        _check(load_library().oak_comm_info(path, 1024, C.byref(v), C.byref(hv)))
+        return {"path": path.value.decode(), "version": int(v.value), "header_version": int(hv.value)}
+
+    def comm_allgatherv(self, local: np.ndarray, counts) -> np.ndarray:
+        """Concatenation, in rank order, of every rank's 1-D block (``counts[r]`` doubles from rank r)."""
+        local = _f64(np.asarray(local).reshape(-1), 1)
+        counts = [int(c) for c in counts]
+        rank = self.comm_rank()
+        if local.size != counts[rank]:
+            raise ValueError("comm_allgatherv: the local block does not have the length this rank announced")
+        total, off = sum(counts), sum(counts[:rank])
+        buf = np.zeros(total)
+        buf[off:off + local.size] = local
+        _check(self._lib.oak_comm_allgatherv(self._h, _dp(buf), total, off, local.size))
+        return buf
+
+    def comm_rank(self) -> int:
+        return getattr(self, "_comm_rank", 0)
+
     def comm_destroy(self):
         _check(self._lib.oak_comm_destroy(self._h))
+        self._host_cb = None
 
     def comm_allreduce_stats(self):
         _check(self._lib.oak_comm_allreduce_stats(self._h))

@@ -309,6 +309,26 @@ def _ctx():
     return _capi.default_context()
 
 
+def _active_communicator():
+    """The job's communicator when this process is one rank of several (oak.distributed.init_from_env), else None."""
+    from . import distributed
+    comm = distributed.current()
+    return comm if (comm is not None and comm.active) else None
+
+
+def _shard_rows(comm, hip, X, Y):
+    """This rank's contiguous row block of (X, Y) and the bookkeeping that goes with it: the context joins the communicator
+    (collective) and learns the row count of the whole problem (what the auto route's size rule looks at)."""
+    if comm is None:
+        return X, Y
+    lo, hi = comm.bounds(len(X))
+    if getattr(hip, "_oak_comm_attached", None) is not comm:
+        comm.attach(hip)
+        hip._oak_comm_attached = comm
+    hip.sgpr_set_global_rows(len(X))
+    return X[lo:hi], Y[lo:hi]
+
+
 class RBF(Kernel):
     """gpflow.kernels.RBF (SquaredExponential, isotropic lengthscale): variance * exp(-|x - z|^2 / (2 l^2))."""
 
@@ -442,6 +462,7 @@ class GPModel(Module):
         self.kernel = kernel
         self.likelihood = Gaussian(noise_variance)
         self._hip = _capi.HipContext(_capi.default_context().device)   # own device state (data stay resident)
+        self._comm = _active_communicator()                            # row sharding (oak/distributed.py); None: single process
 
     def mean_function(self, X):
         return np.zeros((np.asarray(X).shape[0], 1))
@@ -540,12 +561,18 @@ class GPR(GPModel):
 class SGPR(GPModel):
     """gpflow.models.SGPR (constructed at oak/model_utils.py:149-157): collapsed Titsias bound."""
 
+    SHARDED_PREDICT_MIN_ROWS = 4096      # per rank: below it a replicated prediction is cheaper than the gather
+
     def __init__(self, data, kernel, inducing_variable, mean_function=None, noise_variance=1.0, num_latent_gps=None):
         super().__init__(data, kernel, mean_function, noise_variance)
         if not isinstance(inducing_variable, InducingPoints):
             inducing_variable = InducingPoints(inducing_variable)
         self.inducing_variable = inducing_variable
-        self._hip.sgpr_set_data(self.data[0], self.data[1])
+        # under a communicator every rank is handed the same (X, Y) and keeps its contiguous row block on the device: the
+        # statistics and the gradient record are summed over the ranks inside the library, the O(M^3) tail is replicated, so
+        # objective and gradient are bit-identical on all ranks and an optimiser simply runs replicated (SURVEY 8e)
+        Xl, Yl = _shard_rows(self._comm, self._hip, self.data[0], self.data[1])
+        self._hip.sgpr_set_data(Xl, Yl)
         self._z_sent = None
         self.route = "auto"
 
@@ -569,7 +596,13 @@ class SGPR(GPModel):
         self._sync_Z()
         desc = self._desc()
         self._hip.sgpr_elbo(desc, float(self.likelihood.variance.numpy()), default_jitter())
-        mean, var = self._hip.sgpr_predict(desc, np.asarray(Xnew, dtype=np.float64))
+        Xnew = np.asarray(Xnew, dtype=np.float64)
+        if self._comm is not None and len(Xnew) >= self.SHARDED_PREDICT_MIN_ROWS * self._comm.world:
+            # test rows are independent: each rank predicts its block from the replicated posterior, one gather
+            from . import distributed
+            mean, var = distributed.sharded_predict(self._hip, desc, Xnew, self._comm.rank, self._comm.world, comm=self._comm)
+        else:
+            mean, var = self._hip.sgpr_predict(desc, Xnew)
         return TensorLike(mean[:, None]), TensorLike(var[:, None])
 
     def alpha(self):
@@ -639,6 +672,7 @@ class SVGP(Module):
                                 transform=positive())
         self.data = None                 # the example assigns ``model.data`` before asking for Sobol indices (:150)
         self._hip = _capi.HipContext(_capi.default_context().device)
+        self._comm = _active_communicator()
         self._z_sent = self._data_sent = self._data_obj = None
 
     # -- device state -----------------------------------------------------------------------------
@@ -665,7 +699,8 @@ class SVGP(Module):
             raise NotImplementedError("the HIP path supports a single output column")
         key = self._data_sent
         if key is None or key[0].shape != X.shape or not (np.array_equal(key[0], X) and np.array_equal(key[1], Y)):
-            self._hip.sgpr_set_data(X, Y)
+            Xl, Yl = _shard_rows(self._comm, self._hip, X, Y)           # row block of this rank under a communicator
+            self._hip.sgpr_set_data(Xl, Yl)
             self._data_sent = (X.copy(), Y.copy())
             if self._z_sent is not None and self._z_sent.shape[1] != X.shape[1]:
                 self._z_sent = None          # the library drops inducing inputs of another column count

@@ -115,8 +115,15 @@ def compute_sobol_oak(model, delta: float, mu: float, share_var_across_orders: O
     Xc = model.inducing_variable.Z.numpy() if isinstance(model, (gpflow.SGPR, gpflow.SVGP)) else model.data[0]
     alpha = get_model_sufficient_statistics(model, get_L=False)
     desc = _capi.KernelDesc(kernel_to_spec(model.kernel))
-    sobol = _capi.default_context().sobol(desc, Xc, np.asarray(alpha).reshape(-1), subsets,
-                                          use_order_var=bool(share_var_across_orders), delta=delta, mu=mu)
+    comm = getattr(model, "_comm", None)
+    if comm is not None and len(subsets) >= 8 * comm.world:
+        # the terms are independent: each rank evaluates a contiguous block of them, one gather of the scalars
+        from . import distributed
+        sobol = distributed.sharded_sobol(model._hip, desc, Xc, np.asarray(alpha).reshape(-1), subsets, comm.rank, comm.world,
+                                          comm=comm, use_order_var=bool(share_var_across_orders), delta=delta, mu=mu)
+    else:
+        sobol = _capi.default_context().sobol(desc, Xc, np.asarray(alpha).reshape(-1), subsets,
+                                              use_order_var=bool(share_var_across_orders), delta=delta, mu=mu)
     assert len(subsets) == len(sobol)
     return subsets, [float(s) for s in sobol]
 

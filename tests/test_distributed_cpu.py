@@ -13,6 +13,22 @@ import torch.multiprocessing as mp
 ROOT = Path(__file__).resolve().parent.parent
 
 
+def _gloo_allreduce(packed):
+    """Sum over the default torch.distributed group (gloo): the CPU stand-in for the RCCL exchange in this suite."""
+    import torch
+    import torch.distributed as dist
+    t = torch.from_numpy(np.ascontiguousarray(packed, dtype=np.float64))
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.numpy()
+
+
+def _gloo_allgather(local):
+    import torch.distributed as dist
+    parts = [None] * dist.get_world_size()
+    dist.all_gather_object(parts, np.ascontiguousarray(local, dtype=np.float64))
+    return parts
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -49,12 +65,12 @@ def _worker(rank, world, port, out_dir, uneven=False):
     if uneven:                                   # user-chosen shards of very different sizes: 101 rows | the rest
         lo, hi = (0, 101) if rank == 0 else (101, len(X))
     local = D.pack_stats(*_oracle_local_stats(o, spec, X[lo:hi], y[lo:hi], Z))
-    total = D.torch_allreduce(local)
+    total = _gloo_allreduce(local)
     Phi, psi, kappa, yy, n = D.unpack_stats(total, len(Z))
     assert total[-1] == world and total[-2] == 0
     elbo = _oracle_elbo_from_stats(o, spec, Z, Phi, psi, kappa, yy, n, s2)
     # ranks that decided differently (one whitened its shard, one did not) must be caught after the all-reduce
-    mixed = D.torch_allreduce(D.pack_stats(Phi, psi, kappa, yy, n, whitened=(rank == 0)))
+    mixed = _gloo_allreduce(D.pack_stats(Phi, psi, kappa, yy, n, whitened=(rank == 0)))
     try:
         D.unpack_stats(mixed, len(Z))
         caught = 0.0
@@ -113,8 +129,8 @@ def _worker_gather(rank, world, port, out_dir):
     ctx = _OracleCtx(o, spec, X, y, Z, s2)
     alpha = o.sgpr_alpha(spec, X, y, Z, s2)
     subsets, _ = o.compute_sobol_oak(spec, Z, alpha)
-    sob = D.sharded_sobol(ctx, None, Z, alpha, subsets, rank, world)
-    mean, var = D.sharded_predict(ctx, None, X[:37], rank, world)
+    sob = D.sharded_sobol(ctx, None, Z, alpha, subsets, rank, world, gather=_gloo_allgather)
+    mean, var = D.sharded_predict(ctx, None, X[:37], rank, world, gather=_gloo_allgather)
     np.savez(Path(out_dir) / f"g{rank}.npz", sob=sob, mean=mean, var=var)
     dist.barrier()
     dist.destroy_process_group()
@@ -160,3 +176,85 @@ def test_shard_bounds_and_packing():
     assert D.stats_whitened(w + w)
     with pytest.raises(ValueError):
         D.unpack_stats(p + w, 5)
+
+
+# ---- the control plane of oak/distributed.py (pure sockets) and the MODEL API on top of it ---------------------------------
+def _worker_plane(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT / "orthogonal-additive-gaussian-processes_amd"))
+    from oak import distributed as D
+    pl = D.HostPlane(rank, world, "127.0.0.1", port)
+    a = pl.allreduce_sum(np.arange(5.0) * (rank + 1))
+    g = pl.allgather(np.full(rank + 1, float(rank)))
+    b = pl.broadcast({"id": b"x" * 128} if rank == 1 else None, src=1)
+    pl.barrier()
+    np.savez(Path(out_dir) / f"p{rank}.npz", a=a, g=np.concatenate(g), b=np.frombuffer(b["id"], dtype=np.uint8))
+    pl.close()
+
+
+def test_host_plane_collectives(tmp_path):
+    world = 3
+    mp.spawn(_worker_plane, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        got = np.load(tmp_path / f"p{r}.npz")
+        np.testing.assert_array_equal(got["a"], np.arange(5.0) * 6)
+        np.testing.assert_array_equal(got["g"], [0, 1, 1, 2, 2, 2])
+        assert got["b"].size == 128 and (got["b"] == ord("x")).all()
+
+
+def _fit_problem():
+    rng = np.random.default_rng(0)
+    X = rng.normal(size=(1201, 2))
+    y = (np.sin(X[:, 0]) + 0.5 * X[:, 1] ** 2 + 0.05 * rng.normal(size=len(X)))[:, None]
+    return X, y
+
+
+def _fit_and_report(out_file):
+    from oak import gpflow_lite as gpflow
+    from oak.model_utils import oak_model
+    X, y = _fit_problem()
+    m = oak_model(max_interaction_depth=2, num_inducing=12, sparse=True, use_normalising_flow=False)
+    m.fit(X, y, optimise=False, initialise_inducing_points=False)
+    m.m.likelihood.variance.assign(0.2)             # a tame starting point: the line search then never leaves the PD region
+    loss0 = m.m.training_loss()
+    res = gpflow.Scipy().minimize(m.m.training_loss_closure(), m.m.trainable_variables, method="BFGS", on_linalg_error="inf",
+                                  options={"maxiter": 3})
+    params = np.concatenate([np.ravel(p.numpy()) for p in m.m.trainable_parameters])
+    m.m.SHARDED_PREDICT_MIN_ROWS = 8               # so that the 40 test rows below really are predicted in shards
+    np.savez(out_file, loss0=loss0, loss=res.fun, nfev=res.nfev, params=params, sobol=m.get_sobol(), pred=m.predict(X[:40]),
+             rows_on_device=len(m.m._hip.X))
+
+
+def _worker_model(rank, world, port, out_dir):
+    for p in (str(ROOT / "orthogonal-additive-gaussian-processes_amd"), str(ROOT), str(ROOT / "tests")):
+        sys.path.insert(0, p)
+    import fake_hip
+    fake_hip.install()                              # no GPU in this suite: the oracle answers behind the binding's interface
+    from oak import distributed as D
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    comm = D.init_from_env(exchange="host")
+    assert D.current() is comm and comm.active == (world > 1)
+    _fit_and_report(Path(out_dir) / f"m{world}_{rank}.npz")
+    D.shutdown()
+
+
+@pytest.mark.timeout(600)
+def test_model_api_runs_row_sharded_and_matches_the_single_process_fit(tmp_path):
+    """oak_model.fit / BFGS / get_sobol / predict under a 2-rank communicator (oak.distributed.init_from_env): every rank keeps
+    its row block, the optimiser runs replicated on identical all-reduced values, and the result is the single-process one
+    (reference flow: oak/model_utils.py:249-408, 429-443, 499-524)."""
+    mp.spawn(_worker_model, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_worker_model, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    ref = np.load(tmp_path / "m1_0.npz")
+    got = [np.load(tmp_path / f"m2_{r}.npz") for r in range(2)]
+    assert int(ref["rows_on_device"]) == 1201 and sorted(int(g["rows_on_device"]) for g in got) == [600, 601]
+    for g in got:
+        np.testing.assert_allclose(g["loss0"], ref["loss0"], rtol=1e-9)          # summation order x cond(Kuu)
+        # the oracle's gradients are finite differences of values that differ by summation order x cond(Kuu) between the two
+        # runs: the trajectories agree to that noise, not to rounding (the GPU suite holds the analytic path to 1e-9)
+        np.testing.assert_allclose(g["params"], ref["params"], rtol=1e-3, atol=1e-5)
+        np.testing.assert_allclose(g["sobol"], ref["sobol"], rtol=1e-3, atol=1e-6)
+        np.testing.assert_allclose(g["pred"], ref["pred"], rtol=1e-3, atol=1e-5)
+    # the ranks themselves ran bit-identical optimisations
+    for k in ("loss", "params", "sobol", "pred"):
+        np.testing.assert_array_equal(got[0][k], got[1][k])
+    assert int(got[0]["nfev"]) == int(got[1]["nfev"])
