@@ -671,9 +671,11 @@ int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, bool check, in
     // are HBM-bound and the pipelined 64 x 64 GEMM kernel moves them faster than the single-stage role-B tiles
     // (n = 16384: 253 ms fused vs 182 ms), so large factorisations fall back to panel + GEMM per step.
     const bool fused = n <= 6144;
-    long long* d_trace = (long long*)peek_buf(ctx, "potrf_trace");     // dev aid (oak_bench_potrf with OAK_POTRF_TRACE=1): 24 stamps per step
+    // dev aid: in-kernel time stamps, 24 per step.  Only while oak_bench_potrf has armed it (ctx->potrf_trace, with its capacity),
+    // only for the main-stream factorisation it times, and never past the end of the buffer.
+    long long* d_trace = (slot == 0) ? ctx->potrf_trace : nullptr;
     for (int64_t j0 = 0; j0 < n; j0 += PO_NB) {
-        long long* trc = d_trace ? d_trace + 24 * (j0 / PO_NB) : nullptr;
+        long long* trc = (d_trace && j0 / PO_NB < ctx->potrf_trace_steps) ? d_trace + 24 * (j0 / PO_NB) : nullptr;
         const int64_t below_rows = nrows - j0 - PO_NB;     // rows under the diagonal block (extra rows included)
         const int nA = below_rows > 0 ? (int)((below_rows + PO_RPW - 1) / PO_RPW) : 1;
         const int64_t tc = n - j0 - PO_NB, tr = nrows - j0 - PO_NB;

@@ -6,8 +6,8 @@
 // RT x CPT block of (row, column) pairs and runs the e_r recurrence  e_r += k_d * e_{r-1}  (r = R..1) over d in
 // registers -- algebraically the same elementary symmetric polynomials, D*R FMAs per pair and no pow().
 //
-// Roofline: fp64-VALU bound (one software exp2 per pair per dimension, exp2w.h: 17 VALU instructions per pair per
-// dimension at R = 2 including the ESP update), not HBM bound.
+// Roofline: fp64-VALU bound (one software exp2 per pair per dimension, exp2w.h: 16.03 VALU wave-instructions per 64
+// pair-dimensions at R = 2 including the ESP update -- PMC, profiles/pmc_counts.json), not HBM bound.
 // fp64 MFMA shares the DP pipe with fp64 VALU on gfx950 (measured, tools/ubench), so there is nothing to
 // overlap with; the kernel is written to issue the minimum number of DP instructions per pair.
 #include "oak_internal.h"

@@ -952,7 +952,10 @@ int oak_bench_potrf(oak_ctx* ctx, int64_t n, int32_t reps, double* ms_out, doubl
         bench_spd_fill_kernel<<<grid, 256, 0, ctx->stream>>>(dA, n);
         bench_delay_kernel<<<1, 64, 0, ctx->stream>>>((long long)(100 * 1000) * (2 + n / 512));   // 100 MHz clock: 2+ ms
         OAK_HIP_CHECK(hipEventRecord(e0, ctx->stream));
-        OAK_CHECK(potrf_lower(ctx, dA, n, n, false));
+        ctx->potrf_trace = d_trace; ctx->potrf_trace_steps = trace ? nsteps : 0;
+        const int prc = potrf_lower(ctx, dA, n, n, false);
+        ctx->potrf_trace = nullptr; ctx->potrf_trace_steps = 0;
+        OAK_CHECK(prc);
         OAK_HIP_CHECK(hipEventRecord(e1, ctx->stream));
         OAK_CHECK(potrf_check(ctx, 0, n));
         float ms = 0.f;

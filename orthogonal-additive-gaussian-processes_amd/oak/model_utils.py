@@ -233,14 +233,7 @@ class oak_model:
                 self.empirical_weights[ii] = (cnt / cnt.sum()).reshape(-1, 1)
                 self.empirical_locations[ii] = loc.reshape(-1, 1)
 
-        assert np.allclose(self.X_scaled[:, self.binary_index], X[:, self.binary_index]), "Flow applied to binary inputs"
-        assert np.allclose(self.X_scaled[:, self.categorical_index], X[:, self.categorical_index]), "Flow applied to categorical inputs"
-        if self.gmm_measure is not None:
-            g = np.flatnonzero(self.gmm_measure)
-            assert np.allclose(self.X_scaled[:, g], X[:, g]), "Flow applied to GMM measure inputs"
-        if self.empirical_measure is not None:
-            back = np.stack([self._get_x_inverse_transformer(i)(self.X_scaled[:, i]) for i in self.empirical_measure], axis=1)
-            assert np.allclose(back, X[:, self.empirical_measure]), "Flow applied to empirical measure inputs"
+        self._check_untransformed_columns(X)
 
         Z = None
         if X.shape[0] > 1000 or self.sparse:     # sparse GP above 1000 rows (:374)
@@ -270,6 +263,19 @@ class oak_model:
             gmm_measures=self.estimated_gmm_measures,
             share_var_across_orders=self.share_var_across_orders,
         )
+
+    def _check_untransformed_columns(self, X):
+        """The input scaling must leave discrete and measure-carrying columns alone (the checks of oak/model_utils.py:346-371):
+        binary, categorical and GMM-measure columns pass through unchanged; empirical-measure columns are only standardised,
+        so their inverse transformer maps them back."""
+        passthrough = {"binary": list(self.binary_index), "categorical": list(self.categorical_index),
+                       "GMM measure": [] if self.gmm_measure is None else [int(i) for i in np.flatnonzero(self.gmm_measure)]}
+        for what, cols in passthrough.items():
+            if cols and not np.allclose(self.X_scaled[:, cols], X[:, cols]):
+                raise AssertionError(f"Flow applied to {what} inputs")
+        for i in (self.empirical_measure or []):
+            if not np.allclose(self._get_x_inverse_transformer(i)(self.X_scaled[:, i]), X[:, i]):
+                raise AssertionError("Flow applied to empirical measure inputs")
 
     def optimise(self, compile: bool = True):
         print("Model prior to optimisation")
@@ -335,31 +341,30 @@ class oak_model:
 
 
 def _calculate_features(X, categorical_feature: List[int], binary_feature: List[int]):
-    """Feature typing and the empirical class probabilities p0 / p (oak/model_utils.py:703-750)."""
+    """Column typing and the empirical class probabilities the discrete sub-kernels are built from
+    (behaviour of oak/model_utils.py:703-750): returns (continuous_index, binary_index, categorical_index, p0, p) where
+    ``p0[j]`` = P(x_j = 0) for a binary column, ``p[j]`` = the class frequencies (C x 1, classes in sorted order) for a
+    categorical one, None elsewhere; both are None altogether when no discrete column was declared."""
+    X = np.asarray(X)
+    D = X.shape[1]
+    binary = set(binary_feature or [])
+    categorical = set(categorical_feature or [])
+    if binary & categorical:
+        raise ValueError(f"Overlapping feature set {binary & categorical}")
+    kind = np.array(["binary" if j in binary else ("categorical" if j in categorical else "continuous") for j in range(D)])
+    binary_index, categorical_index, continuous_index = ([int(j) for j in np.flatnonzero(kind == k)]
+                                                         for k in ("binary", "categorical", "continuous"))
     if binary_feature is None and categorical_feature is None:
         p0 = p = None
-        continuous_index, binary_index, categorical_index = list(range(X.shape[1])), [], []
     else:
-        if binary_feature is not None and categorical_feature is not None:
-            overlap = set(binary_feature).intersection(categorical_feature)
-            if len(overlap) > 0:
-                raise ValueError(f"Overlapping feature set {overlap}")
-        binary_index, categorical_index, continuous_index, p0, p = [], [], [], [], []
-        for j in range(X.shape[1]):
-            if binary_feature is not None and j in binary_feature:
-                p0.append(1 - X[:, j].mean())
-                p.append(None)
-                binary_index.append(j)
-            elif categorical_feature is not None and j in categorical_feature:
-                p0.append(None)
-                _, counts = np.unique(X[:, j], return_counts=True)
-                p.append((counts / len(X[:, j])).reshape(-1, 1))
-                assert np.abs(p[-1].sum() - 1) < 1e-6
-                categorical_index.append(j)
-            else:
-                p.append(None)
-                p0.append(None)
-                continuous_index.append(j)
+        p0, p = [None] * D, [None] * D
+        for j in binary_index:
+            p0[j] = 1 - X[:, j].mean()
+        for j in categorical_index:
+            freq = np.unique(X[:, j], return_counts=True)[1] / X.shape[0]
+            if abs(freq.sum() - 1) >= 1e-6:
+                raise AssertionError("class frequencies do not sum to one")
+            p[j] = freq.reshape(-1, 1)
     print("indices of binary feature ", binary_index)
     print("indices of continuous feature ", continuous_index)
     print("indices of categorical feature ", categorical_index)

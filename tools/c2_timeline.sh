@@ -1,5 +1,7 @@
+set -eu
+ROOT=${GRAFT_REPO_ROOT:-$(git rev-parse --show-toplevel)}
 cd /tmp && export TMPDIR=/tmp
-cd $GRAFT_REPO_ROOT
+cd "$ROOT"
 mkdir -p gpurun_out/c2tl
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/c2tl -o c2 -- python3 bench.py --config c2 --steps 20 --warmup 5 --no-cpu-baseline > gpurun_out/c2tl/bench.log 2>&1
 tail -1 gpurun_out/c2tl/bench.log | cut -c1-200
