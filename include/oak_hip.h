@@ -38,7 +38,11 @@ extern "C" {
 #define OAK_E_STATE  -5   /* call order violated (e.g. predict before posterior)  */
 
 #define OAK_MAX_DIMS   64  /* sub-kernels per OAK kernel                          */
-#define OAK_MAX_DEPTH  16  /* max_interaction_depth supported by the fused kernels (the reference's examples go to 13) */
+#define OAK_MAX_DEPTH  16  /* EFFECTIVE depth min(max_interaction_depth, num_dims) of the fused kernels (SGPR / GPR / SVGP paths,
+                               gradients, Sobol; the reference's examples go to 13).  e_r vanishes for r > num_dims, so any
+                               max_interaction_depth is accepted while num_dims <= 16 */
+#define OAK_MAX_DEPTH_DESC 64 /* max_interaction_depth a description may carry; beyond an effective depth of 16 only the explicit
+                               Gram entry points (oak_gram / oak_gram_diag: OAKKernel.K / K_diag) evaluate it, by a generic kernel */
 
 /* dim_type: which constrained base kernel a sub-kernel is */
 #define OAK_DIM_RBF          0  /* oak/ortho_rbf_kernel.py:20-177         */
@@ -105,6 +109,13 @@ int oak_gram(oak_ctx* ctx, const oak_kernel_desc* desc,
              const double* X1, int64_t n1, const double* X2, int64_t n2, int32_t ldx,
              double* out);
 /* out[n] = K_diag(X) */
+/* A/B switch of the explicit Gram entry points (oak_gram, oak_gram_diag): 0 (default) = this library's arithmetic --
+   squared distance formed directly as (x/l - z/l)^2, elementary symmetric polynomials by the exact-sum recurrence;
+   1 = the REFERENCE's arithmetic reproduced on the device -- GPflow's expanded |x/l|^2 + |z/l|^2 - 2 (x/l)(z/l), exp,
+   power sums and the Newton-Girard alternating sum (oak/oak_kernel.py:236-249, ortho_rbf_kernel.py:157-172) -- so that
+   "identical to the reference" can be shown entry by entry and the two deliberate deviations quantified
+   (tests/test_gpu_gram.py).  A debug aid: one thread per entry, not a fast path. */
+int oak_set_gram_form(oak_ctx* ctx, int32_t form);
 int oak_gram_diag(oak_ctx* ctx, const oak_kernel_desc* desc,
                   const double* X, int64_t n, int32_t ldx, double* out);
 /* KernelComponenent.K (oak_kernel.py:300-320): sigma2_{|S|} * prod_{d in S} k_d; subset = indices

@@ -1096,7 +1096,7 @@ int set_identity(oak_ctx* ctx, double* dA, int64_t n) {
 // [lengthscale (D) | base_var (D) | order_var (n_order_var) | noise | dTable (meas_data_len)]
 void scatter_record(const oak_kernel_desc* desc, const PreparedKernel& pk, const std::vector<double>& rec, double dnoise,
                            double* grad_out) {
-    const int D = desc->num_dims, R = desc->max_depth;
+    const int D = desc->num_dims, R = pk.dd.R;       // the record is laid out for the effective depth min(max_depth, D)
     const int64_t glen = 2 * D + desc->n_order_var + 1 + desc->meas_data_len;
     for (int64_t i = 0; i < glen; ++i) grad_out[i] = 0.0;
     for (int d = 0; d < D; ++d) {

@@ -336,6 +336,105 @@ int gram(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int6
     return OAK_E_ARG;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Generic Gram: one thread per entry, runtime depth (<= OAK_MAX_DIMS), two arithmetic forms (oak_internal.h: gram_generic).
+// FORM 1 follows oracle/oak_oracle.py -- i.e. the reference -- operation by operation: u = x / l (IEEE division, as NumPy),
+// r2 = ((-2 u_x) u_z + u_x^2) + u_z^2, k = variance * exp(-r2 / 2) - c(x) c(z) / var_s, s_p = sum_d k^p by repeated products,
+// e_n = (1 / n) sum_k (-1)^(k-1) e_{n-k} s_k, K = sum_n sigma2_n e_n; no FMA contraction (the file is built with
+// -ffp-contract=off), the library's exp.  FORM 0 is this library's arithmetic in the same slow shape: (u_x - u_z)^2 and the
+// recurrence e_r += k_d e_{r-1}.
+// ---------------------------------------------------------------------------------------------
+struct GenericDims {
+    int D, R;
+    unsigned char type[OAK_MAX_DIMS];
+    short col[OAK_MAX_DIMS];
+    int ncat[OAK_MAX_DIMS], tab_off[OAK_MAX_DIMS];
+    double ls[OAK_MAX_DIMS], bv[OAK_MAX_DIMS];
+};
+
+template <int FORM, bool DIAG>
+__global__ void __launch_bounds__(256)
+gram_generic_kernel(const GenericDims g, const double* __restrict__ w, const double* __restrict__ tables, const double* __restrict__ Xa,
+                    const double* __restrict__ Axs, const double* __restrict__ Acn, int64_t a_ld, int64_t na, const double* __restrict__ Xb,
+                    const double* __restrict__ Bxs, const double* __restrict__ Bcn, int64_t b_ld, int64_t nb, int32_t ldx,
+                    double* __restrict__ out, int64_t ldo) {
+    const int64_t j = DIAG ? 0 : (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = DIAG ? (int64_t)blockIdx.x * 256 + threadIdx.x : (int64_t)blockIdx.y;
+    if (i >= na || (!DIAG && j >= nb)) return;
+    const int D = g.D, R = g.R;
+    double acc[OAK_MAX_DIMS + 1];                 // FORM 1: power sums s_0..s_R; FORM 0: e_1..e_R (acc[r - 1])
+    for (int r = 0; r <= R; ++r) acc[r] = 0.0;
+    for (int d = 0; d < D; ++d) {
+        double k;
+        if (g.type[d] == OAK_DIM_RBF) {
+            const double ca = Acn[(int64_t)d * a_ld + i];
+            if (DIAG) {
+                k = g.bv[d] - ca * ca;                                            // oak/ortho_rbf_kernel.py:174-177
+            } else {
+                const double ux = Xa[i * ldx + g.col[d]] / g.ls[d], uz = Xb[j * ldx + g.col[d]] / g.ls[d];
+                double r2;
+                if (FORM == 1) r2 = ((-2.0 * ux) * uz + ux * ux) + uz * uz;        // gpflow square_distance
+                else { const double dz = ux - uz; r2 = dz * dz; }
+                k = g.bv[d] * exp(-0.5 * r2) - ca * Bcn[(int64_t)d * b_ld + j];
+            }
+        } else {
+            const int xi = (int)Axs[(int64_t)d * a_ld + i];
+            k = DIAG ? tables[g.tab_off[d] + g.ncat[d] * g.ncat[d] + xi]
+                     : tables[g.tab_off[d] + xi * g.ncat[d] + (int)Bxs[(int64_t)d * b_ld + j]];
+        }
+        if (FORM == 1) {
+            double kp = 1.0;
+            for (int p = 0; p <= R; ++p) { acc[p] += kp; kp *= k; }
+        } else {
+            for (int q = R - 1; q >= 1; --q) acc[q] = acc[q] + k * acc[q - 1];
+            if (R >= 1) acc[0] += k;
+        }
+    }
+    double K;
+    if (FORM == 1) {
+        double e[OAK_MAX_DIMS + 1];
+        e[0] = 1.0;
+        for (int n = 1; n <= R; ++n) {
+            double t = 0.0;
+            for (int kk = 1; kk <= n; ++kk) t += (((kk - 1) & 1) ? -1.0 : 1.0) * e[n - kk] * acc[kk];
+            e[n] = (1.0 / n) * t;
+        }
+        K = 0.0;
+        for (int n = 0; n <= R; ++n) K += w[n] * e[n];
+    } else {
+        K = w[0];
+        for (int r = 1; r <= R; ++r) K += w[r] * acc[r - 1];
+    }
+    out[DIAG ? i : i * ldo + j] = K;
+}
+
+int gram_generic(oak_ctx* ctx, const PreparedKernel& pk, int form, const double* dXa, const Feat& A, int64_t na, const double* dXb,
+                 const Feat& B, int64_t nb, int32_t ldx, double* d_out, int64_t ldo, bool diag) {
+    if (na <= 0 || (!diag && nb <= 0)) return OAK_OK;
+    GenericDims g;
+    memset(&g, 0, sizeof(g));
+    g.D = pk.dd.D; g.R = (int)pk.w_full.size() - 1;
+    for (int d = 0; d < g.D; ++d) {
+        g.type[d] = pk.dd.type[d]; g.col[d] = pk.dd.col[d]; g.ncat[d] = pk.dd.ncat[d]; g.tab_off[d] = pk.dd.tab_off[d];
+        g.ls[d] = pk.dm.ls[d]; g.bv[d] = pk.dd.bv[d];
+    }
+    double* d_w = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "gram_generic_w", (size_t)OAK_MAX_DIMS + 1, &d_w));
+    OAK_CHECK(copy_sync(ctx, d_w, pk.w_full.data(), sizeof(double) * pk.w_full.size(), hipMemcpyHostToDevice));
+    if (dXb == nullptr) dXb = dXa;
+#define OAK_GG(F, DG, GRID) gram_generic_kernel<F, DG><<<GRID, 256, 0, ctx->stream>>>(g, d_w, pk.d_tables, dXa, A.xs, A.cn, A.ld, na, dXb, B.xs, B.cn, B.ld, nb, ldx, d_out, ldo)
+    if (diag) {
+        const dim3 grid((unsigned)((na + 255) / 256));
+        if (form == 1) OAK_GG(1, true, grid); else OAK_GG(0, true, grid);
+    } else {
+        const dim3 grid((unsigned)((nb + 255) / 256), (unsigned)na);
+        if (form == 1) OAK_GG(1, false, grid); else OAK_GG(0, false, grid);
+    }
+#undef OAK_GG
+    OAK_HIP_CHECK(hipGetLastError());
+    return OAK_OK;
+}
+
 int gram_diag(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, double* d_out, double* d_sum_accum) {
     const int64_t n = A.n;
     if (n <= 0) return OAK_OK;

@@ -87,6 +87,12 @@ struct PendingEvt { std::string name; hipEvent_t a, b; };   // a recorded phase 
 struct PreparedKernel {
     DevDesc dd;
     DevMeasure dm;
+    // Depth bookkeeping.  e_r of D sub-kernels vanishes identically for r > D, so the kernels run at depth min(R, D) = dd.R
+    // (R_desc is what the caller described: the public gradient layout has R_desc + 1 order-variance slots).  Only the explicit
+    // Gram entry points accept min(R, D) > OAK_MAX_DEPTH (deep = true: generic kernel, weights in w_full); dd.R is then unusable.
+    int R_desc = 0;
+    bool deep = false;
+    std::vector<double> w_full;      // weights of e_0..e_{min(R, D)} (always filled)
     std::vector<double> tables;      // host copy of the discrete tables
     double* d_tables = nullptr;      // device (ctx scratch "tables")
     double* d_meas = nullptr;        // device (ctx scratch "meas")
@@ -110,6 +116,7 @@ struct oak_ctx {
     bool have_data = false, have_Z = false, have_stats = false, have_post = false, stats_whitened = false, have_alpha = false;
     bool have_linv = false;          // buffers "Linv" / "LinvT" hold L^-1 and its transpose for the current L
     int route = 0;   // 0 auto, 1 phi, 2 whitened
+    int gram_form = 0;               // explicit Gram entry points: 0 native arithmetic, 1 the reference's (oak_set_gram_form)
     int precision = 0;               // 0: fp64 throughout; 1: fp32 Kfu panel + fp32-MFMA Phi partials on the phi route (forward only)
     int auto_whiten = -1;            // decision of the conditioning check for this evaluation (-1: none, use the size rule)
     bool auto_pending = false;       // the check's result (cond_mm) is still in flight on the side stream
@@ -155,7 +162,7 @@ struct PhaseTimer {   // hipEvent timing of a phase on the ctx stream (accumulat
 void reset_timings(oak_ctx* ctx);
 
 // kernel description ----------------------------------------------------------------------------
-int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk);
+int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk, bool allow_deep = false);
 // component (single subset) description derived from a full one
 int prepare_component(oak_ctx* ctx, const oak_kernel_desc* desc, const int32_t* subset, int32_t len,
                       int32_t apply_order_var, PreparedKernel* pk);
@@ -172,6 +179,12 @@ int featurize(oak_ctx* ctx, const PreparedKernel& pk, const double* dX, int64_t 
 int gram(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int64_t na, const Feat& B,
          double* d_out, int64_t ldo, const double* d_yA, double* d_psi, int64_t zero_pad_to);
 int gram_diag(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, double* d_out, double* d_sum_accum);
+// Generic Gram (one thread per entry, any depth <= OAK_MAX_DIMS): the fallback of the explicit Gram entry points beyond depth
+// 16 and the A/B path that reproduces the REFERENCE's arithmetic on the device (form 1: GPflow's expanded squared distance
+// from x / l, exp, power sums + Newton-Girard, oak/oak_kernel.py:236-249; form 0: this library's own, direct distance and the
+// exact-sum recurrence).  dXa / dXb: the raw inputs (row-major, ldx); B = A when dXb is NULL.  diag: K_diag of A into out[na].
+int gram_generic(oak_ctx* ctx, const PreparedKernel& pk, int form, const double* dXa, const Feat& A, int64_t na, const double* dXb,
+                 const Feat& B, int64_t nb, int32_t ldx, double* d_out, int64_t ldo, bool diag);
 
 // dense linear algebra on the device (fp64) -------------------------------------------------------
 int syrk_panel(oak_ctx* ctx, const double* d_panel, int64_t ldp, int64_t nrows, int64_t M, double* d_part,

@@ -286,18 +286,30 @@ static double host_var_s(int kind, double l, double bv, double p0, double p1, co
     }
 }
 
-int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk) {
+int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk, bool allow_deep) {
     OAK_REQUIRE(desc != nullptr, "kernel description is NULL");
-    const int D = desc->num_dims, R = desc->max_depth;
+    const int D = desc->num_dims, Rd = desc->max_depth;
     OAK_REQUIRE(D >= 1 && D <= OAK_MAX_DIMS, "num_dims=%d outside [1,%d]", D, OAK_MAX_DIMS);
-    OAK_REQUIRE(R >= 0 && R <= OAK_MAX_DEPTH, "max_interaction_depth=%d outside [0,%d]", R, OAK_MAX_DEPTH);
-    OAK_REQUIRE(desc->n_order_var == (desc->share_var ? R + 1 : 1), "n_order_var=%d inconsistent", desc->n_order_var);
+    OAK_REQUIRE(Rd >= 0 && Rd <= OAK_MAX_DEPTH_DESC, "max_interaction_depth=%d outside [0,%d]", Rd, OAK_MAX_DEPTH_DESC);
+    OAK_REQUIRE(desc->n_order_var == (desc->share_var ? Rd + 1 : 1), "n_order_var=%d inconsistent", desc->n_order_var);
+    // the elementary symmetric polynomial e_r of D values is identically zero for r > D (the reference's Newton-Girard loop
+    // computes those zeros, oak/oak_kernel.py:236-249): every kernel runs at depth min(R, D)
+    const int R = Rd < D ? Rd : D;
+    pk->R_desc = Rd;
+    pk->deep = R > OAK_MAX_DEPTH;
+    if (pk->deep && !allow_deep) {
+        set_error("effective interaction depth min(max_interaction_depth, num_dims) = %d exceeds the %d of the fused kernels "
+                  "(only the explicit Gram entry points K / K_diag go deeper)", R, OAK_MAX_DEPTH);
+        return OAK_E_ARG;
+    }
     DevDesc& dd = pk->dd;
     DevMeasure& dm = pk->dm;
     memset(&dd, 0, sizeof(dd));
     memset(&dm, 0, sizeof(dm));
-    dd.D = D; dd.R = R;
-    for (int r = 0; r <= R; ++r) dd.w[r] = desc->share_var ? desc->order_var[r] : (r == 0 ? desc->order_var[0] : 1.0);
+    dd.D = D; dd.R = pk->deep ? OAK_MAX_DEPTH : R;
+    pk->w_full.assign((size_t)R + 1, 0.0);
+    for (int r = 0; r <= R; ++r) pk->w_full[r] = desc->share_var ? desc->order_var[r] : (r == 0 ? desc->order_var[0] : 1.0);
+    for (int r = 0; r <= dd.R && r <= R; ++r) dd.w[r] = pk->w_full[r];
     pk->tables.clear();
     // upload measure data first (needed by the empirical variance kernel)
     double* d_meas = nullptr;

@@ -52,8 +52,15 @@ static int gram_to_host(oak_ctx* ctx, const PreparedKernel& pk, const double* X1
     if (chunk > n1) chunk = n1;
     double* dK = nullptr;
     OAK_CHECK(get_buf_t(ctx, "gK", (size_t)chunk * n2, &dK));
+    const bool generic = pk.deep || ctx->gram_form != 0;      // beyond depth 16, or the reference-arithmetic A/B form
+    if (generic) OAK_REQUIRE(n1 <= 65535, "the generic Gram kernel (depth > %d or oak_set_gram_form) takes at most 65535 rows per call", OAK_MAX_DEPTH);
     for (int64_t a0 = 0; a0 < n1; a0 += chunk) {
         const int64_t na = (a0 + chunk <= n1) ? chunk : n1 - a0;
+        if (generic) {
+            Feat FAc = FA;                          // rows a0.. of the A side
+            FAc.xs += a0; FAc.cn += a0;
+            OAK_CHECK(gram_generic(ctx, pk, ctx->gram_form, dX1 + a0 * ldx, FAc, na, X2 != nullptr ? dX2 : dX1, FB, n2, ldx, dK, n2, false));
+        } else
         OAK_CHECK(gram(ctx, pk, FA, a0, na, FB, dK, n2, nullptr, nullptr, 0));
         OAK_HIP_CHECK(hipMemcpyAsync(out + a0 * n2, dK, sizeof(double) * (size_t)na * n2, hipMemcpyDeviceToHost, ctx->stream));
         OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -68,6 +75,8 @@ static int gram_diag_to_host(oak_ctx* ctx, const PreparedKernel& pk, const doubl
     OAK_CHECK(featurize(ctx, pk, dX, n, ldx, "gF1", &FA));
     double* dD = nullptr;
     OAK_CHECK(get_buf_t(ctx, "gD", (size_t)n, &dD));
+    if (pk.deep || ctx->gram_form != 0) OAK_CHECK(gram_generic(ctx, pk, ctx->gram_form, dX, FA, n, nullptr, FA, n, ldx, dD, 0, true));
+    else
     OAK_CHECK(gram_diag(ctx, pk, FA, dD, nullptr));
     OAK_HIP_CHECK(hipMemcpyAsync(out, dD, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -566,8 +575,15 @@ int oak_gram(oak_ctx* ctx, const oak_kernel_desc* desc, const double* X1, int64_
     OAK_REQUIRE(X1 && out && n1 >= 0 && ldx >= 1, "oak_gram: bad arguments");
     if (n1 == 0 || (X2 && n2 == 0)) return OAK_OK;
     PreparedKernel pk;
-    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk, true));
     return gram_to_host(ctx, pk, X1, n1, X2, n2, ldx, out);
+}
+
+int oak_set_gram_form(oak_ctx* ctx, int32_t form) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(form == 0 || form == 1, "gram form must be 0 (native arithmetic) or 1 (the reference's arithmetic)");
+    ctx->gram_form = form;
+    return OAK_OK;
 }
 
 int oak_gram_diag(oak_ctx* ctx, const oak_kernel_desc* desc, const double* X, int64_t n, int32_t ldx, double* out) {
@@ -575,7 +591,7 @@ int oak_gram_diag(oak_ctx* ctx, const oak_kernel_desc* desc, const double* X, in
     OAK_REQUIRE(X && out && n >= 0 && ldx >= 1, "oak_gram_diag: bad arguments");
     if (n == 0) return OAK_OK;
     PreparedKernel pk;
-    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk, true));
     return gram_diag_to_host(ctx, pk, X, n, ldx, out);
 }
 

@@ -16,7 +16,8 @@ import numpy as np
 OAK_OK, OAK_E_ARG, OAK_E_HIP, OAK_E_NOTPD, OAK_E_NCCL, OAK_E_STATE = 0, -1, -2, -3, -4, -5
 DIM_RBF, DIM_BINARY, DIM_CATEGORICAL = 0, 1, 2
 MEAS_NONE, MEAS_GAUSSIAN, MEAS_UNIFORM, MEAS_EMPIRICAL, MEAS_MOG = 0, 1, 2, 3, 4
-MAX_DIMS, MAX_DEPTH = 64, 16
+MAX_DIMS, MAX_DEPTH = 64, 16        # MAX_DEPTH: EFFECTIVE depth min(max_interaction_depth, D) of the fused kernels
+MAX_DEPTH_DESC = 64                  # what a description may carry (deeper than 16: explicit Gram entry points only)
 
 _PKG_ROOT = Path(__file__).resolve().parent.parent
 LIB_PATH = Path(os.environ.get("OAK_HIP_LIB", _PKG_ROOT / "lib" / "liboak_hip.so"))
@@ -65,6 +66,7 @@ SIGNATURES = {
     "oak_device_mem_info": (C.c_int, [_CTX, _D, _D]),
     "oak_gram": (C.c_int, [_CTX, _DESC, _D, C.c_int64, _D, C.c_int64, C.c_int32, _D]),
     "oak_gram_diag": (C.c_int, [_CTX, _DESC, _D, C.c_int64, C.c_int32, _D]),
+    "oak_set_gram_form": (C.c_int, [_CTX, C.c_int32]),
     "oak_gram_component": (C.c_int, [_CTX, _DESC, _I, C.c_int32, C.c_int32, _D, C.c_int64, _D, C.c_int64, C.c_int32, _D]),
     "oak_gram_component_diag": (C.c_int, [_CTX, _DESC, _I, C.c_int32, C.c_int32, _D, C.c_int64, C.c_int32, _D]),
     "oak_sgpr_set_data": (C.c_int, [_CTX, _D, _D, C.c_int64, C.c_int32]),
@@ -187,8 +189,8 @@ class KernelDesc:
         R = int(spec["max_interaction_depth"])
         if not (1 <= D <= MAX_DIMS):
             raise ValueError(f"number of sub-kernels {D} outside [1, {MAX_DIMS}]")
-        if not (0 <= R <= MAX_DEPTH):
-            raise ValueError(f"max_interaction_depth {R} outside [0, {MAX_DEPTH}] supported by the fused HIP kernels")
+        if not (0 <= R <= MAX_DEPTH_DESC):
+            raise ValueError(f"max_interaction_depth {R} outside [0, {MAX_DEPTH_DESC}]")
         share = bool(spec.get("share_var_across_orders", True))
         ov = _f64(np.asarray(spec["order_variances"], dtype=np.float64).reshape(-1))
         if ov.size != (R + 1 if share else 1):
@@ -338,6 +340,14 @@ class HipContext:
         return f.value, t.value
 
     # -- Gram ---------------------------------------------------------------------------------
+    def set_gram_form(self, form: str):
+        """A/B switch of ``gram`` / ``gram_diag``: "native" (default) or "reference" -- the reference's arithmetic (GPflow's
+        expanded squared distance, power sums + Newton-Girard) reproduced on the device, entry by entry."""
+        code = {"native": 0, "reference": 1}.get(form)
+        if code is None:
+            raise ValueError("gram form must be 'native' or 'reference'")
+        _check(self._lib.oak_set_gram_form(self._h, code))
+
     def gram(self, desc: KernelDesc, X, X2=None) -> np.ndarray:
         X = _f64(X, 2)
         self._check_cols(desc, X)

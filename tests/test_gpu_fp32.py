@@ -125,3 +125,41 @@ def test_fp32_mode_under_a_communicator():
     ctx.sgpr_elbo(_capi.KernelDesc(spec2), 0.01)
     assert ctx.sgpr_stats_precision() == "fp64"
     ctx.close(); ref.close()
+
+
+def test_c5_full_size_in_fp32_as_baseline_config_5_states_it():
+    """BASELINE.json configs[4] literally: N = 262 144, D = 32 mixed (20 RBF + 8 binary + 4 categorical), M = 2048, depth 4,
+    fp32.  The fp32 statistics mode must be honoured at that size (well-conditioned Kuu) and stay within its stated
+    tolerance of the fp64 path -- ELBO and every kernel-dependent term <= 1e-5 relative, Phi <= 1e-5 of max|Phi| -- while a
+    16 384-row sample ties the fp64 path itself to the oracle at the full M (1e-10), so the fp32 numbers are anchored to
+    the restated reference through it.  Sobol indices computed from the fp32-statistics posterior still sum to one."""
+    import bench
+    N5, D5, M5, R5 = 262144, 32, 2048, 4
+    X, y, Z = bench.synthetic(N5, D5, M5, mixed=True)
+    spec = bench.make_spec(D5, R5, mixed=True)
+    d = _capi.KernelDesc(spec)
+    ctx = _capi.HipContext(0)
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("phi")
+    e64, t64, e32, t32, used = _both(ctx, d, 0.01)
+    assert used == "fp32" and e32 != e64
+    assert abs(e32 - e64) <= 1e-5 * abs(e64), (e32, e64)
+    est = t32.pop("cond_estimate"); t64.pop("cond_estimate")
+    assert 0 < est <= 1e2
+    cases.assert_terms_match(t32, t64, rtol=1e-5, what="C5 full size, fp32 statistics vs fp64:")
+    ctx.sgpr_set_precision("fp32"); ctx.sgpr_elbo(d, 0.01); s32 = ctx.sgpr_get_stats()
+    alpha32 = ctx.sgpr_alpha(M5)
+    ctx.sgpr_set_precision("fp64"); ctx.sgpr_elbo(d, 0.01); s64 = ctx.sgpr_get_stats()
+    P32, P64 = s32[:M5 * M5], s64[:M5 * M5]
+    assert np.abs(P32 - P64).max() <= 1e-5 * np.abs(P64).max()
+    # the fp64 path against the oracle on a row sample at the full M and depth
+    ns = 16384
+    ctx.sgpr_set_data(X[:ns], y[:ns])
+    e = ctx.sgpr_elbo(d, 0.01)
+    er, parts = c_oracle.sgpr_elbo_chunked(spec, X[:ns], y[:ns], Z, 0.01, 1e-6, chunk=4096, return_parts=True)
+    assert abs(e - er) <= 1e-10 * abs(er)
+    # Sobol path from the fp32-statistics posterior: all 41 448 terms, normalised
+    subsets = [list(s) for s in o.list_representation(D5, R5)[1:]]
+    sob = ctx.sobol(d, Z, alpha32, subsets)
+    assert len(sob) == 41448 and np.all(np.isfinite(sob)) and sob.min() >= -1e-12
+    assert abs((sob / sob.sum()).sum() - 1.0) <= 1e-12
+    ctx.close()

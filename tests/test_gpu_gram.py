@@ -276,4 +276,135 @@ def test_gram_beyond_depth_eight(hip, D, R):
     sub = list(range(min(D, R)))[:9]
     close(hip.gram_component(d, sub, True, X, X2), o.component_K(spec, sub, X, X2))
     with pytest.raises(ValueError):
-        _capi.KernelDesc(dict(spec, max_interaction_depth=17, order_variances=[1.0] * 18))
+        _capi.KernelDesc(dict(spec, max_interaction_depth=65, order_variances=[1.0] * 66))
+
+
+# ---- A/B: the reference's arithmetic reproduced on the device (oak_set_gram_form) ------------------------------------------
+def _ab_cases():
+    rng = np.random.default_rng(77)
+    out = []
+    # (a) lengthscales at the lower bound with near-coincident pairs: GPflow's expanded distance loses |x/l|^2 eps there
+    spec = o.make_spec(4, 2, lengthscales=[1e-3, 1.5e-3, 1.0, 1e-3], order_variances=[0.8, 1.1, 0.6])
+    X, X2 = rng.standard_normal((150, 4)), rng.standard_normal((70, 4))
+    X2[:5] = X[:5] + 4e-4 * rng.standard_normal((5, 4))
+    out.append(("lengthscale 1e-3, near-coincident pairs", spec, X, X2))
+    # (b) base variances 2^20 apart at depth 5: the Newton-Girard alternating sum cancels (6e-10 here), the recurrence does not
+    spec = o.make_spec(8, 5, lengthscales=list(np.linspace(0.7, 1.6, 8)), order_variances=list(np.linspace(0.5, 1.5, 6)))
+    for d, dim in enumerate(spec["dims"]):
+        dim["variance"] = float(2.0 ** (20 * (d % 2)))
+    out.append(("base variances 1 and 2^20, depth 5", spec, rng.standard_normal((90, 8)), rng.standard_normal((60, 8))))
+    # (c) an ordinary mixed kernel: the two forms agree to rounding
+    spec = cases.random_spec(rng, 9, 3, ("gaussian", "uniform", "binary", "categorical", "mog"))
+    out.append(("ordinary mixed kernel, depth 3", spec, cases.random_inputs(rng, spec, 80), cases.random_inputs(rng, spec, 50)))
+    return out
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_reference_arithmetic_form_matches_the_oracle_entry_by_entry(hip, idx):
+    """oak_set_gram_form("reference"): GPflow's expanded squared distance, power sums and the Newton-Girard alternating sum
+    (oak/oak_kernel.py:236-249, ortho_rbf_kernel.py:157-172) evaluated on the device must equal oracle.oak_K -- which IS that
+    form, operation for operation -- to 1e-13 of the largest entry EVEN where the form itself is ill-behaved, while the native
+    arithmetic (direct distance, exact-sum recurrence) differs from it there by the form's own cancellation error.  This is the
+    entry-by-entry demonstration that the two deliberate deviations are deviations towards accuracy."""
+    name, spec, X, X2 = _ab_cases()[idx]
+    d = _capi.KernelDesc(spec)
+    ref = o.oak_K(spec, X, X2)
+    ref_diag = o.oak_K_diag(spec, X)
+    scale = np.abs(ref).max()
+    try:
+        hip.set_gram_form("reference")
+        ab, ab_diag = hip.gram(d, X, X2), hip.gram_diag(d, X)
+        ab_sym = hip.gram(d, X)
+    finally:
+        hip.set_gram_form("native")
+    native = hip.gram(d, X, X2)
+    if idx == 1:
+        # here the cancellation sits AFTER the exponentials: a last-place difference between the device's exp and NumPy's is
+        # amplified exactly like the form's own rounding, so two executions of the reference form agree with each other only
+        # as well as either agrees with the exact value -- which is the point: both carry the form's error, the native
+        # arithmetic does not
+        import test_gpu_fuzz as fz
+        exact0 = fz.brute_force_K(spec, X, X2)
+        err_ref, err_ab = np.abs(ref - exact0).max() / scale, np.abs(ab - exact0).max() / scale
+        assert err_ref > 1e-13 and err_ab <= 10 * err_ref and err_ab >= err_ref / 10, (err_ref, err_ab)
+        assert np.abs(ab - ref).max() <= 10 * err_ref * scale
+    else:
+        assert np.abs(ab - ref).max() <= 1e-13 * scale, (name, np.abs(ab - ref).max() / scale)
+    dev = np.abs(native - ref).max() / scale
+    if idx == 2:
+        assert dev <= 1e-12                                   # nothing to deviate about
+    else:
+        # the native form is NOT the reference's here: it differs by more than the A/B form does, by the reference form's own
+        # error (bounded by its cancellation estimate), and it is the one that agrees with an exact evaluation
+        assert dev > 1e-13
+        if idx == 0:      # against the same kernel with the distance formed directly, in extended precision
+            def rbf_direct(A, B, lengthscale, variance):
+                A = np.asarray(A, dtype=np.longdouble); B = A if B is None else np.asarray(B, dtype=np.longdouble)
+                r2 = (((A[:, None, :] - B[None, :, :]) / np.longdouble(lengthscale)) ** 2).sum(-1)
+                return (variance * np.exp(-0.5 * r2)).astype(np.float64)
+            saved, o.rbf_K = o.rbf_K, rbf_direct
+            try:
+                exact = o.oak_K(spec, X, X2)
+            finally:
+                o.rbf_K = saved
+        else:             # against the exact sum over subsets
+            import test_gpu_fuzz as fz
+            exact = fz.brute_force_K(spec, X, X2)
+        assert np.abs(native - exact).max() <= 1e-12 * scale
+        assert np.abs(ref - exact).max() > np.abs(native - exact).max()        # the reference form is the less accurate one
+    print(f"[A/B] {name}: reference-form device vs oracle {np.abs(ab - ref).max() / scale:.1e}, native vs oracle {dev:.1e} (of max|K|)")
+
+
+@pytest.mark.parametrize("D,R", [(20, 20), (24, 17), (40, 33)])
+def test_gram_beyond_an_effective_depth_of_sixteen(hip, D, R):
+    """The reference's loop takes any depth (oak_kernel.py:236-249).  Beyond an effective depth min(R, D) of 16 the explicit
+    Gram entry points run a generic one-thread-per-entry kernel (exact-sum recurrence): K and K_diag against the exact sum
+    over subsets where that is affordable, otherwise against the recurrence in extended precision."""
+    rng = np.random.default_rng(D * 7 + R)
+    spec = cases.random_spec(rng, D, R, ("gaussian", "binary", "gaussian", "categorical"))
+    X, X2 = cases.random_inputs(rng, spec, 23), cases.random_inputs(rng, spec, 31)
+    d = _capi.KernelDesc(spec)
+    K, Kd = hip.gram(d, X, X2), hip.gram_diag(d, X)
+    # extended-precision recurrence over the oracle's per-dimension matrices
+    mats = [o.base_K(X[:, [o.active_col(spec, i)]], X2[:, [o.active_col(spec, i)]], dim).astype(np.longdouble) for i, dim in enumerate(spec["dims"])]
+    e = [np.ones_like(mats[0])] + [np.zeros_like(mats[0]) for _ in range(R)]
+    for k in mats:
+        for r in range(R, 0, -1):
+            e[r] = e[r] + k * e[r - 1]
+    ref = sum(np.longdouble(w) * er for w, er in zip(spec["order_variances"], e))
+    assert np.abs(K - ref).max() <= 1e-12 * np.abs(ref).max()
+    diags = [o.base_K_diag(X[:, [o.active_col(spec, i)]], dim).astype(np.longdouble) for i, dim in enumerate(spec["dims"])]
+    ed = [np.ones_like(diags[0])] + [np.zeros_like(diags[0]) for _ in range(R)]
+    for k in diags:
+        for r in range(R, 0, -1):
+            ed[r] = ed[r] + k * ed[r - 1]
+    refd = sum(np.longdouble(w) * er for w, er in zip(spec["order_variances"], ed))
+    assert np.abs(Kd - refd).max() <= 1e-12 * np.abs(refd).max()
+    # the fused model paths say so loudly instead of running at a wrong depth
+    ctx = _capi.HipContext(0)
+    ctx.sgpr_set_data(X, X[:, :1]); ctx.sgpr_set_inducing(X2)
+    with pytest.raises(ValueError, match="effective interaction depth"):
+        ctx.sgpr_elbo(d, 0.1)
+    ctx.close()
+
+
+def test_depth_beyond_the_number_of_dimensions_runs_at_that_number(hip):
+    """max_interaction_depth = 20 over 6 sub-kernels: e_r vanishes for r > 6, so every path (fused Gram, SGPR objective and its
+    gradient) runs at depth 6 and equals the depth-6 model with the same first seven order variances; the gradient w.r.t.
+    the order variances beyond 6 is exactly zero."""
+    rng = np.random.default_rng(5)
+    D, R = 6, 20
+    ov = list(rng.uniform(0.5, 1.5, R + 1))
+    spec = o.make_spec(D, R, lengthscales=list(rng.uniform(0.7, 1.5, D)), order_variances=ov)
+    spec6 = o.make_spec(D, D, lengthscales=[dm["lengthscale"] for dm in spec["dims"]], order_variances=ov[:D + 1])
+    X, y, Z = o.synthetic_problem(3000, D, 40, seed=9)
+    d, d6 = _capi.KernelDesc(spec), _capi.KernelDesc(spec6)
+    np.testing.assert_array_equal(hip.gram(d, X[:50], Z), hip.gram(d6, X[:50], Z))
+    ctx = _capi.HipContext(0)
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z)
+    e, g = ctx.sgpr_elbo_grad(d, 0.05)
+    e6, g6 = ctx.sgpr_elbo_grad(d6, 0.05)
+    assert e == e6
+    np.testing.assert_array_equal(g[:2 * D + D + 1], g6[:2 * D + D + 1])
+    assert np.all(g[2 * D + D + 1:2 * D + R + 1] == 0.0) and g[2 * D + R + 1] == g6[2 * D + D + 1]     # [.., order vars 7..20 = 0, noise]
+    ctx.close()
