@@ -82,6 +82,13 @@ typedef struct oak_kernel_desc {
     int32_t meas_data_len;
     int32_t grad_base_var;      /* gradient calls: also return d/d base_var (0 when the base variances are the
                                    constants of share_var_across_orders=True, oak_kernel.py:163-166,179,187)  */
+    /* Grouped sub-kernels (OAKKernel(active_dims=[[0, 1], [2]]), oak_kernel.py:74-82,199-210: an unconstrained RBF over several
+       columns with one lengthscale, i.e. the product of its one-column RBFs).  extra_col_off [D + 1] / extra_cols: the columns
+       of sub-kernel d BEYOND active_col[d] are extra_cols[extra_col_off[d] .. extra_col_off[d + 1]).  Both NULL = every
+       sub-kernel reads one column.  Evaluated by the explicit Gram entry points (oak_gram / oak_gram_diag) only; the fused
+       model paths refuse a grouped description. */
+    const int32_t* extra_col_off;
+    const int32_t* extra_cols;
 } oak_kernel_desc;
 
 typedef struct oak_ctx oak_ctx;

@@ -235,12 +235,24 @@ def active_col(spec, d):
     return spec["dims"][d].get("active_dim", d)
 
 
+def active_cols(spec, d):
+    """Columns sub-kernel d reads: gpflow slices ``active_dims`` before calling K (oak/oak_kernel.py:253,268); a grouped
+    sub-kernel (active_dims=[[0, 1], ...], :74-82) is an unconstrained RBF over several columns."""
+    dim = spec["dims"][d]
+    return [int(c) for c in dim["active_dims"]] if dim.get("active_dims") is not None else [active_col(spec, d)]
+
+
 def oak_K(spec, X, X2=None):
     """oak/oak_kernel.py:251-265."""
     X = np.asarray(X, dtype=np.float64)
     mats = []
     for d, dim in enumerate(spec["dims"]):
-        c = active_col(spec, d)
+        c = active_cols(spec, d)
+        if len(c) > 1:
+            assert dim["type"] == "rbf" and dim["measure"] is None, "only the unconstrained RBF is multi-dimensional"
+            mats.append(rbf_K(X[:, c], None if X2 is None else np.asarray(X2, dtype=np.float64)[:, c], dim["lengthscale"], dim["variance"]))
+            continue
+        c = c[0]
         mats.append(base_K(X[:, c:c + 1], None if X2 is None else np.asarray(X2, dtype=np.float64)[:, c:c + 1], dim))
     return _combine(spec, compute_additive_terms(mats, spec["max_interaction_depth"]))
 

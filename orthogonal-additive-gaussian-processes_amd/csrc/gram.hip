@@ -350,11 +350,12 @@ struct GenericDims {
     short col[OAK_MAX_DIMS];
     int ncat[OAK_MAX_DIMS], tab_off[OAK_MAX_DIMS];
     double ls[OAK_MAX_DIMS], bv[OAK_MAX_DIMS];
+    short xoff[OAK_MAX_DIMS + 1];       // grouped sub-kernels: further columns of dim d are xcols[xoff[d] .. xoff[d + 1])
 };
 
 template <int FORM, bool DIAG>
 __global__ void __launch_bounds__(256)
-gram_generic_kernel(const GenericDims g, const double* __restrict__ w, const double* __restrict__ tables, const double* __restrict__ Xa,
+gram_generic_kernel(const GenericDims g, const double* __restrict__ w, const int* __restrict__ xcols, const double* __restrict__ tables, const double* __restrict__ Xa,
                     const double* __restrict__ Axs, const double* __restrict__ Acn, int64_t a_ld, int64_t na, const double* __restrict__ Xb,
                     const double* __restrict__ Bxs, const double* __restrict__ Bcn, int64_t b_ld, int64_t nb, int32_t ldx,
                     double* __restrict__ out, int64_t ldo) {
@@ -373,7 +374,24 @@ gram_generic_kernel(const GenericDims g, const double* __restrict__ w, const dou
             } else {
                 const double ux = Xa[i * ldx + g.col[d]] / g.ls[d], uz = Xb[j * ldx + g.col[d]] / g.ls[d];
                 double r2;
-                if (FORM == 1) r2 = ((-2.0 * ux) * uz + ux * ux) + uz * uz;        // gpflow square_distance
+                if (g.xoff[d + 1] > g.xoff[d]) {
+                    // a sub-kernel over several columns: one RBF of the group's squared distance (oak_kernel.py:199-210)
+                    if (FORM == 1) {                                               // gpflow: -2 X X2^T + |X|^2 + |X2|^2, sums over columns
+                        double xz = ux * uz, xx = ux * ux, zz = uz * uz;
+                        for (int q = g.xoff[d]; q < g.xoff[d + 1]; ++q) {
+                            const double vx = Xa[i * ldx + xcols[q]] / g.ls[d], vz = Xb[j * ldx + xcols[q]] / g.ls[d];
+                            xz += vx * vz; xx += vx * vx; zz += vz * vz;
+                        }
+                        r2 = (-2.0 * xz + xx) + zz;
+                    } else {
+                        const double dz0 = ux - uz;
+                        r2 = dz0 * dz0;
+                        for (int q = g.xoff[d]; q < g.xoff[d + 1]; ++q) {
+                            const double dz = Xa[i * ldx + xcols[q]] / g.ls[d] - Xb[j * ldx + xcols[q]] / g.ls[d];
+                            r2 += dz * dz;
+                        }
+                    }
+                } else if (FORM == 1) r2 = ((-2.0 * ux) * uz + ux * ux) + uz * uz;  // gpflow square_distance
                 else { const double dz = ux - uz; r2 = dz * dz; }
                 k = g.bv[d] * exp(-0.5 * r2) - ca * Bcn[(int64_t)d * b_ld + j];
             }
@@ -418,11 +436,15 @@ int gram_generic(oak_ctx* ctx, const PreparedKernel& pk, int form, const double*
         g.type[d] = pk.dd.type[d]; g.col[d] = pk.dd.col[d]; g.ncat[d] = pk.dd.ncat[d]; g.tab_off[d] = pk.dd.tab_off[d];
         g.ls[d] = pk.dm.ls[d]; g.bv[d] = pk.dd.bv[d];
     }
+    for (int d = 0; d <= g.D; ++d) g.xoff[d] = (short)pk.extra_off[d];
     double* d_w = nullptr;
+    int* d_xc = nullptr;
     OAK_CHECK(get_buf_t(ctx, "gram_generic_w", (size_t)OAK_MAX_DIMS + 1, &d_w));
+    OAK_CHECK(get_buf_t(ctx, "gram_generic_cols", pk.extra_cols.size() + 1, &d_xc));
     OAK_CHECK(copy_sync(ctx, d_w, pk.w_full.data(), sizeof(double) * pk.w_full.size(), hipMemcpyHostToDevice));
+    if (!pk.extra_cols.empty()) OAK_CHECK(copy_sync(ctx, d_xc, pk.extra_cols.data(), sizeof(int) * pk.extra_cols.size(), hipMemcpyHostToDevice));
     if (dXb == nullptr) dXb = dXa;
-#define OAK_GG(F, DG, GRID) gram_generic_kernel<F, DG><<<GRID, 256, 0, ctx->stream>>>(g, d_w, pk.d_tables, dXa, A.xs, A.cn, A.ld, na, dXb, B.xs, B.cn, B.ld, nb, ldx, d_out, ldo)
+#define OAK_GG(F, DG, GRID) gram_generic_kernel<F, DG><<<GRID, 256, 0, ctx->stream>>>(g, d_w, d_xc, pk.d_tables, dXa, A.xs, A.cn, A.ld, na, dXb, B.xs, B.cn, B.ld, nb, ldx, d_out, ldo)
     if (diag) {
         const dim3 grid((unsigned)((na + 255) / 256));
         if (form == 1) OAK_GG(1, true, grid); else OAK_GG(0, true, grid);

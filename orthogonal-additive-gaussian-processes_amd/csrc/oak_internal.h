@@ -93,6 +93,8 @@ struct PreparedKernel {
     int R_desc = 0;
     bool deep = false;
     std::vector<double> w_full;      // weights of e_0..e_{min(R, D)} (always filled)
+    bool grouped = false;            // some sub-kernel reads more than one column (explicit Gram entry points only)
+    std::vector<int> extra_off, extra_cols;   // columns beyond dd.col[d]: extra_cols[extra_off[d] .. extra_off[d + 1])
     std::vector<double> tables;      // host copy of the discrete tables
     double* d_tables = nullptr;      // device (ctx scratch "tables")
     double* d_meas = nullptr;        // device (ctx scratch "meas")

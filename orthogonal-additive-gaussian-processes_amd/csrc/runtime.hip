@@ -302,6 +302,31 @@ int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk
                   "(only the explicit Gram entry points K / K_diag go deeper)", R, OAK_MAX_DEPTH);
         return OAK_E_ARG;
     }
+    pk->grouped = false;
+    pk->extra_off.assign((size_t)D + 1, 0);
+    pk->extra_cols.clear();
+    if (desc->extra_col_off != nullptr) {
+        for (int d = 0; d < D; ++d) {
+            const int n0 = desc->extra_col_off[d], n1 = desc->extra_col_off[d + 1];
+            OAK_REQUIRE(n0 >= 0 && n1 >= n0 && n1 - n0 < 64, "extra_col_off[%d] invalid", d);
+            if (n1 > n0) {
+                OAK_REQUIRE(desc->extra_cols != nullptr && desc->dim_type[d] == OAK_DIM_RBF && desc->measure[d] == OAK_MEAS_NONE,
+                            "sub-kernel %d: only an unconstrained RBF reads several columns (the constrained kernels are one-dimensional, "
+                            "oak/ortho_rbf_kernel.py:50,83)", d);
+                pk->grouped = true;
+            }
+            for (int q = n0; q < n1; ++q) {
+                OAK_REQUIRE(desc->extra_cols[q] >= 0 && desc->extra_cols[q] < 32768, "extra column of sub-kernel %d invalid", d);
+                pk->extra_cols.push_back(desc->extra_cols[q]);
+            }
+            pk->extra_off[d + 1] = (int)pk->extra_cols.size();
+        }
+    }
+    if (pk->grouped && !allow_deep) {
+        set_error("a sub-kernel over several columns (OAKKernel(active_dims=[[0, 1], ...])) is evaluated by the explicit Gram entry "
+                  "points K / K_diag only; the fused model paths take one column per sub-kernel");
+        return OAK_E_ARG;
+    }
     DevDesc& dd = pk->dd;
     DevMeasure& dm = pk->dm;
     memset(&dd, 0, sizeof(dd));

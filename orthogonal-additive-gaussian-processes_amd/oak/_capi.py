@@ -44,6 +44,7 @@ class KernelDescStruct(C.Structure):
         ("meas_p0", C.POINTER(C.c_double)), ("meas_p1", C.POINTER(C.c_double)),
         ("meas_k", C.POINTER(C.c_int32)), ("meas_off", C.POINTER(C.c_int32)),
         ("meas_data", C.POINTER(C.c_double)), ("meas_data_len", C.c_int32), ("grad_base_var", C.c_int32),
+        ("extra_col_off", C.POINTER(C.c_int32)), ("extra_cols", C.POINTER(C.c_int32)),
     ]
 
 
@@ -181,6 +182,8 @@ class KernelDesc:
     dim entries: {"type": "rbf", "lengthscale", "variance", "measure": None | ("gaussian", mu, var) |
     ("uniform", a, b) | ("empirical", loc, w) | ("mog", means, vars, w), "active_dim": col (optional)},
     {"type": "binary", "p0", "variance"}, {"type": "categorical", "p", "W", "kappa", "variance"}.
+    An unconstrained rbf dim may carry "active_dims": [c0, c1, ...] instead of "active_dim": one RBF over those columns
+    (OAKKernel(active_dims=[[0, 1], ...]), oak_kernel.py:74-82) -- evaluated by ``gram`` / ``gram_diag`` only.
     """
 
     def __init__(self, spec: dict):
@@ -208,8 +211,14 @@ class KernelDesc:
         data = []
         off = 0
         self.cat_blocks = {}   # dim -> (offset, C) of the categorical table inside meas_data
+        extra_off, extra_cols = [0], []
         for d, dim in enumerate(dims):
-            self.active_col[d] = int(dim.get("active_dim", d))
+            group = [int(c) for c in dim["active_dims"]] if dim.get("active_dims") is not None else [int(dim.get("active_dim", d))]
+            if len(group) > 1 and not (dim["type"] == "rbf" and dim.get("measure") is None):
+                raise NotImplementedError("only an unconstrained RBF sub-kernel reads several columns")
+            self.active_col[d] = group[0]
+            extra_cols += group[1:]
+            extra_off.append(len(extra_cols))
             self.base_var[d] = float(np.asarray(dim.get("variance", 1.0)).reshape(-1)[0])
             t = dim["type"]
             if t == "rbf":
@@ -275,9 +284,14 @@ class KernelDesc:
         s.meas_data_len = int(off)
         # default: base variances are differentiated unless every one of them is the constant 1 of a shared-variance kernel
         s.grad_base_var = int(bool(spec.get("base_var_grad", (not share) or bool(np.any(self.base_var != 1.0)))))
+        self.extra_col_off = np.asarray(extra_off, dtype=np.int32)
+        self.extra_cols = np.asarray(extra_cols if extra_cols else [0], dtype=np.int32)
+        self.grouped = bool(extra_cols)
+        if self.grouped:
+            s.extra_col_off, s.extra_cols = _ip(self.extra_col_off), _ip(self.extra_cols)
         self.struct = s
         self.D, self.R, self.share = D, R, share
-        self.min_cols = int(self.active_col.max()) + 1
+        self.min_cols = int(max(self.active_col.max(), max(extra_cols) if extra_cols else 0)) + 1
 
     @property
     def ref(self):

@@ -26,17 +26,20 @@ def bounded_param(low: float, high: float, param: float) -> Parameter:
     return Parameter(param, transform=gpflow.Sigmoid(low, high))
 
 
-def _first_col(k) -> int:
+def _columns(k) -> List[int]:
+    """Columns of X a sub-kernel reads.  One for every constrained kernel (they are one-dimensional); an unconstrained RBF may
+    read a group (OAKKernel(active_dims=[[0, 1], ...]), oak_kernel.py:74-82,199-210)."""
     dims = k.active_dims
     if isinstance(dims, slice):
-        return 0
-    cols = np.asarray(dims).reshape(-1)
-    if cols.size != 1:
-        # the reference evaluates a grouped sub-kernel (active_dims=[[0, 1], ...]) as a multi-column base kernel
-        # (oak_kernel.py:74-82); the fused HIP kernel is built from one-column sub-kernels only
-        raise NotImplementedError(f"sub-kernel with {cols.size} active columns {cols.tolist()}: the HIP path "
-                                  "supports one column per sub-kernel")
-    return int(cols[0])
+        return [0]
+    return [int(c) for c in np.asarray(dims).reshape(-1)]
+
+
+def _first_col(k) -> int:
+    cols = _columns(k)
+    if len(cols) != 1:
+        raise NotImplementedError(f"sub-kernel with {len(cols)} active columns {cols}: only an unconstrained RBF reads several")
+    return cols[0]
 
 
 def _has_trainable_base_variance(k) -> bool:
@@ -48,15 +51,22 @@ def _sub_kernel_spec(k, col: int) -> dict:
     if isinstance(k, (OrthogonalRBFKernel, OrthogonalBinary, OrthogonalCategorical)):
         return k.dim_spec(col)
     if isinstance(k, gpflow.RBF):   # unconstrained additive model, oak_kernel.py:199-210
-        return dict(type="rbf", lengthscale=float(np.asarray(_as_value(k.lengthscales)).reshape(-1)[0]),
-                    variance=float(np.asarray(_as_value(k.variance)).reshape(-1)[0]), measure=None, active_dim=col)
+        ls = np.asarray(_as_value(k.lengthscales)).reshape(-1)
+        if ls.size != 1:
+            raise NotImplementedError("ARD lengthscales inside one sub-kernel are not on the OAK path (the reference builds "
+                                      "base_kernels[d](active_dims=...) with the default scalar lengthscale)")
+        out = dict(type="rbf", lengthscale=float(ls[0]), variance=float(np.asarray(_as_value(k.variance)).reshape(-1)[0]),
+                   measure=None, active_dim=col)
+        if len(_columns(k)) > 1:
+            out["active_dims"] = _columns(k)        # one RBF over the group's columns: explicit Gram entry points only
+        return out
     raise NotImplementedError(f"no HIP description for sub-kernel {type(k).__name__}")
 
 
 def kernel_to_spec(kernel) -> dict:
     """Plain-data description (see _capi.KernelDesc) of an OAKKernel or of a single constrained sub-kernel."""
     if isinstance(kernel, OAKKernel):
-        dims = [_sub_kernel_spec(k, _first_col(k)) for k in kernel.kernels]
+        dims = [_sub_kernel_spec(k, _columns(k)[0] if isinstance(k, gpflow.RBF) else _first_col(k)) for k in kernel.kernels]
         # OAKKernel pins the base variance to a constant 1 only for Gaussian-measure / binary / categorical dims under
         # share_var_across_orders (oak_kernel.py:163-166,179,187); empirical- and MOG-measure dims keep a trainable
         # base_kernel.variance, whose gradient needs the pair-kernel contribution (grad_base_var)

@@ -408,3 +408,48 @@ def test_depth_beyond_the_number_of_dimensions_runs_at_that_number(hip):
     np.testing.assert_array_equal(g[:2 * D + D + 1], g6[:2 * D + D + 1])
     assert np.all(g[2 * D + D + 1:2 * D + R + 1] == 0.0) and g[2 * D + R + 1] == g6[2 * D + D + 1]     # [.., order vars 7..20 = 0, noise]
     ctx.close()
+
+
+def test_grouped_active_dims_are_one_rbf_over_the_group(hip):
+    """OAKKernel(active_dims=[[0, 1], [2], [4, 3, 5]], constrain_orthogonal=False): the reference evaluates each group as ONE
+    base kernel over the group's columns (oak/oak_kernel.py:74-82,199-210) -- for the RBF a product of one-column RBFs with a
+    shared lengthscale.  K and K_diag through the host mirror against the oracle (rbf_K on the group's columns), in the
+    native and in the reference arithmetic; the fused model paths refuse a grouped kernel loudly."""
+    from oak import gpflow_lite as gpflow
+    from oak.oak_kernel import OAKKernel, kernel_to_spec
+    groups = [[0, 1], [2], [4, 3, 5]]
+    k = OAKKernel([gpflow.RBF] * 3, num_dims=6, max_interaction_depth=3, active_dims=groups, constrain_orthogonal=False)
+    for sub, ls in zip(k.kernels, (0.8, 1.7, 1.2)):
+        sub.lengthscales.assign(ls)
+    for v, val in zip(k.variances, (0.7, 1.3, 0.9, 0.4)):
+        v.assign(val)
+    rng = np.random.default_rng(11)
+    X, X2 = rng.standard_normal((70, 6)), rng.standard_normal((45, 6))
+    spec = kernel_to_spec(k)
+    assert [d.get("active_dims") for d in spec["dims"]] == [[0, 1], None, [4, 3, 5]]
+    # the oracle on the same description, and by hand: e_r of the three group matrices
+    mats = [o.rbf_K(X[:, g], X2[:, g], ls, 1.0) for g, ls in zip(groups, (0.8, 1.7, 1.2))]
+    e1 = mats[0] + mats[1] + mats[2]
+    e2 = mats[0] * mats[1] + mats[0] * mats[2] + mats[1] * mats[2]
+    e3 = mats[0] * mats[1] * mats[2]
+    by_hand = 0.7 + 1.3 * e1 + 0.9 * e2 + 0.4 * e3
+    ref = o.oak_K(spec, X, X2)
+    np.testing.assert_allclose(ref, by_hand, rtol=1e-12)
+    got = k.K(X, X2).numpy()
+    assert np.abs(got - ref).max() <= 1e-12 * np.abs(ref).max()
+    np.testing.assert_allclose(k.K(X).numpy(), o.oak_K(spec, X), rtol=0, atol=1e-12 * np.abs(ref).max())
+    np.testing.assert_allclose(k.K_diag(X).numpy(), np.full(70, 0.7 + 1.3 * 3 + 0.9 * 3 + 0.4), rtol=1e-13)
+    try:
+        hip.set_gram_form("reference")
+        assert np.abs(hip.gram(_capi.KernelDesc(spec), X, X2) - ref).max() <= 1e-13 * np.abs(ref).max()
+    finally:
+        hip.set_gram_form("native")
+    ctx = _capi.HipContext(0)
+    ctx.sgpr_set_data(X, X[:, :1]); ctx.sgpr_set_inducing(X2)
+    with pytest.raises(ValueError, match="several columns"):
+        ctx.sgpr_elbo(_capi.KernelDesc(spec), 0.1)
+    ctx.close()
+    # a constrained kernel is one-dimensional in the reference too (ortho_rbf_kernel.py:50,83)
+    with pytest.raises(NotImplementedError):
+        _capi.KernelDesc(dict(dims=[dict(type="rbf", lengthscale=1.0, variance=1.0, measure=("gaussian", 0.0, 1.0), active_dims=[0, 1])],
+                              order_variances=[1.0, 1.0], max_interaction_depth=1, share_var_across_orders=True))

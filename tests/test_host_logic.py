@@ -185,16 +185,23 @@ def test_normalising_flow_transforms():
         np.testing.assert_allclose(orc, direct, rtol=1e-12)
 
 
-def test_grouped_active_dims_are_rejected_not_silently_truncated():
-    """OAKKernel(active_dims=[[0, 1], [2]]) builds (as in the reference, oak_kernel.py:74-82), but a sub-kernel spanning two
-    columns has no description in the one-column-per-sub-kernel HIP path: describing it must raise, not evaluate a 1-D
-    kernel on the first column."""
+def test_grouped_active_dims_are_described_as_groups_not_truncated():
+    """OAKKernel(active_dims=[[0, 1], [2]]) builds as in the reference (oak_kernel.py:74-82); an unconstrained RBF over two columns
+    is described with BOTH columns (evaluated by the explicit Gram entry points, tests/test_gpu_gram.py) -- never as a 1-D kernel
+    on the first one -- while a constrained kernel over two columns has no meaning (the reference asserts [N, 1] inputs,
+    ortho_rbf_kernel.py:50,83) and raises."""
     from oak import gpflow_lite as gpflow
     from oak.oak_kernel import OAKKernel, kernel_to_spec
     k = OAKKernel([gpflow.kernels.RBF, gpflow.kernels.RBF], num_dims=3, max_interaction_depth=2, active_dims=[[0, 1], [2]],
                   constrain_orthogonal=False)
+    spec = kernel_to_spec(k)
+    assert spec["dims"][0]["active_dims"] == [0, 1] and spec["dims"][0]["measure"] is None and spec["dims"][1].get("active_dims") is None
+    d = _capi.KernelDesc(spec)
+    assert d.grouped and d.min_cols == 3 and d.extra_col_off.tolist() == [0, 1, 1] and d.extra_cols.tolist() == [1]
+    kc = OAKKernel([gpflow.kernels.RBF, gpflow.kernels.RBF], num_dims=3, max_interaction_depth=2, active_dims=[[0, 1], [2]],
+                   constrain_orthogonal=True)
     with pytest.raises(NotImplementedError, match="active columns"):
-        kernel_to_spec(k)
+        kernel_to_spec(kc)
     ok = OAKKernel([gpflow.kernels.RBF, gpflow.kernels.RBF], num_dims=3, max_interaction_depth=2, active_dims=[[1], [2]],
                    constrain_orthogonal=True)
     spec = kernel_to_spec(ok)
