@@ -100,6 +100,10 @@ int oak_device_count(int* count);
 int oak_ctx_create(int device, oak_ctx** out);
 int oak_ctx_destroy(oak_ctx* ctx);
 int oak_sync(oak_ctx* ctx);
+/* Post-mortem aid for a stalled process: one text record per live context -- whether its two streams have drained, its
+   communicator, and the last 16 phases / collectives it enqueued with their age.  Call it from ANOTHER host thread than the
+   stuck one (tests/conftest.py's watchdog, tools/soak.py). */
+int oak_debug_state(char* buf, int64_t cap);
 /* GPU time (ms, hipEvents on the ctx stream) accumulated per phase since oak_reset_timings; name in {"featurize","gram",
    "trsm","syrk","reduce","allreduce","tail","total","bwd_tail","bwd_gemm","bwd_gram","bwd_small","bwd_z","predict",
    "kmeans","kmeans_pp","flow_forward"}; count = number of

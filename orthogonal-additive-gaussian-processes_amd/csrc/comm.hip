@@ -96,6 +96,8 @@ bool comm_is_loopback(const oak_ctx* ctx) { return is_loopback(ctx); }
 
 int comm_allreduce_dev(oak_ctx* ctx, double* d_buf, int64_t n, const char* stage) {
     if (ctx->comm == nullptr || ctx->nranks <= 1 || n <= 0) return OAK_OK;
+    debug_mark(ctx, "allreduce>");
+    struct Leave { oak_ctx* c; ~Leave() { debug_mark(c, "allreduce<"); } } leave{ctx};
     if (is_host(ctx)) {
         std::vector<double> h((size_t)n);
         OAK_HIP_CHECK(hipMemcpyAsync(h.data(), d_buf, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
@@ -173,7 +175,9 @@ int oak_comm_init(oak_ctx* ctx, const char* id_128, int32_t nranks, int32_t rank
     ncclUniqueId id;
     memcpy(&id, id_128, 128);
     ncclComm_t comm = nullptr;
+    debug_mark(ctx, "commInit>");
     OAK_NCCL_CHECK(g_rccl.CommInitRank(&comm, nranks, id, rank));
+    debug_mark(ctx, "commInit<");
     ctx->comm = (void*)comm; ctx->nranks = nranks; ctx->rank = rank; ctx->n_global_comm = 0;
     return OAK_OK;
 }

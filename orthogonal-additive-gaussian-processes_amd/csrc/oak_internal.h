@@ -142,6 +142,8 @@ struct oak_ctx {
     int64_t flow_n = 0;              // length of the resident normalising-flow sample "flow_g"
     int syrk_desc_ntile = -1;        // ntile the device descriptor table "syrk_desc" was built for
     int syrk_desc_blocks_ntile = -1; // same for "syrk_desc_blocks" (the fp32 variant's table: full diagonal 64-blocks)
+    // breadcrumbs for oak_debug_state (a watchdog on another thread reads them without locks: literals and integers only)
+    const char* marks[16] = {nullptr}; double mark_t[16] = {0}; unsigned mark_n = 0;
     bool keep_kfu = false;           // set by the gradient entry points: a whitening forward works on a COPY of the Kfu panel
     bool kfu_kept = false;           // ... and reports here that "panel" still holds the raw Kfu rows of the whole data set
 };
@@ -162,6 +164,7 @@ struct PhaseTimer {   // hipEvent timing of a phase on the ctx stream (accumulat
     void stop();
 };
 void reset_timings(oak_ctx* ctx);
+void debug_mark(oak_ctx* ctx, const char* literal);      // breadcrumb: the last 16 are shown by oak_debug_state
 
 // kernel description ----------------------------------------------------------------------------
 int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk, bool allow_deep = false);

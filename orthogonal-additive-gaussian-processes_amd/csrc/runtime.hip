@@ -4,6 +4,8 @@
 #include <set>
 #include <cstdarg>
 #include <cmath>
+#include <ctime>
+#include <string>
 
 namespace oak {
 
@@ -43,7 +45,20 @@ void* peek_buf(oak_ctx* ctx, const char* name) {
     return it == ctx->bufs.end() ? nullptr : it->second.p;
 }
 
+static std::mutex g_ctx_mu;
+static std::set<oak_ctx*> g_ctxs;                 // live contexts (oak_debug_state walks them)
+static double wall_s() {
+    struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+void debug_mark(oak_ctx* ctx, const char* literal) {
+    const unsigned i = ctx->mark_n & 15u;
+    ctx->marks[i] = literal; ctx->mark_t[i] = wall_s();
+    ctx->mark_n = ctx->mark_n + 1;
+}
+
 PhaseTimer::PhaseTimer(oak_ctx* c, const char* n) : ctx(c), name(n), a(nullptr), b(nullptr), active(false) {
+    debug_mark(c, n);
     if (hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess) {
         (void)hipEventRecord(a, ctx->stream);
         active = true;
@@ -566,12 +581,43 @@ int oak_ctx_create(int device, oak_ctx** out) {
         hipEventCreateWithFlags(&ctx->ev2, hipEventDisableTiming) != hipSuccess) {
         delete ctx; oak::set_error("hipStreamCreate / hipEventCreate failed"); return OAK_E_HIP;
     }
+    { std::lock_guard<std::mutex> lock(oak::g_ctx_mu); oak::g_ctxs.insert(ctx); }
     *out = ctx;
+    return OAK_OK;
+}
+
+/* Post-mortem aid for a stalled process: what every live context last enqueued and whether its streams have drained.  Meant to
+   be called from ANOTHER host thread than the stuck one (a test watchdog, tools/soak.py); takes no stream-level locks. */
+int oak_debug_state(char* buf, int64_t cap) {
+    if (!buf || cap <= 0) { oak::set_error("bad argument"); return OAK_E_ARG; }
+    std::string out;
+    char line[512];
+    const double now = oak::wall_s();
+    std::lock_guard<std::mutex> lock(oak::g_ctx_mu);
+    snprintf(line, sizeof line, "%zu live context(s)\n", oak::g_ctxs.size()); out += line;
+    for (oak_ctx* c : oak::g_ctxs) {
+        const hipError_t qm = hipStreamQuery(c->stream), qs = hipStreamQuery(c->side);
+        snprintf(line, sizeof line, "ctx %p dev %d: main stream %s, side stream %s, comm %s (rank %d of %d), N=%lld M=%lld route=%d\n", (void*)c,
+                 c->device, qm == hipSuccess ? "idle" : (qm == hipErrorNotReady ? "BUSY" : hipGetErrorString(qm)),
+                 qs == hipSuccess ? "idle" : (qs == hipErrorNotReady ? "BUSY" : hipGetErrorString(qs)),
+                 c->comm == nullptr ? "none" : (c->host_allreduce ? "host" : "rccl/loopback"), c->rank, c->nranks, (long long)c->N,
+                 (long long)c->M, c->route);
+        out += line;
+        const unsigned n = c->mark_n;
+        for (unsigned k = (n > 16 ? n - 16 : 0); k < n; ++k) {
+            const char* m = c->marks[k & 15u];
+            snprintf(line, sizeof line, "    [%u] %-14s %.3f s ago\n", k, m ? m : "?", now - c->mark_t[k & 15u]);
+            out += line;
+        }
+    }
+    strncpy(buf, out.c_str(), (size_t)cap - 1);
+    buf[cap - 1] = 0;
     return OAK_OK;
 }
 
 int oak_ctx_destroy(oak_ctx* ctx) {
     if (!ctx) return OAK_OK;
+    { std::lock_guard<std::mutex> lock(oak::g_ctx_mu); oak::g_ctxs.erase(ctx); }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->side);

@@ -62,6 +62,7 @@ SIGNATURES = {
     "oak_ctx_create": (C.c_int, [C.c_int, C.POINTER(_CTX)]),
     "oak_ctx_destroy": (C.c_int, [_CTX]),
     "oak_sync": (C.c_int, [_CTX]),
+    "oak_debug_state": (C.c_int, [C.c_char_p, C.c_int64]),
     "oak_last_timing": (C.c_int, [_CTX, C.c_char_p, _D, _I]),
     "oak_reset_timings": (C.c_int, [_CTX]),
     "oak_device_mem_info": (C.c_int, [_CTX, _D, _D]),
@@ -806,6 +807,13 @@ def default_context() -> HipContext:
         dev = int(os.environ.get("OAK_HIP_DEVICE", os.environ.get("LOCAL_RANK", "0")))
         _default_ctx = HipContext(dev)
     return _default_ctx
+
+
+def debug_state() -> str:
+    """What every live context last enqueued and whether its streams have drained (for watchdogs on another thread)."""
+    buf = C.create_string_buffer(1 << 16)
+    load_library().oak_debug_state(buf, len(buf))
+    return buf.value.decode(errors="replace")
 
 
 def device_count() -> int:

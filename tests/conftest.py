@@ -34,13 +34,40 @@ import os as _os
 WATCHDOG_S = int(_os.environ.get("OAK_TEST_WATCHDOG_S", "420"))
 
 
+def _post_mortem(nodeid):
+    """Ten seconds before the watchdog ends the process: every thread's Python stack and the library's own view of its contexts
+    (which stream is still busy, the last phases / collectives enqueued) into gpurun_out/watchdog/, so that a stall leaves
+    evidence behind even when the terminal log is lost."""
+    import faulthandler
+    try:
+        out = ROOT / "gpurun_out" / "watchdog"
+        out.mkdir(parents=True, exist_ok=True)
+        name = "".join(ch if ch.isalnum() or ch in "-_." else "_" for ch in nodeid)[-150:]
+        with open(out / f"{name}.txt", "w") as f:
+            f.write(f"watchdog: {nodeid} made no progress for {WATCHDOG_S - 10} s (pid {_os.getpid()})\n\n")
+            try:
+                from oak import _capi
+                f.write(_capi.debug_state() + "\n")
+            except Exception as ex:                                  # noqa: BLE001
+                f.write(f"(no library state: {ex!r})\n")
+            f.flush()
+            faulthandler.dump_traceback(file=f, all_threads=True)
+    except Exception:                                                # noqa: BLE001
+        pass
+
+
 @pytest.hookimpl(hookwrapper=True)
 def pytest_runtest_protocol(item, nextitem):
     import faulthandler
+    import threading
     faulthandler.dump_traceback_later(WATCHDOG_S, exit=True)
+    timer = threading.Timer(max(WATCHDOG_S - 10, 1), _post_mortem, args=(item.nodeid,))
+    timer.daemon = True
+    timer.start()
     try:
         yield
     finally:
+        timer.cancel()
         faulthandler.cancel_dump_traceback_later()
 
 
