@@ -89,28 +89,36 @@ __global__ void __launch_bounds__(128) trsm_block_inverse_kernel(const double* _
     }
 }
 
-// ---- hand-counted memory pipeline ------------------------------------------------------------------------------------
-// Both streams of a stage go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write pass), two
-// stages ahead, into rings of three slots: the pack tile (16 KiB, shared by the four waves) and the stage's 16 older X
-// columns (8 KiB; each wave fetches and reads only its own 16 rows).  vmcnt retires in order, so ONE counted wait at the
-// end of stage s -- "all but the operations issued during stage s" -- retires exactly what stage s + 1 consumes (issued in
-// stage s - 1) while everything issued in stage s stays in flight across the barrier.  The counts are exact because every
-// lane issues every operation (rows past the end are redirected to a scratch row instead of being masked), and nothing
-// asynchronous targets a register, so the compiler's own bookkeeping stays valid.
-template <int N> __device__ __forceinline__ void tf_wait() { asm volatile("s_waitcnt vmcnt(%0)" : : "n"(N) : "memory"); }
+// ---- memory pipeline ---------------------------------------------------------------------------------------------------
+// Both streams of a stage go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write pass) one
+// stage ahead, into two slots each: the pack tile (16 KiB, shared by the four waves) and the stage's 16 older X columns
+// (8 KiB; each wave fetches and reads only its own 16 rows).  A stage ends with  s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier :
+//   vmcnt(0)   everything this wave issued during the stage has landed -- the next tile (in flight for a whole stage of
+//              >= 2048 MFMA cycles, so the wait is normally free), the right-hand sides of the next block, the stores;
+//   lgkmcnt(0) this wave's LDS reads of the current tile are complete before any wave, past the barrier, lets the DMA
+//              overwrite that slot (the barrier is the raw s_barrier: a __syncthreads() would add nothing but its own waits).
+// Measured and NOT kept (r03): counted waits -- vmcnt(N) leaving the N youngest operations in flight across the barrier, two
+// tiles ahead in three slots.  They were no faster (10.3 vs 10.1 ms on 2^19 rows: the latencies already fit inside a stage)
+// and they were WRONG under load: the scheme needs loads to retire in issue order, and LDS-DMA loads, register loads and
+// stores in one queue do not (LLVM's waitcnt pass also treats such a mix as unordered); 1e-4 errors in a few rows of a
+// 2^20-row solve, two runs in three, nothing at 2^13 rows.  tests/test_gpu_trsm.py now compares every row at 2^18.
+__device__ __forceinline__ void tf_stage_end() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
 
 constexpr int TF_XT = TF_ROWS * TF_KC;       // doubles per X stage tile
-constexpr int TF_NSLOT = 3;
 
 __global__ void __launch_bounds__(256, 2)
 trsm_fused_kernel(const double* __restrict__ pack, const double* Bin, double* Xout, double* scratch, int64_t nrhs, int64_t ldin,
                   int64_t ldout, int nb) {
-    __shared__ __attribute__((aligned(16))) double Ls[TF_NSLOT * (TF_TILE + TF_XT)];     // 72 KiB: two workgroups per CU
-    double* const Xs = Ls + TF_NSLOT * TF_TILE;
+    __shared__ __attribute__((aligned(16))) double Ls[2 * (TF_TILE + TF_XT)];     // 48 KiB
+    double* const Xs = Ls + 2 * TF_TILE;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fi = lane & 15, fk = lane >> 4;
     const int64_t row = (int64_t)blockIdx.x * TF_ROWS + 16 * wave + fi;
+    // rows past the end are redirected to a scratch row instead of being masked: every lane issues every operation
     // B tile / X store: register v <-> column 16 ct + 4 v + fk
     const double* bin = row < nrhs ? Bin + row * ldin + fk : scratch + fk;
     double* xst = row < nrhs ? Xout + row * ldout + fk : scratch + fk;
@@ -132,46 +140,34 @@ trsm_fused_kernel(const double* __restrict__ pack, const double* Bin, double* Xo
         xoff[v] = wave * 256 + fi * 16 + 2 * ((k >> 1) ^ ((fi >> 1) & 7)) + (k & 1);
     }
     const int64_t nst = tf_stages_before(nb);
-    int64_t s = 0;
-    int slot = 0;                                   // s % 3
-    auto slot_of = [&](int ahead) { const int t = slot + ahead; return t >= TF_NSLOT ? t - TF_NSLOT : t; };
-    auto glds_pack = [&](int64_t t, int sl) {      // tile t (clamped) -> slot sl; four 1 KiB pieces per wave
+    int64_t s = 0;                                  // stage; its tile sits in slot s & 1
+    auto glds_pack = [&](int64_t t) {              // tile t (clamped) -> slot t & 1; four 1 KiB pieces per wave
         const int64_t tc = t < nst ? t : nst - 1;
         const double* src = pack + tc * TF_TILE + wave * 512 + lane * 2;
-        double* dst = Ls + sl * TF_TILE + wave * 512;
+        double* dst = Ls + (t & 1) * TF_TILE + wave * 512;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q * 128),
                                              (__attribute__((address_space(3))) void*)(dst + q * 128), 16, 0, 0);
     };
-    auto glds_x = [&](int64_t k0, int sl) {         // this wave's 16 rows x 16 columns from k0 -> its part of X slot sl
-        double* dst = Xs + sl * TF_XT + wave * 256;
+    auto glds_x = [&](int64_t k0, int64_t t) {      // this wave's 16 rows x 16 columns from k0 -> its part of X slot t & 1
+        double* dst = Xs + (t & 1) * TF_XT + wave * 256;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + k0),
                                              (__attribute__((address_space(3))) void*)(dst + i * 128), 16, 0, 0);
     };
-    auto next_stage = [&]() { __builtin_amdgcn_s_barrier(); ++s; slot = slot_of(1); };
 
     double4_t bnext[8], xprev[8];
-    glds_pack(0, 0);
-    glds_pack(1, 1);
+    glds_pack(0);
 #pragma unroll
     for (int h = 0; h < 8; ++h) {
         xprev[h] = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int v = 0; v < 4; ++v) bnext[h][v] = bin[16 * h + 4 * v];      // right-hand sides of block 0
     }
-    tf_wait<0>();
-    __builtin_amdgcn_s_barrier();
+    tf_stage_end();
 
-    // Operation counts per stage (every stage starts with the 4 pack fetches, which the NEXT stage's end must retire; the
-    // "lazy" operations behind them -- stores, right-hand-side loads, X fetches -- may stay in flight one stage longer,
-    // because vmcnt retires in order and they are younger than the pack fetches of their stage):
-    //   wait at the end of stage s = vmcnt(4 + lazy(s) + lazy(s - 1))
-    //   update from registers, stage h : lazy = 4 stores of the previous block's tile h (+ 2 X fetches for h >= 6)
-    //   update from older columns      : lazy = 2 X fetches
-    //   diagonal product, stage h      : lazy = 8 right-hand-side loads of the next block for h < 4, else none
     for (int j = 0; j < nb; ++j) {
         const int64_t j0 = (int64_t)j * TF_NB;
         // acc starts as B_j (loaded under the previous block's diagonal product); the pack holds -L, so the update stages add
@@ -183,24 +179,24 @@ trsm_fused_kernel(const double* __restrict__ pack, const double* Bin, double* Xo
             // the block finished last, straight from its registers -- and on its way to memory: tile h is stored under stage h
 #pragma unroll
             for (int h = 0; h < 8; ++h) {
-                glds_pack(s + 2, slot_of(2));
+                glds_pack(s + 1);
 #pragma unroll
                 for (int v = 0; v < 4; ++v) xst[kold + 16 * h + 4 * v] = xprev[h][v];
-                if (h >= 6) glds_x((h == 7 && kold > TF_KC) ? TF_KC : 0, slot_of(2));    // X of the first two older-column stages
-                const double* Lt = Ls + slot * TF_TILE;
+                if (h == 7) glds_x(0, s + 1);              // X of the first older-column stage (a tile nobody reads when kold = 0)
+                const double* Lt = Ls + (s & 1) * TF_TILE;
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
 #pragma unroll
                     for (int h2 = 0; h2 < 8; ++h2)
                         acc[h2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[h2 * 256 + off[v]], xprev[h][v], acc[h2], 0, 0, 0);
-                if (h == 0) tf_wait<8>(); else if (h < 6) tf_wait<12>(); else if (h == 6) tf_wait<14>(); else tf_wait<16>();
-                next_stage();
+                tf_stage_end();
+                ++s;
             }
             for (int64_t k0 = 0; k0 < kold; k0 += TF_KC) {
-                glds_pack(s + 2, slot_of(2));
-                glds_x(k0 + 2 * TF_KC < kold ? k0 + 2 * TF_KC : kold - TF_KC, slot_of(2));   // (the last two fetch a tile nobody reads)
-                const double* Lt = Ls + slot * TF_TILE;
-                const double* Xt = Xs + slot * TF_XT;
+                glds_pack(s + 1);
+                glds_x(k0 + TF_KC < kold ? k0 + TF_KC : k0, s + 1);      // (the last one fetches a tile nobody reads)
+                const double* Lt = Ls + (s & 1) * TF_TILE;
+                const double* Xt = Xs + (s & 1) * TF_XT;
 #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                     const double xv = Xt[xoff[v]];
@@ -208,8 +204,8 @@ trsm_fused_kernel(const double* __restrict__ pack, const double* Bin, double* Xo
                     for (int h2 = 0; h2 < 8; ++h2)
                         acc[h2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[h2 * 256 + off[v]], xv, acc[h2], 0, 0, 0);
                 }
-                if (k0 == 0) tf_wait<12>(); else tf_wait<8>();
-                next_stage();
+                tf_stage_end();
+                ++s;
             }
         }
         // acc = residual T = B_j - X_{<j} L_{j,<j}^T;  X_j = T inv(L_jj)^T  (the inverse is lower triangular: stage h feeds the
@@ -221,24 +217,21 @@ trsm_fused_kernel(const double* __restrict__ pack, const double* Bin, double* Xo
         const int64_t jn = (j + 1 < nb) ? j0 + TF_NB : j0;
 #pragma unroll
         for (int h = 0; h < 8; ++h) {
-            glds_pack(s + 2, slot_of(2));
+            glds_pack(s + 1);
             if (h < 4) {
 #pragma unroll
                 for (int t = 2 * h; t < 2 * h + 2; ++t)
 #pragma unroll
                     for (int v = 0; v < 4; ++v) bnext[t][v] = bin[jn + 16 * t + 4 * v];
             }
-            const double* Lt = Ls + slot * TF_TILE;
+            const double* Lt = Ls + (s & 1) * TF_TILE;
 #pragma unroll
             for (int v = 0; v < 4; ++v)
 #pragma unroll
                 for (int ct = h; ct < 8; ++ct)
                     out[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[ct * 256 + off[v]], acc[h][v], out[ct], 0, 0, 0);
-            if (h == 0) { if (j == 0) tf_wait<12>(); else if (j == 1) tf_wait<18>(); else tf_wait<14>(); }
-            else if (h < 4) tf_wait<20>();
-            else if (h == 4) tf_wait<12>();
-            else tf_wait<4>();
-            next_stage();
+            tf_stage_end();
+            ++s;
         }
 #pragma unroll
         for (int h = 0; h < 8; ++h) xprev[h] = out[h];

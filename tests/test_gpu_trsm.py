@@ -44,3 +44,19 @@ def test_rows_solve_against_extended_precision(hip, M, nrhs, trans):
     fwd = np.abs(xs - ref).max(axis=1) / np.abs(ref).max(axis=1)
     assert float(resid.max()) <= 1e-13, f"residual {float(resid.max()):.2e} (cond {cond:.1e})"
     assert float(fwd.max()) <= max(1e-13, 1e-16 * np.sqrt(cond) * 1e3), f"forward error {float(fwd.max()):.2e} (cond(L) {np.sqrt(cond):.1e})"
+
+
+def test_every_row_of_a_large_solve(hip):
+    """All rows of a 2^18-row solve, three times over.  The sampled-row checks above cannot see a memory-ordering fault in the
+    fused kernel's pipeline: the one r03 had touched a few rows in a million and only with the chip full of workgroups."""
+    M, nrhs = 512, 1 << 18
+    spec, X, Z, L, cond = _factor(M)
+    rng = np.random.default_rng(5)
+    B = rng.standard_normal((nrhs, M))
+    X0, _ = hip.bench_trsm(L, B, trans=False, reps=1)
+    resid = np.abs(X0 @ L.T - B).max(axis=1) / np.maximum((np.abs(X0) @ np.abs(L.T)).max(axis=1), 1e-300)
+    bad = np.flatnonzero(resid > 1e-13)
+    assert bad.size == 0, f"{bad.size} rows above 1e-13, first {bad[:8]}, worst {float(resid.max()):.2e}"
+    for rep in range(2):
+        Xr, _ = hip.bench_trsm(L, B, trans=False, reps=1)
+        assert np.array_equal(Xr, X0), f"run {rep + 2} differs from run 1 in {int((Xr != X0).any(axis=1).sum())} rows"
