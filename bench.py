@@ -10,8 +10,9 @@ generation of the N x M Kuf panel, fp64-MFMA SYRK into Phi = Kuf Kuf^T, all-redu
 With ``--grad`` the step also computes the analytic gradient (what one BFGS iteration of the reference needs).
 
 Rank 0 prints ONE JSON line (see the task contract): whole-job steps/s, the roofline of the dominant kernel
-measured live with HIP events on the library's stream, and a CPU baseline timed on this box's host cores
-(the oracle's C/OpenMP Gram + BLAS solve in GPflow's op order, on a bounded row sample).
+measured live with HIP events on the library's stream, the same workload on GPflow's whitened route (`whitened`),
+a bounded `oak_model.fit` + BFGS (`fit`), and a CPU baseline timed on this box's host cores (the oracle's C/OpenMP
+Gram + BLAS solve in GPflow's op order, all rows by default).
 """
 from __future__ import annotations
 
@@ -134,7 +135,7 @@ def main():
                          "NOT the reference's arithmetic, reported as its own labelled line, never the headline")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "host"],
                     help="N>1: 'rccl' = reduce-scatter + all-gather over xGMI inside liboak_hip (default); 'host' = debug path that "
-                         "sums the packed statistics through the gloo control plane (lets several ranks share one GPU)")
+                         "sums the packed statistics through the TCP control plane (oak.distributed.HostPlane) (lets several ranks share one GPU)")
     ap.add_argument("--allow-host-exchange", action="store_true",
                     help="N>1 with --exchange rccl: if the RCCL communicator cannot be created, fall back to the host exchange and "
                          "still print a (degraded) line; without this flag such a run exits non-zero")
