@@ -107,6 +107,14 @@ __device__ __forceinline__ void tf_stage_end() {
     __builtin_amdgcn_s_barrier();
 }
 
+// The MFMAs of a stage go accumulator group by accumulator group (TF_GRP tiles, all four k-steps of each), not k-step by k-step
+// over all eight accumulators, which is the order hipcc's scheduler restores unless scheduling barriers pin the groups.  Same
+// box, 2^19 rows, M = 1024: 10.25 ms for groups of 8 (the compiler's order), 9.70-9.91 for 4, 9.75-9.88 for 1 -- although each
+// group now waits for its own fragment reads with nothing to cover them; combining the grouping with fragment reads issued
+// two groups ahead (counted lgkmcnt waits) measured the same 9.71-9.79.  tools/ubench/mfma_chain.hip shows no such effect for
+// MFMAs alone (71.3 TFLOP/s at two waves per SIMD for any rotation of <= 12 accumulators), so it is the interleaving with
+// the LDS reads, not the MFMA pipe itself.
+constexpr int TF_GRP = 4;
 constexpr int TF_XT = TF_ROWS * TF_KC;       // doubles per X stage tile
 
 __global__ void __launch_bounds__(256, 2)
@@ -185,10 +193,14 @@ trsm_fused_kernel(const double* __restrict__ pack, const double* Bin, double* Xo
                 if (h == 7) glds_x(0, s + 1);              // X of the first older-column stage (a tile nobody reads when kold = 0)
                 const double* Lt = Ls + (s & 1) * TF_TILE;
 #pragma unroll
-                for (int v = 0; v < 4; ++v)
+                for (int hp = 0; hp < 8; hp += TF_GRP) {
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int h2 = 0; h2 < 8; ++h2)
-                        acc[h2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[h2 * 256 + off[v]], xprev[h][v], acc[h2], 0, 0, 0);
+                    for (int v = 0; v < 4; ++v)
+#pragma unroll
+                        for (int h2 = hp; h2 < hp + TF_GRP; ++h2)
+                            acc[h2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[h2 * 256 + off[v]], xprev[h][v], acc[h2], 0, 0, 0);
+                }
                 tf_stage_end();
                 ++s;
             }
@@ -197,12 +209,17 @@ trsm_fused_kernel(const double* __restrict__ pack, const double* Bin, double* Xo
                 glds_x(k0 + TF_KC < kold ? k0 + TF_KC : k0, s + 1);      // (the last one fetches a tile nobody reads)
                 const double* Lt = Ls + (s & 1) * TF_TILE;
                 const double* Xt = Xs + (s & 1) * TF_XT;
+                double xv[4];
 #pragma unroll
-                for (int v = 0; v < 4; ++v) {
-                    const double xv = Xt[xoff[v]];
+                for (int v = 0; v < 4; ++v) xv[v] = Xt[xoff[v]];
 #pragma unroll
-                    for (int h2 = 0; h2 < 8; ++h2)
-                        acc[h2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[h2 * 256 + off[v]], xv, acc[h2], 0, 0, 0);
+                for (int hp = 0; hp < 8; hp += TF_GRP) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int v = 0; v < 4; ++v)
+#pragma unroll
+                        for (int h2 = hp; h2 < hp + TF_GRP; ++h2)
+                            acc[h2] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[h2 * 256 + off[v]], xv[v], acc[h2], 0, 0, 0);
                 }
                 tf_stage_end();
                 ++s;
@@ -226,10 +243,14 @@ trsm_fused_kernel(const double* __restrict__ pack, const double* Bin, double* Xo
             }
             const double* Lt = Ls + (s & 1) * TF_TILE;
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
+            for (int cp = h; cp < 8; cp += TF_GRP) {
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int ct = h; ct < 8; ++ct)
-                    out[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[ct * 256 + off[v]], acc[h][v], out[ct], 0, 0, 0);
+                for (int v = 0; v < 4; ++v)
+#pragma unroll
+                    for (int ct = cp; ct < cp + TF_GRP && ct < 8; ++ct)
+                        out[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(Lt[ct * 256 + off[v]], acc[h][v], out[ct], 0, 0, 0);
+            }
             tf_stage_end();
             ++s;
         }
