@@ -203,7 +203,7 @@ int syrk_panel_f32(oak_ctx* ctx, const float* d_panel, int64_t ldp, int64_t nrow
 int syrk_reduce(oak_ctx* ctx, const double* d_part, int nsplit, int64_t M, double* d_phi /*[M*M]*/, bool accumulate);
 // in place; strict upper zeroed.  nrows > n carries nrows - n extra rows through the panel solves and trailing updates
 // (row r >= n ends up as  A[r, :n] L^-T,  i.e. the solution of L x = A[r, :n]^T: a right-hand side rides for free).
-int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, bool check = true, int64_t nrows = -1);
+int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, bool check = true, int64_t nrows = -1, bool identity_below = false);
 int set_identity(oak_ctx* ctx, double* dA, int64_t n);
 int potrf_check(oak_ctx* ctx, int slot, int64_t n);   // deferred status of a check=false factorisation (slot 1 = side stream)
 // rows-trsm: each of the nrhs rows of BT (row stride ldb) is a right-hand side; solves L x = b (trans=0)

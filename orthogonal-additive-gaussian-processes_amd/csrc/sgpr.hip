@@ -335,7 +335,7 @@ static int chol_with_inverse(oak_ctx* ctx, double* dL, int64_t M) {
     OAK_CHECK(get_buf_t(ctx, "LinvT", (size_t)M * M, &dLinvT));
     OAK_CHECK(get_buf_t(ctx, "Linv", (size_t)M * M, &dLinv));
     OAK_CHECK(set_identity(ctx, dL + M * M, M));
-    OAK_CHECK(potrf_lower(ctx, dL, M, M, false, 2 * M));
+    OAK_CHECK(potrf_lower(ctx, dL, M, M, false, 2 * M, true));
     OAK_CHECK(copy_d2d(ctx, dLinvT, dL + M * M, sizeof(double) * (size_t)M * M));
     OAK_CHECK(transpose(ctx, dLinvT, M, M, M, dLinv, M));
     return OAK_OK;
