@@ -144,6 +144,10 @@ int oak_gram_component_diag(oak_ctx* ctx, const oak_kernel_desc* desc,
 /* Upload training data (X [N x ldx], Y [N], single output column) and inducing inputs Z [M x ldx].
    Data stay resident in HBM until replaced. */
 int oak_sgpr_set_data(oak_ctx* ctx, const double* X, const double* Y, int64_t N, int32_t ldx);
+/* Replace the target column of the rows set by oak_sgpr_set_data (same N; X stays resident).  A model with P output columns
+   (GPflow's N x P Y: independent outputs sharing kernel and noise, oak/utils.py:182-198 is written for it) is the sum of P
+   single-output bounds; the host mirror evaluates them one after the other through this call. */
+int oak_sgpr_set_targets(oak_ctx* ctx, const double* Y, int64_t N);
 int oak_sgpr_set_inducing(oak_ctx* ctx, const double* Z, int64_t M, int32_t ldx);
 /* Row budget of the N x M Kuf panel kept in HBM per pass (0 = library default). */
 int oak_sgpr_set_panel_rows(oak_ctx* ctx, int64_t rows);
@@ -221,6 +225,8 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
 /* ---- GPR (replaces gpflow.models.GPR constructed at oak/model_utils.py:159;
  *      in-tree mirror oak/utils.py:206-211) -------------------------------------------------- */
 int oak_gpr_set_data(oak_ctx* ctx, const double* X, const double* Y, int64_t N, int32_t ldx);
+/* Likewise for the full GP. */
+int oak_gpr_set_targets(oak_ctx* ctx, const double* Y, int64_t N);
 int oak_gpr_log_marginal(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, double* out);
 int oak_gpr_alpha(oak_ctx* ctx, double* alpha_out);
 /* L = chol(K + noise I) of the full GP, N x N row-major (get_model_sufficient_statistics(get_L=True),

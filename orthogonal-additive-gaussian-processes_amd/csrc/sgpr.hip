@@ -633,6 +633,21 @@ int oak_sgpr_set_data(oak_ctx* ctx, const double* X, const double* Y, int64_t N,
     return OAK_OK;
 }
 
+int oak_sgpr_set_targets(oak_ctx* ctx, const double* Y, int64_t N) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(Y != nullptr, "oak_sgpr_set_targets: Y is NULL");
+    OAK_REQUIRE(ctx->have_data && N == ctx->N, "oak_sgpr_set_targets: %lld targets for the %lld rows set by oak_sgpr_set_data", (long long)N,
+                (long long)(ctx->have_data ? ctx->N : 0));
+    double* dY;
+    OAK_CHECK(HostUpload::run(ctx, "Y", Y, (size_t)N, &dY));
+    double* dyy = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "yy_const", 1, &dyy));
+    OAK_CHECK(reduce_sum(ctx, dY, N, dyy, 1, 1));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->have_stats = false; ctx->have_post = false;
+    return OAK_OK;
+}
+
 int oak_sgpr_set_global_rows(oak_ctx* ctx, int64_t n_total) {
     OAK_CHECK(guard(ctx));
     OAK_REQUIRE(n_total >= 0, "global row count must be >= 0 (0 = unknown)");
@@ -812,6 +827,18 @@ int oak_gpr_set_data(oak_ctx* ctx, const double* X, const double* Y, int64_t N, 
     OAK_CHECK(HostUpload::run(ctx, "gprY", Y, (size_t)N, &dY));
     OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ctx->gN = N; ctx->gldx = ldx; ctx->g_have_data = true; ctx->g_have_post = false;
+    return OAK_OK;
+}
+
+int oak_gpr_set_targets(oak_ctx* ctx, const double* Y, int64_t N) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(Y != nullptr, "oak_gpr_set_targets: Y is NULL");
+    OAK_REQUIRE(ctx->g_have_data && N == ctx->gN, "oak_gpr_set_targets: %lld targets for the %lld rows set by oak_gpr_set_data", (long long)N,
+                (long long)(ctx->g_have_data ? ctx->gN : 0));
+    double* dY;
+    OAK_CHECK(HostUpload::run(ctx, "gprY", Y, (size_t)N, &dY));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->g_have_post = false;
     return OAK_OK;
 }
 

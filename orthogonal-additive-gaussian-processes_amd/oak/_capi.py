@@ -72,6 +72,7 @@ SIGNATURES = {
     "oak_gram_component": (C.c_int, [_CTX, _DESC, _I, C.c_int32, C.c_int32, _D, C.c_int64, _D, C.c_int64, C.c_int32, _D]),
     "oak_gram_component_diag": (C.c_int, [_CTX, _DESC, _I, C.c_int32, C.c_int32, _D, C.c_int64, C.c_int32, _D]),
     "oak_sgpr_set_data": (C.c_int, [_CTX, _D, _D, C.c_int64, C.c_int32]),
+    "oak_sgpr_set_targets": (C.c_int, [_CTX, _D, C.c_int64]),
     "oak_sgpr_set_inducing": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32]),
     "oak_sgpr_set_panel_rows": (C.c_int, [_CTX, C.c_int64]),
     "oak_sgpr_local_stats": (C.c_int, [_CTX, _DESC, C.c_double]),
@@ -98,6 +99,7 @@ SIGNATURES = {
                                    C.c_int32, C.c_double]),
     "oak_svgp_posterior": (C.c_int, [_CTX, _DESC, _D, _D, C.c_double, _D, _D]),
     "oak_gpr_set_data": (C.c_int, [_CTX, _D, _D, C.c_int64, C.c_int32]),
+    "oak_gpr_set_targets": (C.c_int, [_CTX, _D, C.c_int64]),
     "oak_gpr_log_marginal": (C.c_int, [_CTX, _DESC, C.c_double, _D]),
     "oak_gpr_alpha": (C.c_int, [_CTX, _D]),
     "oak_gpr_predict": (C.c_int, [_CTX, _DESC, _D, C.c_int64, C.c_int32, _D, _D]),
@@ -419,6 +421,11 @@ class HipContext:
             raise ValueError("X and Y differ in their number of rows")
         _check(self._lib.oak_sgpr_set_data(self._h, _dp(X), _dp(Y), X.shape[0], X.shape[1]))
 
+    def sgpr_set_targets(self, y):
+        """Another target column for the rows already on the device (one output of an N x P ``Y``)."""
+        y = _f64(np.asarray(y).reshape(-1))
+        _check(self._lib.oak_sgpr_set_targets(self._h, _dp(y), y.shape[0]))
+
     def sgpr_set_inducing(self, Z):
         Z = _f64(Z, 2)
         _check(self._lib.oak_sgpr_set_inducing(self._h, _dp(Z), Z.shape[0], Z.shape[1]))
@@ -530,6 +537,10 @@ class HipContext:
         if Y.shape[0] != X.shape[0]:
             raise ValueError("X and Y differ in their number of rows")
         _check(self._lib.oak_gpr_set_data(self._h, _dp(X), _dp(Y), X.shape[0], X.shape[1]))
+
+    def gpr_set_targets(self, y):
+        y = _f64(np.asarray(y).reshape(-1))
+        _check(self._lib.oak_gpr_set_targets(self._h, _dp(y), y.shape[0]))
 
     def gpr_log_marginal(self, desc: KernelDesc, noise_var: float) -> float:
         e = C.c_double()

@@ -455,8 +455,14 @@ class GPModel(Module):
     def __init__(self, data, kernel, mean_function=None, noise_variance=1.0):
         X, Y = data
         self.data = (np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64).reshape(len(X), -1))
-        if self.data[1].shape[1] != 1:
-            raise NotImplementedError("the HIP path supports a single output column (the reference only ever uses one)")
+        # P output columns are GPflow's independent outputs sharing kernel and noise: bound, gradient and posterior mean are sums /
+        # stacks over single-output problems, and that is how they are evaluated here -- one pass of the device path per column
+        # (`_outputs`).  The reference itself only ever passes one column; the y-independent statistics are NOT shared between the
+        # passes, so P columns cost P evaluations.
+        self._P = self.data[1].shape[1]
+        if self._P < 1:
+            raise ValueError("Y has no columns")
+        self._col = 0                                                  # the target column currently on the device
         if mean_function is not None:
             raise NotImplementedError("only the zero mean function is supported (model_utils.py:152,159 pass None)")
         self.kernel = kernel
@@ -465,7 +471,18 @@ class GPModel(Module):
         self._comm = _active_communicator()                            # row sharding (oak/distributed.py); None: single process
 
     def mean_function(self, X):
-        return np.zeros((np.asarray(X).shape[0], 1))
+        return np.zeros((np.asarray(X).shape[0], self._P))
+
+    def _set_column(self, p):                                          # subclasses: put target column p on the device
+        raise NotImplementedError
+
+    def _outputs(self):
+        """Iterate over the output columns, each one on the device while the caller's loop body runs."""
+        for p in range(self._P):
+            if p != self._col:
+                self._set_column(p)
+                self._col = p
+            yield p
 
     # -- kernel -> POD description ---------------------------------------------------------------
     def _spec(self):
@@ -526,10 +543,14 @@ class GPR(GPModel):
 
     def __init__(self, data, kernel, mean_function=None, noise_variance=1.0):
         super().__init__(data, kernel, mean_function, noise_variance)
-        self._hip.gpr_set_data(self.data[0], self.data[1])
+        self._hip.gpr_set_data(self.data[0], self.data[1][:, 0])
+
+    def _set_column(self, p):
+        self._hip.gpr_set_targets(self.data[1][:, p])
 
     def log_marginal_likelihood(self):
-        return self._hip.gpr_log_marginal(self._desc(), float(self.likelihood.variance.numpy()))
+        desc, s2 = self._desc(), float(self.likelihood.variance.numpy())
+        return float(sum(self._hip.gpr_log_marginal(desc, s2) for _ in self._outputs()))
 
     def maximum_log_likelihood_objective(self):
         return self.log_marginal_likelihood()
@@ -537,15 +558,22 @@ class GPR(GPModel):
     def predict_f(self, Xnew, full_cov=False, full_output_cov=False):
         if full_cov:
             raise NotImplementedError("full_cov=True is not on the OAK path")
-        desc = self._desc()
-        self._hip.gpr_log_marginal(desc, float(self.likelihood.variance.numpy()))
-        mean, var = self._hip.gpr_predict(desc, np.asarray(Xnew, dtype=np.float64))
-        return TensorLike(mean[:, None]), TensorLike(var[:, None])
+        desc, s2 = self._desc(), float(self.likelihood.variance.numpy())
+        Xnew = np.asarray(Xnew, dtype=np.float64)
+        means, var = [], None
+        for _ in self._outputs():
+            self._hip.gpr_log_marginal(desc, s2)
+            mean, var = self._hip.gpr_predict(desc, Xnew)
+            means.append(mean)
+        return TensorLike(np.stack(means, axis=1)), TensorLike(np.tile(var[:, None], (1, self._P)))
 
     def alpha(self):
-        """cholesky_solve(L, Y) of oak/utils.py:206-211."""
-        self._hip.gpr_log_marginal(self._desc(), float(self.likelihood.variance.numpy()))
-        return TensorLike(self._hip.gpr_alpha(self.data[0].shape[0])[:, None])
+        """cholesky_solve(L, Y) of oak/utils.py:206-211 (one column per output)."""
+        desc, s2, cols = self._desc(), float(self.likelihood.variance.numpy()), []
+        for _ in self._outputs():
+            self._hip.gpr_log_marginal(desc, s2)
+            cols.append(self._hip.gpr_alpha(self.data[0].shape[0]))
+        return TensorLike(np.stack(cols, axis=1))
 
     def effective_L(self):
         """chol(K + noise I) of oak/utils.py:206-211."""
@@ -553,8 +581,11 @@ class GPR(GPModel):
         return self._hip.gpr_chol(self.data[0].shape[0])
 
     def _objective_and_constrained_grad(self):
-        desc = self._desc()
-        obj, g = self._hip.gpr_log_marginal_grad(desc, float(self.likelihood.variance.numpy()))
+        desc, s2 = self._desc(), float(self.likelihood.variance.numpy())
+        obj, g = 0.0, 0.0
+        for _ in self._outputs():
+            o_p, g_p = self._hip.gpr_log_marginal_grad(desc, s2)
+            obj, g = obj + o_p, g + g_p
         return obj, g, desc
 
 
@@ -572,9 +603,13 @@ class SGPR(GPModel):
         # statistics and the gradient record are summed over the ranks inside the library, the O(M^3) tail is replicated, so
         # objective and gradient are bit-identical on all ranks and an optimiser simply runs replicated
         Xl, Yl = _shard_rows(self._comm, self._hip, self.data[0], self.data[1])
-        self._hip.sgpr_set_data(Xl, Yl)
+        self._Yl = Yl                                                  # this rank's rows, all output columns
+        self._hip.sgpr_set_data(Xl, Yl[:, 0])
         self._z_sent = None
         self.route = "auto"
+
+    def _set_column(self, p):
+        self._hip.sgpr_set_targets(self._Yl[:, p])
 
     def _sync_Z(self):
         Z = self.inducing_variable.Z.numpy()
@@ -585,7 +620,8 @@ class SGPR(GPModel):
 
     def elbo(self):
         self._sync_Z()
-        return self._hip.sgpr_elbo(self._desc(), float(self.likelihood.variance.numpy()), default_jitter())
+        desc, s2 = self._desc(), float(self.likelihood.variance.numpy())
+        return float(sum(self._hip.sgpr_elbo(desc, s2, default_jitter()) for _ in self._outputs()))
 
     def maximum_log_likelihood_objective(self):
         return self.elbo()
@@ -594,21 +630,28 @@ class SGPR(GPModel):
         if full_cov:
             raise NotImplementedError("full_cov=True is not on the OAK path")
         self._sync_Z()
-        desc = self._desc()
-        self._hip.sgpr_elbo(desc, float(self.likelihood.variance.numpy()), default_jitter())
+        desc, s2 = self._desc(), float(self.likelihood.variance.numpy())
         Xnew = np.asarray(Xnew, dtype=np.float64)
-        if self._comm is not None and len(Xnew) >= self.SHARDED_PREDICT_MIN_ROWS * self._comm.world:
-            # test rows are independent: each rank predicts its block from the replicated posterior, one gather
-            from . import distributed
-            mean, var = distributed.sharded_predict(self._hip, desc, Xnew, self._comm.rank, self._comm.world, comm=self._comm)
-        else:
-            mean, var = self._hip.sgpr_predict(desc, Xnew)
-        return TensorLike(mean[:, None]), TensorLike(var[:, None])
+        means, var = [], None
+        for _ in self._outputs():
+            self._hip.sgpr_elbo(desc, s2, default_jitter())
+            if self._comm is not None and len(Xnew) >= self.SHARDED_PREDICT_MIN_ROWS * self._comm.world:
+                # test rows are independent: each rank predicts its block from the replicated posterior, one gather
+                from . import distributed
+                mean, var = distributed.sharded_predict(self._hip, desc, Xnew, self._comm.rank, self._comm.world, comm=self._comm)
+            else:
+                mean, var = self._hip.sgpr_predict(desc, Xnew)
+            means.append(mean)
+        return TensorLike(np.stack(means, axis=1)), TensorLike(np.tile(var[:, None], (1, self._P)))
 
     def alpha(self):
-        """alpha of oak/utils.py:180-198."""
-        self.elbo()
-        return TensorLike(self._hip.sgpr_alpha(len(self.inducing_variable))[:, None])
+        """alpha of oak/utils.py:180-198 (one column per output)."""
+        self._sync_Z()
+        desc, s2, cols = self._desc(), float(self.likelihood.variance.numpy()), []
+        for _ in self._outputs():
+            self._hip.sgpr_elbo(desc, s2, default_jitter())
+            cols.append(self._hip.sgpr_alpha(len(self.inducing_variable)))
+        return TensorLike(np.stack(cols, axis=1))
 
     def effective_L(self):
         """inv(L^-1 - LB^-1 L^-1) of oak/utils.py:199-204."""
@@ -621,12 +664,18 @@ class SGPR(GPModel):
         Zp = self.inducing_variable.Z
         want_z = any(v is Zp for v in getattr(self, "_want_extra", ()))
         self._extra_grads = {}
-        if want_z:      # trainable inducing inputs (create_model_oak(zfixed=False)): one more pass over the pairs
-            Z = Zp.numpy()
-            obj, g, gz = self._hip.sgpr_elbo_grad_z(desc, float(self.likelihood.variance.numpy()), Z.shape[0], Z.shape[1], default_jitter())
+        s2 = float(self.likelihood.variance.numpy())
+        obj, g, gz = 0.0, 0.0, 0.0
+        for _ in self._outputs():
+            if want_z:  # trainable inducing inputs (create_model_oak(zfixed=False)): one more pass over the pairs
+                Z = Zp.numpy()
+                o_p, g_p, gz_p = self._hip.sgpr_elbo_grad_z(desc, s2, Z.shape[0], Z.shape[1], default_jitter())
+                gz = gz + gz_p
+            else:
+                o_p, g_p = self._hip.sgpr_elbo_grad(desc, s2, default_jitter())
+            obj, g = obj + o_p, g + g_p
+        if want_z:
             self._extra_grads[id(Zp)] = gz
-        else:
-            obj, g = self._hip.sgpr_elbo_grad(desc, float(self.likelihood.variance.numpy()), default_jitter())
         return obj, g, desc
 
 

@@ -102,6 +102,13 @@ def _sobol_inputs(model):
     return num_dims, selected[1:], kernel_list
 
 
+def _first_output(alpha) -> np.ndarray:
+    """alpha as a vector.  With several output columns the reference's expressions pick output 0
+    (``...numpy()[0][0]`` at oak/utils.py:428-430, ``predictive_component_mean[:, 0]`` at :529) -- so does this."""
+    a = np.asarray(alpha, dtype=np.float64)
+    return np.ascontiguousarray(a.reshape(len(a), -1)[:, 0])
+
+
 def compute_sobol_oak(model, delta: float, mu: float, share_var_across_orders: Optional[bool] = True
                       ) -> Tuple[List[List[int]], List[float]]:
     """Sobol index alpha^T (prod_{d in S} L_d) alpha of every non-constant term (oak/utils.py:338-435)."""
@@ -119,10 +126,10 @@ def compute_sobol_oak(model, delta: float, mu: float, share_var_across_orders: O
     if comm is not None and len(subsets) >= 8 * comm.world:
         # the terms are independent: each rank evaluates a contiguous block of them, one gather of the scalars
         from . import distributed
-        sobol = distributed.sharded_sobol(model._hip, desc, Xc, np.asarray(alpha).reshape(-1), subsets, comm.rank, comm.world,
+        sobol = distributed.sharded_sobol(model._hip, desc, Xc, _first_output(alpha), subsets, comm.rank, comm.world,
                                           comm=comm, use_order_var=bool(share_var_across_orders), delta=delta, mu=mu)
     else:
-        sobol = _capi.default_context().sobol(desc, Xc, np.asarray(alpha).reshape(-1), subsets,
+        sobol = _capi.default_context().sobol(desc, Xc, _first_output(alpha), subsets,
                                               use_order_var=bool(share_var_across_orders), delta=delta, mu=mu)
     assert len(subsets) == len(sobol)
     return subsets, [float(s) for s in sobol]
@@ -136,7 +143,7 @@ def get_prediction_component(m, alpha, X: np.ndarray = None, share_var_across_or
     subsets = get_list_representation(m.kernel, num_dims=X.shape[1])[0][1:]
     Xc = m.data[0] if isinstance(m, gpflow.GPR) else m.inducing_variable.Z.numpy()
     desc = _capi.KernelDesc(kernel_to_spec(m.kernel))
-    out = _capi.default_context().component_predict(desc, X, Xc, np.asarray(alpha).reshape(-1), subsets,
+    out = _capi.default_context().component_predict(desc, X, Xc, _first_output(alpha), subsets,
                                                     use_order_var=bool(share_var_across_orders))
     return [TensorLike(row) for row in out]
 

@@ -62,6 +62,12 @@ class FakeContext:
     def sgpr_set_data(self, X, Y):
         self.X, self.Y = np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64).reshape(len(X), 1)
 
+    def sgpr_set_targets(self, y):
+        y = np.asarray(y, dtype=np.float64).reshape(-1, 1)
+        if len(y) != len(self.X):
+            raise ValueError("oak_sgpr_set_targets: row count differs from the data on the device")
+        self.Y = y
+
     def sgpr_set_inducing(self, Z):
         self.Z = np.asarray(Z, dtype=np.float64)
 

@@ -452,3 +452,42 @@ def test_no_test_rows_and_no_training_rows(hip):
         assert mean0.shape == (0,) and var0.shape == (0,)
     with pytest.raises(ValueError):
         hip.sgpr_set_data(X[:0], y[:0])
+
+
+def test_several_output_columns(hip):
+    """Y with P = 3 columns through the model classes (GPflow's independent outputs sharing kernel and noise; oak/utils.py:182-198
+    is written for N x P): bound, posterior mean / variance and alpha against the oracle's N x P formulas, the gradient against the
+    sum of the single-output gradients, for the sparse and the full model."""
+    from oak import gpflow_lite as gpflow
+    from oak.oak_kernel import OAKKernel, kernel_to_spec
+    rng = np.random.default_rng(4)
+    N, D, M, P = 3000, 4, 96, 3
+    X, Z, Y = rng.standard_normal((N, D)), rng.standard_normal((M, D)), rng.standard_normal((N, P))
+    k = OAKKernel([gpflow.kernels.RBF] * D, num_dims=D, max_interaction_depth=2, constrain_orthogonal=True)
+    spec = kernel_to_spec(k)
+    m = gpflow.models.SGPR((X, Y), k, Z, noise_variance=0.2)
+    m.route = "whitened"
+    assert rel(m.elbo(), o.sgpr_elbo(spec, X, Y, Z, 0.2)) <= 1e-10
+    mean, var = m.predict_f(X[:50])
+    mo, vo = o.sgpr_predict_f(spec, X, Y, Z, 0.2, X[:50])
+    np.testing.assert_allclose(mean.numpy(), mo, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(var.numpy(), vo, rtol=1e-9, atol=1e-11)
+    np.testing.assert_allclose(m.alpha().numpy(), o.sgpr_alpha(spec, X, Y, Z, 0.2), rtol=1e-8, atol=1e-10)
+    obj, g, _ = m._objective_and_constrained_grad()
+    singles = [gpflow.models.SGPR((X, Y[:, p:p + 1]), k, Z, noise_variance=0.2) for p in range(P)]
+    for s_ in singles:
+        s_.route = "whitened"
+    parts = [s_._objective_and_constrained_grad() for s_ in singles]
+    assert rel(obj, sum(p_[0] for p_ in parts)) <= 1e-12
+    np.testing.assert_allclose(g, sum(p_[1] for p_ in parts), rtol=1e-10, atol=1e-10)
+    # full GP
+    Xg, Yg = X[:400], Y[:400]
+    mg = gpflow.models.GPR((Xg, Yg), k, noise_variance=0.2)
+    ref = sum(o.gpr_log_marginal_likelihood(spec, Xg, Yg[:, p:p + 1], 0.2) for p in range(P))
+    assert rel(mg.log_marginal_likelihood(), ref) <= 1e-10
+    mean_g, var_g = mg.predict_f(X[400:420])
+    assert mean_g.numpy().shape == (20, P) and var_g.numpy().shape == (20, P)
+    for p in range(P):
+        mp, vp = gpflow.models.GPR((Xg, Yg[:, p:p + 1]), k, noise_variance=0.2).predict_f(X[400:420])
+        np.testing.assert_allclose(mean_g.numpy()[:, p], mp.numpy()[:, 0], rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(var_g.numpy()[:, p], vp.numpy()[:, 0], rtol=1e-12, atol=1e-14)
