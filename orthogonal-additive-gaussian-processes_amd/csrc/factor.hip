@@ -706,6 +706,92 @@ int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, bool check, in
 }
 
 // ---------------------------------------------------------------------------------------------
+// One right-hand side, L x = b, with the inverses of L's 128 x 128 diagonal blocks at hand (the diagonal blocks of the L^-1 that
+// rode through the factorisation): x_j = inv(L_jj) (b_j - L_{j,<j} x_{<j}) -- the arithmetic of the fused many-row solve
+// (trsm_fused.hip), i.e. the inverse is only ever applied to an already-cancelled residual.  One workgroup, x kept in LDS; a
+// wave owns eight rows of the block and its lanes stride over k (1 KiB coalesced row segments), wave-reduced in a fixed
+// order.  Replaces 15 dependent launches (8 leaf solves + 7 GEMMs, 0.3 ms at n = 1024) by one of ~40 us.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) trsv_blockinv_kernel(const double* __restrict__ L, int64_t n, int64_t ldl, const double* __restrict__ Linv,
+                                                             int64_t ldinv, double* __restrict__ b) {
+    extern __shared__ __attribute__((aligned(16))) double xs[];      // [n] solution so far (zero beyond it), then [128] residual of the current block
+    double* rb = xs + n;
+    double* bs = rb + 128;                                            // [n] the right-hand side
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);       // 16 waves, eight rows of the current block each
+    auto wave_sum = [](double v) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+        return v;
+    };
+    for (int64_t i = tid; i < n; i += 1024) { xs[i] = 0.0; bs[i] = b[i]; }
+    __syncthreads();
+    for (int64_t j0 = 0; j0 < n; j0 += 128) {
+        // The chain is latency-bound (one workgroup, L comes from HBM): 16 independent 16-byte loads per lane are issued before
+        // the first is used -- eight rows x two 128-column chunks (four would spill at the 128 VGPRs of a 1024-thread workgroup).  Chunks at or beyond j0 meet x = 0 (L is finite there), so the
+        // chunk loop needs no tail case; it stops at the matrix edge.
+        const double* Lr = L + (j0 + 8 * wave) * ldl + 2 * lane;
+        double s[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        for (int64_t k0 = 0; k0 < j0; k0 += 256) {
+            double2 lv[8][2], xv[2];
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const int64_t k = (k0 + 128 * c < n) ? k0 + 128 * c : k0;       // a repeated chunk is multiplied by zero below
+#pragma unroll
+                for (int q = 0; q < 8; ++q) lv[q][c] = *reinterpret_cast<const double2*>(Lr + q * ldl + k);
+            }
+            __builtin_amdgcn_sched_barrier(0);          // all 16 loads leave before anything waits on the first
+#pragma unroll
+            for (int c = 0; c < 2; ++c) {
+                const bool in = k0 + 128 * c < j0;
+                const double2 x2 = *reinterpret_cast<const double2*>(&xs[(k0 + 128 * c < n ? k0 + 128 * c : k0) + 2 * lane]);
+                xv[c] = make_double2(in ? x2.x : 0.0, in ? x2.y : 0.0);
+            }
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    s[q] = __builtin_fma(lv[q][c].x, xv[c].x, s[q]);
+                    s[q] = __builtin_fma(lv[q][c].y, xv[c].y, s[q]);
+                }
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s[q] = wave_sum(s[q]);
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q) rb[8 * wave + q] = bs[j0 + 8 * wave + q] - s[q];
+        }
+        __syncthreads();
+        {
+            const double2 rv = *reinterpret_cast<const double2*>(&rb[2 * lane]);
+            const double* Ir = Linv + (j0 + 8 * wave) * ldinv + j0 + 2 * lane;
+            double2 iv[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) iv[q] = *reinterpret_cast<const double2*>(Ir + q * ldinv);
+            double t[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) t[q] = wave_sum(__builtin_fma(iv[q].y, rv.y, iv[q].x * rv.x));
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) xs[j0 + 8 * wave + q] = t[q];
+            }
+        }
+        __syncthreads();
+    }
+    for (int64_t i = tid; i < n; i += 1024) b[i] = xs[i];
+}
+
+// n a multiple of 128 and <= 8192 (LDS); dLinv = full row-major inverse of L (only its diagonal blocks are read)
+int trsv_lower_blockinv(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, const double* dLinv, int64_t ldinv, double* d_b) {
+    OAK_REQUIRE(n > 0 && n % 128 == 0 && n <= 8192 && (ldl % 2) == 0 && (ldinv % 2) == 0, "trsv_lower_blockinv: n=%lld not supported", (long long)n);
+    const size_t lds = sizeof(double) * (size_t)(2 * n + 128);
+    if (lds > 64 * 1024) OAK_CHECK(ensure_max_dynamic_lds((const void*)trsv_blockinv_kernel));
+    trsv_blockinv_kernel<<<1, 1024, lds, ctx->stream>>>(dL, n, ldl, dLinv, ldinv, d_b);
+    OAK_HIP_CHECK(hipGetLastError());
+    return OAK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // rows-TRSM leaf: n <= 256.  Each right-hand side is a contiguous row of BT; a group of 32 lanes owns one rhs.
 // ---------------------------------------------------------------------------------------------
 template <int TRANS>

@@ -221,6 +221,7 @@ int scale_add_eye(oak_ctx* ctx, const double* dW, int64_t n, double s, double* d
 int scaled_copy(oak_ctx* ctx, double a, const double* d_src, double* d_dst, int64_t n);               // dst = a * src
 int reduce_sum(oak_ctx* ctx, const double* d_x, int64_t n, double* d_out /*1*/, int mode /*0 sum,1 sumsq,2 sumlog*/, int64_t stride);
 int dot(oak_ctx* ctx, const double* d_x, const double* d_y, int64_t n, double* d_out);
+int trsv_lower_blockinv(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, const double* dLinv, int64_t ldinv, double* d_b);   // factor.hip
 int gemv_rows(oak_ctx* ctx, const double* dA, int64_t rows, int64_t cols, int64_t lda, const double* d_x, double* d_y); // y = A x
 int row_sumsq(oak_ctx* ctx, const double* dA, int64_t rows, int64_t cols, int64_t lda, double* d_out);                  // out_i = sum_j A_ij^2
 int copy_d2d(oak_ctx* ctx, void* dst, const void* src, size_t bytes);
