@@ -66,26 +66,42 @@ __global__ void __launch_bounds__(256) trsm_pack_kernel(const double* __restrict
 
 // Inverses of the 128 x 128 diagonal blocks of L (identity-padded past n) by forward substitution, one workgroup per block,
 // thread c owning column c of the inverse: x_i = (e_c[i] - sum_{c <= k < i} L_ik x_k) / L_ii.  The column's history lives in
-// LDS ([k][c]: conflict-free), L_ik is wave-uniform (scalar loads).  One launch instead of three per block.
+// LDS ([k][c]: conflict-free).  Row i of the block is fetched with two coalesced vector loads one row ahead and L_ik handed out
+// by v_readlane (k is wave-uniform) -- as wave-uniform scalar loads from global memory the same loop was latency-bound at
+// 0.6 ms per call.
+__device__ __forceinline__ double tf_readlane(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
 __global__ void __launch_bounds__(128) trsm_block_inverse_kernel(const double* __restrict__ L, int64_t n, int64_t ldl, double* __restrict__ inv) {
     extern __shared__ __attribute__((aligned(16))) double xs[];     // [128][128]
-    const int c = threadIdx.x;
+    const int c = threadIdx.x, lane = c & 63;
     const int64_t b0 = (int64_t)blockIdx.x * TF_NB;
     const int kmin = __builtin_amdgcn_readfirstlane(c) & ~63;        // first column of this wave: everything before it is zero
     double* out = inv + (int64_t)blockIdx.x * TF_NB * TF_NB;
-    for (int i = 0; i < TF_NB; ++i) {
+    // lane l holds L[b0 + i][b0 + l] and L[b0 + i][b0 + 64 + l] of the row in hand (identity outside the matrix)
+    auto load_row = [&](int i, double& ra, double& rb) {
         const int64_t gi = b0 + i;
-        double x;
-        if (gi < n) {
-            const double* Li = L + gi * ldl + b0;
-            double sum = (i == c) ? 1.0 : 0.0;
-            for (int k = kmin; k < i; ++k) sum = __builtin_fma(-Li[k], xs[k * TF_NB + c], sum);
-            x = (i >= c) ? sum / Li[i] : 0.0;
-        } else {
-            x = (i == c) ? 1.0 : 0.0;
-        }
+        const bool rin = gi < n;
+        ra = (rin && b0 + lane < n) ? L[gi * ldl + b0 + lane] : ((i == lane) ? 1.0 : 0.0);
+        rb = (rin && b0 + 64 + lane < n) ? L[gi * ldl + b0 + 64 + lane] : ((i == 64 + lane) ? 1.0 : 0.0);
+    };
+    double ra, rb, na = 0.0, nb = 0.0;
+    load_row(0, ra, rb);
+    for (int i = 0; i < TF_NB; ++i) {
+        if (i + 1 < TF_NB) load_row(i + 1, na, nb);
+        double sum = (i == c) ? 1.0 : 0.0;
+        const int kend = i < 64 ? i : 64;
+        for (int k = kmin; k < kend; ++k) sum = __builtin_fma(-tf_readlane(ra, k), xs[k * TF_NB + c], sum);
+        for (int k = (kmin > 64 ? kmin : 64); k < i; ++k) sum = __builtin_fma(-tf_readlane(rb, k - 64), xs[k * TF_NB + c], sum);
+        const double lii = i < 64 ? tf_readlane(ra, i) : tf_readlane(rb, i - 64);
+        const double x = (i >= c) ? sum / lii : 0.0;
         xs[i * TF_NB + c] = x;
         out[(int64_t)i * TF_NB + c] = x;           // row-major inverse: out[i][c]
+        ra = na; rb = nb;
     }
 }
 
