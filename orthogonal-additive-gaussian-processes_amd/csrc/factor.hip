@@ -1036,6 +1036,9 @@ int trsm_rows(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, double* dB
         }
     } else {
         const int64_t last = ((n - 1) / NB) * NB;
+        // whole column blocks: the fused kernel on column-reversed panels against J L^T J (trsm_fused.hip), in place
+        if (nrhs >= 4096 && n <= 4096 && (n % NB) == 0 && (ldb % 2) == 0 && ((uintptr_t)dBT & 15) == 0 && getenv("OAK_TRSM_UNFUSED") == nullptr)
+            return trsm_rows_fused(ctx, dL, n, ldl, nullptr, 0, nullptr, dBT, ldb, dBT, ldb, nrhs, true);
         if (nrhs >= 8192) {
             // Same formulation for the transposed solve (rows x with x L = b, i.e. L^T x^T = b^T; the N-sized adjoint solve of
             // the SVGP reverse pass): blocks from the last to the first, left-looking.  Block j receives the finished

@@ -214,7 +214,8 @@ int trsm_rows(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, double* dB
 // copied).  The inverses of the 128 x 128 diagonal blocks come either from a full inverse dLinv (row-major, leading
 // dimension ldinv: its diagonal blocks are those inverses) or from dInvBlocks = compact [n/128][128][128] block inverses.
 int trsm_rows_fused(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, const double* dLinv, int64_t ldinv,
-                    const double* dInvBlocks, const double* dBin, int64_t ldin, double* dXout, int64_t ldout, int64_t nrhs);
+                    const double* dInvBlocks, const double* dBin, int64_t ldin, double* dXout, int64_t ldout, int64_t nrhs,
+                    bool transposed = false);
 int transpose(oak_ctx* ctx, const double* dA, int64_t rows, int64_t cols, int64_t lda, double* dB, int64_t ldb);
 int add_diag(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, double v);
 int scale_add_eye(oak_ctx* ctx, const double* dW, int64_t n, double s, double* dB, int extra_rows = 0);   // B = I + s*W (+ rows copied as they are)

@@ -38,6 +38,9 @@ __host__ __device__ inline int64_t tf_stages_before(int64_t j) { return 4 * j * 
 __host__ __device__ inline int tf_swz(int r) { return r & 15; }
 
 // grid (8 * nb, nb): blockIdx.y = column block j, blockIdx.x = stage within the block (those beyond 8 j + 8 exit)
+// REV: the factor seen by the solve is  Lt = J L^T J  (J = index reversal; n a multiple of 128): X L = B  is  (X J) Lt^T = B J, the
+// same row solve on column-reversed panels -- how the transposed solve L^T x = b of many rows runs through this kernel.
+template <bool REV>
 __global__ void __launch_bounds__(256) trsm_pack_kernel(const double* __restrict__ L, int64_t n, int64_t ldl,
                                                         const double* __restrict__ Inv, int64_t inv_bs, int64_t inv_ld,
                                                         double* __restrict__ pack) {
@@ -54,7 +57,11 @@ __global__ void __launch_bounds__(256) trsm_pack_kernel(const double* __restrict
         const int kk = p;
         const int64_t gi = j0 + r, gk = k0 + kk;
         double v;
-        if (diag) {
+        if (REV) {
+            // Lt[gi][gk] = L[n-1-gk][n-1-gi];  inv(Lt_jj)[r][q] = inv(L_bb)[127-q][127-r] with b = nb - 1 - j
+            if (diag) v = (gk <= gi) ? Inv[(int64_t)(gridDim.y - 1 - j) * inv_bs + (int64_t)(TF_NB - 1 - (gk - j0)) * inv_ld + (TF_NB - 1 - r)] : 0.0;
+            else v = -L[(n - 1 - gk) * ldl + (n - 1 - gi)];
+        } else if (diag) {
             if (gi < n && gk < n) v = (gk <= gi) ? Inv[(int64_t)j * inv_bs + (int64_t)r * inv_ld + (gk - j0)] : 0.0;
             else v = (gi == gk) ? 1.0 : 0.0;        // identity padding up to the next multiple of 128
         } else {
@@ -133,9 +140,13 @@ __device__ __forceinline__ void tf_stage_end() {
 constexpr int TF_GRP = 4;
 constexpr int TF_XT = TF_ROWS * TF_KC;       // doubles per X stage tile
 
+template <bool REV>
 __global__ void __launch_bounds__(256, 2)
 trsm_fused_kernel(const double* __restrict__ pack, const double* Bin, double* Xout, double* scratch, int64_t nrhs, int64_t ldin,
                   int64_t ldout, int nb) {
+    // REV: logical column c of the panels is memory column 128 nb - 1 - c (see trsm_pack_kernel): column offsets are subtracted
+    constexpr int64_t SG = REV ? -1 : 1;
+    const int64_t ctop = REV ? (int64_t)nb * TF_NB - 1 : 0;
     __shared__ __attribute__((aligned(16))) double Ls[2 * (TF_TILE + TF_XT)];     // 48 KiB
     double* const Xs = Ls + 2 * TF_TILE;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -144,8 +155,8 @@ trsm_fused_kernel(const double* __restrict__ pack, const double* Bin, double* Xo
     const int64_t row = (int64_t)blockIdx.x * TF_ROWS + 16 * wave + fi;
     // rows past the end are redirected to a scratch row instead of being masked: every lane issues every operation
     // B tile / X store: register v <-> column 16 ct + 4 v + fk
-    const double* bin = row < nrhs ? Bin + row * ldin + fk : scratch + fk;
-    double* xst = row < nrhs ? Xout + row * ldout + fk : scratch + fk;
+    const double* bin = (row < nrhs ? Bin + row * ldin : scratch) + ctop + SG * fk;
+    double* xst = (row < nrhs ? Xout + row * ldout : scratch) + ctop + SG * fk;
     // X fetch: lane l of piece i brings 16 bytes of row 8 i + l / 8; the 16-byte chunk it brings is the one that belongs
     // at its (lane-linear) LDS position under the XOR swizzle  chunk' = chunk ^ ((row >> 1) & 7)
     const double* xsrc[2];
@@ -154,14 +165,15 @@ trsm_fused_kernel(const double* __restrict__ pack, const double* Bin, double* Xo
         const int r = 8 * i + (lane >> 3);
         const int64_t grow = (int64_t)blockIdx.x * TF_ROWS + 16 * wave + r;
         const int chunk = (lane & 7) ^ ((r >> 1) & 7);
-        xsrc[i] = (grow < nrhs ? Xout + grow * ldout : scratch) + 2 * chunk;
+        // (REV: the 16 bytes at memory columns [m, m + 1], m = top - 1 - 2 chunk, are the logical columns 2 chunk + 1, 2 chunk)
+        xsrc[i] = (grow < nrhs ? Xout + grow * ldout : scratch) + (REV ? ctop - 1 - 2 * chunk : 2 * chunk);
     }
     int off[4], xoff[4];
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
         off[v] = fi * 16 + ((4 * v + fk) ^ tf_swz(fi));
         const int k = 4 * v + fk;
-        xoff[v] = wave * 256 + fi * 16 + 2 * ((k >> 1) ^ ((fi >> 1) & 7)) + (k & 1);
+        xoff[v] = wave * 256 + fi * 16 + 2 * ((k >> 1) ^ ((fi >> 1) & 7)) + ((k & 1) ^ (REV ? 1 : 0));
     }
     const int64_t nst = tf_stages_before(nb);
     int64_t s = 0;                                  // stage; its tile sits in slot s & 1
@@ -178,7 +190,7 @@ trsm_fused_kernel(const double* __restrict__ pack, const double* Bin, double* Xo
         double* dst = Xs + (t & 1) * TF_XT + wave * 256;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + k0),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[i] + SG * k0),
                                              (__attribute__((address_space(3))) void*)(dst + i * 128), 16, 0, 0);
     };
 
@@ -188,7 +200,7 @@ trsm_fused_kernel(const double* __restrict__ pack, const double* Bin, double* Xo
     for (int h = 0; h < 8; ++h) {
         xprev[h] = (double4_t){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int v = 0; v < 4; ++v) bnext[h][v] = bin[16 * h + 4 * v];      // right-hand sides of block 0
+        for (int v = 0; v < 4; ++v) bnext[h][v] = bin[SG * (16 * h + 4 * v)];      // right-hand sides of block 0
     }
     tf_stage_end();
 
@@ -205,7 +217,7 @@ trsm_fused_kernel(const double* __restrict__ pack, const double* Bin, double* Xo
             for (int h = 0; h < 8; ++h) {
                 glds_pack(s + 1);
 #pragma unroll
-                for (int v = 0; v < 4; ++v) xst[kold + 16 * h + 4 * v] = xprev[h][v];
+                for (int v = 0; v < 4; ++v) xst[SG * (kold + 16 * h + 4 * v)] = xprev[h][v];
                 if (h == 7) glds_x(0, s + 1);              // X of the first older-column stage (a tile nobody reads when kold = 0)
                 const double* Lt = Ls + (s & 1) * TF_TILE;
 #pragma unroll
@@ -255,7 +267,7 @@ trsm_fused_kernel(const double* __restrict__ pack, const double* Bin, double* Xo
 #pragma unroll
                 for (int t = 2 * h; t < 2 * h + 2; ++t)
 #pragma unroll
-                    for (int v = 0; v < 4; ++v) bnext[t][v] = bin[jn + 16 * t + 4 * v];
+                    for (int v = 0; v < 4; ++v) bnext[t][v] = bin[SG * (jn + 16 * t + 4 * v)];
             }
             const double* Lt = Ls + (s & 1) * TF_TILE;
 #pragma unroll
@@ -277,15 +289,17 @@ trsm_fused_kernel(const double* __restrict__ pack, const double* Bin, double* Xo
 #pragma unroll
     for (int h = 0; h < 8; ++h)
 #pragma unroll
-        for (int v = 0; v < 4; ++v) xst[jl + 16 * h + 4 * v] = xprev[h][v];
+        for (int v = 0; v < 4; ++v) xst[SG * (jl + 16 * h + 4 * v)] = xprev[h][v];
 }
 
 // dLinv != nullptr: a full row-major inverse of L (leading dimension ldinv; its diagonal blocks ARE the inverses of L's
 // diagonal blocks); else dInvBlocks: compact [nb][128][128] inverses of the diagonal blocks; neither: computed here.
+// transposed: rows x with L^T x = b instead of L x = b (n must then be a multiple of 128).
 int trsm_rows_fused(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, const double* dLinv, int64_t ldinv,
-                    const double* dInvBlocks, const double* dBin, int64_t ldin, double* dXout, int64_t ldout, int64_t nrhs) {
+                    const double* dInvBlocks, const double* dBin, int64_t ldin, double* dXout, int64_t ldout, int64_t nrhs, bool transposed) {
     if (n <= 0 || nrhs <= 0) return OAK_OK;
     const int64_t npad = ((n + TF_NB - 1) / TF_NB) * TF_NB;
+    OAK_REQUIRE(!transposed || npad == n, "trsm_rows_fused: the transposed solve needs n = %lld to be a multiple of 128", (long long)n);
     OAK_REQUIRE(ldin >= npad && ldout >= npad && (ldin % 2) == 0 && (ldout % 2) == 0 &&
                     (((uintptr_t)dBin | (uintptr_t)dXout) & 15) == 0,
                 "trsm_rows_fused: the panels need %lld (padded) columns, even row strides and 16-byte alignment", (long long)npad);
@@ -304,13 +318,15 @@ int trsm_rows_fused(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, cons
     const double* inv = dLinv ? dLinv : dInvBlocks;
     const int64_t inv_bs = dLinv ? TF_NB * ldinv + TF_NB : (int64_t)TF_NB * TF_NB;
     const int64_t inv_ld = dLinv ? ldinv : TF_NB;
-    trsm_pack_kernel<<<dim3((unsigned)(8 * nb), (unsigned)nb), 256, 0, ctx->stream>>>(dL, n, ldl, inv, inv_bs, inv_ld, dPack);
+    if (transposed) trsm_pack_kernel<true><<<dim3((unsigned)(8 * nb), (unsigned)nb), 256, 0, ctx->stream>>>(dL, n, ldl, inv, inv_bs, inv_ld, dPack);
+    else trsm_pack_kernel<false><<<dim3((unsigned)(8 * nb), (unsigned)nb), 256, 0, ctx->stream>>>(dL, n, ldl, inv, inv_bs, inv_ld, dPack);
     OAK_HIP_CHECK(hipGetLastError());
     const unsigned grid = (unsigned)((nrhs + TF_ROWS - 1) / TF_ROWS);
     double* dScratch = nullptr;                       // where the lanes of rows past the end read and write
     OAK_CHECK(get_buf_t(ctx, "trsm_scratch_row", (size_t)npad + 64, &dScratch));
     OAK_CHECK(fill_zero(ctx, dScratch, sizeof(double) * ((size_t)npad + 64)));
-    trsm_fused_kernel<<<grid, 256, 0, ctx->stream>>>(dPack, dBin, dXout, dScratch, nrhs, ldin, ldout, nb);
+    if (transposed) trsm_fused_kernel<true><<<grid, 256, 0, ctx->stream>>>(dPack, dBin, dXout, dScratch, nrhs, ldin, ldout, nb);
+    else trsm_fused_kernel<false><<<grid, 256, 0, ctx->stream>>>(dPack, dBin, dXout, dScratch, nrhs, ldin, ldout, nb);
     OAK_HIP_CHECK(hipGetLastError());
     return OAK_OK;
 }

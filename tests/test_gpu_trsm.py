@@ -46,17 +46,20 @@ def test_rows_solve_against_extended_precision(hip, M, nrhs, trans):
     assert float(fwd.max()) <= max(1e-13, 1e-16 * np.sqrt(cond) * 1e3), f"forward error {float(fwd.max()):.2e} (cond(L) {np.sqrt(cond):.1e})"
 
 
-def test_every_row_of_a_large_solve(hip):
+@pytest.mark.parametrize("trans", [False, True])
+def test_every_row_of_a_large_solve(hip, trans):
     """All rows of a 2^18-row solve, three times over.  The sampled-row checks above cannot see a memory-ordering fault in the
-    fused kernel's pipeline: the one r03 had touched a few rows in a million and only with the chip full of workgroups."""
+    fused kernel's pipeline: the one r03 had touched a few rows in a million and only with the chip full of workgroups.
+    trans: the same kernel on column-reversed panels (L^T x = b)."""
     M, nrhs = 512, 1 << 18
     spec, X, Z, L, cond = _factor(M)
     rng = np.random.default_rng(5)
     B = rng.standard_normal((nrhs, M))
-    X0, _ = hip.bench_trsm(L, B, trans=False, reps=1)
-    resid = np.abs(X0 @ L.T - B).max(axis=1) / np.maximum((np.abs(X0) @ np.abs(L.T)).max(axis=1), 1e-300)
+    A = L.T if trans else L                            # rows x solve A x = b, i.e. X A^T = B
+    X0, _ = hip.bench_trsm(L, B, trans=trans, reps=1)
+    resid = np.abs(X0 @ A.T - B).max(axis=1) / np.maximum((np.abs(X0) @ np.abs(A.T)).max(axis=1), 1e-300)
     bad = np.flatnonzero(resid > 1e-13)
     assert bad.size == 0, f"{bad.size} rows above 1e-13, first {bad[:8]}, worst {float(resid.max()):.2e}"
     for rep in range(2):
-        Xr, _ = hip.bench_trsm(L, B, trans=False, reps=1)
+        Xr, _ = hip.bench_trsm(L, B, trans=trans, reps=1)
         assert np.array_equal(Xr, X0), f"run {rep + 2} differs from run 1 in {int((Xr != X0).any(axis=1).sum())} rows"
