@@ -1,3 +1,6 @@
+"""Run-to-run repeatability of prediction at the headline size: objective, posterior mean (large and small batches), alpha, and the
+whitened posterior against the phi posterior, several times over (what exposed the memory-ordering fault of r03's first fused
+triangular solve: DESIGN.md section 5b).  python tools/dev_predict_flaky.py"""
 import sys
 from pathlib import Path
 import numpy as np
