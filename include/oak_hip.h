@@ -38,10 +38,10 @@ extern "C" {
 #define OAK_E_STATE  -5   /* call order violated (e.g. predict before posterior)  */
 
 #define OAK_MAX_DIMS   64  /* sub-kernels per OAK kernel                          */
-#define OAK_MAX_DEPTH  16  /* EFFECTIVE depth min(max_interaction_depth, num_dims) of the fused kernels (SGPR / GPR / SVGP paths,
-                               gradients, Sobol; the reference's examples go to 13).  e_r vanishes for r > num_dims, so any
-                               max_interaction_depth is accepted while num_dims <= 16 */
-#define OAK_MAX_DEPTH_DESC 64 /* max_interaction_depth a description may carry; beyond an effective depth of 16 only the explicit
+#define OAK_MAX_DEPTH  32  /* EFFECTIVE depth min(max_interaction_depth, num_dims) of the fused kernels (SGPR / GPR / SVGP paths,
+                               gradients, Sobol; the reference's examples use depth = num_dims, up to 32 on pumadyn32nm).  e_r
+                               vanishes for r > num_dims, so any max_interaction_depth is accepted while num_dims <= 32 */
+#define OAK_MAX_DEPTH_DESC 64 /* max_interaction_depth a description may carry; beyond an effective depth of 32 only the explicit
                                Gram entry points (oak_gram / oak_gram_diag: OAKKernel.K / K_diag) evaluate it, by a generic kernel */
 
 /* dim_type: which constrained base kernel a sub-kernel is */

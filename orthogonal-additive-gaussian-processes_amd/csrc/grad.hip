@@ -908,7 +908,7 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     bool allrbf = true;
     for (int d = 0; d < D; ++d) allrbf = allrbf && pk.dd.type[d] == OAK_DIM_RBF;
     const int dmax = D <= 8 ? 8 : (D <= 16 ? 16 : 32);
-    const int cpt = fast ? (dmax <= 16 ? 2 : 1) : ((D <= 40) ? 2 : 1);
+    const int cpt = fast ? (dmax <= 16 ? 2 : 1) : ((D <= 40 && R <= 16) ? 2 : 1);     // depth > 16: 2 pairs x (R + 1) polynomials per lane
     const int TJ = 64 * cpt, RS = 8;
     bool unitbv = true;
     for (int d = 0; d < D; ++d) unitbv = unitbv && (pk.dd.type[d] != OAK_DIM_RBF || pk.dd.bv[d] == 1.0);
@@ -965,9 +965,11 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
             case 332: OAK_BWD_FAST(3, 32) break;  case 432: OAK_BWD_FAST(4, 32) break;
         }
     } else
-    switch (R <= 8 ? R : (R <= 12 ? 12 : 16)) {      // depths 9..16: the next larger instantiation, zero weights above R
+    switch (template_depth(R)) {      // depths 9..32: the next larger instantiation, zero weights above R
         OAK_BWD_CASE(0) OAK_BWD_CASE(1) OAK_BWD_CASE(2) OAK_BWD_CASE(3) OAK_BWD_CASE(4)
         OAK_BWD_CASE(5) OAK_BWD_CASE(6) OAK_BWD_CASE(7) OAK_BWD_CASE(8) OAK_BWD_CASE(12) OAK_BWD_CASE(16)
+        case 24: OAK_BWD_LAUNCH(24, 1) break;
+        case 32: OAK_BWD_LAUNCH(32, 1) break;
         default: set_error("gram_bwd: unsupported depth %d", R); return OAK_E_ARG;
     }
 #undef OAK_BWD_CASE
@@ -1047,12 +1049,13 @@ int diag_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, double gcons
     nwg = (A.n + rows - 1) / rows;
     double* d_part = nullptr;
     OAK_CHECK(get_buf_t(ctx, "bwd_part_diag", (size_t)(nwg * reclen), &d_part));
-    const int RTP = R <= 8 ? R : (R <= 12 ? 12 : 16);          // template depth the launch below instantiates
+    const int RTP = template_depth(R);                         // template depth the launch below instantiates
     const size_t lds = sizeof(double) * ((size_t)8 * D + 4 * tablen + 4 * (RTP + 1) + 8);
 #define OAK_DB_CASE(RR) case RR: diag_bwd_kernel<RR><<<(unsigned)nwg, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen, A.xs, A.cn, A.dcn, A.ld, A.n, gconst, d_gvec, rows, d_part); break;
-    switch (R <= 8 ? R : (R <= 12 ? 12 : 16)) {
+    switch (RTP) {
         OAK_DB_CASE(0) OAK_DB_CASE(1) OAK_DB_CASE(2) OAK_DB_CASE(3) OAK_DB_CASE(4)
         OAK_DB_CASE(5) OAK_DB_CASE(6) OAK_DB_CASE(7) OAK_DB_CASE(8) OAK_DB_CASE(12) OAK_DB_CASE(16)
+        OAK_DB_CASE(24) OAK_DB_CASE(32)
         default: set_error("diag_bwd: unsupported depth %d", R); return OAK_E_ARG;
     }
 #undef OAK_DB_CASE

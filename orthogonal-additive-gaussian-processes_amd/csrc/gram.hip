@@ -307,8 +307,11 @@ static int launch_gram_r(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, 
     } else if constexpr (R <= 4) {
         if (D <= 16) return launch_gram_t<R, 2, 4>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
         return launch_gram_t<R, 4, 2>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
-    } else {
+    } else if constexpr (R <= 16) {
         if (D <= 16) return launch_gram_t<R, 1, 4>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+        return launch_gram_t<R, 1, 2>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+    } else {
+        // effective depth > 16 means more than 16 sub-kernels: two pairs per lane, R + 1 polynomials each
         return launch_gram_t<R, 1, 2>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
     }
 }
@@ -331,6 +334,10 @@ int gram(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int6
         // elementary symmetric polynomials are formed and weighted by 0.
         case 9: case 10: case 11: case 12: return launch_gram_r<12>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
         case 13: case 14: case 15: case 16: return launch_gram_r<16>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+        case 17: case 18: case 19: case 20: case 21: case 22: case 23: case 24:
+            return launch_gram_r<24>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+        case 25: case 26: case 27: case 28: case 29: case 30: case 31: case 32:
+            return launch_gram_r<32>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
     }
     set_error("gram: unsupported depth %d", pk.dd.R);
     return OAK_E_ARG;
@@ -462,9 +469,10 @@ int gram_diag(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, double* d_o
     if (n <= 0) return OAK_OK;
     const unsigned g = (unsigned)((n + 255) / 256);
 #define OAK_DIAG_CASE(RR) case RR: gram_diag_kernel<RR><<<g, 256, 0, ctx->stream>>>(pk.dd, pk.d_tables, A.xs, A.cn, A.ld, n, d_out); break;
-    switch (pk.dd.R <= 8 ? pk.dd.R : (pk.dd.R <= 12 ? 12 : 16)) {
+    switch (template_depth(pk.dd.R)) {
         OAK_DIAG_CASE(0) OAK_DIAG_CASE(1) OAK_DIAG_CASE(2) OAK_DIAG_CASE(3) OAK_DIAG_CASE(4)
         OAK_DIAG_CASE(5) OAK_DIAG_CASE(6) OAK_DIAG_CASE(7) OAK_DIAG_CASE(8) OAK_DIAG_CASE(12) OAK_DIAG_CASE(16)
+        OAK_DIAG_CASE(24) OAK_DIAG_CASE(32)
         default: set_error("gram_diag: unsupported depth %d", pk.dd.R); return OAK_E_ARG;
     }
 #undef OAK_DIAG_CASE

@@ -213,7 +213,7 @@ int gram_f32(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
              const double* d_yA, double* d_psi, int64_t zero_pad_to) {
     if (na <= 0 || B.n <= 0) return OAK_OK;
 #define OAK_G32(RR, RTT) return launch_gram32<RR, RTT>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
-    switch (pk.dd.R <= 8 ? pk.dd.R : (pk.dd.R <= 12 ? 12 : 16)) {
+    switch (pk.dd.R <= 16 ? template_depth(pk.dd.R) : -1) {      // (depth > 16 never gets here: sgpr_local_stats keeps it in fp64)
         case 0: OAK_G32(0, 4) case 1: OAK_G32(1, 4) case 2: OAK_G32(2, 4) case 3: OAK_G32(3, 4) case 4: OAK_G32(4, 4)
         case 5: OAK_G32(5, 2) case 6: OAK_G32(6, 2) case 7: OAK_G32(7, 2) case 8: OAK_G32(8, 2)
         case 12: OAK_G32(12, 1) case 16: OAK_G32(16, 1)

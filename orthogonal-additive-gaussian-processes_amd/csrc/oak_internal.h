@@ -167,6 +167,8 @@ void reset_timings(oak_ctx* ctx);
 void debug_mark(oak_ctx* ctx, const char* literal);      // breadcrumb: the last 16 are shown by oak_debug_state
 
 // kernel description ----------------------------------------------------------------------------
+// template depth a kernel of effective depth R is run with (zero weights above R): 0..8 exact, then 12, 16, 24, 32
+inline int template_depth(int R) { return R <= 8 ? R : (R <= 12 ? 12 : (R <= 16 ? 16 : (R <= 24 ? 24 : 32))); }
 int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk, bool allow_deep = false);
 // component (single subset) description derived from a full one
 int prepare_component(oak_ctx* ctx, const oak_kernel_desc* desc, const int32_t* subset, int32_t len,

@@ -171,7 +171,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     }
     const bool lazy = ctx->auto_pending;
     bool whiten = lazy ? false : sgpr_route_whitened(ctx);
-    const bool use32 = want32 && !whiten;
+    const bool use32 = want32 && !whiten && pk.dd.R <= 16;       // the fp32 Gram kernel is instantiated to depth 16
     float* dPanel32 = nullptr;
     if (use32) OAK_CHECK(get_buf_t(ctx, "panel_f32", (size_t)rows * Mp, &dPanel32));
     double *dLw = nullptr, *dLinvw = nullptr;      // whitened route: L and (when it exists) the explicit L^-1 whose diagonal blocks the solve applies

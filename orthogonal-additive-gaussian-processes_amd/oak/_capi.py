@@ -16,8 +16,8 @@ import numpy as np
 OAK_OK, OAK_E_ARG, OAK_E_HIP, OAK_E_NOTPD, OAK_E_NCCL, OAK_E_STATE = 0, -1, -2, -3, -4, -5
 DIM_RBF, DIM_BINARY, DIM_CATEGORICAL = 0, 1, 2
 MEAS_NONE, MEAS_GAUSSIAN, MEAS_UNIFORM, MEAS_EMPIRICAL, MEAS_MOG = 0, 1, 2, 3, 4
-MAX_DIMS, MAX_DEPTH = 64, 16        # MAX_DEPTH: EFFECTIVE depth min(max_interaction_depth, D) of the fused kernels
-MAX_DEPTH_DESC = 64                  # what a description may carry (deeper than 16: explicit Gram entry points only)
+MAX_DIMS, MAX_DEPTH = 64, 32        # MAX_DEPTH: EFFECTIVE depth min(max_interaction_depth, D) of the fused kernels
+MAX_DEPTH_DESC = 64                  # what a description may carry (deeper than 32: explicit Gram entry points only)
 
 _PKG_ROOT = Path(__file__).resolve().parent.parent
 LIB_PATH = Path(os.environ.get("OAK_HIP_LIB", _PKG_ROOT / "lib" / "liboak_hip.so"))

@@ -355,11 +355,12 @@ def test_reference_arithmetic_form_matches_the_oracle_entry_by_entry(hip, idx):
     print(f"[A/B] {name}: reference-form device vs oracle {np.abs(ab - ref).max() / scale:.1e}, native vs oracle {dev:.1e} (of max|K|)")
 
 
-@pytest.mark.parametrize("D,R", [(20, 20), (24, 17), (40, 33)])
+@pytest.mark.parametrize("D,R", [(20, 20), (24, 17), (32, 32), (40, 33)])
 def test_gram_beyond_an_effective_depth_of_sixteen(hip, D, R):
-    """The reference's loop takes any depth (oak_kernel.py:236-249).  Beyond an effective depth min(R, D) of 16 the explicit
-    Gram entry points run a generic one-thread-per-entry kernel (exact-sum recurrence): K and K_diag against the exact sum
-    over subsets where that is affordable, otherwise against the recurrence in extended precision."""
+    """The reference's loop takes any depth (oak_kernel.py:236-249; its regression example runs depth = D, 32 on pumadyn32nm).
+    Effective depths min(R, D) of 17..32 run the R = 24 / 32 instantiations of the fused kernels -- K, K_diag, the SGPR objective and
+    its gradient; beyond 32 the explicit Gram entry points run a generic one-thread-per-entry kernel and the model paths refuse.
+    K and K_diag against the exact-sum recurrence in extended precision."""
     rng = np.random.default_rng(D * 7 + R)
     spec = cases.random_spec(rng, D, R, ("gaussian", "binary", "gaussian", "categorical"))
     X, X2 = cases.random_inputs(rng, spec, 23), cases.random_inputs(rng, spec, 31)
@@ -380,11 +381,53 @@ def test_gram_beyond_an_effective_depth_of_sixteen(hip, D, R):
             ed[r] = ed[r] + k * ed[r - 1]
     refd = sum(np.longdouble(w) * er for w, er in zip(spec["order_variances"], ed))
     assert np.abs(Kd - refd).max() <= 1e-12 * np.abs(refd).max()
-    # the fused model paths say so loudly instead of running at a wrong depth
     ctx = _capi.HipContext(0)
-    ctx.sgpr_set_data(X, X[:, :1]); ctx.sgpr_set_inducing(X2)
-    with pytest.raises(ValueError, match="effective interaction depth"):
-        ctx.sgpr_elbo(d, 0.1)
+    y = rng.standard_normal((len(X), 1))
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(X2[:9])
+    if min(R, D) > 32:
+        # the fused model paths say so loudly instead of running at a wrong depth
+        with pytest.raises(ValueError, match="effective interaction depth"):
+            ctx.sgpr_elbo(d, 0.1)
+    else:
+        # the bound from the extended-precision Gram matrices (the oracle's Newton-Girard form is no reference at this depth), and the
+        # gradient against central differences of the device objective
+        def kmat(A, B_):
+            ms = [o.base_K(A[:, [o.active_col(spec, i)]], B_[:, [o.active_col(spec, i)]], dim).astype(np.longdouble) for i, dim in enumerate(spec["dims"])]
+            ee = [np.ones_like(ms[0])] + [np.zeros_like(ms[0]) for _ in range(R)]
+            for k in ms:
+                for r in range(R, 0, -1):
+                    ee[r] = ee[r] + k * ee[r - 1]
+            return np.asarray(sum(np.longdouble(w) * er for w, er in zip(spec["order_variances"], ee)), dtype=np.float64)
+        Z = X2[:9]
+        s2, N, M = 0.1, len(X), 9
+        Kuu, Kuf = kmat(Z, Z) + 1e-6 * np.eye(M), kmat(Z, X)
+        L = np.linalg.cholesky(Kuu)
+        A = np.linalg.solve(L, Kuf) / np.sqrt(s2)
+        LB = np.linalg.cholesky(np.eye(M) + A @ A.T)
+        c = np.linalg.solve(LB, A @ y) / np.sqrt(s2)
+        bound = (-0.5 * N * np.log(2 * np.pi * s2) - np.log(np.diag(LB)).sum() - 0.5 * float((y ** 2).sum()) / s2 + 0.5 * float((c ** 2).sum())
+                 - 0.5 * float(np.asarray(refd, dtype=np.float64).sum()) / s2 + 0.5 * np.trace(A @ A.T))
+        for route in ("phi", "whitened"):
+            ctx.sgpr_set_route(route)
+            assert abs(ctx.sgpr_elbo(d, s2) - bound) <= 1e-9 * abs(bound), route
+        e0, g = ctx.sgpr_elbo_grad(d, s2)
+        assert np.isfinite(g).all()
+        import copy
+        for which, idx in (("lengthscale", 0), ("order", R)):
+            gi = idx if which == "lengthscale" else 2 * D + idx
+            if which == "lengthscale" and spec["dims"][0]["type"] != "rbf":
+                continue
+            def at(v):
+                sp = copy.deepcopy(spec)
+                if which == "lengthscale":
+                    sp["dims"][0]["lengthscale"] = v
+                else:
+                    sp["order_variances"][idx] = v
+                return ctx.sgpr_elbo(_capi.KernelDesc(sp), s2)
+            x0 = float(spec["dims"][0]["lengthscale"]) if which == "lengthscale" else float(spec["order_variances"][idx])
+            h = 1e-5 * max(1.0, abs(x0))
+            fd = (at(x0 + h) - at(x0 - h)) / (2 * h)
+            assert abs(g[gi] - fd) <= 1e-5 * max(1.0, abs(fd)), (which, g[gi], fd)
     ctx.close()
 
 

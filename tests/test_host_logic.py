@@ -121,7 +121,7 @@ def test_kernel_desc_packs_every_measure():
     with pytest.raises(ValueError):
         _capi.KernelDesc(dict(dims=spec["dims"][:1], order_variances=[1.0] * 66, max_interaction_depth=65, share_var_across_orders=True))
     # any depth up to 64 can be described (e_r vanishes beyond the number of sub-kernels, so the kernels run at min(R, D);
-    # the fused paths take an EFFECTIVE depth up to 16 -- the reference's examples go to 13 -- the explicit Gram goes deeper)
+    # the fused paths take an EFFECTIVE depth up to 32 -- the reference's examples go to 32 (pumadyn32nm) -- the explicit Gram goes deeper)
     assert _capi.KernelDesc(dict(dims=spec["dims"][:1], order_variances=[1.0] * 18, max_interaction_depth=17,
                                  share_var_across_orders=True)).R == 17
     assert _capi.KernelDesc(dict(dims=spec["dims"][:1], order_variances=[1.0] * 14, max_interaction_depth=13,
