@@ -20,7 +20,6 @@ This module is the process-level plumbing, with no dependency beyond NumPy and t
 from __future__ import annotations
 
 import os
-import pickle
 import socket
 import struct
 import time
@@ -151,10 +150,12 @@ class HostPlane:
     def barrier(self):
         self._through_root(b"", lambda parts: b"")
 
-    def broadcast(self, obj=None, src: int = 0):
-        """``obj`` of rank ``src`` on every rank (pickled: control-plane sized objects only)."""
-        out = self._through_root(pickle.dumps(obj if self.rank == src else None), lambda parts: parts[src])
-        return pickle.loads(out)
+    def broadcast(self, data: Optional[bytes] = None, src: int = 0) -> Optional[bytes]:
+        """The byte string ``data`` of rank ``src`` on every rank (``None`` travels as ``None``).  Plain bytes, no pickling: what
+        goes over this socket is never executed."""
+        mine = b"\x00" if (self.rank != src or data is None) else b"\x01" + bytes(data)
+        out = self._through_root(mine, lambda parts: parts[src])
+        return None if out[:1] == b"\x00" else out[1:]
 
     def allreduce_sum(self, a: np.ndarray) -> np.ndarray:
         """Sum over ranks of a float64 array, added in rank order on rank 0 (deterministic, identical on every rank)."""
@@ -168,10 +169,18 @@ class HostPlane:
         return np.frombuffer(self._through_root(a.tobytes(), combine), dtype=np.float64).reshape(a.shape).copy()
 
     def allgather(self, a: np.ndarray) -> List[np.ndarray]:
-        """Every rank's float64 array (any lengths), in rank order."""
-        a = np.ascontiguousarray(a, dtype=np.float64)
-        out = self._through_root(pickle.dumps(a), lambda parts: pickle.dumps([pickle.loads(p) for p in parts]))
-        return pickle.loads(out)
+        """Every rank's 1-D float64 array (any lengths), in rank order."""
+        a = np.ascontiguousarray(a, dtype=np.float64).reshape(-1)
+
+        def combine(parts):
+            return struct.pack(f"<{len(parts)}Q", *[len(p_) for p_ in parts]) + b"".join(parts)
+        out = self._through_root(a.tobytes(), combine)
+        lens = struct.unpack(f"<{self.world}Q", out[:8 * self.world])
+        res, off = [], 8 * self.world
+        for n in lens:
+            res.append(np.frombuffer(out[off:off + n], dtype=np.float64).copy())
+            off += n
+        return res
 
     def close(self):
         for s in self._peers + [self._root]:

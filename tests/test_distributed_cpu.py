@@ -185,9 +185,10 @@ def _worker_plane(rank, world, port, out_dir):
     pl = D.HostPlane(rank, world, "127.0.0.1", port)
     a = pl.allreduce_sum(np.arange(5.0) * (rank + 1))
     g = pl.allgather(np.full(rank + 1, float(rank)))
-    b = pl.broadcast({"id": b"x" * 128} if rank == 1 else None, src=1)
+    b = pl.broadcast(b"x" * 128 if rank == 1 else None, src=1)
+    assert pl.broadcast(None, src=0) is None
     pl.barrier()
-    np.savez(Path(out_dir) / f"p{rank}.npz", a=a, g=np.concatenate(g), b=np.frombuffer(b["id"], dtype=np.uint8))
+    np.savez(Path(out_dir) / f"p{rank}.npz", a=a, g=np.concatenate(g), b=np.frombuffer(b, dtype=np.uint8))
     pl.close()
 
 
