@@ -491,3 +491,44 @@ def test_several_output_columns(hip):
         mp, vp = gpflow.models.GPR((Xg, Yg[:, p:p + 1]), k, noise_variance=0.2).predict_f(X[400:420])
         np.testing.assert_allclose(mean_g.numpy()[:, p], mp.numpy()[:, 0], rtol=1e-12, atol=1e-14)
         np.testing.assert_allclose(var_g.numpy()[:, p], vp.numpy()[:, 0], rtol=1e-12, atol=1e-14)
+
+
+def test_full_gp_at_depth_twenty(hip):
+    """The full GP with 20 sub-kernels at depth 20 (the R = 24 instantiations): marginal likelihood against the value formed from
+    extended-precision Gram matrices, gradient against differences of the device objective, prediction against the same matrices."""
+    import copy
+    rng = np.random.default_rng(9)
+    D = R = 20
+    spec = cases.random_spec(rng, D, R, ("gaussian", "binary", "gaussian", "categorical"))
+    X, Xs = cases.random_inputs(rng, spec, 150), cases.random_inputs(rng, spec, 20)
+    y = rng.standard_normal((150, 1))
+
+    def kmat(A, B):
+        ms = [o.base_K(A[:, [o.active_col(spec, i)]], B[:, [o.active_col(spec, i)]], dim).astype(np.longdouble) for i, dim in enumerate(spec["dims"])]
+        e = [np.ones_like(ms[0])] + [np.zeros_like(ms[0]) for _ in range(R)]
+        for k in ms:
+            for r in range(R, 0, -1):
+                e[r] = e[r] + k * e[r - 1]
+        return np.asarray(sum(np.longdouble(w) * er for w, er in zip(spec["order_variances"], e)), dtype=np.float64)
+    s2 = 0.05
+    K = kmat(X, X) + s2 * np.eye(len(X))
+    L = np.linalg.cholesky(K)
+    a = np.linalg.solve(L, y)
+    ref = float(-0.5 * (a ** 2).sum() - np.log(np.diag(L)).sum() - 0.5 * len(X) * np.log(2 * np.pi))
+    d = _capi.KernelDesc(spec)
+    hip.gpr_set_data(X, y)
+    assert rel(hip.gpr_log_marginal(d, s2), ref) <= 1e-10
+    m, v = hip.gpr_predict(d, Xs)
+    Ks = kmat(X, Xs)
+    t = np.linalg.solve(L, Ks)
+    np.testing.assert_allclose(m, (t.T @ a)[:, 0], rtol=1e-8, atol=1e-9)
+    obj, g = hip.gpr_log_marginal_grad(d, s2)
+    assert rel(obj, ref) <= 1e-10 and np.isfinite(g).all()
+    idx = next(i for i, dim in enumerate(spec["dims"]) if dim["type"] == "rbf")
+    x0 = float(spec["dims"][idx]["lengthscale"]); h = 1e-5 * max(1.0, x0)
+    vals = []
+    for v_ in (x0 + h, x0 - h):
+        sp = copy.deepcopy(spec); sp["dims"][idx]["lengthscale"] = v_
+        vals.append(hip.gpr_log_marginal(_capi.KernelDesc(sp), s2))
+    fd = (vals[0] - vals[1]) / (2 * h)
+    assert abs(g[idx] - fd) <= 1e-5 * max(1.0, abs(fd)), (g[idx], fd)
