@@ -77,6 +77,23 @@ def make_spec(D, R, mixed=False):
     return dict(dims=dims, order_variances=[1.0] * (R + 1), max_interaction_depth=R, share_var_across_orders=True)
 
 
+class _stdout_to_stderr:
+    """File descriptor 1 points at stderr inside the block: stdout carries ONE line, the JSON -- not the model classes' prints
+    (they print like the reference's) nor the banner librccl writes when a communicator is created."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def log_prior(order_variances):
     """sum_r log Gamma(sigma2_r; concentration 1, rate 0.2)  (oak/model_utils.py:161-165)."""
     v = np.asarray(order_variances, dtype=np.float64)
@@ -210,14 +227,15 @@ def main():
 
             def _init():
                 try:
-                    ctx.comm_init(uid, world, rank)
+                    ctx.comm_init(uid, world, rank)      # (librccl's banner: see the fd redirection around the thread)
                     box["ok"] = True
                 except Exception as e:                             # noqa: BLE001
                     box["err"] = e
 
             th = threading.Thread(target=_init, daemon=True)
-            th.start()
-            th.join(float(os.environ.get("OAK_BENCH_RCCL_TIMEOUT", "240")))
+            with _stdout_to_stderr():
+                th.start()
+                th.join(float(os.environ.get("OAK_BENCH_RCCL_TIMEOUT", "240")))
             if th.is_alive():
                 ok, abandoned_thread = 0, True
                 print(f"[bench] rank {rank}: RCCL communicator init still running after the timeout; abandoning it", file=sys.stderr)
@@ -449,7 +467,8 @@ def main():
     # ---- a bounded real fit through the model API: what a user of oak_model.fit gets (auto route, k-means inducing points) ----
     if not args.no_fit and world == 1 and args.precision == "fp64":
         try:
-            out["fit"] = bounded_fit(X, y, M, R, args.fit_maxiter)
+            with _stdout_to_stderr():
+                out["fit"] = bounded_fit(X, y, M, R, args.fit_maxiter)
         except Exception as ex:
             out["fit"] = {"error": repr(ex)}
 

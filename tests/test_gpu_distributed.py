@@ -396,3 +396,30 @@ def test_bench_fails_loudly_when_rccl_cannot_be_used():
     assert rc != 0 and line is None, (rc, line, err[-1500:])
     rc, line, err = _run_bench(["--gpus", "2", "--allow-host-exchange"], {"OAK_BENCH_RCCL_TIMEOUT": "60"})
     assert rc != 0 and line is not None and line["degraded"] is True and "host" in line["config"]["exchange"], (rc, line, err[-1500:])
+
+
+def test_bench_stdout_is_exactly_one_json_line():
+    """The driver parses the bench's stdout: ONE line, the JSON -- with the bounded model fit and the CPU baseline enabled (the
+    model classes print like the reference's, and the oracle build may chat), and under the two-rank launcher."""
+    import json, os, socket, subprocess, sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    for extra in ([], ["--gpus", "2", "--exchange", "host"]):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ, MASTER_PORT=str(port), MASTER_ADDR="127.0.0.1", OAK_BENCH_DEVICE="0")
+        for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+            env.pop(k, None)
+        cmd = [sys.executable, str(root / "bench.py"), "--config", "tiny", "--steps", "2", "--warmup", "1", "--fit-maxiter", "2",
+               "--cpu-sample-rows", "4096"] + extra
+        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        lines = p.stdout.splitlines()
+        assert len(lines) == 1, lines[:6]
+        d = json.loads(lines[0])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                    "dtype", "data", "config", "roofline"):
+            assert key in d, key
+        if not extra:
+            assert "cpu_baseline" in d and "fit" in d and "error" not in d["fit"], d.get("fit")
