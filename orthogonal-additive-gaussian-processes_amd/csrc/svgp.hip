@@ -94,35 +94,78 @@ __global__ void __launch_bounds__(256) svgp_rows_kernel(const double* __restrict
 }
 
 // Abar[n][j] = q_mu_j gmu_n + 2 (q_sqrt_j^2 - 1) A[n][j] gv_n     (adjoint of A, row layout)
-// P[n][j]    = sqrt(-gv_n) A[n][j] for rows with gv_n < 0, else 0   (panel of the weighted SYRK, see below)
+// P[r(n)][j] = sqrt|gv_n| A[n][j]                                  (panel of the weighted SYRK, rows regrouped by the sign of gv_n)
 // upart[by][j] = sum over this block's rows of A[n][j] gmu_n       (u = A gmu, finished by svgp_usum_kernel)
-// W2 = A diag(gv) A^T is a SYRK with signed weights: rows are split by the sign of gv_n (negative for a log-concave
-// likelihood; the jittered links leave a few positive ones), each part runs through the MFMA SYRK of the SGPR path on a
-// panel scaled by sqrt|gv_n|, and W2 = P+^T P+ - P-^T P-.  (A plain M x M x N GEMM on a transposed copy ran at 16 TFLOP/s.)
+// W2 = A diag(gv) A^T is a SYRK with signed weights: W2 = P+^T P+ - P-^T P-, each part through the MFMA SYRK of the SGPR path on a
+// panel scaled by sqrt|gv_n|.  (A plain M x M x N GEMM on a transposed copy ran at 16 TFLOP/s.)  gv_n < 0 for a log-concave
+// likelihood; the jittered links leave some positive ones.  The rows are COMPACTED by sign -- the non-positive ones to the rows
+// [0, n_neg) of P in their original order, the positive ones behind them -- so the two SYRKs together stream N rows, not 2 N
+// (r03: they used to run over zero-filled full-height panels, 2 x 17.3 ms at N = 2^20).  Destinations come from per-block counts
+// (svgp_sign_counts_kernel), scanned on the host, plus a rank inside the block that every column workgroup recomputes.
 constexpr int SV_ROWS = 1024;     // rows per block: N / SV_ROWS partial rows of u
+__global__ void __launch_bounds__(256) svgp_sign_counts_kernel(const double* __restrict__ gv, int64_t N, int* __restrict__ npos) {
+    __shared__ int red[256];
+    const int64_t n0 = (int64_t)blockIdx.x * SV_ROWS;
+    int c = 0;
+    for (int r = threadIdx.x; r < SV_ROWS; r += 256) c += (n0 + r < N && gv[n0 + r] > 0.0) ? 1 : 0;
+    red[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) npos[blockIdx.x] = red[0];
+}
+
 __global__ void __launch_bounds__(256) svgp_adjoint_kernel(const double* __restrict__ AT, int64_t lda, int64_t N, int64_t M,
                                                            const double* __restrict__ qmu, const double* __restrict__ s2m1,
                                                            const double* __restrict__ gmu, const double* __restrict__ gv,
-                                                           double* __restrict__ Abar, double* __restrict__ P,
+                                                           const int64_t* __restrict__ neg_off, const int64_t* __restrict__ pos_off,
+                                                           int64_t n_neg, double* __restrict__ Abar, double* __restrict__ P,
                                                            double* __restrict__ upart) {
     __shared__ double red[8][33];
+    __shared__ int rankp[SV_ROWS + 1];                           // exclusive count of positive rows before row r of this block
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 columns x 8 rows per step
     const int64_t jc = (int64_t)blockIdx.x * 32 + tx;            // < lda (grid covers the padded width)
     const bool live = jc < M;
     const double qm = live ? qmu[jc] : 0.0, sm = live ? s2m1[jc] : 0.0;
     const int64_t n_begin = (int64_t)blockIdx.y * SV_ROWS;
     const int64_t n_end = (n_begin + SV_ROWS < N) ? n_begin + SV_ROWS : N;
+    {   // ranks: four consecutive rows per thread, then a scan of the 256 per-thread counts
+        __shared__ int tsum[256];
+        int f[4], c = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t n = n_begin + 4 * threadIdx.x + q;
+            f[q] = (n < n_end && gv[n] > 0.0) ? 1 : 0;
+            c += f[q];
+        }
+        tsum[threadIdx.x] = c;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int run = 0;
+            for (int t = 0; t < 256; ++t) { const int v = tsum[t]; tsum[t] = run; run += v; }
+        }
+        __syncthreads();
+        int run = tsum[threadIdx.x];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { rankp[4 * threadIdx.x + q] = run; run += f[q]; }
+        __syncthreads();
+    }
+    const int64_t nbase = neg_off[blockIdx.y], pbase = n_neg + pos_off[blockIdx.y];
     double cu = 0.0;
     for (int64_t n = n_begin + ty; n < n_end; n += 8) {
         const double g = gv[n], gm = gmu[n];
+        const int r = (int)(n - n_begin), rp = rankp[r];
+        const int64_t dest = g > 0.0 ? pbase + rp : nbase + (r - rp);
         double pv = 0.0;
         if (live) {
             const double x = AT[n * lda + jc];
             Abar[n * lda + jc] = __builtin_fma(qm, gm, 2.0 * sm * x * g);
             cu = __builtin_fma(x, gm, cu);
-            pv = g < 0.0 ? sqrt(-g) * x : 0.0;
+            pv = sqrt(fabs(g)) * x;
         }
-        P[n * lda + jc] = pv;
+        P[dest * lda + jc] = pv;
     }
     red[ty][tx] = cu;
     __syncthreads();
@@ -133,24 +176,12 @@ __global__ void __launch_bounds__(256) svgp_adjoint_kernel(const double* __restr
         upart[(int64_t)blockIdx.y * M + jc] = s;
     }
 }
-// the positive-weight panel (rare): P[n][j] = sqrt(gv_n) A[n][j] for rows with gv_n > 0, else 0
-__global__ void __launch_bounds__(256) svgp_pospanel_kernel(const double* __restrict__ AT, int64_t lda, int64_t N, int64_t M,
-                                                            const double* __restrict__ gv, double* __restrict__ P) {
-    const int64_t jc = (int64_t)blockIdx.x * 256 + threadIdx.x, n = blockIdx.y;
-    if (jc >= lda) return;
-    const double g = gv[n];
-    P[n * lda + jc] = (jc < M && g > 0.0) ? sqrt(g) * AT[n * lda + jc] : 0.0;
-}
 __global__ void svgp_usum_kernel(const double* __restrict__ upart, int64_t nby, int64_t M, double* __restrict__ u) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= M) return;
     double s = 0.0;
     for (int64_t b = 0; b < nby; ++b) s += upart[b * M + j];
     u[j] = s;
-}
-__global__ void svgp_anypos_kernel(const double* __restrict__ gv, int64_t N, double* __restrict__ flag) {
-    const int64_t n = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (n < N && gv[n] > 0.0) *flag = 1.0;        // every writer stores the same value
 }
 // W2 = Wpos - Wneg (Wpos may be NULL)
 __global__ void svgp_w2_kernel(const double* __restrict__ Wpos, const double* __restrict__ Wneg, int64_t len, double* __restrict__ W2) {
@@ -264,14 +295,20 @@ int oak_svgp_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, const double* 
     // Row shards (one rank per GPU): the sum of the expectations, the sign flag, u, the SYRK results and the gradient
     // record are sums over rows and are all-reduced; K(Z), its factor and everything M-sized is replicated.
     OAK_CHECK(reduce_sum(ctx, dve, N, dsc, 0, 1));
-    OAK_CHECK(fill_zero(ctx, dsc + 1, sizeof(double)));
+    // per 1024-row block: how many rows have gv_n > 0 (the reverse pass regroups the rows by that sign)
+    const int64_t nby = (N + SV_ROWS - 1) / SV_ROWS;
+    int* dnpos = nullptr;
+    std::vector<int> hnpos;
     if (want_grad) {
-        svgp_anypos_kernel<<<(unsigned)((N + 255) / 256), 256, 0, ctx->stream>>>(dgv, N, dsc + 1);
+        OAK_CHECK(get_buf_t(ctx, "svnpos", (size_t)nby, &dnpos));
+        svgp_sign_counts_kernel<<<(unsigned)nby, 256, 0, ctx->stream>>>(dgv, N, dnpos);
         OAK_HIP_CHECK(hipGetLastError());
+        hnpos.resize((size_t)nby);
+        OAK_HIP_CHECK(hipMemcpyAsync(hnpos.data(), dnpos, sizeof(int) * (size_t)nby, hipMemcpyDeviceToHost, ctx->stream));
     }
-    OAK_CHECK(comm_allreduce_dev(ctx, dsc, 2));
+    OAK_CHECK(comm_allreduce_dev(ctx, dsc, 1));
     double hsc[2] = {0.0, 0.0};
-    OAK_HIP_CHECK(hipMemcpyAsync(hsc, dsc, sizeof(double) * 2, hipMemcpyDeviceToHost, ctx->stream));
+    OAK_HIP_CHECK(hipMemcpyAsync(hsc, dsc, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     const double& sum_ve = hsc[0];
     double kl = 0.0;
     for (int64_t j = 0; j < M; ++j) {
@@ -299,29 +336,50 @@ int oak_svgp_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, const double* 
     OAK_CHECK(get_buf_t(ctx, "svPm", (size_t)M * M, &dPm));
     OAK_CHECK(get_buf_t(ctx, "svGuu", (size_t)M * M, &dGuu));
     {
-        const int64_t nby = (N + SV_ROWS - 1) / SV_ROWS;
         double *dup = nullptr, *dPart = nullptr, *dWn = nullptr, *dWp = nullptr;
         OAK_CHECK(get_buf_t(ctx, "svupart", (size_t)nby * M, &dup));
+        // destinations of the regrouped rows: exclusive scans of the per-block counts (host: nby values)
+        OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));                        // the counts (and sum_ve) have landed
+        std::vector<int64_t> hoff((size_t)2 * nby);
+        int64_t n_pos = 0, n_negs = 0;
+        for (int64_t b = 0; b < nby; ++b) {
+            const int64_t rows_b = ((b + 1) * SV_ROWS <= N) ? SV_ROWS : N - b * SV_ROWS;
+            hoff[(size_t)b] = n_negs; hoff[(size_t)(nby + b)] = n_pos;
+            n_pos += hnpos[(size_t)b]; n_negs += rows_b - hnpos[(size_t)b];
+        }
+        int64_t* doff = nullptr;
+        OAK_CHECK(get_buf_t(ctx, "svoff", (size_t)2 * nby, &doff));
+        OAK_HIP_CHECK(hipMemcpyAsync(doff, hoff.data(), sizeof(int64_t) * hoff.size(), hipMemcpyHostToDevice, ctx->stream));
         dim3 grid((unsigned)(Mp / 32), (unsigned)nby);
-        svgp_adjoint_kernel<<<grid, 256, 0, ctx->stream>>>(dAT, Mp, N, M, dqmu, ds2m1, dgmu, dgv, dAbar, dP, dup);
+        svgp_adjoint_kernel<<<grid, 256, 0, ctx->stream>>>(dAT, Mp, N, M, dqmu, ds2m1, dgmu, dgv, doff, doff + nby, n_negs, dAbar, dP, dup);
         OAK_HIP_CHECK(hipGetLastError());
+        OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));                        // hoff leaves scope below; cheap next to the SYRKs
         svgp_usum_kernel<<<(unsigned)((M + 255) / 256), 256, 0, ctx->stream>>>(dup, nby, M, du);   // u = A gmu
         OAK_HIP_CHECK(hipGetLastError());
-        const int nsplit = syrk_plan_splits(ctx, M, N);
-        OAK_CHECK(get_buf_t(ctx, "syrk_part", (size_t)nsplit * Mp * Mp, &dPart));
         OAK_CHECK(get_buf_t(ctx, "svWn", (size_t)M * M, &dWn));
-        OAK_CHECK(syrk_panel(ctx, dP, Mp, N, M, dPart, nsplit, false));
-        OAK_CHECK(syrk_reduce(ctx, dPart, nsplit, M, dWn, false));
+        auto weighted_syrk = [&](const double* panel, int64_t rows, double* dW) -> int {
+            if (rows <= 0) return fill_zero(ctx, dW, sizeof(double) * (size_t)M * M);
+            const int nsplit = syrk_plan_splits(ctx, M, rows);
+            OAK_CHECK(get_buf_t(ctx, "syrk_part", (size_t)nsplit * Mp * Mp, &dPart));
+            OAK_CHECK(syrk_panel(ctx, panel, Mp, rows, M, dPart, nsplit, false));
+            return syrk_reduce(ctx, dPart, nsplit, M, dW, false);
+        };
+        OAK_CHECK(weighted_syrk(dP, n_negs, dWn));
         OAK_CHECK(comm_allreduce_dev(ctx, du, M));
         OAK_CHECK(comm_allreduce_dev(ctx, dWn, M * M));
-        OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));                        // the sign flag (and sum_ve) have landed
-        if (hsc[1] > 0.0) {
+        // whether ANY rank has positive rows decides, for all ranks alike, whether the second product (and its collective) runs
+        double any_pos = n_pos > 0 ? 1.0 : 0.0;
+        if (ctx->comm != nullptr && ctx->nranks > 1) {
+            double* dflag = nullptr;
+            OAK_CHECK(get_buf_t(ctx, "svflag", 1, &dflag));
+            OAK_HIP_CHECK(hipMemcpyAsync(dflag, &any_pos, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            OAK_CHECK(comm_allreduce_dev(ctx, dflag, 1));
+            OAK_HIP_CHECK(hipMemcpyAsync(&any_pos, dflag, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        }
+        if (any_pos > 0.0) {
             OAK_CHECK(get_buf_t(ctx, "svWp", (size_t)M * M, &dWp));
-            dim3 gp((unsigned)((Mp + 255) / 256), (unsigned)N);
-            svgp_pospanel_kernel<<<gp, 256, 0, ctx->stream>>>(dAT, Mp, N, M, dgv, dP);
-            OAK_HIP_CHECK(hipGetLastError());
-            OAK_CHECK(syrk_panel(ctx, dP, Mp, N, M, dPart, nsplit, false));
-            OAK_CHECK(syrk_reduce(ctx, dPart, nsplit, M, dWp, false));
+            OAK_CHECK(weighted_syrk(dP + n_negs * Mp, n_pos, dWp));
             OAK_CHECK(comm_allreduce_dev(ctx, dWp, M * M));
         }
         svgp_w2_kernel<<<(unsigned)((M * M + 255) / 256), 256, 0, ctx->stream>>>(dWp, dWn, M * M, dW2);   // W2 = A diag(gv) A^T
