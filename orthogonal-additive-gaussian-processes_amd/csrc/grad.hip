@@ -1147,13 +1147,16 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
     const int frc = sgpr_forward(ctx, pk, noise_var, jitter, &elbo, terms);
     ctx->keep_kfu = false;
     OAK_CHECK(frc);
-    OAK_CHECK(sgpr_ensure_alpha(ctx));
     const int64_t N = ctx->N, M = ctx->M, Mp = ((M + 127) / 128) * 128;
     const double s2 = noise_var;
     double* dL = (double*)peek_buf(ctx, "L");
     double* dLB = (double*)peek_buf(ctx, "LB");
     double* dW = (double*)peek_buf(ctx, "T2");
-    double* da = (double*)peek_buf(ctx, "alpha");
+    // a = Sigma^-1 psi / sigma^2 = L^-T LB^-T c.  The posterior entry points get it from two transposed triangular solves
+    // (sgpr_ensure_alpha); for ONE right-hand side those are 2 x 15 dependent launches, 0.6 ms at M = 1024 -- here the matrix
+    // (LB^-1 L^-1)^T is formed anyway (dPT below, it also gives Sigma^-1), so a is one matrix-vector product with it.
+    double* da = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "g_a", (size_t)M, &da));
     double* dY = (double*)peek_buf(ctx, "Y");
     // ---- M x M adjoints -----------------------------------------------------------------------------------
     double *dLinvT, *dPT, *dKinv, *dSinv, *dTmp, *dKWK, *dH, *dGuu, *dKuu, *dsc, *dvec;
@@ -1178,6 +1181,8 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
         }
         OAK_CHECK(copy_d2d(ctx, dPT, dLinvT, sizeof(double) * (size_t)M * M));
         OAK_CHECK(trsm_rows(ctx, dLB, M, M, dPT, M, M, 0));                         // rows = columns of LB^-1 L^-1
+        if (ctx->have_alpha) OAK_CHECK(copy_d2d(ctx, da, peek_buf(ctx, "alpha"), sizeof(double) * (size_t)M));
+        else OAK_CHECK(gemv_rows(ctx, dPT, M, M, M, (const double*)peek_buf(ctx, "c"), da));         // a = (LB^-1 L^-1)^T c
         // LinvT (rows = columns of L^-1) and PT are upper triangular, L lower: the products below skip the zero k ranges and
         // slice k over gridDim.z (gemm_tail)
         const int UU = OAK_TRI_A_UPPER | OAK_TRI_B_UPPER;
