@@ -1213,8 +1213,13 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
     OAK_CHECK(get_buf_t(ctx, "g_rec", (size_t)reclen, &d_rec));
     OAK_CHECK(fill_zero(ctx, d_rec, sizeof(double) * (size_t)reclen));
     Feat FX, FZ;
-    OAK_CHECK(featurize(ctx, pk, (double*)peek_buf(ctx, "Z"), M, ctx->ldx, "featZg", &FZ, true));
-    OAK_CHECK(featurize(ctx, pk, (double*)peek_buf(ctx, "X"), N, ctx->ldx, "featXg", &FX, true));
+    if (ctx->feat_grad_valid) {                    // left by this call's forward pass
+        FX = ctx->featXg; FZ = ctx->featZg;
+        ctx->feat_grad_valid = false;
+    } else {
+        OAK_CHECK(featurize(ctx, pk, (double*)peek_buf(ctx, "Z"), M, ctx->ldx, "featZg", &FZ, true));
+        OAK_CHECK(featurize(ctx, pk, (double*)peek_buf(ctx, "X"), N, ctx->ldx, "featXg", &FX, true));
+    }
     // optional: gradient w.r.t. the inducing inputs (second pair pass, column-side accumulators)
     const int zdmax = pk.dd.D <= 8 ? 8 : (pk.dd.D <= 16 ? 16 : 32);
     double *d_dzb = nullptr, *d_gz = nullptr;

@@ -144,6 +144,9 @@ struct oak_ctx {
     int syrk_desc_blocks_ntile = -1; // same for "syrk_desc_blocks" (the fp32 variant's table: full diagonal 64-blocks)
     // breadcrumbs for oak_debug_state (a watchdog on another thread reads them without locks: literals and integers only)
     const char* marks[16] = {nullptr}; double mark_t[16] = {0}; unsigned mark_n = 0;
+    // a gradient entry point's forward pass featurizes X and Z WITH the backward pass's arrays (one pass over X instead of two);
+    // valid only between that forward and the backward of the same call
+    bool feat_grad_valid = false; oak::Feat featXg, featZg;
     bool keep_kfu = false;           // set by the gradient entry points: a whitening forward works on a COPY of the Kfu panel
     bool kfu_kept = false;           // ... and reports here that "panel" still holds the raw Kfu rows of the whole data set
 };

@@ -125,8 +125,17 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     bool kappa_done = false;       // kappa = sum K_diag comes out of the featurize pass when its tiled form runs
     {
         PhaseTimer t(ctx, "featurize");
-        OAK_CHECK(featurize(ctx, pk, dZ, M, ctx->ldx, "featZ", &FZ));
-        OAK_CHECK(featurize(ctx, pk, dX, N, ctx->ldx, "featX", &FX, false, st.kappa, &kappa_done));
+        ctx->feat_grad_valid = false;
+        if (ctx->keep_kfu) {
+            // a gradient follows: write the backward pass's feature arrays now (40 N D bytes instead of 16 N D) and spare it a
+            // second pass over X
+            OAK_CHECK(featurize(ctx, pk, dZ, M, ctx->ldx, "featZg", &FZ, true));
+            OAK_CHECK(featurize(ctx, pk, dX, N, ctx->ldx, "featXg", &FX, true, st.kappa, &kappa_done));
+            ctx->featXg = FX; ctx->featZg = FZ; ctx->feat_grad_valid = true;
+        } else {
+            OAK_CHECK(featurize(ctx, pk, dZ, M, ctx->ldx, "featZ", &FZ));
+            OAK_CHECK(featurize(ctx, pk, dX, N, ctx->ldx, "featX", &FX, false, st.kappa, &kappa_done));
+        }
         t.stop();
     }
     int64_t rows = ctx->panel_rows > 0 ? ctx->panel_rows : (int64_t)(((size_t)16 << 30) / (sizeof(double) * (size_t)Mp));
