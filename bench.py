@@ -94,6 +94,80 @@ class _stdout_to_stderr:
         return False
 
 
+def spawn_ranks(world, argv):
+    """One child process per GPU (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment, the same
+    contract a cluster launcher provides).  The children are started before anything in this process touches the GPU; when
+    one fails the others are terminated by PID; returns the worst exit status."""
+    import subprocess
+    env0 = dict(os.environ)
+    env0.setdefault("MASTER_ADDR", "127.0.0.1")
+    env0.setdefault("MASTER_PORT", "29531")
+    env0["WORLD_SIZE"] = str(world)
+    env0["LOCAL_WORLD_SIZE"] = str(world)
+    procs = []
+    for r in range(world):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, str(Path(__file__).resolve())] + list(argv), env=env))
+    worst, live = 0, set(range(world))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                worst = max(worst, rc if rc > 0 else 1)
+                for q in live:                      # a rank died: the others would wait for it in a collective forever
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return worst
+
+
+def sobol_record(ctx, desc, spec, Z, M, D, R):
+    """All Sobol terms of the model (oak/utils.py:338-435) from the posterior of the last evaluation: the Gram-of-products pass
+    (two fp64-MFMA SYRKs over the index-pair panel) timed with HIP events on the library's stream, against the fp64 matrix peak."""
+    from oracle import oak_oracle               # list_representation only (test-infrastructure helper; nothing is computed by it)
+    from oak import _capi
+    alpha = ctx.sgpr_alpha(M)
+    subsets = oak_oracle.list_representation(D, R)[1:]
+    packed = _capi.HipContext.pack_subsets(subsets)
+    ctx.sobol(desc, Z, alpha, packed)             # warm-up (scratch buffers, descriptor tables)
+    reps = 5
+    ctx.reset_timings()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        sob = ctx.sobol(desc, Z, alpha, packed)
+    wall_ms = (time.perf_counter() - t0) / reps * 1e3
+    info = ctx.sobol_last_info()
+    ph = {k: ctx.timing(k)[0] / reps for k in ("sobol", "sobol_panel", "sobol_syrk")}
+    rec = {"terms": len(subsets), "path": info["path"], "ms_per_call_wall": wall_ms, "ms_per_call_device": ph["sobol"],
+           "normalised_sum_check": float(np.sum(sob / sob.sum())), "min_term": float(sob.min())}
+    if info["path"] == "gram":
+        nc, rows = info["columns"], info["pair_rows"]
+        mp = -(-nc // 128) * 128
+        flop_alg, flop_exec = float(nc) * (nc + 1) * rows, float(mp) * (mp + 1) * rows
+        rec.update({"kernel": "sobol_panel_kernel + syrk_kernel (v_mfma_f64_16x16x4_f64), one pass per sign of alpha_i alpha_j",
+                    "gram_columns": nc, "pair_rows": rows, "panel_ms": ph["sobol_panel"], "syrk_ms": ph["sobol_syrk"],
+                    "algorithmic_flops_per_call": flop_alg, "executed_flops_per_call_padded_to_128": flop_exec,
+                    "achieved_TFLOPs": flop_alg / (ph["sobol_syrk"] * 1e-3) / 1e12 if ph["sobol_syrk"] else None,
+                    "executed_TFLOPs": flop_exec / (ph["sobol_syrk"] * 1e-3) / 1e12 if ph["sobol_syrk"] else None,
+                    "peak_TFLOPs": FP64_PEAK_TFLOPS,
+                    "frac": flop_alg / (ph["sobol_syrk"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if ph["sobol_syrk"] else None,
+                    "order4_pairing_disagreement": info["pairing_disagreement"]})
+    # the independent per-term kernel (a fused product-reduction over the stacked L_d) on a sample of the terms
+    pick = np.random.default_rng(0).choice(len(subsets), min(512, len(subsets)), replace=False)
+    ctx.sobol_set_path("terms")
+    try:
+        t0 = time.perf_counter()
+        ref = ctx.sobol(desc, Z, alpha, [subsets[i] for i in pick])
+        rec["terms_kernel_ms_per_term"] = (time.perf_counter() - t0) * 1e3 / len(pick)
+    finally:
+        ctx.sobol_set_path("auto")
+    rec["max_abs_diff_vs_terms_kernel_over_max_term"] = float(np.abs(sob[pick] - ref).max() / np.abs(sob).max())
+    return rec
+
+
 def log_prior(order_variances):
     """sum_r log Gamma(sigma2_r; concentration 1, rate 0.2)  (oak/model_utils.py:161-165)."""
     v = np.asarray(order_variances, dtype=np.float64)
@@ -168,18 +242,15 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        # started as plain `python bench.py --gpus N`: run the one-process-per-GPU job as a child (nothing has touched the
-        # GPU yet in this process) and exit with its status
-        import subprocess
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29531"), str(Path(__file__).resolve())] + sys.argv[1:]
-        raise SystemExit(subprocess.call(cmd))
+        # started as plain `python bench.py --gpus N`: this process (which has not touched the GPU) starts one fresh child per
+        # GPU with the launcher's environment contract and exits with the worst of their statuses
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")      # one node: RCCL's bootstrap over loopback, data over xGMI
     from oak import _capi
     from oak import distributed as oakdist
 
-    # control plane: the package's own TCP star (rank 0 listens on MASTER_PORT + 1); torch is only the launcher of this file
+    # control plane: the package's own TCP star (rank 0 listens on MASTER_PORT + 1)
     comm = oakdist.init_from_env(exchange=args.exchange)
     plane = comm.plane
 
@@ -463,6 +534,14 @@ def main():
         "forward_plus_gradient": grad_info,
         "whitened": whitened_info,
     }
+
+    # ---- Sobol indices of every term of the model (BASELINE configs[4] names the Sobol path) ----------------
+    if world == 1 and args.precision == "fp64":
+        try:
+            ctx.sgpr_elbo(_capi.KernelDesc(spec), noise, jitter)
+            out["sobol"] = sobol_record(ctx, _capi.KernelDesc(spec), spec, Z, M, D, R)
+        except Exception as ex:
+            out["sobol"] = {"error": repr(ex)}
 
     # ---- a bounded real fit through the model API: what a user of oak_model.fit gets (auto route, k-means inducing points) ----
     if not args.no_fit and world == 1 and args.precision == "fp64":

@@ -269,6 +269,20 @@ int oak_svgp_posterior(oak_ctx* ctx, const oak_kernel_desc* desc, const double* 
 int oak_sobol(oak_ctx* ctx, const oak_kernel_desc* desc, const double* Xc, int64_t n, int32_t ldx,
               const double* alpha, const int32_t* subsets, const int32_t* subset_off,
               int32_t n_subsets, int32_t use_order_var, double delta, double mu, double* out);
+/* The same evaluation as a collective over the context's communicator (oak_comm_init*): every rank makes the
+   identical call and receives every term; the pair rows of the Gram of products (or blocks of terms) are sharded
+   over the ranks and summed on the device.  Without a communicator it is oak_sobol. */
+int oak_sobol_collective(oak_ctx* ctx, const oak_kernel_desc* desc, const double* Xc, int64_t n, int32_t ldx,
+                         const double* alpha, const int32_t* subsets, const int32_t* subset_off,
+                         int32_t n_subsets, int32_t use_order_var, double delta, double mu, double* out);
+/* How oak_sobol evaluates the terms: 0 = automatic (cost model), 1 = one workgroup per term (a fused
+   product-reduction over the stacked L_d, any subset size), 2 = Gram of products (every term one entry of the
+   weighted fp64-MFMA Gram matrix of [1 | L_a | L_a L_b | L_a L_b L_c] over the index pairs; subsets of <= 6
+   distinct dims, OAK_E_ARG otherwise). */
+int oak_sobol_set_path(oak_ctx* ctx, int32_t path);
+/* About the most recent oak_sobol call: info4 = {path taken (1 | 2), Gram columns, largest relative disagreement
+   between the three pairings ab|cd, ac|bd, ad|bc of an order-4 term (0 when none was evaluated), pair rows}. */
+int oak_sobol_last_info(oak_ctx* ctx, double* info4);
 /* One per-dimension integral matrix L_d(v) [n x n] as the reference's compute_L* helpers return it
    (v = the helper's `variance` argument; delta is used as a standard deviation, utils.py:116-165). */
 int oak_sobol_L(oak_ctx* ctx, const oak_kernel_desc* desc, int32_t dim, double v, double delta, double mu,
@@ -307,9 +321,12 @@ int oak_comm_info(char* path_out, int64_t cap, int32_t* version_out, int32_t* he
 int oak_comm_destroy(oak_ctx* ctx);
 int oak_comm_allreduce_stats(oak_ctx* ctx);                    /* in-place sum of packed stats */
 int oak_comm_allreduce_host(oak_ctx* ctx, double* buf, int64_t n); /* small host vector (gradients) */
-/* All-gather of variable-sized blocks of a host vector: buf has `total` doubles, this rank owns [offset, offset + count),
-   on return every rank holds all blocks (Sobol terms and predictions are sharded with no other exchange). */
-int oak_comm_allgatherv(oak_ctx* ctx, double* buf, int64_t total, int64_t offset, int64_t count);
+/* All-gather of variable-sized blocks of a host vector: buf has sum(counts) doubles, rank r owns counts[r] of them at
+   offset sum(counts[:r]); on return every rank holds all blocks (predictions are sharded with no other exchange).
+   RCCL communicator: a device all-gather (one grouped ncclBroadcast per block); host communicator: the sum of
+   zero-padded copies through the callback.  n_counts must equal the communicator's size (1 without one):
+   OAK_E_STATE otherwise -- blocks announced for ranks the context cannot reach are never silently left empty. */
+int oak_comm_allgatherv(oak_ctx* ctx, double* buf, const int64_t* counts, int32_t n_counts);
 
 /* ---- input preprocessing ----------------------------------------------------------------------- */
 /* KL objective of the per-feature normalising flow and its gradient (oak/normalising_flow.py:79-85

@@ -482,38 +482,55 @@ def compute_L_empirical_measure(loc, w, dim_spec, z):  # utils.py:312-335
     return (w * kxu.T) @ kxu
 
 
-def compute_sobol_oak(spec, Xc, alpha, delta=1.0, mu=0.0, share_var_across_orders=True):
-    """oak/utils.py:338-435. Xc = Z (sparse) or training X (full); alpha [rows(Xc),1]."""
+def compute_sobol_oak(spec, Xc, alpha, delta=1.0, mu=0.0, share_var_across_orders=True, subsets=None, L_cache=None):
+    """oak/utils.py:338-435. Xc = Z (sparse) or training X (full); alpha [rows(Xc),1].
+    ``subsets``: evaluate only these terms (the reference always walks the whole list; the per-term arithmetic is unchanged).
+    ``L_cache``: a dict that memoises the per-dimension matrices by (dim, v) -- the reference recomputes them per term; the
+    values are identical, a checker at n = 2048 just cannot afford 4 closed-form n x n evaluations per term."""
     Xc = np.asarray(Xc, dtype=np.float64)
     D = len(spec["dims"])
-    subsets = list_representation(D, spec["max_interaction_depth"])[1:]
+    if subsets is None:
+        subsets = list_representation(D, spec["max_interaction_depth"])[1:]
     N = Xc.shape[0]
+
+    def L_of(d, v):
+        key = (d, float(v))
+        if L_cache is not None and key in L_cache:
+            return L_cache[key]
+        dim = spec["dims"][d]
+        col = active_col(spec, d)
+        if dim["type"] == "rbf":
+            kind = None if dim["measure"] is None else dim["measure"][0]
+            if kind not in ("empirical", "mog"):                    # :388-400
+                Ld = compute_L(Xc, dim["lengthscale"], v, col, delta, mu)
+            elif kind == "empirical":                                 # :402-412
+                Ld = compute_L_empirical_measure(dim["measure"][1], dim["measure"][2], dim, Xc[:, col].reshape(-1, 1))
+            else:
+                raise NotImplementedError                             # :413-414
+        elif dim["type"] == "binary":                                 # :416-418
+            Ld = compute_L_binary_kernel(Xc, dim["p0"], v, col)
+        elif dim["type"] == "categorical":                            # :420-424
+            Ld = compute_L_categorical_kernel(Xc, dim["W"], dim["kappa"], dim["p"], v, col)
+        else:
+            raise NotImplementedError
+        if L_cache is not None:
+            L_cache[key] = Ld
+        return Ld
+
     sobol = []
     for S in subsets:
         L = np.ones((N, N))
         n_order = len(S)
         for j, d in enumerate(S):
-            dim = spec["dims"][d]
             if share_var_across_orders:
                 v = spec["order_variances"][n_order] if j < 1 else 1.0   # :376-380
             else:
-                v = dim["variance"]
-            col = active_col(spec, d)
-            if dim["type"] == "rbf":
-                kind = None if dim["measure"] is None else dim["measure"][0]
-                if kind not in ("empirical", "mog"):                    # :388-400
-                    L = L * compute_L(Xc, dim["lengthscale"], v, col, delta, mu)
-                elif kind == "empirical":                                 # :402-412
-                    L = v ** 2 * L * compute_L_empirical_measure(dim["measure"][1], dim["measure"][2], dim,
-                                                                 Xc[:, col].reshape(-1, 1))
-                else:
-                    raise NotImplementedError                             # :413-414
-            elif dim["type"] == "binary":                                 # :416-418
-                L = L * compute_L_binary_kernel(Xc, dim["p0"], v, col)
-            elif dim["type"] == "categorical":                            # :420-424
-                L = L * compute_L_categorical_kernel(Xc, dim["W"], dim["kappa"], dim["p"], v, col)
+                v = spec["dims"][d]["variance"]
+            dim = spec["dims"][d]
+            if dim["type"] == "rbf" and dim["measure"] is not None and dim["measure"][0] == "empirical":
+                L = v ** 2 * L * L_of(d, 1.0)                             # :402-412 (the variance multiplies outside)
             else:
-                raise NotImplementedError
+                L = L * L_of(d, v)
         sobol.append(float((alpha.T @ L @ alpha)[0, 0]))                  # :429-432
     return subsets, sobol
 

@@ -20,6 +20,9 @@ struct Rccl {
     decltype(&ncclReduceScatter) ReduceScatter = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
     decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclBroadcast) Broadcast = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
 };
 static Rccl g_rccl;
@@ -50,6 +53,9 @@ static int load_rccl() {
     OAK_SYM(ReduceScatter, "ncclReduceScatter")
     OAK_SYM(AllGather, "ncclAllGather")
     OAK_SYM(AllReduce, "ncclAllReduce")
+    OAK_SYM(Broadcast, "ncclBroadcast")
+    OAK_SYM(GroupStart, "ncclGroupStart")
+    OAK_SYM(GroupEnd, "ncclGroupEnd")
     OAK_SYM(GetErrorString, "ncclGetErrorString")
 #undef OAK_SYM
     auto get_version = (ncclResult_t(*)(int*))dlsym(h, "ncclGetVersion");
@@ -241,14 +247,63 @@ int oak_comm_allreduce_host(oak_ctx* ctx, double* buf, int64_t n) {
     return OAK_OK;
 }
 
-// All-gather of variable-sized host blocks: buf has `total` doubles, this rank's block sits at [offset, offset + count), the
-// rest is overwritten with the other ranks' blocks (sum of zero-padded copies: every block is owned by exactly one rank).
-int oak_comm_allgatherv(oak_ctx* ctx, double* buf, int64_t total, int64_t offset, int64_t count) {
-    if (!ctx || (!buf && total > 0) || total < 0 || offset < 0 || count < 0 || offset + count > total) { set_error("bad argument"); return OAK_E_ARG; }
-    if (ctx->comm == nullptr || ctx->nranks <= 1 || total == 0) return OAK_OK;
-    for (int64_t i = 0; i < offset; ++i) buf[i] = 0.0;
-    for (int64_t i = offset + count; i < total; ++i) buf[i] = 0.0;
-    return oak_comm_allreduce_host(ctx, buf, total);
+// All-gather of variable-sized host blocks: buf has sum(counts) doubles, rank r's block (counts[r] doubles) sits at offset
+// sum(counts[:r]); this rank's block is read, every other block is overwritten with its owner's.
+//   RCCL communicator:  a true all-gather on the device -- one grouped ncclBroadcast per non-empty block, each rank sending
+//                       only its own block over xGMI (total bytes on the wire = the gathered vector, not nranks times it);
+//   host communicator:  the sum of zero-padded copies through the callback (every block is owned by exactly one rank);
+//   loopback:           every "rank" holds the same local block (the test communicator's premise), so the blocks must all have
+//                       this rank's length and the result is that block repeated.
+int oak_comm_allgatherv(oak_ctx* ctx, double* buf, const int64_t* counts, int32_t n_counts) {
+    if (!ctx || !counts || n_counts < 1) { set_error("bad argument"); return OAK_E_ARG; }
+    int64_t total = 0;
+    for (int r = 0; r < n_counts; ++r) {
+        OAK_REQUIRE(counts[r] >= 0, "oak_comm_allgatherv: negative block length");
+        total += counts[r];
+    }
+    OAK_REQUIRE(buf || total == 0, "oak_comm_allgatherv: buf is NULL");
+    const int nranks = (ctx->comm != nullptr) ? ctx->nranks : 1;
+    if (n_counts != nranks) {
+        // blocks were announced for ranks this context knows nothing about: returning would hand back a buffer that looks
+        // gathered and holds zeros for them
+        set_error("oak_comm_allgatherv: %d blocks announced but the context's communicator has %d rank(s)", n_counts, nranks);
+        return OAK_E_STATE;
+    }
+    if (nranks <= 1 || total == 0) return OAK_OK;
+    OAK_HIP_CHECK(hipSetDevice(ctx->device));
+    int64_t offset = 0;
+    for (int r = 0; r < ctx->rank; ++r) offset += counts[r];
+    const int64_t count = counts[ctx->rank];
+    if (is_loopback(ctx)) {
+        for (int r = 0; r < nranks; ++r) OAK_REQUIRE(counts[r] == count, "oak_comm_allgatherv (loopback): every block must have the local length");
+        int64_t o = 0;
+        for (int r = 0; r < nranks; ++r, o += count)
+            if (o != offset) memcpy(buf + o, buf + offset, sizeof(double) * (size_t)count);
+        return OAK_OK;
+    }
+    if (is_host(ctx)) {
+        for (int64_t i = 0; i < offset; ++i) buf[i] = 0.0;
+        for (int64_t i = offset + count; i < total; ++i) buf[i] = 0.0;
+        return oak_comm_allreduce_host(ctx, buf, total);
+    }
+    OAK_CHECK(load_rccl());
+    double* d = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "comm_gather", (size_t)total, &d));
+    if (count > 0) OAK_HIP_CHECK(hipMemcpyAsync(d + offset, buf + offset, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, ctx->stream));
+    ncclComm_t comm = (ncclComm_t)ctx->comm;
+    OAK_NCCL_CHECK(g_rccl.GroupStart());
+    int64_t o = 0;
+    for (int r = 0; r < nranks; ++r) {
+        if (counts[r] > 0) {
+            const ncclResult_t rc = g_rccl.Broadcast(d + o, d + o, (size_t)counts[r], ncclFloat64, r, comm, ctx->stream);
+            if (rc != ncclSuccess) { (void)g_rccl.GroupEnd(); set_error("ncclBroadcast failed: %s", g_rccl.GetErrorString(rc)); return OAK_E_NCCL; }
+        }
+        o += counts[r];
+    }
+    OAK_NCCL_CHECK(g_rccl.GroupEnd());
+    OAK_HIP_CHECK(hipMemcpyAsync(buf, d, sizeof(double) * (size_t)total, hipMemcpyDeviceToHost, ctx->stream));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return OAK_OK;
 }
 
 }  // extern "C"

@@ -149,6 +149,8 @@ struct oak_ctx {
     bool feat_grad_valid = false; oak::Feat featXg, featZg;
     bool keep_kfu = false;           // set by the gradient entry points: a whitening forward works on a COPY of the Kfu panel
     bool kfu_kept = false;           // ... and reports here that "panel" still holds the raw Kfu rows of the whole data set
+    int sobol_path = 0;              // 0 automatic (cost model), 1 one workgroup per term, 2 Gram of products (oak_sobol_set_path)
+    double sobol_info[4] = {0, 0, 0, 0};   // last oak_sobol: path taken, Gram columns, largest order-4 pairing disagreement, pair rows
 };
 
 namespace oak {

@@ -7,6 +7,7 @@ device is usable, the first compute call raises :class:`OakHipError`.
 from __future__ import annotations
 
 import ctypes as C
+import itertools
 import os
 from pathlib import Path
 from typing import Optional, Sequence
@@ -105,6 +106,9 @@ SIGNATURES = {
     "oak_gpr_predict": (C.c_int, [_CTX, _DESC, _D, C.c_int64, C.c_int32, _D, _D]),
     "oak_gpr_log_marginal_grad": (C.c_int, [_CTX, _DESC, C.c_double, _D, _D]),
     "oak_sobol": (C.c_int, [_CTX, _DESC, _D, C.c_int64, C.c_int32, _D, _I, _I, C.c_int32, C.c_int32, C.c_double, C.c_double, _D]),
+    "oak_sobol_collective": (C.c_int, [_CTX, _DESC, _D, C.c_int64, C.c_int32, _D, _I, _I, C.c_int32, C.c_int32, C.c_double, C.c_double, _D]),
+    "oak_sobol_set_path": (C.c_int, [_CTX, C.c_int32]),
+    "oak_sobol_last_info": (C.c_int, [_CTX, _D]),
     "oak_sobol_L": (C.c_int, [_CTX, _DESC, C.c_int32, C.c_double, C.c_double, C.c_double, _D, C.c_int64, C.c_int32, _D]),
     "oak_cov_x_s": (C.c_int, [_CTX, _DESC, C.c_int32, _D, C.c_int64, C.c_int32, _D, _D]),
     "oak_additive_terms": (C.c_int, [_CTX, _D, C.c_int32, C.c_int64, C.c_int32, _D]),
@@ -117,7 +121,7 @@ SIGNATURES = {
     "oak_comm_allreduce_host": (C.c_int, [_CTX, _D, C.c_int64]),
     "oak_comm_init_host": (C.c_int, [_CTX, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "oak_comm_info": (C.c_int, [C.c_char_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
-    "oak_comm_allgatherv": (C.c_int, [_CTX, _D, C.c_int64, C.c_int64, C.c_int64]),
+    "oak_comm_allgatherv": (C.c_int, [_CTX, _D, C.POINTER(C.c_int64), C.c_int32]),
     "oak_bench_gram_resident": (C.c_int, [_CTX, _DESC, _D]),
     "oak_bench_potrf": (C.c_int, [_CTX, C.c_int64, C.c_int32, _D, _D]),
     "oak_bench_trsm": (C.c_int, [_CTX, _D, C.c_int64, _D, C.c_int64, C.c_int32, C.c_int32, _D]),
@@ -618,20 +622,42 @@ class HipContext:
     # -- Sobol / components -------------------------------------------------------------------
     @staticmethod
     def _pack_subsets(subsets):
-        off = np.zeros(len(subsets) + 1, np.int32)
-        flat = []
-        for i, s in enumerate(subsets):
-            flat += [int(v) for v in s]
-            off[i + 1] = len(flat)
-        return np.ascontiguousarray(flat if flat else [0], dtype=np.int32), off
+        """(flat dim indices, offsets[len + 1]) of a list of subsets.  A caller that evaluates the same term list repeatedly
+        can pack once (``pack_subsets``) and pass the pair: walking 41 448 Python lists costs more than the device pass."""
+        if isinstance(subsets, tuple) and len(subsets) == 2 and isinstance(subsets[0], np.ndarray):
+            return subsets
+        n = len(subsets)
+        lens = np.fromiter(map(len, subsets), dtype=np.int64, count=n)
+        off = np.zeros(n + 1, np.int32)
+        np.cumsum(lens, out=off[1:])
+        total = int(off[-1])
+        flat = np.fromiter(itertools.chain.from_iterable(subsets), dtype=np.int32, count=total) if total else np.zeros(1, np.int32)
+        return np.ascontiguousarray(flat), off
 
-    def sobol(self, desc: KernelDesc, Xc, alpha, subsets, use_order_var=True, delta=1.0, mu=0.0) -> np.ndarray:
+    pack_subsets = _pack_subsets
+
+    SOBOL_PATHS = {"auto": 0, "terms": 1, "gram": 2}
+
+    def sobol(self, desc: KernelDesc, Xc, alpha, subsets, use_order_var=True, delta=1.0, mu=0.0, collective=False) -> np.ndarray:
+        """alpha^T (prod_{d in S} L_d) alpha for every subset S.  ``collective``: every rank of the attached communicator makes
+        this call with the same arguments (work sharded on the device side, every rank gets every term)."""
         Xc, alpha = _f64(Xc, 2), _f64(np.asarray(alpha).reshape(-1))
         flat, off = self._pack_subsets(subsets)
-        out = np.zeros(len(subsets))
-        _check(self._lib.oak_sobol(self._h, desc.ref, _dp(Xc), Xc.shape[0], Xc.shape[1], _dp(alpha), _ip(flat), _ip(off),
-                                   len(subsets), int(use_order_var), float(delta), float(mu), _dp(out)))
+        out = np.zeros(len(off) - 1)
+        fn = self._lib.oak_sobol_collective if collective else self._lib.oak_sobol
+        _check(fn(self._h, desc.ref, _dp(Xc), Xc.shape[0], Xc.shape[1], _dp(alpha), _ip(flat), _ip(off),
+                  len(out), int(use_order_var), float(delta), float(mu), _dp(out)))
         return out
+
+    def sobol_set_path(self, path="auto") -> None:
+        """'auto' (cost model), 'terms' (one workgroup per term) or 'gram' (Gram of products on the matrix pipe)."""
+        _check(self._lib.oak_sobol_set_path(self._h, self.SOBOL_PATHS[path] if isinstance(path, str) else int(path)))
+
+    def sobol_last_info(self) -> dict:
+        info = np.zeros(4)
+        _check(self._lib.oak_sobol_last_info(self._h, _dp(info)))
+        return dict(path={1: "terms", 2: "gram"}.get(int(info[0]), "none"), columns=int(info[1]), pairing_disagreement=float(info[2]),
+                    pair_rows=int(info[3]))
 
     def sobol_L(self, desc: KernelDesc, dim: int, v: float, delta: float, mu: float, Xc) -> np.ndarray:
         Xc = _f64(Xc, 2)
@@ -700,17 +726,19 @@ class HipContext:
         return {"path": path.value.decode(), "version": int(v.value), "header_version": int(hv.value)}
 
     def comm_allgatherv(self, local: np.ndarray, counts) -> np.ndarray:
-        """Concatenation, in rank order, of every rank's 1-D block (``counts[r]`` doubles from rank r)."""
+        """Concatenation, in rank order, of every rank's 1-D block (``counts[r]`` doubles from rank r).  ``len(counts)`` must
+        be the size of the context's communicator (the library refuses anything else: a block nobody delivers would come
+        back as zeros)."""
         local = _f64(np.asarray(local).reshape(-1), 1)
-        counts = [int(c) for c in counts]
+        counts = np.ascontiguousarray([int(c) for c in counts], dtype=np.int64)
         rank = self.comm_rank()
-        if local.size != counts[rank]:
+        if rank >= len(counts) or local.size != counts[rank]:
             raise ValueError("comm_allgatherv: the local block does not have the length this rank announced")
-        total, off = sum(counts), sum(counts[:rank])
-        buf = np.zeros(total)
+        total, off = int(counts.sum()), int(counts[:rank].sum())
+        buf = np.zeros(max(total, 1))
         buf[off:off + local.size] = local
-        _check(self._lib.oak_comm_allgatherv(self._h, _dp(buf), total, off, local.size))
-        return buf
+        _check(self._lib.oak_comm_allgatherv(self._h, _dp(buf), counts.ctypes.data_as(C.POINTER(C.c_int64)), len(counts)))
+        return buf[:total]
 
     def comm_rank(self) -> int:
         return getattr(self, "_comm_rank", 0)

@@ -218,6 +218,7 @@ class Communicator:
             return
         if self.exchange == "host":
             ctx.comm_init_host(self.world, self.rank, self.plane.allreduce_sum)
+            ctx._oak_comm_attached = self
             return
         # ncclCommInitRank is collective: first make sure every rank can load librccl at all, then ship rank 0's id
         ok, uid = 1, None
@@ -232,6 +233,7 @@ class Communicator:
             raise RuntimeError("RCCL is not usable on every rank (set the exchange to 'host' to run without it)")
         uid = self.plane.broadcast(uid, src=0)
         ctx.comm_init(uid, self.world, self.rank)
+        ctx._oak_comm_attached = self
 
     def allgatherv(self, ctx, local: np.ndarray) -> np.ndarray:
         """Concatenation (rank order) of every rank's 1-D float64 block, through the context's communicator."""
@@ -330,9 +332,19 @@ def _gather_blocks(ctx, local: np.ndarray, comm: Optional[Communicator], gather)
 
 def sharded_sobol(ctx, desc, Xc, alpha, subsets, rank: int, world: int, gather: Optional[Callable[[np.ndarray], list]] = None,
                   comm: Optional[Communicator] = None, **kwargs) -> np.ndarray:
-    """Sobol terms are independent: rank g evaluates the contiguous block ``subsets[lo:hi]`` on its GPU (``ctx.sobol``),
-    the scalars are gathered (``oak_comm_allgatherv`` through the context's communicator, or ``gather``).  Returns all
-    len(subsets) values on every rank, in the order of ``subsets``."""
+    """All len(subsets) Sobol terms on every rank, in the order of ``subsets``.
+
+    With the context attached to a communicator (``Communicator.attach``) this is ONE collective call of the library
+    (``oak_sobol_collective``): the index-pair rows of the Gram of products -- or, for the per-term kernel, blocks of terms --
+    are sharded over the ranks and summed on the device.  With a caller-supplied ``gather`` (a control plane outside the
+    library) rank g evaluates the contiguous block ``subsets[lo:hi]`` and the scalars are gathered."""
+    if gather is None:
+        comm = comm or current()
+        if comm is not None and comm.active:
+            if getattr(ctx, "_oak_comm_attached", None) is not comm:
+                raise RuntimeError("sharded_sobol: the context has not joined the communicator (Communicator.attach)")
+            return np.asarray(ctx.sobol(desc, Xc, alpha, subsets, collective=True, **kwargs), dtype=np.float64)
+        return np.asarray(ctx.sobol(desc, Xc, alpha, subsets, **kwargs), dtype=np.float64)
     lo, hi = shard_bounds(len(subsets), rank, world)
     local = np.asarray(ctx.sobol(desc, Xc, alpha, list(subsets[lo:hi]), **kwargs), dtype=np.float64) if hi > lo else np.empty(0)
     out = _gather_blocks(ctx, local, comm, gather)

@@ -123,14 +123,16 @@ def compute_sobol_oak(model, delta: float, mu: float, share_var_across_orders: O
     alpha = get_model_sufficient_statistics(model, get_L=False)
     desc = _capi.KernelDesc(kernel_to_spec(model.kernel))
     comm = getattr(model, "_comm", None)
-    if comm is not None and len(subsets) >= 8 * comm.world:
-        # the terms are independent: each rank evaluates a contiguous block of them, one gather of the scalars
-        from . import distributed
-        sobol = distributed.sharded_sobol(model._hip, desc, Xc, _first_output(alpha), subsets, comm.rank, comm.world,
-                                          comm=comm, use_order_var=bool(share_var_across_orders), delta=delta, mu=mu)
+    hip = getattr(model, "_hip", None)
+    kw = dict(use_order_var=bool(share_var_across_orders), delta=delta, mu=mu)
+    if comm is not None and hip is not None and getattr(hip, "_oak_comm_attached", None) is comm and len(subsets) >= 8 * comm.world:
+        # the model's context has joined the job's communicator (row-sharded SGPR / SVGP): one collective call, the index-pair
+        # rows of the Gram of products (or blocks of terms) sharded over the ranks and summed on the device.  A model whose
+        # context never joined (a full GPR under a multi-rank job, an SVGP that has not seen its data yet) evaluates every
+        # term on its own: replicated, identical on every rank, no exchange.
+        sobol = hip.sobol(desc, Xc, _first_output(alpha), subsets, collective=True, **kw)
     else:
-        sobol = _capi.default_context().sobol(desc, Xc, _first_output(alpha), subsets,
-                                              use_order_var=bool(share_var_across_orders), delta=delta, mu=mu)
+        sobol = _capi.default_context().sobol(desc, Xc, _first_output(alpha), subsets, **kw)
     assert len(subsets) == len(sobol)
     return subsets, [float(s) for s in sobol]
 

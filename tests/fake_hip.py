@@ -152,11 +152,32 @@ class FakeContext:
     def sgpr_last_terms(self):
         return {}
 
+    # -- GPR (just what get_sobol of a full model touches) --------------------------------------------------------------
+    def gpr_set_data(self, X, y):
+        self.gX, self.gy = np.asarray(X, dtype=np.float64), np.asarray(y, dtype=np.float64).reshape(-1, 1)
+
+    def gpr_set_targets(self, y):
+        self.gy = np.asarray(y, dtype=np.float64).reshape(-1, 1)
+
+    def gpr_log_marginal(self, desc, noise_var):
+        self._gpost = (desc.spec, float(noise_var))
+        return o.gpr_log_marginal_likelihood(desc.spec, self.gX, self.gy, noise_var)
+
+    def gpr_alpha(self, n):
+        spec, s2 = self._gpost
+        return o.gpr_alpha(spec, self.gX, self.gy, s2)[:, 0]
+
     # -- Sobol / preprocessing ---------------------------------------------------------------------------------------
-    def sobol(self, desc, Xc, alpha, subsets, use_order_var=True, delta=1.0, mu=0.0):
+    def sobol(self, desc, Xc, alpha, subsets, use_order_var=True, delta=1.0, mu=0.0, collective=False):
+        """``collective``: the real library shards the index-pair rows over the ranks and sums partial Gram matrices through the
+        communicator; the double keeps the exchange (a share of every term per rank, summed by the host all-reduce) so that a
+        rank that skips the call, or calls it with different arguments, still fails the job."""
         all_subsets, vals = o.compute_sobol_oak(desc.spec, np.asarray(Xc), np.asarray(alpha).reshape(-1, 1), delta, mu, use_order_var)
         look = {tuple(s): v for s, v in zip(all_subsets, vals)}
-        return np.array([look[tuple(s)] for s in subsets])
+        out = np.array([look[tuple(s)] for s in subsets])
+        if collective and self._world > 1:
+            out = self._sum(out / self._world)
+        return out
 
     def flow_forward(self, X, kind, params):
         X = np.asarray(X, dtype=np.float64).copy()

@@ -259,3 +259,37 @@ def test_model_api_runs_row_sharded_and_matches_the_single_process_fit(tmp_path)
     for k in ("loss", "params", "sobol", "pred"):
         np.testing.assert_array_equal(got[0][k], got[1][k])
     assert int(got[0]["nfev"]) == int(got[1]["nfev"])
+
+
+def _worker_gpr_sobol(rank, world, port, out_dir):
+    for p in (str(ROOT / "orthogonal-additive-gaussian-processes_amd"), str(ROOT), str(ROOT / "tests")):
+        sys.path.insert(0, p)
+    import fake_hip
+    fake_hip.install()
+    from oak import distributed as D
+    from oak.model_utils import oak_model
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    D.init_from_env(exchange="host")
+    rng = np.random.default_rng(5)
+    X = rng.normal(size=(60, 6))
+    y = (np.sin(X[:, 0]) + X[:, 1] * X[:, 2] + 0.05 * rng.normal(size=60))[:, None]
+    m = oak_model(max_interaction_depth=2, sparse=False, use_normalising_flow=False)
+    m.fit(X, y, optimise=False)
+    from oak import gpflow_lite as gpflow
+    assert isinstance(m.m, gpflow.GPR) and getattr(m.m._hip, "_oak_comm_attached", None) is None
+    sob = m.get_sobol()                           # 21 terms >= 8 * world: the sharded branch would be taken if it could
+    np.savez(Path(out_dir) / f"g{world}_{rank}.npz", sobol=sob)
+    D.shutdown()
+
+
+@pytest.mark.timeout(600)
+def test_full_gpr_under_a_multi_rank_job_evaluates_sobol_replicated(tmp_path):
+    """A full GPR (<= 1000 rows, sparse=False) never joins the communicator: get_sobol under a 2-rank job must evaluate every
+    term on every rank (round-3 advisor finding: the sharded branch used to run on the unattached context and returned each
+    rank's own block with zeros elsewhere)."""
+    mp.spawn(_worker_gpr_sobol, args=(1, _free_port(), str(tmp_path)), nprocs=1, join=True)
+    mp.spawn(_worker_gpr_sobol, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    ref = np.load(tmp_path / "g1_0.npz")["sobol"]
+    assert len(ref) == 21 and (ref > 0).all()
+    for r in range(2):
+        np.testing.assert_array_equal(np.load(tmp_path / f"g2_{r}.npz")["sobol"], ref)

@@ -423,3 +423,76 @@ def test_bench_stdout_is_exactly_one_json_line():
             assert key in d, key
         if not extra:
             assert "cpu_baseline" in d and "fit" in d and "error" not in d["fit"], d.get("fit")
+
+
+def _two_party_callbacks():
+    """Host all-reduce callbacks for two contexts driven in lock step from two host threads (a two-party sum)."""
+    import threading
+    slots, bar = [None, None], threading.Barrier(2)
+
+    def make_cb(r):
+        def cb(a):
+            slots[r] = np.array(a, copy=True)
+            bar.wait()
+            out = slots[0] + slots[1]
+            bar.wait()
+            return out
+        return cb
+    return make_cb(0), make_cb(1)
+
+
+@pytest.mark.parametrize("path", ["gram", "terms"])
+def test_collective_sobol_shards_pair_rows_or_terms_over_the_ranks(path):
+    """oak_sobol_collective under a 2-rank host-exchange communicator: each rank builds the Gram of products over ITS half of
+    the index-pair rows (or evaluates its block of terms), the partial results are summed through the communicator, and both
+    ranks end with every term -- equal to the one-context answer, identical on both ranks."""
+    import threading
+    import cases
+    rng = np.random.default_rng(21)
+    spec = cases.random_spec(rng, 8, 4, kinds=("gaussian", "binary", "categorical", "gauss2"))
+    d = _capi.KernelDesc(spec)
+    n = 130
+    Z = cases.random_inputs(rng, spec, n)
+    alpha = rng.standard_normal(n)
+    subsets = o.list_representation(8, 4)[1:]
+    ref_ctx = _capi.HipContext(0)
+    ref_ctx.sobol_set_path(path)
+    ref = ref_ctx.sobol(d, Z, alpha, subsets)
+    oracle = np.array(o.compute_sobol_oak(spec, Z, alpha.reshape(-1, 1))[1])
+    np.testing.assert_allclose(ref, oracle, rtol=1e-9, atol=1e-11 * np.abs(oracle).max())
+    cb0, cb1 = _two_party_callbacks()
+    ranks = [_capi.HipContext(0), _capi.HipContext(0)]
+    ranks[0].comm_init_host(2, 0, cb0); ranks[1].comm_init_host(2, 1, cb1)
+    res, info = {}, {}
+
+    def run(r):
+        ranks[r].sobol_set_path(path)
+        res[r] = ranks[r].sobol(d, Z, alpha, subsets, collective=True)
+        info[r] = ranks[r].sobol_last_info()
+    th = [threading.Thread(target=run, args=(r,)) for r in (0, 1)]
+    [t.start() for t in th]; [t.join(120) for t in th]
+    assert not any(t.is_alive() for t in th) and set(res) == {0, 1}
+    assert np.array_equal(res[0], res[1])
+    np.testing.assert_allclose(res[0], ref, rtol=1e-11, atol=1e-13 * np.abs(ref).max())
+    assert info[0]["path"] == path
+    # a non-collective call on an attached context still evaluates everything on its own
+    np.testing.assert_allclose(ranks[0].sobol(d, Z, alpha, subsets), ref, rtol=1e-12, atol=1e-14 * np.abs(ref).max())
+    for c in ranks + [ref_ctx]:
+        c.close()
+
+
+def test_allgatherv_refuses_blocks_for_ranks_it_cannot_reach():
+    """A context with no communicator (or a smaller one) asked to gather blocks of several ranks must fail, not hand back a
+    buffer with zeros where the other ranks' blocks belong (round-3 advisor finding)."""
+    ctx = _capi.HipContext(0)
+    np.testing.assert_array_equal(ctx.comm_allgatherv(np.arange(3.0), [3]), np.arange(3.0))
+    with pytest.raises(_capi.OakHipError) as ei:
+        ctx.comm_allgatherv(np.arange(3.0), [3, 4])
+    assert ei.value.status == _capi.OAK_E_STATE
+    ctx.comm_init_loopback(2)
+    np.testing.assert_array_equal(ctx.comm_allgatherv(np.arange(3.0), [3, 3]), np.tile(np.arange(3.0), 2))
+    with pytest.raises(ValueError):
+        ctx.comm_allgatherv(np.arange(3.0), [3, 4])           # loopback ranks hold the same block by construction
+    with pytest.raises(_capi.OakHipError):
+        ctx.comm_allgatherv(np.arange(3.0), [3, 3, 3])
+    ctx.close()

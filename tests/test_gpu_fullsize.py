@@ -141,7 +141,8 @@ def test_c5_size_mixed_kernel_properties():
     """BASELINE.json config 5 at full size (N = 262 144, D = 32 mixed: 20 RBF + 8 binary + 4 categorical, M = 2048, depth 4):
     row-shard additivity, a 16 384-row sample against the multicore oracle at the full M (1e-10, literal route), a
     directional difference of the forward against the analytic gradient (D <= 32 fast backward kernel, one column per lane),
-    and the Sobol indices of all 41 448 terms normalising to 1."""
+    and the Sobol indices of all 41 448 terms: the Gram-of-products evaluation against the per-term kernel (all terms) and
+    against the oracle (320 sampled terms of every order and first-factor type) at this size."""
     import bench
     N5, D5, M5, R5 = 262144, 32, 2048, 4
     X, y, Z = bench.synthetic(N5, D5, M5, mixed=True)
@@ -188,5 +189,36 @@ def test_c5_size_mixed_kernel_properties():
     subsets = o.list_representation(D5, R5)[1:]
     assert len(subsets) == 41448
     sob = ctx.sobol(d, Z, alpha, subsets)
-    assert (sob >= 0).all() and np.isfinite(sob).all()
+    info = ctx.sobol_last_info()
+    assert info["path"] == "gram" and info["columns"] == 512     # 527 canonical columns trimmed to four 128-tiles (sobol_make_plan_budgeted) and info["pair_rows"] == M5 * (M5 + 1) // 2
+    assert np.isfinite(sob).all() and (sob >= -1e-12 * sob.max()).all()
+    # each order-4 term is read from the Gram matrix under its three pairings ab|cd, ac|bd, ad|bc: they agree
+    assert 0.0 < info["pairing_disagreement"] < 1e-11
+    # ... against the independent per-term kernel (a fused product-reduction over the stacked L_d), every one of the 41 448 terms
+    ctx.sobol_set_path("terms")
+    sob_terms = ctx.sobol(d, Z, alpha, subsets)
+    ctx.sobol_set_path("auto")
+    np.testing.assert_allclose(sob, sob_terms, rtol=1e-8, atol=1e-12 * sob.max())
+    np.testing.assert_allclose(sob / sob.sum(), sob_terms / sob_terms.sum(), atol=1e-10)
+    # ... and against the ORACLE at this size on 320 sampled terms: every order, and among the order-3 / order-4 samples every
+    # sub-kernel type (RBF / binary / categorical) as first factor (the factor that carries the order variance, utils.py:376-380;
+    # binary first factors enter with v instead of v^2, :266)
+    rng = np.random.default_rng(11)
+    types = [dm["type"] for dm in spec["dims"]]
+    by_order = {k: [i for i, S in enumerate(subsets) if len(S) == k] for k in (1, 2, 3, 4)}
+    pick = list(by_order[1])
+    pick += list(rng.choice(by_order[2], 64, replace=False))
+    for k in (3, 4):
+        for t in ("rbf", "binary", "categorical"):
+            cand = [i for i in by_order[k] if types[subsets[i][0]] == t]
+            assert cand, (k, t)
+            pick += list(rng.choice(cand, min(45, len(cand)), replace=False))
+    pick = sorted(set(int(i) for i in pick))
+    assert len(pick) >= 256
+    chosen = [subsets[i] for i in pick]
+    _, ref = o.compute_sobol_oak(spec, Z, alpha.reshape(-1, 1), subsets=chosen, L_cache={})
+    ref = np.array(ref)
+    total = sob.sum()
+    np.testing.assert_allclose(sob[pick] / total, ref / total, atol=1e-9)                 # the normalised indices
+    np.testing.assert_allclose(sob[pick], ref, rtol=1e-7, atol=1e-11 * np.abs(ref).max())  # and the raw values
     ctx.close()

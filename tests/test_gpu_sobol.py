@@ -69,3 +69,145 @@ def test_categorical_L_clamps_codes_outside_the_table(hip):
     Xbad[Xc[:, 0] == 0] = -4.0         # below it -> 0
     np.testing.assert_array_equal(hip.sobol_L(dc, 0, 1.3, 1.0, 0.0, Xbad), hip.sobol_L(dc, 0, 1.3, 1.0, 0.0, Xc))
     np.testing.assert_array_equal(hip.gram(dc, Xbad), hip.gram(dc, Xc))
+
+
+# ---- Gram of products (every term one entry of a weighted fp64-MFMA Gram matrix over the index pairs) ---------------------
+def _both_paths(hip, desc, Z, alpha, subsets, **kw):
+    try:
+        hip.sobol_set_path("terms")
+        terms = hip.sobol(desc, Z, alpha, subsets, **kw)
+        assert hip.sobol_last_info()["path"] == "terms"
+        hip.sobol_set_path("gram")
+        gram = hip.sobol(desc, Z, alpha, subsets, **kw)
+        info = hip.sobol_last_info()
+        assert info["path"] == "gram"
+    finally:
+        hip.sobol_set_path("auto")
+    return terms, gram, info
+
+
+@pytest.mark.parametrize("name", ["A", "B"])
+def test_gram_of_products_matches_oracle_on_golden_cases(hip, name):
+    spec, X, y, Z, noise = getattr(cases, f"case_{name}")()
+    if name == "B":
+        spec["dims"][2]["measure"] = ("gaussian", 0.0, 1.0)
+    alpha = o.sgpr_alpha(spec, X, y, Z, noise)
+    subsets, ref = o.compute_sobol_oak(spec, Z, alpha)
+    terms, gram, info = _both_paths(hip, _capi.KernelDesc(spec), Z, alpha[:, 0], subsets)
+    np.testing.assert_allclose(gram, ref, rtol=1e-9, atol=1e-12 * np.abs(ref).max())
+    np.testing.assert_allclose(gram / gram.sum(), np.array(ref) / np.sum(ref), atol=1e-9)
+    np.testing.assert_allclose(gram, terms, rtol=1e-9, atol=1e-12 * np.abs(ref).max())
+    assert info["pair_rows"] == len(Z) * (len(Z) + 1) // 2
+
+
+@pytest.mark.parametrize("depth,share,n", [(1, True, 33), (2, False, 64), (3, True, 70), (4, True, 129), (4, False, 40), (5, True, 50),
+                                           (6, True, 37)])
+def test_gram_of_products_every_depth_and_variance_mode(hip, depth, share, n):
+    """Depths 1..6 (halves of up to three dims), shared and per-dimension variances, every sub-kernel type as first factor,
+    sizes that are not multiples of the builder's 32-row blocks; the three pairings of each order-4 term agree."""
+    rng = np.random.default_rng(100 * depth + n)
+    D = 7
+    spec = cases.random_spec(rng, D, depth, kinds=("binary", "gaussian", "categorical", "gauss2", "uniform"), share=share)
+    Z = cases.random_inputs(rng, spec, n)
+    alpha = rng.standard_normal((n, 1)) * rng.uniform(0.1, 3.0, (n, 1))
+    subsets, ref = o.compute_sobol_oak(spec, Z, alpha, share_var_across_orders=share)
+    terms, gram, info = _both_paths(hip, _capi.KernelDesc(spec), Z, alpha[:, 0], subsets, use_order_var=share)
+    scale = np.abs(ref).max()
+    np.testing.assert_allclose(gram, ref, rtol=1e-9, atol=1e-11 * scale)
+    np.testing.assert_allclose(terms, ref, rtol=1e-9, atol=1e-11 * scale)
+    assert info["pairing_disagreement"] < 1e-12
+    if depth >= 4:
+        assert info["pairing_disagreement"] > 0.0        # the redundant entries were really read
+
+
+def test_gram_of_products_sign_patterns_and_odd_subset_lists(hip):
+    """All-positive, all-negative, zero and single-point alphas; an arbitrary (unsorted, partial) subset list; the automatic
+    choice falls back to the per-term kernel for a subset with a repeated dim and the forced Gram path refuses it."""
+    rng = np.random.default_rng(5)
+    spec = cases.random_spec(rng, 6, 4, kinds=("gaussian", "binary", "categorical"))
+    d = _capi.KernelDesc(spec)
+    n = 45
+    Z = cases.random_inputs(rng, spec, n)
+    subsets = [[4], [2, 0], [5, 1, 3], [3, 0, 4, 1], [1], [0, 1, 2, 3]]
+    for alpha in (np.abs(rng.standard_normal(n)), -np.abs(rng.standard_normal(n)), np.zeros(n),
+                  np.where(np.arange(n) == 7, 1.5, 0.0), rng.standard_normal(n)):
+        ref = np.array(o.compute_sobol_oak(spec, Z, alpha.reshape(-1, 1), subsets=subsets)[1])
+        terms, gram, _ = _both_paths(hip, d, Z, alpha, subsets)
+        np.testing.assert_allclose(gram, ref, rtol=1e-9, atol=1e-12 * max(np.abs(ref).max(), 1e-300))
+        np.testing.assert_allclose(terms, ref, rtol=1e-9, atol=1e-12 * max(np.abs(ref).max(), 1e-300))
+    one = hip.sobol(d, Z[:1], np.array([0.7]), subsets)
+    ref1 = np.array(o.compute_sobol_oak(spec, Z[:1], np.array([[0.7]]), subsets=subsets)[1])
+    np.testing.assert_allclose(one, ref1, rtol=1e-10)
+    rep = [[0, 0], [1, 2]]
+    auto = hip.sobol(d, Z, rng.standard_normal(n), rep)
+    assert hip.sobol_last_info()["path"] == "terms" and np.isfinite(auto).all()
+    try:
+        hip.sobol_set_path("gram")
+        with pytest.raises(ValueError):
+            hip.sobol(d, Z, np.ones(n), rep)
+        with pytest.raises(ValueError):
+            hip.sobol(d, Z, np.ones(n), [[0, 1, 2, 3, 4, 5, 0]])
+    finally:
+        hip.sobol_set_path("auto")
+
+
+def test_gram_of_products_row_chunks(hip, monkeypatch):
+    """Panels that do not fit one chunk accumulate into the same split partials: many small chunks == one."""
+    rng = np.random.default_rng(8)
+    spec = cases.random_spec(rng, 9, 4, kinds=("gaussian", "binary", "gauss2", "categorical"))
+    d = _capi.KernelDesc(spec)
+    n = 150
+    Z = cases.random_inputs(rng, spec, n)
+    alpha = rng.standard_normal(n)
+    subsets = o.list_representation(9, 4)[1:]
+    try:
+        hip.sobol_set_path("gram")
+        whole = hip.sobol(d, Z, alpha, subsets)
+        monkeypatch.setenv("OAK_SOBOL_CHUNK_ROWS", "992")
+        parts = hip.sobol(d, Z, alpha, subsets)
+    finally:
+        hip.sobol_set_path("auto")
+    np.testing.assert_allclose(parts, whole, rtol=1e-12, atol=1e-14 * np.abs(whole).max())
+    ref = np.array(o.compute_sobol_oak(spec, Z, alpha.reshape(-1, 1))[1])
+    np.testing.assert_allclose(whole, ref, rtol=1e-9, atol=1e-11 * np.abs(ref).max())
+
+
+def test_automatic_path_choice(hip):
+    """Few terms at a small n stay on the per-term kernel; thousands of terms go to the matrix pipe."""
+    rng = np.random.default_rng(9)
+    spec = cases.random_spec(rng, 12, 4, kinds=("gaussian",))
+    d = _capi.KernelDesc(spec)
+    Z = cases.random_inputs(rng, spec, 256)
+    alpha = rng.standard_normal(256)
+    hip.sobol(d, Z, alpha, [[0], [1, 2]])
+    assert hip.sobol_last_info()["path"] == "terms"
+    subsets = o.list_representation(12, 4)[1:]
+    got = hip.sobol(d, Z, alpha, subsets)
+    assert hip.sobol_last_info()["path"] == "gram"
+    hip.sobol_set_path("terms")
+    try:
+        np.testing.assert_allclose(got, hip.sobol(d, Z, alpha, subsets), rtol=1e-9, atol=1e-12 * np.abs(got).max())
+    finally:
+        hip.sobol_set_path("auto")
+
+
+@pytest.mark.parametrize("D,depth,expect", [(16, 4, 128), (16, 3, None)])
+def test_gram_of_products_column_budget(hip, D, depth, expect):
+    """A plan a few columns above a multiple of 128 is trimmed to it (no constant column: order-1 terms evaluated directly;
+    a matching of pair columns spared, the affected subsets re-paired) -- D = 16 at depth 4: 135 -> 128 columns, same values."""
+    rng = np.random.default_rng(77)
+    spec = cases.random_spec(rng, D, depth, kinds=("gaussian", "binary", "gauss2", "categorical"))
+    n = 90
+    Z = cases.random_inputs(rng, spec, n)
+    alpha = rng.standard_normal(n)
+    subsets = o.list_representation(D, depth)[1:]
+    terms, gram, info = _both_paths(hip, _capi.KernelDesc(spec), Z, alpha, subsets)
+    if expect is not None:
+        assert info["columns"] == expect
+    np.testing.assert_allclose(gram, terms, rtol=1e-9, atol=1e-12 * np.abs(terms).max())
+    pick = np.random.default_rng(1).choice(len(subsets), 150, replace=False)
+    pick = sorted(set(pick) | set(range(D)))                    # every (directly evaluated) order-1 term among them
+    ref = np.array(o.compute_sobol_oak(spec, Z, alpha.reshape(-1, 1), subsets=[subsets[i] for i in pick], L_cache={})[1])
+    np.testing.assert_allclose(gram[pick], ref, rtol=1e-9, atol=1e-11 * np.abs(ref).max())
+    if depth >= 4:
+        assert 0.0 < info["pairing_disagreement"] < 1e-12
