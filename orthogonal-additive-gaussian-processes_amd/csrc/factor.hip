@@ -379,6 +379,9 @@ __device__ __forceinline__ double quad_bcast_f64(double v, int o) {
 // column the compiler sinks every deferred FMA into the block that consumes it and spills the multipliers.
 // Measured alone (tools/ubench/potf2_bench): see DESIGN.md.  invd[j] = 1 / L_jj is kept for the panel solve; Dg receives L
 // row-major, Lt is scratch.
+// COLUMN_FENCE: a scheduling barrier closes every column, so the multiplier reads issued in column j stay there (they are
+// consumed one column later, off the chain) instead of being sunk next to their uses with a wait in front of each.
+template <bool COLUMN_FENCE = false>
 __device__ __forceinline__ void potf2_wave(double* Dg /*[NB][PO_P]*/, double* Lt /*[NB][PO_P]*/, double* invd /*[NB]*/, int lane,
                                            int64_t j0, int* info) {
     const int i = lane % PO_NB;                 // with NB = 32 lanes 32..63 shadow lanes 0..31
@@ -405,6 +408,7 @@ __device__ __forceinline__ void potf2_wave(double* Dg /*[NB][PO_P]*/, double* Lt
 #pragma unroll
         for (int c = j + 2; c < PO_NB; ++c) mp[c] = mc[c];
         lprev = l;
+        if constexpr (COLUMN_FENCE) __builtin_amdgcn_sched_barrier(0);
     }
     // A pivot d <= 0 (or NaN) makes 1/sqrt(d) and with it L_jj = d / sqrt(d) non-finite: the first such diagonal entry is the
     // failing leading minor.  Checked once here rather than per column: d is wave-uniform, so a per-column test compiles to a
@@ -630,6 +634,292 @@ __global__ void __launch_bounds__(320) potrf_step_kernel(double* __restrict__ A,
 #undef PO_STAMP
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Two-level step (the default): panels of 32 columns inside outer blocks of PO_BLK = 128.  The trailing matrix behind an
+// outer block is read and written ONCE per block (one rank-128 MFMA update, role B of the block's successor's first step)
+// instead of once per panel; inside a block the factorisation is left-looking:
+//   role A of panel j applies the KP pending columns itself -- the earlier panels of its own block (KP = 32, 64, 96) or, for
+//          the first panel of a block, the whole previous block (KP = 128) -- to the diagonal block and to its 64 rows, both
+//          as fp64 MFMA products against the staged rows j0 .. j0+31 of the pending columns (the 32-long dot products per
+//          entry from LDS that the one-level step used cost 1.6 us on the critical path in front of the one-wave factorisation;
+//          as 16 x 16 x 4 MFMAs they cost ~0.3 us per 32 pending columns);
+//   role B (only in the launch of a block's first panel, KP = 128): C[r, c] -= P[r, :] P[c, :]^T over the 128 columns of the
+//          previous block, for the lower 64 x 64 tiles right of panel j.
+// Everything else (one-wave factorisation of the diagonal block, four lanes per row in the panel solve, the last loader
+// writing the factor back) is the one-level step's.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int PO_BLK = 128;
+
+// amdgpu_waves_per_eu(1, 2): with the workers' registers gone the kernel would fit four waves per SIMD, and the scheduler, aiming
+// for that occupancy, sinks every LDS read of the one-wave factorisation next to its use (216 waits instead of 90 in its 32
+// columns, 4.9 -> 7.4 us).  Five waves per workgroup never occupy more than two slots of a SIMD, so the register budget of two is
+// what the factorisation's schedule should be built for.
+template <int KP>
+__global__ void __launch_bounds__(384) __attribute__((amdgpu_waves_per_eu(1, 2))) potrf_blk_kernel(double* __restrict__ A, int64_t n, int64_t nrows, int64_t lda, int64_t j0,
+                                                        int* __restrict__ info, int* __restrict__ arrivals, int nA, int ntc,
+                                                        long long* __restrict__ trace /* dev aid, normally NULL */) {
+#define PO_STAMP(slot) do { if (trace != nullptr && do_stamp) trace[slot] = wall_clock64(); } while (0)
+    constexpr int PJP = (KP > 0 ? KP : 32) + 2;                      // LDS pitch of the staged pending rows
+    // separate static arrays for the one-wave factorisation's scratch (distinct objects: the compiler may reorder their LDS
+    // traffic freely; carved out of one dynamic block the same accesses may alias and every load waited for the store before it,
+    // 4.9 -> 6.3 us per diagonal block); only the staged pending rows, whose size depends on KP, are dynamic
+    __shared__ __attribute__((aligned(16))) double Dg[PO_NB * PO_P];
+    __shared__ __attribute__((aligned(16))) double Lt[PO_NB * PO_P];
+    __shared__ __attribute__((aligned(16))) double Pc[64 * PO_P];       // role A: C-layout -> quad-layout exchange; role B: operand tile
+    __shared__ double invd[PO_NB];
+    __shared__ int last_loader;
+    extern __shared__ __attribute__((aligned(16))) double Pj[];         // role A: [32][PJP]; role B: [64][PO_P]
+    const int tid = threadIdx.x;
+    const int64_t p0 = j0 - KP;
+    if ((int)blockIdx.x >= nA) {
+        // ---------------- role B: C[r0:+64, c0:+64] -= P[r0:+64, :] P[c0:+64, :]^T,  P = A[:, p0 : p0 + KP] ----------------
+        if constexpr (KP == PO_BLK) {
+            const int t = blockIdx.x - nA;
+            const int by = t / ntc, bx = t - by * ntc;
+            if (bx > by || tid >= 256) return;
+            const bool do_stamp = tid == 0 && (t == 0 || blockIdx.x == gridDim.x - 1);
+            PO_STAMP(t == 0 ? 16 : 20);
+            const int64_t s0 = j0 + PO_NB;
+            const int64_t r0 = s0 + 64 * (int64_t)by, c0 = s0 + 64 * (int64_t)bx;
+            const int r = tid >> 2, k8 = (tid & 3) * 8;
+            const int64_t ra = (r0 + r < nrows) ? r0 + r : nrows - 1, rb = (c0 + r < n) ? c0 + r : n - 1;
+            const double* pa = A + ra * lda + p0 + k8;
+            const double* pb = A + rb * lda + p0 + k8;
+            double va[8], vb[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { va[q] = pa[q]; vb[q] = pb[q]; }
+            const int lane = tid & 63;
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+            const int wr = wave >> 1, wc = wave & 1, fi = lane & 15, fk = lane >> 4;
+            double4_t acc[2][2];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) acc[g][h] = (double4_t){0.0, 0.0, 0.0, 0.0};
+            // the C tile's own entries: loaded early, consumed by the epilogue
+            double cv[2][2][4];
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int64_t row = r0 + wr * 32 + 16 * g + 4 * reg + fk, col = c0 + wc * 32 + 16 * h + fi;
+                        const int64_t rc = row < nrows ? row : nrows - 1, cc = col < n ? col : n - 1;
+                        cv[g][h][reg] = A[rc * lda + cc];
+                    }
+#pragma unroll
+            for (int kc = 0; kc < KP / 32; ++kc) {
+                if (kc > 0) __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { Pj[r * PO_P + k8 + q] = va[q]; Pc[r * PO_P + k8 + q] = vb[q]; }
+                __syncthreads();
+                if (kc + 1 < KP / 32) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { va[q] = pa[32 * (kc + 1) + q]; vb[q] = pb[32 * (kc + 1) + q]; }
+                }
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    double a[2], b[2];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) a[g] = Pj[(wr * 32 + 16 * g + fi) * PO_P + 4 * ks + fk];
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) b[h] = Pc[(wc * 32 + 16 * h + fi) * PO_P + 4 * ks + fk];
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) acc[g][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g], b[h], acc[g][h], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int reg = 0; reg < 4; ++reg) {
+                        const int64_t row = r0 + wr * 32 + 16 * g + 4 * reg + fk, col = c0 + wc * 32 + 16 * h + fi;
+                        if (row < nrows && col < n) A[row * lda + col] = cv[g][h][reg] - acc[g][h][reg];
+                    }
+            PO_STAMP(t == 0 ? 17 : 21);
+        }
+        return;
+    }
+    // ---------------- role A: panel j ----------------
+    // Six waves: wave 0 factors the diagonal block; waves 1, 2, 3 and 5 are the 256 workers; wave 4 -- the one that shares wave 0's
+    // SIMD (waves of a workgroup go to the SIMDs round-robin) -- only takes part in the barriers.  A worker wave on the factor
+    // wave's SIMD puts its 64-cycle MFMAs into the one-wave factorisation's dependent chain (+1.6 us at KP = 128); two worker
+    // waves sharing SIMD 1 merely take twice as long for an update that hides under the factorisation anyway.
+    const int wv = tid >> 6;
+    const int wid = (wv >= 1 && wv <= 3) ? tid - 64 : (wv == 5 ? tid - 128 : -1);     // worker id 0..255, < 0: factor wave / idle wave
+    const bool worker = wid >= 0;
+    const bool do_stamp = blockIdx.x == 0 && (tid == 0 || tid == 64);
+    const int sb = tid == 0 ? 0 : 8;
+    PO_STAMP(sb + 0);
+    const int nb = (n - j0 < PO_NB) ? (int)(n - j0) : PO_NB;
+    const int q = wid & 3;
+    const int64_t row0 = j0 + nb + (int64_t)blockIdx.x * PO_RPW;        // first of this workgroup's 64 rows
+    const int64_t row = row0 + (wid >> 2);
+    const bool has_row = worker && row < nrows && nb == PO_NB;
+    const int ww = wid >> 6;                                            // worker wave 0..3 (valid for workers)
+    const int fi = tid & 15, fk = (tid & 63) >> 4;
+    // the diagonal block's pending update runs BEFORE the factorisation starts, so it may use wave 4: waves 1..4 sit on four
+    // different SIMDs and take one 16 x 16 tile each (with waves 1, 2, 3, 5 two tiles would queue on SIMD 1, on the critical path)
+    const bool dworker = wv >= 1 && wv <= 4;
+    const int tr = (wv - 1) >> 1, tc = (wv - 1) & 1;                    // this wave's 16 x 16 tile of the diagonal block
+    // in front of the first barrier only what the critical path needs: the staged rows and the diagonal block
+    constexpr int PJ_PER = KP > 0 ? KP / 16 : 1;
+    double2 pjv[PJ_PER];
+    double dacc[4], cacc[2][4], aop[KP > 0 ? KP / 4 : 1];
+    const int pj_r = wid >> 3, pj_k = 2 * (wid & 7);                    // staging: eight workers per row, 16 bytes each per 128-byte piece
+    if (worker) {
+        if constexpr (KP > 0) {                                         // rows j0 .. j0+31 of the pending columns
+            // ONE address per thread and immediate offsets (an index / KP, a clamp and a 64-bit row product per element made the
+            // integer pipe, not the memory, the limit of this phase: +0.5 us per 32 pending columns)
+            const int64_t rr = (j0 + pj_r < n) ? j0 + pj_r : n - 1;
+            const double2* src = reinterpret_cast<const double2*>(A + rr * lda + p0 + pj_k);
+#pragma unroll
+            for (int e = 0; e < PJ_PER; ++e) pjv[e] = src[8 * e];
+        }
+    }
+    // the staged rows are what the first barrier waits for: their loads go out first (left alone the compiler issues them last,
+    // behind the operand loads, and the LDS writes in front of the barrier then wait for everything)
+    __builtin_amdgcn_sched_barrier(0);
+    if (dworker) {
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {                             // the diagonal block, MFMA C layout
+            const int i = 16 * tr + 4 * reg + fk, j = 16 * tc + fi;
+            const int ic = i < nb ? i : nb - 1, jc = j < nb ? j : nb - 1;
+            dacc[reg] = A[(j0 + ic) * lda + j0 + jc];
+        }
+    }
+    if (worker) {
+        if constexpr (KP > 0) {
+            const bool live = j0 + pj_r < n;
+#pragma unroll
+            for (int e = 0; e < PJ_PER; ++e)
+                *reinterpret_cast<double2*>(&Pj[pj_r * PJP + pj_k + 16 * e]) = live ? pjv[e] : make_double2(0.0, 0.0);
+        }
+    }
+    __syncthreads();
+    PO_STAMP(sb + 1);
+    if (dworker) {
+        // diagonal block with the pending update applied; identity padding beyond nb; strict upper part zeroed
+        double4_t acc = (double4_t){0.0, 0.0, 0.0, 0.0};
+        if constexpr (KP > 0) {
+#pragma unroll
+            for (int ks = 0; ks < KP / 4; ++ks) {
+                const double a = Pj[(16 * tr + fi) * PJP + 4 * ks + fk];
+                const double b = Pj[(16 * tc + fi) * PJP + 4 * ks + fk];
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+            const int i = 16 * tr + 4 * reg + fk, j = 16 * tc + fi;
+            const double xx = dacc[reg] - acc[reg];
+            Dg[i * PO_P + j] = (i < nb && j < nb) ? ((j <= i) ? xx : 0.0) : ((i == j) ? 1.0 : 0.0);
+        }
+    }
+    __syncthreads();
+    PO_STAMP(sb + 2);
+    if (tid == 383) last_loader = (atomicAdd(arrivals, 1) == nA - 1);
+    double x[PO_NB / 4];
+    if (__builtin_amdgcn_readfirstlane(tid >> 6) == 0) {
+        potf2_wave<true>(Dg, Lt, invd, tid, j0, blockIdx.x == 0 ? info : nullptr);
+        PO_STAMP(sb + 3);
+        __syncthreads();
+        PO_STAMP(sb + 4);
+    } else {
+        if (worker && nb == PO_NB) {
+            // The workers' own operands are issued only now, behind the second barrier: they are consumed under the one-wave
+            // factorisation (~5 us), which hides their latency.  Issued earlier, their ~80 KiB of requests queued in the CU's one
+            // address path ahead of the staged rows (first barrier, +1.5 us at KP = 128) or ahead of the diagonal update.
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {                     // this wave's 16 rows of panel j, C layout
+                    const int64_t rr = row0 + 16 * ww + 4 * reg + fk;
+                    const int64_t rc = rr < nrows ? rr : nrows - 1;
+                    cacc[h][reg] = A[rc * lda + j0 + 16 * h + fi];
+                }
+            if constexpr (KP > 0) {
+                // A operand of the rows' pending update, straight into MFMA layout.  The k index of a 16 x 16 x 4 step is the lane
+                // group fk; which pending column a (step, group) pair stands for is free as long as both operands agree.  Steps
+                // 2 k2 and 2 k2 + 1 of group fk take columns 8 k2 + 2 fk + {0, 1}: one 16-byte load per lane, the four groups of a
+                // row reading 64 contiguous bytes per instruction (8-byte loads 32 bytes apart fetched every line four times over
+                // four instructions; a contiguous run per group made every instruction touch 64 different lines and thrashed L1).
+                const int64_t ra = row0 + 16 * ww + fi;
+                const double2* ap = reinterpret_cast<const double2*>(A + (ra < nrows ? ra : nrows - 1) * lda + p0 + 2 * fk);
+#pragma unroll
+                for (int k2 = 0; k2 < KP / 8; ++k2) { const double2 v = ap[4 * k2]; aop[2 * k2] = v.x; aop[2 * k2 + 1] = v.y; }
+            }
+            // this wave's 16 rows x 32 columns of panel j with the pending update applied, then from the MFMA C layout to the
+            // solve's four-lanes-per-row layout through LDS (rows 16 ww .. 16 ww + 15 are written and read by this wave only)
+            double4_t c0 = (double4_t){0.0, 0.0, 0.0, 0.0}, c1 = (double4_t){0.0, 0.0, 0.0, 0.0};
+            if constexpr (KP > 0) {
+#pragma unroll
+                for (int ks = 0; ks < KP / 4; ++ks) {
+                    const double b0 = Pj[fi * PJP + 8 * (ks >> 1) + 2 * fk + (ks & 1)];
+                    const double b1 = Pj[(16 + fi) * PJP + 8 * (ks >> 1) + 2 * fk + (ks & 1)];
+                    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ks], b0, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ks], b1, c1, 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                Pc[(16 * ww + 4 * reg + fk) * PO_P + fi] = cacc[0][reg] - c0[reg];
+                Pc[(16 * ww + 4 * reg + fk) * PO_P + 16 + fi] = cacc[1][reg] - c1[reg];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int t = 0; t < PO_NB / 4; ++t) x[t] = Pc[(wid >> 2) * PO_P + 4 * t + q];
+        }
+        PO_STAMP(sb + 3);
+        __syncthreads();
+        PO_STAMP(sb + 4);
+        if (has_row) {
+            // X L_jj^T = A_panel, right-looking over the columns (potrf_step_kernel)
+#pragma unroll
+            for (int c = 0; c < PO_NB; ++c) {
+                const int to = c >> 2, owner = c & 3;
+                const double xc = quad_bcast_f64(x[to] * invd[c], owner);
+                x[to] = (q == owner) ? xc : x[to];
+#pragma unroll
+                for (int t = to; t < PO_NB / 4; ++t) {
+                    const double l = Dg[(4 * t + q) * PO_P + c];
+                    const double m = (t > to || q > owner) ? l : 0.0;
+                    x[t] = __builtin_fma(-xc, m, x[t]);
+                }
+            }
+            double* ap = A + row * lda + j0 + q;
+#pragma unroll
+            for (int t = 0; t < PO_NB / 4; ++t) ap[4 * t] = x[t];
+        }
+    }
+    if (last_loader && worker) {
+        for (int idx = wid; idx < nb * nb; idx += 256) {
+            const int i = idx / nb, j = idx - i * nb;
+            A[(j0 + i) * lda + j0 + j] = Dg[i * PO_P + j];
+        }
+    }
+    PO_STAMP(sb + 5);
+#undef PO_STAMP
+}
+
+template <int KP>
+static int potrf_blk_launch(oak_ctx* ctx, unsigned grid, double* dA, int64_t n, int64_t nr, int64_t lda, int64_t j0, int* d_info,
+                            int* d_arr, int nA, int ntc, long long* trc) {
+    constexpr int PJP = (KP > 0 ? KP : 32) + 2;
+    constexpr size_t pj_elems = (size_t)(32 * PJP > 64 * PO_P ? 32 * PJP : 64 * PO_P);
+    constexpr size_t lds = sizeof(double) * pj_elems;                   // dynamic part; ~35 KiB more are static
+    if (lds + 36 * 1024 > 64 * 1024) OAK_CHECK(ensure_dynamic_lds((const void*)potrf_blk_kernel<KP>, lds));
+    potrf_blk_kernel<KP><<<grid, 384, lds, ctx->stream>>>(dA, n, nr, lda, j0, d_info, d_arr, nA, ntc, trc);
+    OAK_HIP_CHECK(hipGetLastError());
+    return OAK_OK;
+}
+
 __global__ void zero_upper_kernel(double* __restrict__ A, int64_t n, int64_t lda) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t i = blockIdx.y;
@@ -674,6 +964,9 @@ int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, bool check, in
     // dev aid: in-kernel time stamps, 24 per step.  Only while oak_bench_potrf has armed it (ctx->potrf_trace, with its capacity),
     // only for the main-stream factorisation it times, and never past the end of the buffer.
     long long* d_trace = (slot == 0) ? ctx->potrf_trace : nullptr;
+    // one-level right-looking step (potrf_step_kernel), kept for A/B runs and for the in-kernel time stamps of oak_bench_potrf
+    bool two_level = true;
+    if (const char* e = getenv("OAK_POTRF_LEVELS")) two_level = atoi(e) != 1;
     for (int64_t j0 = 0; j0 < n; j0 += PO_NB) {
         long long* trc = (d_trace && j0 / PO_NB < ctx->potrf_trace_steps) ? d_trace + 24 * (j0 / PO_NB) : nullptr;
         // identity_below: the extra rows are the identity that the panel solves turn into L^-T (chol_with_inverse).  Row i of that
@@ -684,6 +977,35 @@ int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, bool check, in
         const int64_t below_rows = nr - j0 - PO_NB;        // rows under the diagonal block (extra rows included)
         const int nA = below_rows > 0 ? (int)((below_rows + PO_RPW - 1) / PO_RPW) : 1;
         const int64_t tc = n - j0 - PO_NB, tr = nr - j0 - PO_NB;
+        if (two_level) {
+            const int jj = (int)((j0 % PO_BLK) / PO_NB);                // panel index inside its outer block
+            int* arr = d_arr + j0 / PO_NB;
+            if (jj == 0 && j0 > 0) {
+                if (fused) {
+                    // pending = the whole previous block; role B applies it to the trailing matrix right of panel j
+                    const int ntc = tc > 0 ? (int)((tc + 63) / 64) : 0, ntr = tc > 0 ? (int)((tr + 63) / 64) : 0;
+                    OAK_CHECK(potrf_blk_launch<PO_BLK>(ctx, (unsigned)(nA + ntr * ntc), dA, n, nr, lda, j0, d_info, arr, nA, ntc > 0 ? ntc : 1, trc));
+                } else {
+                    // large n: the previous block was applied to everything behind it by the pipelined GEMM below
+                    OAK_CHECK(potrf_blk_launch<0>(ctx, (unsigned)nA, dA, n, nr, lda, j0, d_info, arr, nA, 1, trc));
+                }
+            } else if (jj == 0) {
+                OAK_CHECK(potrf_blk_launch<0>(ctx, (unsigned)nA, dA, n, nr, lda, j0, d_info, arr, nA, 1, trc));
+            } else if (jj == 1) {
+                OAK_CHECK(potrf_blk_launch<32>(ctx, (unsigned)nA, dA, n, nr, lda, j0, d_info, arr, nA, 1, trc));
+            } else if (jj == 2) {
+                OAK_CHECK(potrf_blk_launch<64>(ctx, (unsigned)nA, dA, n, nr, lda, j0, d_info, arr, nA, 1, trc));
+            } else {
+                OAK_CHECK(potrf_blk_launch<96>(ctx, (unsigned)nA, dA, n, nr, lda, j0, d_info, arr, nA, 1, trc));
+            }
+            if (!fused && jj == PO_BLK / PO_NB - 1 && tc > 0) {        // A22 -= L21 L21^T (lower tiles only), K = 128, behind the finished block
+                const int64_t b0 = j0 + PO_NB - PO_BLK;
+                const double* L21 = dA + (j0 + PO_NB) * lda + b0;
+                double* A22 = dA + (j0 + PO_NB) * lda + (j0 + PO_NB);
+                OAK_CHECK(gemm_nt(ctx, L21, L21, A22, tr, tc, PO_BLK, lda, lda, lda, -1.0, 1.0, 1));
+            }
+            continue;
+        }
         if (fused) {
             // role B applies panel j-1 to the trailing matrix behind panel j: columns >= j0 + 32 (none on the first step)
             const int ntc = (j0 > 0 && tc > 0) ? (int)((tc + 63) / 64) : 0;

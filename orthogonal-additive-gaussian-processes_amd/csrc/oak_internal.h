@@ -240,6 +240,7 @@ int copy_sync(oak_ctx* ctx, void* dst, const void* src, size_t bytes, hipMemcpyK
 // raises the dynamic-LDS limit of a kernel to the hardware's 160 KiB, once per kernel and process (the attribute belongs to
 // the function, not to the launch: setting it to each launch's own size would race between contexts on different threads)
 int ensure_max_dynamic_lds(const void* kernel);
+int ensure_dynamic_lds(const void* kernel, size_t bytes);      // for kernels that also hold static LDS: raises the DYNAMIC limit to `bytes`
 int fill_zero(oak_ctx* ctx, void* dst, size_t bytes);
 int axpy(oak_ctx* ctx, double a, const double* x, double* y, int64_t n);  // y += a x
 int scale_vec(oak_ctx* ctx, double a, double* x, int64_t n);

@@ -532,6 +532,19 @@ int ensure_max_dynamic_lds(const void* kernel) {
     done.insert({dev, kernel});
     return OAK_OK;
 }
+// the same for a kernel that also has static LDS: the attribute is the DYNAMIC size, and static + dynamic must fit 160 KiB
+int ensure_dynamic_lds(const void* kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> done;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    OAK_HIP_CHECK(hipGetDevice(&dev));
+    auto it = done.find({dev, kernel});
+    if (it != done.end() && it->second >= bytes) return OAK_OK;
+    OAK_HIP_CHECK(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    done[{dev, kernel}] = bytes;
+    return OAK_OK;
+}
 }  // namespace oak
 
 extern "C" {

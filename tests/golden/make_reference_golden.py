@@ -1,0 +1,99 @@
+"""Generates tests/golden/reference_sobol_L.npz by EXECUTING THE REFERENCE'S OWN CODE (build container only).
+
+    python tests/golden/make_reference_golden.py          # needs /root/reference; nothing of it travels with the repo
+
+What is executed: ``oak.utils.f1 / f2 / f3 / f4`` (oak/utils.py:116-165), ``compute_L`` (:221-240) and
+``compute_L_binary_kernel`` (:243-272) -- pure NumPy functions.  The module that holds them imports TensorFlow, GPflow
+and TensorFlow-Probability at its top (oak/utils.py:6-24), none of which exists in this image (and none can be
+installed: no network).  Those imports are satisfied with INERT placeholders: objects that implement nothing -- every
+attribute of a placeholder is another placeholder, calling one returns a placeholder.  They only let the module body
+run to the end; a function that touched one would return a placeholder instead of numbers, so the generator
+ * calls ONLY the six functions above, whose bodies use nothing but NumPy (read them: no ``tf.``, no ``gpflow.``), and
+ * refuses to write anything that is not a plain float64 ndarray of the expected shape.
+Nothing else of the reference is pinned by this file: the ELBO scalar, predictive variance and the transforms stay
+"parity unpinned" (DESIGN.md section 3).
+
+The fixture holds inputs and outputs only (a few KB of numbers).  It is labelled inside the file:
+``label = "reference-executed: f1-f4 / compute_L / compute_L_binary_kernel only"``.
+"""
+import sys
+import types
+from pathlib import Path
+
+sys.dont_write_bytecode = True          # /root/reference is read-only by contract: importing from it must not leave __pycache__ there
+
+import numpy as np
+
+REFERENCE = Path("/root/reference")
+OUT = Path(__file__).resolve().parent / "reference_sobol_L.npz"
+LABEL = "reference-executed: f1-f4 / compute_L / compute_L_binary_kernel only"
+PLACEHOLDERS = ("tensorflow", "tensorflow_probability", "gpflow", "gpflow.config", "gpflow.covariances", "gpflow.covariances.dispatch",
+                "gpflow.models", "gpflow.base", "gpflow.utilities", "gpflow.kernels", "gpflow.inducing_variables", "tensorflow_probability.python",
+                "tensorflow_probability.python.bijectors")
+
+
+class Inert(types.ModuleType):
+    """Implements nothing.  Attribute -> Inert, call -> Inert, base class -> dropped."""
+
+    def __getattr__(self, name):
+        if name.startswith("__") and name.endswith("__"):
+            raise AttributeError(name)
+        child = Inert(f"{self.__name__}.{name}")
+        setattr(self, name, child)
+        return child
+
+    def __call__(self, *args, **kwargs):
+        return Inert(f"{self.__name__}()")
+
+    def __mro_entries__(self, bases):
+        return ()
+
+    def __iter__(self):
+        return iter(())
+
+
+def load_reference_utils():
+    if not REFERENCE.is_dir():
+        raise SystemExit("the reference tree is not here: this generator only runs in the build container")
+    for name in PLACEHOLDERS:
+        sys.modules.setdefault(name, Inert(name))
+    sys.path.insert(0, str(REFERENCE))
+    import oak.utils as ref_utils       # the reference's module, from /root/reference
+    assert Path(ref_utils.__file__).resolve().is_relative_to(REFERENCE), ref_utils.__file__
+    return ref_utils
+
+
+def plain(a, shape):
+    if not isinstance(a, np.ndarray) or a.dtype != np.float64 or a.shape != shape or not np.isfinite(a).all():
+        raise SystemExit(f"not a plain finite float64 array of shape {shape}: {type(a)} -- a placeholder was touched?")
+    return a
+
+
+def main():
+    ref = load_reference_utils()
+    rng = np.random.default_rng(20240601)
+    out = {"label": np.array(LABEL)}
+    # f1..f4 on scattered arguments (the closed forms of eq. 44-47)
+    n = 64
+    x, y = rng.normal(size=n) * 1.5, rng.normal(size=n) * 1.5
+    params = np.array([[1.0, 1.0, 1.0, 0.0], [0.7, 0.35, 1.0, 0.0], [1.3, 2.4, 1.6, 0.4], [2.1, 0.9, 0.5, -0.8], [0.4, 5.0, 2.2, 1.1]])
+    out["f_x"], out["f_y"], out["f_params"] = x, y, params              # columns: sigma, lengthscale, delta, mu
+    for k, fn in enumerate((ref.f1, ref.f2, ref.f3, ref.f4), start=1):
+        out[f"f{k}"] = np.stack([plain(fn(x, y, *p), (n,)) for p in params])
+    # compute_L: Gaussian-measure RBF sub-kernel; column `dim` of X
+    X = rng.normal(size=(23, 3))
+    X[:, 2] *= 2.5
+    L_params = np.array([[1.0, 1.0, 0, 1.0, 0.0], [0.6, 1.7, 1, 1.0, 0.0], [2.2, 0.8, 2, 1.4, 0.3], [0.25, 2.5, 1, 0.7, -0.5]])
+    out["L_X"], out["L_params"] = X, L_params                            # columns: lengthscale, variance, dim, delta, mu
+    out["L"] = np.stack([plain(ref.compute_L(X, p[0], p[1], int(p[2]), p[3], p[4]), (23, 23)) for p in L_params])
+    # compute_L_binary_kernel
+    Xb = rng.integers(0, 2, size=(19, 2)).astype(np.float64)
+    b_params = np.array([[0.5, 1.0, 0], [0.77, 1.0, 1], [0.12, 2.3, 0], [1.0, 0.6, 1], [0.0, 1.0, 0]])
+    out["Lb_X"], out["Lb_params"] = Xb, b_params                         # columns: p0, variance, dim
+    out["Lb"] = np.stack([plain(ref.compute_L_binary_kernel(Xb, p[0], p[1], int(p[2])), (19, 19)) for p in b_params])
+    np.savez_compressed(OUT, **out)
+    print(f"wrote {OUT} ({OUT.stat().st_size} bytes): {LABEL}")
+
+
+if __name__ == "__main__":
+    main()

@@ -211,3 +211,26 @@ def test_gram_of_products_column_budget(hip, D, depth, expect):
     np.testing.assert_allclose(gram[pick], ref, rtol=1e-9, atol=1e-11 * np.abs(ref).max())
     if depth >= 4:
         assert 0.0 < info["pairing_disagreement"] < 1e-12
+
+
+def test_L_matrices_match_reference_executed_vectors(hip):
+    """oak_sobol_L against the reference's OWN compute_L / compute_L_binary_kernel outputs (tests/golden/reference_sobol_L.npz,
+    generated by executing /root/reference/oak/utils.py in the build container), and the package's f1..f4 helpers against the
+    reference's."""
+    from pathlib import Path
+    from oak import utils as oak_utils
+    d = np.load(Path(__file__).resolve().parent / "golden" / "reference_sobol_L.npz")
+    assert str(d["label"]).startswith("reference-executed")
+    for p, ref in zip(d["L_params"], d["L"]):
+        desc = _capi.KernelDesc(dict(dims=[dict(type="rbf", lengthscale=float(p[0]), variance=1.0, measure=("gaussian", 0.0, 1.0),
+                                                 active_dim=int(p[2]))],
+                                     order_variances=[0.0, 1.0], max_interaction_depth=1, share_var_across_orders=True))
+        got = hip.sobol_L(desc, 0, float(p[1]), float(p[3]), float(p[4]), d["L_X"])
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-11 * np.abs(ref).max())
+        np.testing.assert_allclose(oak_utils.compute_L(d["L_X"], p[0], p[1], int(p[2]), p[3], p[4]), ref, rtol=0, atol=1e-11 * np.abs(ref).max())
+    for p, ref in zip(d["Lb_params"], d["Lb"]):
+        got = oak_utils.compute_L_binary_kernel(d["Lb_X"], float(p[0]), float(p[1]), int(p[2]))
+        np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-15)
+    for k, fn in enumerate((oak_utils.f1, oak_utils.f2, oak_utils.f3, oak_utils.f4), start=1):
+        for p, ref in zip(d["f_params"], d[f"f{k}"]):
+            np.testing.assert_allclose(fn(d["f_x"], d["f_y"], *p), ref, rtol=1e-14, atol=0)

@@ -118,3 +118,26 @@ def test_sobol_empirical_equals_sample_variance():
     alpha = o.gpr_alpha(spec, x, y, 1.0)
     L = o.compute_L_empirical_measure(x, np.ones(x.shape) / 10, dim, x)
     np.testing.assert_array_almost_equal(np.var(mean), float((alpha.T @ L @ alpha)[0, 0]), decimal=5)
+
+
+# ---- reference-EXECUTED vectors (tests/golden/make_reference_golden.py: the reference's own f1..f4 / compute_L /
+# compute_L_binary_kernel, run in the build container; inputs + outputs only) -------------------------------------------
+def _reference_fixture():
+    from pathlib import Path
+    d = np.load(Path(__file__).resolve().parent / "golden" / "reference_sobol_L.npz")
+    assert str(d["label"]) == "reference-executed: f1-f4 / compute_L / compute_L_binary_kernel only"
+    return d
+
+
+def test_oracle_closed_forms_match_reference_executed_vectors():
+    d = _reference_fixture()
+    x, y = d["f_x"], d["f_y"]
+    for k, fn in enumerate((o.f1, o.f2, o.f3, o.f4), start=1):
+        for p, ref in zip(d["f_params"], d[f"f{k}"]):
+            np.testing.assert_allclose(fn(x, y, *p), ref, rtol=1e-15, atol=0)
+    for p, ref in zip(d["L_params"], d["L"]):
+        got = o.compute_L(d["L_X"], p[0], p[1], int(p[2]), p[3], p[4])
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-15 * np.abs(ref).max())
+    for p, ref in zip(d["Lb_params"], d["Lb"]):
+        got = o.compute_L_binary_kernel(d["Lb_X"], p[0], p[1], int(p[2]))
+        np.testing.assert_allclose(got, ref, rtol=1e-15, atol=1e-17)
