@@ -148,6 +148,17 @@ int oak_sgpr_set_data(oak_ctx* ctx, const double* X, const double* Y, int64_t N,
    (GPflow's N x P Y: independent outputs sharing kernel and noise, oak/utils.py:182-198 is written for it) is the sum of P
    single-output bounds; the host mirror evaluates them one after the other through this call. */
 int oak_sgpr_set_targets(oak_ctx* ctx, const double* Y, int64_t N);
+/* The other output columns of a P-column model (oak/utils.py:182-198: err, A err, c are N x P, M x P there): Yt holds
+   columns 1 .. n_extra of Y, ONE COLUMN PER ROW ([n_extra x N], contiguous).  From then on oak_sgpr_elbo /
+   oak_sgpr_elbo_grad(_z) return the bound and the gradient SUMMED over the 1 + n_extra outputs while everything that does
+   not depend on y -- the Kuf panel, Phi, both Cholesky factors, the M x M adjoints -- is computed once: each extra output
+   costs one more column of a pass over the resident Kuf panel (psi_p = Kuf y_p), two M-sized triangular solves and, in the
+   gradient, one more rank-one term of the adjoint panel.  n_extra = 0 forgets them; oak_sgpr_set_data also does.
+   (oak_sgpr_last_terms keeps reporting output 0's terms; the fp32 statistics mode is not combined with extra columns.) */
+int oak_sgpr_set_extra_targets(oak_ctx* ctx, const double* Yt, int64_t N, int32_t n_extra);
+/* Which output's posterior oak_sgpr_alpha / oak_sgpr_predict / oak_component_predict callers see (0 after every
+   evaluation; 1 .. n_extra: the extra columns). */
+int oak_sgpr_select_output(oak_ctx* ctx, int32_t p);
 int oak_sgpr_set_inducing(oak_ctx* ctx, const double* Z, int64_t M, int32_t ldx);
 /* Row budget of the N x M Kuf panel kept in HBM per pass (0 = library default). */
 int oak_sgpr_set_panel_rows(oak_ctx* ctx, int64_t rows);

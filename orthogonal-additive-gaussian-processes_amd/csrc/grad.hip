@@ -1071,15 +1071,41 @@ __global__ void set_identity_kernel(double* __restrict__ A, int64_t n) {
     const int64_t i = blockIdx.y;
     if (j < n) A[i * n + j] = (i == j) ? 1.0 : 0.0;
 }
-// H = Kinv - Sinv - a a^T ;  Guu = 0.5 H - 0.5 KWK / s2
+// H = Kinv - Sinv - a a^T ;  Guu = 0.5 H - 0.5 KWK / s2.  With nx extra outputs (rows of ax): the sum over the outputs,
+// H = (1 + nx) (Kinv - Sinv) - sum_p a_p a_p^T ;  Guu = 0.5 H - 0.5 (1 + nx) KWK / s2
 __global__ void combine_h_kernel(const double* __restrict__ Kinv, const double* __restrict__ Sinv, const double* __restrict__ a,
-                                 const double* __restrict__ KWK, double s2, int64_t n, double* __restrict__ H, double* __restrict__ Guu) {
+                                 const double* __restrict__ KWK, double s2, int64_t n, double* __restrict__ H, double* __restrict__ Guu,
+                                 const double* __restrict__ ax, int nx) {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t i = blockIdx.y;
     if (j >= n) return;
-    const double h = Kinv[i * n + j] - Sinv[i * n + j] - a[i] * a[j];
+    const double pt = (double)(1 + nx);
+    double h = pt * (Kinv[i * n + j] - Sinv[i * n + j]) - a[i] * a[j];
+    for (int p = 0; p < nx; ++p) h = __builtin_fma(-ax[(int64_t)p * n + i], ax[(int64_t)p * n + j], h);
     H[i * n + j] = h;
-    Guu[i * n + j] = 0.5 * h - 0.5 * KWK[i * n + j] / s2;
+    Guu[i * n + j] = 0.5 * h - 0.5 * pt * KWK[i * n + j] / s2;
+}
+// G[r][m] += sum_p Yx[p][a0 + r] * ax[p][m]: the other outputs' rank-one adjoints y_p a_p^T folded into the adjoint panel
+// (output 0's rides in the pair kernel)
+__global__ void __launch_bounds__(256) rank_add_kernel(double* __restrict__ G, int64_t ldg, int64_t na, int64_t M, const double* __restrict__ Yx,
+                                                       int64_t ldy, const double* __restrict__ ax, int nx) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * 16;
+    if (m >= M) return;
+    double acc[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc[u] = 0.0;
+    for (int p = 0; p < nx; ++p) {
+        const double av = ax[(int64_t)p * M + m];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int64_t r = r0 + u < na ? r0 + u : na - 1;
+            acc[u] = __builtin_fma(Yx[(int64_t)p * ldy + r], av, acc[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+        if (r0 + u < na) G[(r0 + u) * ldg + m] += acc[u];
 }
 // GPR: G = 0.5 (alpha alpha^T - Kinv)
 __global__ void combine_gpr_kernel(const double* __restrict__ Kinv, const double* __restrict__ a, int64_t n, double* __restrict__ G) {
@@ -1158,6 +1184,8 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
     double* da = nullptr;
     OAK_CHECK(get_buf_t(ctx, "g_a", (size_t)M, &da));
     double* dY = (double*)peek_buf(ctx, "Y");
+    const int nx = ctx->n_extra;           // extra target columns: the objective is the sum over 1 + nx outputs
+    double* d_ax = nullptr;
     // ---- M x M adjoints -----------------------------------------------------------------------------------
     double *dLinvT, *dPT, *dKinv, *dSinv, *dTmp, *dKWK, *dH, *dGuu, *dKuu, *dsc, *dvec;
     {
@@ -1193,20 +1221,32 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
         OAK_CHECK(gemm_tail(ctx, 1, dLinvT, dW, dTmp, M, M, M, M, M, M, 1.0, 0.0, OAK_TRI_A_UPPER));         // L^-T W
         OAK_CHECK(gemm_tail(ctx, 1, dTmp, dLinvT, dKWK, M, M, M, M, M, M, 1.0, 0.0, OAK_TRI_B_UPPER));       // Kuu^-1 Phi Kuu^-1
         dim3 grid((unsigned)((M + 255) / 256), (unsigned)M);
-        combine_h_kernel<<<grid, 256, 0, ctx->stream>>>(dKinv, dSinv, da, dKWK, s2, M, dH, dGuu);
+        if (nx > 0) {                      // a_p = (LB^-1 L^-1)^T c_p for the other outputs: one product with the matrix at hand
+            OAK_CHECK(get_buf_t(ctx, "g_ax", (size_t)nx * M, &d_ax));
+            const double* d_cx = (const double*)peek_buf(ctx, "c_all") + M;
+            OAK_CHECK(gemm_nt(ctx, d_cx, dPT, d_ax, nx, M, M, M, M, M, 1.0, 0.0, 0));
+        }
+        combine_h_kernel<<<grid, 256, 0, ctx->stream>>>(dKinv, dSinv, da, dKWK, s2, M, dH, dGuu, d_ax, nx);
         OAK_HIP_CHECK(hipGetLastError());
         // Kuu (+ jitter) = L L^T, for tr(Sigma^-1 Kuu) and a^T Kuu a
         OAK_CHECK(gemm_tail(ctx, 1, dL, dL, dKuu, M, M, M, M, M, M, 1.0, 0.0, OAK_TRI_A_LOWER | OAK_TRI_B_LOWER));
         OAK_CHECK(dot(ctx, dSinv, dKuu, M * M, dsc + 0));                            // tr(Sigma^-1 Kuu)
         OAK_CHECK(gemv_rows(ctx, dKuu, M, M, M, da, dvec));
         OAK_CHECK(dot(ctx, dvec, da, M, dsc + 1));                                   // a^T Kuu a
+        if (nx > 0) {                                                                // ... and sum_p a_p^T Kuu a_p
+            double* d_kax = nullptr;
+            OAK_CHECK(get_buf_t(ctx, "g_kax", (size_t)nx * M, &d_kax));
+            OAK_CHECK(gemm_nt(ctx, d_ax, dKuu, d_kax, nx, M, M, M, M, M, 1.0, 0.0, 0));     // Kuu is symmetric
+            OAK_CHECK(dot(ctx, d_kax, d_ax, (int64_t)nx * M, dsc + 3));
+        }
         t.stop();
     }
     // psi^T a needs the raw psi: in the whitened route stats.psi is still raw (only Phi is replaced by W)
     double* d_stats = (double*)peek_buf(ctx, "stats");
     OAK_CHECK(dot(ctx, d_stats + M * M, da, M, dsc + 2));
-    double hs[3];
-    OAK_HIP_CHECK(hipMemcpyAsync(hs, dsc, sizeof(double) * 3, hipMemcpyDeviceToHost, ctx->stream));
+    if (nx > 0) OAK_CHECK(dot(ctx, (const double*)peek_buf(ctx, "psix"), d_ax, (int64_t)nx * M, dsc + 4));
+    double hs[5] = {0, 0, 0, 0, 0};
+    OAK_HIP_CHECK(hipMemcpyAsync(hs, dsc, sizeof(double) * 5, hipMemcpyDeviceToHost, ctx->stream));
     // ---- N-sized contractions ---------------------------------------------------------------------------------
     const int64_t reclen = record_len(pk);
     double* d_rec = nullptr;
@@ -1253,6 +1293,11 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
         {
             PhaseTimer t(ctx, "bwd_gemm");      // Gfu = Kfu H   (scaled by 1/s2 inside the pair kernel)
             OAK_CHECK(gemm_nt(ctx, dPanel, dH, dG, na, M, M, Mp, M, Mp, 1.0, 0.0, 0));
+            if (nx > 0) {
+                rank_add_kernel<<<dim3((unsigned)((M + 255) / 256), (unsigned)((na + 15) / 16)), 256, 0, ctx->stream>>>(
+                    dG, Mp, na, M, (const double*)peek_buf(ctx, "Yx") + a0, N, d_ax, nx);
+                OAK_HIP_CHECK(hipGetLastError());
+            }
             t.stop();
         }
         {
@@ -1270,7 +1315,7 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
         PhaseTimer t(ctx, "bwd_small");
         // <G_uu, dKuu> is replicated on every rank; each contributes 1/nranks so the all-reduce below restores it once
         OAK_CHECK(gram_bwd(ctx, pk, FZ, 0, M, FZ, dGuu, M, 1.0 / (double)(ctx->comm ? ctx->nranks : 1), nullptr, nullptr, d_rec, desc->grad_base_var != 0));
-        OAK_CHECK(diag_bwd(ctx, pk, FX, -0.5 / s2, d_rec));                                      // -1/(2 s2) sum dKdiag
+        OAK_CHECK(diag_bwd(ctx, pk, FX, -0.5 * (double)(1 + nx) / s2, d_rec));                   // -1/(2 s2) sum dKdiag, once per output
         t.stop();
     }
     if (gradZ_out != nullptr) {
@@ -1285,9 +1330,15 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
     OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ttot.stop();
     const double n_tot = terms[5], kappa = terms[3], yy = terms[4], trW = terms[2] * s2;
-    const double trSK = hs[0], aKa = hs[1], psia = hs[2];
-    const double dnoise = -0.5 * n_tot / s2 + 0.5 * (yy + kappa) / (s2 * s2) - 0.5 * trW / (s2 * s2) - psia / (s2 * s2) +
-                          0.5 * ((double)M - trSK) / s2 + 0.5 * (psia - s2 * aKa) / (s2 * s2);
+    const double trSK = hs[0], aKa = hs[1] + (nx > 0 ? hs[3] : 0.0), psia = hs[2] + (nx > 0 ? hs[4] : 0.0), pt = (double)(1 + nx);
+    double yy_all = yy;
+    if (nx > 0) {                           // y_p^T y_p of the other outputs (summed over the ranks with their Kuf y)
+        std::vector<double> yyx((size_t)nx);
+        OAK_CHECK(copy_sync(ctx, yyx.data(), (const double*)peek_buf(ctx, "psix") + (int64_t)nx * M, sizeof(double) * (size_t)nx, hipMemcpyDeviceToHost));
+        for (double v : yyx) yy_all += v;
+    }
+    const double dnoise = pt * (-0.5 * n_tot / s2 + 0.5 * kappa / (s2 * s2) - 0.5 * trW / (s2 * s2) + 0.5 * ((double)M - trSK) / s2) +
+                          0.5 * yy_all / (s2 * s2) - psia / (s2 * s2) + 0.5 * (psia - s2 * aKa) / (s2 * s2);
     scatter_record(desc, pk, rec, dnoise, grad_out);
     if (gradZ_out != nullptr) {
         std::vector<double> gz((size_t)M * zdmax);

@@ -149,6 +149,12 @@ struct oak_ctx {
     bool feat_grad_valid = false; oak::Feat featXg, featZg;
     bool keep_kfu = false;           // set by the gradient entry points: a whitening forward works on a COPY of the Kfu panel
     bool kfu_kept = false;           // ... and reports here that "panel" still holds the raw Kfu rows of the whole data set
+    // Extra target columns (oak_sgpr_set_extra_targets): outputs 1 .. n_extra of a model with 1 + n_extra output columns that
+    // share kernel, inducing points and noise.  Buffers: "Yx" [n_extra x N], "yyx" [n_extra] (y^T y of this rank's rows),
+    // "psix" [n_extra x M | n_extra] (Kuf y per column, then the y^T y), "c_all" [(1 + n_extra) x M] (c of every output).
+    int n_extra = 0;
+    int psix_nwg = 0;                // row blocks whose partial sums "psix_part" holds (set by the first panel chunk)
+    int out_sel = 0;                 // the output whose c sits in buffer "c" (alpha / predict): oak_sgpr_select_output
     int sobol_path = 0;              // 0 automatic (cost model), 1 one workgroup per term, 2 Gram of products (oak_sobol_set_path)
     double sobol_info[4] = {0, 0, 0, 0};   // last oak_sobol: path taken, Gram columns, largest order-4 pairing disagreement, pair rows
 };
@@ -264,6 +270,9 @@ bool sgpr_route_whitened(const oak_ctx* ctx);
 int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter, double* cond_out = nullptr);
 int sgpr_forward(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out);
 int sgpr_ensure_alpha(oak_ctx* ctx);
+// psix[p][m] (+)= sum_r panel[r][m] * Yx[p][a0 + r] for the extra target columns, one pass over a raw Kfu panel chunk
+int sgpr_extra_psi(oak_ctx* ctx, const double* d_panel, int64_t ldp, int64_t a0, int64_t na, bool first_chunk);
+int sgpr_extra_psi_finish(oak_ctx* ctx);
 
 // backward pieces shared with the SVGP path (grad.hip) ------------------------------------------------
 int64_t record_len(const PreparedKernel& pk);      // [d/d lengthscale' (D) | d/d log base_var (D) | d/d w (R+1) | d/d tables]

@@ -1,5 +1,6 @@
 // Host-side orchestration of the Gram / SGPR / GPR paths and their C ABI entry points.
 #include "oak_internal.h"
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <vector>
@@ -111,6 +112,87 @@ static int check_route_counts(double nwhite, double nparts, bool expect_whitened
     return OAK_OK;
 }
 
+// ---- extra target columns: psi_p = Kuf y_p for outputs 1 .. n_extra in ONE more pass over each raw Kfu panel chunk -----------------
+// (the Gram kernel's fused partial sums serve output 0).  Workgroup w owns XP_ROWS panel rows and every column; a thread keeps
+// XP_G accumulators for each of its columns (coalesced panel reads, the target values are wave-uniform scalar loads), more than
+// XP_G extra outputs are served in groups.  Partials [workgroup][output][column] are summed in a fixed order afterwards.
+constexpr int XP_ROWS = 1024, XP_G = 8;
+__global__ void __launch_bounds__(256) extra_psi_kernel(const double* __restrict__ panel, int64_t ldp, int64_t na, int64_t M,
+                                                        const double* __restrict__ Yx, int64_t ldy, int p0, int np, int n_extra,
+                                                        double* __restrict__ part, int accumulate) {
+    const int64_t r0 = (int64_t)blockIdx.x * XP_ROWS;
+    const int64_t r1 = (r0 + XP_ROWS < na) ? r0 + XP_ROWS : na;
+    const int64_t m = (int64_t)blockIdx.y * 256 + threadIdx.x;
+    const int64_t mc = m < M ? m : M - 1;
+    double acc[XP_G];
+#pragma unroll
+    for (int q = 0; q < XP_G; ++q) acc[q] = 0.0;
+    int64_t r = r0;
+    for (; r + 8 <= r1; r += 8) {                      // eight panel rows in flight per thread
+        double k[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) k[u] = panel[(r + u) * ldp + mc];
+#pragma unroll
+        for (int q = 0; q < XP_G; ++q)
+            if (q < np) {
+                const double* yq = Yx + (int64_t)(p0 + q) * ldy + r;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc[q] = __builtin_fma(k[u], yq[u], acc[q]);
+            }
+    }
+    for (; r < r1; ++r) {
+        const double k = panel[r * ldp + mc];
+#pragma unroll
+        for (int q = 0; q < XP_G; ++q)
+            if (q < np) acc[q] = __builtin_fma(k, Yx[(int64_t)(p0 + q) * ldy + r], acc[q]);
+    }
+    if (m >= M) return;
+#pragma unroll
+    for (int q = 0; q < XP_G; ++q)
+        if (q < np) {
+            double* dst = part + ((int64_t)blockIdx.x * n_extra + p0 + q) * M + m;
+            *dst = accumulate ? (*dst + acc[q]) : acc[q];
+        }
+}
+__global__ void __launch_bounds__(256) extra_psi_reduce_kernel(const double* __restrict__ part, int nwg, int64_t len, double* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= len) return;
+    double s = 0.0;
+    for (int w = 0; w < nwg; ++w) s += part[(int64_t)w * len + e];
+    out[e] = s;
+}
+
+int sgpr_extra_psi(oak_ctx* ctx, const double* d_panel, int64_t ldp, int64_t a0, int64_t na, bool first_chunk) {
+    const int64_t M = ctx->M, N = ctx->N;
+    const int nx = ctx->n_extra;
+    const int nwg = (int)((na + XP_ROWS - 1) / XP_ROWS);
+    const int nwg_cap = (int)((std::min<int64_t>(N, ctx->panel_rows > 0 ? ctx->panel_rows : N) + XP_ROWS - 1) / XP_ROWS);
+    double* d_part = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "psix_part", (size_t)std::max(nwg, nwg_cap) * nx * M, &d_part));
+    const double* dYx = (const double*)peek_buf(ctx, "Yx");
+    for (int p0 = 0; p0 < nx; p0 += XP_G) {
+        const int np = std::min(XP_G, nx - p0);
+        extra_psi_kernel<<<dim3((unsigned)nwg, (unsigned)((M + 255) / 256)), 256, 0, ctx->stream>>>(d_panel, ldp, na, M, dYx + a0, N, p0, np, nx, d_part,
+                                                                                                      first_chunk ? 0 : 1);
+        OAK_HIP_CHECK(hipGetLastError());
+    }
+    if (first_chunk) ctx->psix_nwg = nwg;          // chunk 0 is the largest: the workgroups whose partials exist
+    return OAK_OK;
+}
+
+int sgpr_extra_psi_finish(oak_ctx* ctx) {
+    const int64_t M = ctx->M;
+    const int nx = ctx->n_extra;
+    double* d_psix = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "psix", (size_t)nx * M + nx, &d_psix));
+    const int nwg = ctx->psix_nwg;
+    extra_psi_reduce_kernel<<<(unsigned)((nx * M + 255) / 256), 256, 0, ctx->stream>>>((const double*)peek_buf(ctx, "psix_part"), nwg,
+                                                                                       (int64_t)nx * M, d_psix);
+    OAK_HIP_CHECK(hipGetLastError());
+    OAK_CHECK(copy_d2d(ctx, d_psix + (int64_t)nx * M, peek_buf(ctx, "yyx"), sizeof(double) * (size_t)nx));
+    return OAK_OK;
+}
+
 int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     OAK_REQUIRE(ctx->have_data && ctx->have_Z, "SGPR: set_data and set_inducing must be called first");
     const int64_t N = ctx->N, M = ctx->M, Mp = pad128(M);
@@ -159,7 +241,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     // in fp64 (oak_sgpr_stats_precision tells).  The estimate selects the panel's TYPE, so it is awaited before the first Gram
     // launch (the auto route's pending whitening decision is settled from the same reading).  Under a communicator every rank
     // must have the same mode set: the decision below is a collective.
-    bool want32 = ctx->precision == 1 && !ctx->keep_kfu && ctx->cond_requested;
+    bool want32 = ctx->precision == 1 && !ctx->keep_kfu && ctx->cond_requested && ctx->n_extra == 0;
     const bool want32_asked = want32;
     if (want32) {
         OAK_HIP_CHECK(hipEventSynchronize(ctx->ev2));
@@ -208,6 +290,11 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
             PhaseTimer t(ctx, "gram");
             if (use32) OAK_CHECK(gram_f32(ctx, pk, FX, a0, na, FZ, dPanel32, Mp, dY, st.psi, Mp));
             else OAK_CHECK(gram(ctx, pk, FX, a0, na, FZ, dPanel, Mp, dY, st.psi, Mp));
+            t.stop();
+        }
+        if (ctx->n_extra > 0) {                  // the other outputs' Kuf y from the raw panel (before any whitening in place)
+            PhaseTimer t(ctx, "extra_psi");
+            OAK_CHECK(sgpr_extra_psi(ctx, dPanel, Mp, a0, na, chunk_idx == 0));
             t.stop();
         }
         if (ctx->auto_pending) {
@@ -272,6 +359,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
         // launches are enqueued while the SYRK is still running
         set_triple_kernel<<<1, 1, 0, ctx->stream>>>(st.nrows, (double)N, whiten ? 1.0 : 0.0, 1.0);
         OAK_HIP_CHECK(hipGetLastError());
+        if (ctx->n_extra > 0) OAK_CHECK(sgpr_extra_psi_finish(ctx));
         t.stop();
     }
     ctx->have_stats = true;
@@ -425,6 +513,8 @@ int sgpr_forward(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, doubl
     ctx->cond_requested = false;
     ctx->kuu_async = false;
     if (rc == OAK_OK && ctx->comm != nullptr) rc = oak_comm_allreduce_stats(ctx);
+    if (rc == OAK_OK && ctx->comm != nullptr && ctx->n_extra > 0)         // the other outputs' [Kuf y | y^T y], summed over the row shards
+        rc = comm_allreduce_dev(ctx, (double*)peek_buf(ctx, "psix"), (int64_t)ctx->n_extra * ctx->M + ctx->n_extra, "comm_stage_x");
     if (rc != OAK_OK) { if (l_state == 2) (void)hipStreamSynchronize(ctx->side); ctx->auto_whiten = -1; return rc; }
     rc = sgpr_tail(ctx, pk, noise_var, jitter, elbo_out, terms_out, l_state);
     ctx->auto_whiten = -1;              // the decision belongs to this evaluation only
@@ -536,6 +626,27 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     // scalars: sum log diag LB, c^T c, tr W, (kappa, yy, nrows), sum log diag L -- one small kernel, fixed reduction trees
     tail_scalars_kernel<<<1, 256, 0, ctx->stream>>>(dLB, dc, dT2, dL, M, st.kappa, dscal);
     OAK_HIP_CHECK(hipGetLastError());
+    // The other outputs share everything above (Kuu, Phi, L, LB); what differs is c_p = LB^-1 L^-1 psi_p / sigma^2 and y_p^T y_p.
+    const int nx = ctx->n_extra;
+    std::vector<double> hx((size_t)2 * nx);
+    double* d_call = nullptr;
+    if (nx > 0) {
+        OAK_REQUIRE(peek_buf(ctx, "psix") != nullptr, "SGPR tail: the statistics of the extra target columns are missing (they are formed by "
+                                                      "oak_sgpr_elbo / oak_sgpr_elbo_grad / oak_sgpr_local_stats, not by oak_sgpr_set_stats)");
+        double *d_psix = (double*)peek_buf(ctx, "psix"), *d_sq = nullptr;
+        OAK_CHECK(get_buf_t(ctx, "c_all", (size_t)(1 + nx) * M, &d_call));
+        OAK_CHECK(get_buf_t(ctx, "cx_sq", (size_t)2 * nx, &d_sq));
+        OAK_CHECK(copy_d2d(ctx, d_call, dc, sizeof(double) * (size_t)M));
+        double* d_cx = d_call + M;
+        OAK_CHECK(copy_d2d(ctx, d_cx, d_psix, sizeof(double) * (size_t)nx * M));
+        OAK_CHECK(trsm_rows(ctx, dL, M, M, d_cx, nx, M, 0));
+        OAK_CHECK(trsm_rows(ctx, dLB, M, M, d_cx, nx, M, 0));
+        OAK_CHECK(scale_vec(ctx, 1.0 / noise_var, d_cx, (int64_t)nx * M));
+        OAK_CHECK(row_sumsq(ctx, d_cx, nx, M, M, d_sq));
+        OAK_CHECK(copy_d2d(ctx, d_sq + nx, d_psix + (int64_t)nx * M, sizeof(double) * (size_t)nx));
+        OAK_HIP_CHECK(hipMemcpyAsync(hx.data(), d_sq, sizeof(double) * (size_t)2 * nx, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    ctx->out_sel = 0;
     double h[9] = {0};
     OAK_HIP_CHECK(hipMemcpyAsync(h, dscal, sizeof(double) * 9, hipMemcpyDeviceToHost, ctx->stream));
     OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -552,6 +663,13 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     bound += 0.5 * cTc;
     bound += -0.5 * kappa / noise_var;
     bound += 0.5 * trAAT;
+    if (nx > 0) {
+        // sum over the outputs: the y-independent terms once per output, (c^T c, y^T y) of each
+        const double shared = bound - (-0.5 * yy / noise_var + 0.5 * cTc);
+        double total = bound;
+        for (int p = 0; p < nx; ++p) total += shared - 0.5 * hx[(size_t)nx + p] / noise_var + 0.5 * hx[(size_t)p];
+        bound = total;
+    }
     if (elbo_out) *elbo_out = bound;
     // slot 7: the conditioning estimate (max diag L / min diag L)^2 when this evaluation asked the side stream for it (auto
     // route on a large problem, fp32 statistics mode), else 0
@@ -643,6 +761,7 @@ int oak_sgpr_set_data(oak_ctx* ctx, const double* X, const double* Y, int64_t N,
     OAK_CHECK(reduce_sum(ctx, dY, N, dyy, 1, 1));              // y^T y does not change between evaluations
     OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ctx->N = N; ctx->ldx = ldx; ctx->have_data = true; ctx->have_stats = false; ctx->have_post = false;
+    ctx->n_extra = 0;                                          // extra target columns belong to the rows they were set for
     ctx->n_global_comm = 0;                                    // the rows changed: the communicator-wide count is stale
     return OAK_OK;
 }
@@ -659,6 +778,35 @@ int oak_sgpr_set_targets(oak_ctx* ctx, const double* Y, int64_t N) {
     OAK_CHECK(reduce_sum(ctx, dY, N, dyy, 1, 1));
     OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ctx->have_stats = false; ctx->have_post = false;
+    return OAK_OK;
+}
+
+int oak_sgpr_set_extra_targets(oak_ctx* ctx, const double* Yt, int64_t N, int32_t n_extra) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(n_extra >= 0 && n_extra <= 1024, "oak_sgpr_set_extra_targets: between 0 and 1024 extra columns");
+    if (n_extra == 0) { ctx->n_extra = 0; ctx->have_stats = false; ctx->have_post = false; return OAK_OK; }
+    OAK_REQUIRE(Yt != nullptr, "oak_sgpr_set_extra_targets: Yt is NULL");
+    OAK_REQUIRE(ctx->have_data && N == ctx->N, "oak_sgpr_set_extra_targets: %lld targets per column for the %lld rows set by oak_sgpr_set_data",
+                (long long)N, (long long)(ctx->have_data ? ctx->N : 0));
+    double *dYx, *dyyx;
+    OAK_CHECK(HostUpload::run(ctx, "Yx", Yt, (size_t)N * n_extra, &dYx));
+    OAK_CHECK(get_buf_t(ctx, "yyx", (size_t)n_extra, &dyyx));
+    for (int p = 0; p < n_extra; ++p) OAK_CHECK(reduce_sum(ctx, dYx + (int64_t)p * N, N, dyyx + p, 1, 1));
+    OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    ctx->n_extra = n_extra; ctx->have_stats = false; ctx->have_post = false;
+    return OAK_OK;
+}
+
+int oak_sgpr_select_output(oak_ctx* ctx, int32_t p) {
+    OAK_CHECK(guard(ctx));
+    if (!ctx->have_post) { set_error("SGPR posterior not available: call oak_sgpr_elbo/oak_sgpr_tail first"); return OAK_E_STATE; }
+    OAK_REQUIRE(p >= 0 && p <= ctx->n_extra, "oak_sgpr_select_output: output %d of %d", p, 1 + ctx->n_extra);
+    if (p == ctx->out_sel) return OAK_OK;
+    const double* d_call = (const double*)peek_buf(ctx, "c_all");
+    OAK_REQUIRE(d_call != nullptr, "oak_sgpr_select_output: no extra target columns were evaluated");
+    OAK_CHECK(copy_d2d(ctx, peek_buf(ctx, "c"), d_call + (int64_t)p * ctx->M, sizeof(double) * (size_t)ctx->M));
+    ctx->out_sel = p;
+    ctx->have_alpha = false;
     return OAK_OK;
 }
 

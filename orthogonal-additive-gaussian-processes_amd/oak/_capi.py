@@ -74,6 +74,8 @@ SIGNATURES = {
     "oak_gram_component_diag": (C.c_int, [_CTX, _DESC, _I, C.c_int32, C.c_int32, _D, C.c_int64, C.c_int32, _D]),
     "oak_sgpr_set_data": (C.c_int, [_CTX, _D, _D, C.c_int64, C.c_int32]),
     "oak_sgpr_set_targets": (C.c_int, [_CTX, _D, C.c_int64]),
+    "oak_sgpr_set_extra_targets": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32]),
+    "oak_sgpr_select_output": (C.c_int, [_CTX, C.c_int32]),
     "oak_sgpr_set_inducing": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32]),
     "oak_sgpr_set_panel_rows": (C.c_int, [_CTX, C.c_int64]),
     "oak_sgpr_local_stats": (C.c_int, [_CTX, _DESC, C.c_double]),
@@ -429,6 +431,18 @@ class HipContext:
         """Another target column for the rows already on the device (one output of an N x P ``Y``)."""
         y = _f64(np.asarray(y).reshape(-1))
         _check(self._lib.oak_sgpr_set_targets(self._h, _dp(y), y.shape[0]))
+
+    def sgpr_set_extra_targets(self, Y_extra):
+        """Columns 1 .. of a P-column target matrix (``Y_extra`` [N x (P - 1)], or None / zero columns to forget them): bound and
+        gradient become sums over all outputs with the y-independent work shared (oak_sgpr_set_extra_targets)."""
+        if Y_extra is None or np.asarray(Y_extra).size == 0:
+            _check(self._lib.oak_sgpr_set_extra_targets(self._h, None, 0, 0))
+            return
+        Yt = np.ascontiguousarray(np.asarray(Y_extra, dtype=np.float64).T)      # one column per row
+        _check(self._lib.oak_sgpr_set_extra_targets(self._h, _dp(Yt), Yt.shape[1], Yt.shape[0]))
+
+    def sgpr_select_output(self, p: int):
+        _check(self._lib.oak_sgpr_select_output(self._h, int(p)))
 
     def sgpr_set_inducing(self, Z):
         Z = _f64(Z, 2)

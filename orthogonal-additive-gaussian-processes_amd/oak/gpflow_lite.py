@@ -456,9 +456,9 @@ class GPModel(Module):
         X, Y = data
         self.data = (np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64).reshape(len(X), -1))
         # P output columns are GPflow's independent outputs sharing kernel and noise: bound, gradient and posterior mean are sums /
-        # stacks over single-output problems, and that is how they are evaluated here -- one pass of the device path per column
-        # (`_outputs`).  The reference itself only ever passes one column; the y-independent statistics are NOT shared between the
-        # passes, so P columns cost P evaluations.
+        # stacks over single-output problems.  The sparse model evaluates them in ONE device pass (the y-independent statistics --
+        # Kuf panel, Phi, both Cholesky factors, the M x M adjoints -- are shared: oak_sgpr_set_extra_targets); the full GP, a
+        # small problem by construction, runs one pass per column (`_outputs`).  The reference itself only ever passes one column.
         self._P = self.data[1].shape[1]
         if self._P < 1:
             raise ValueError("Y has no columns")
@@ -605,11 +605,18 @@ class SGPR(GPModel):
         Xl, Yl = _shard_rows(self._comm, self._hip, self.data[0], self.data[1])
         self._Yl = Yl                                                  # this rank's rows, all output columns
         self._hip.sgpr_set_data(Xl, Yl[:, 0])
+        if self._P > 1:
+            self._hip.sgpr_set_extra_targets(Yl[:, 1:])                # outputs 1 .. P-1 share every y-independent statistic
         self._z_sent = None
         self.route = "auto"
 
-    def _set_column(self, p):
-        self._hip.sgpr_set_targets(self._Yl[:, p])
+    def _posteriors(self):
+        """Iterate over the outputs with that output's posterior selected on the device (one evaluation serves all of them)."""
+        for p in range(self._P):
+            self._hip.sgpr_select_output(p)
+            yield p
+        if self._P > 1:
+            self._hip.sgpr_select_output(0)
 
     def _sync_Z(self):
         Z = self.inducing_variable.Z.numpy()
@@ -621,7 +628,7 @@ class SGPR(GPModel):
     def elbo(self):
         self._sync_Z()
         desc, s2 = self._desc(), float(self.likelihood.variance.numpy())
-        return float(sum(self._hip.sgpr_elbo(desc, s2, default_jitter()) for _ in self._outputs()))
+        return float(self._hip.sgpr_elbo(desc, s2, default_jitter()))   # the sum over the output columns
 
     def maximum_log_likelihood_objective(self):
         return self.elbo()
@@ -633,8 +640,8 @@ class SGPR(GPModel):
         desc, s2 = self._desc(), float(self.likelihood.variance.numpy())
         Xnew = np.asarray(Xnew, dtype=np.float64)
         means, var = [], None
-        for _ in self._outputs():
-            self._hip.sgpr_elbo(desc, s2, default_jitter())
+        self._hip.sgpr_elbo(desc, s2, default_jitter())
+        for _ in self._posteriors():
             if self._comm is not None and len(Xnew) >= self.SHARDED_PREDICT_MIN_ROWS * self._comm.world:
                 # test rows are independent: each rank predicts its block from the replicated posterior, one gather
                 from . import distributed
@@ -648,8 +655,8 @@ class SGPR(GPModel):
         """alpha of oak/utils.py:180-198 (one column per output)."""
         self._sync_Z()
         desc, s2, cols = self._desc(), float(self.likelihood.variance.numpy()), []
-        for _ in self._outputs():
-            self._hip.sgpr_elbo(desc, s2, default_jitter())
+        self._hip.sgpr_elbo(desc, s2, default_jitter())
+        for _ in self._posteriors():
             cols.append(self._hip.sgpr_alpha(len(self.inducing_variable)))
         return TensorLike(np.stack(cols, axis=1))
 
@@ -665,17 +672,13 @@ class SGPR(GPModel):
         want_z = any(v is Zp for v in getattr(self, "_want_extra", ()))
         self._extra_grads = {}
         s2 = float(self.likelihood.variance.numpy())
-        obj, g, gz = 0.0, 0.0, 0.0
-        for _ in self._outputs():
-            if want_z:  # trainable inducing inputs (create_model_oak(zfixed=False)): one more pass over the pairs
-                Z = Zp.numpy()
-                o_p, g_p, gz_p = self._hip.sgpr_elbo_grad_z(desc, s2, Z.shape[0], Z.shape[1], default_jitter())
-                gz = gz + gz_p
-            else:
-                o_p, g_p = self._hip.sgpr_elbo_grad(desc, s2, default_jitter())
-            obj, g = obj + o_p, g + g_p
-        if want_z:
+        # one call: bound and gradient summed over the output columns (shared statistics, oak_sgpr_set_extra_targets)
+        if want_z:  # trainable inducing inputs (create_model_oak(zfixed=False)): one more pass over the pairs
+            Z = Zp.numpy()
+            obj, g, gz = self._hip.sgpr_elbo_grad_z(desc, s2, Z.shape[0], Z.shape[1], default_jitter())
             self._extra_grads[id(Zp)] = gz
+        else:
+            obj, g = self._hip.sgpr_elbo_grad(desc, s2, default_jitter())
         return obj, g, desc
 
 

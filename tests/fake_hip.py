@@ -61,12 +61,23 @@ class FakeContext:
     # -- SGPR ------------------------------------------------------------------------------------------------------
     def sgpr_set_data(self, X, Y):
         self.X, self.Y = np.asarray(X, dtype=np.float64), np.asarray(Y, dtype=np.float64).reshape(len(X), 1)
+        self._sel = 0
 
     def sgpr_set_targets(self, y):
         y = np.asarray(y, dtype=np.float64).reshape(-1, 1)
         if len(y) != len(self.X):
             raise ValueError("oak_sgpr_set_targets: row count differs from the data on the device")
-        self.Y = y
+        self.Y = np.concatenate([y, self.Y[:, 1:]], axis=1)
+
+    def sgpr_set_extra_targets(self, Y_extra):
+        if Y_extra is None or np.asarray(Y_extra).size == 0:
+            self.Y = self.Y[:, :1]
+            return
+        Y_extra = np.asarray(Y_extra, dtype=np.float64).reshape(len(self.X), -1)
+        self.Y = np.concatenate([self.Y[:, :1], Y_extra], axis=1)
+
+    def sgpr_select_output(self, p):
+        self._sel = int(p)
 
     def sgpr_set_inducing(self, Z):
         self.Z = np.asarray(Z, dtype=np.float64)
@@ -89,11 +100,14 @@ class FakeContext:
     def _elbo(self, spec, s2, jitter):
         M = len(self.Z)
         kuf = o.oak_K(spec, self.Z, self.X)
-        local = np.concatenate([(kuf @ kuf.T).reshape(-1), (kuf @ self.Y)[:, 0],
-                                [float(o.oak_K_diag(spec, self.X).sum()), float((self.Y ** 2).sum()), float(len(self.X))]])
+        P = self.Y.shape[1]
+        yy_loc = (self.Y ** 2).sum(axis=0)
+        local = np.concatenate([(kuf @ kuf.T).reshape(-1), (kuf @ self.Y).T.reshape(-1),
+                                [float(o.oak_K_diag(spec, self.X).sum()), float(yy_loc[0]), float(len(self.X))], yy_loc[1:]])
         tot = self._sum(local)
-        Phi, psi = tot[:M * M].reshape(M, M), tot[M * M:M * M + M]
-        kappa, yy, n = tot[M * M + M:]
+        Phi, psi = tot[:M * M].reshape(M, M), tot[M * M:M * M + P * M].reshape(P, M).T
+        kappa, yy0, n = tot[M * M + P * M:M * M + P * M + 3]
+        yy = np.concatenate([[yy0], tot[M * M + P * M + 3:]])
         from oak import _capi
         try:
             L = np.linalg.cholesky(o.oak_K(spec, self.Z) + jitter * np.eye(M))
@@ -101,13 +115,14 @@ class FakeContext:
             LB = np.linalg.cholesky(np.eye(M) + W / s2)
         except np.linalg.LinAlgError as ex:                   # what the binding raises for OAK_E_NOTPD
             raise _capi.NotPositiveDefiniteError(str(ex)) from ex
-        c = sla.solve_triangular(LB, sla.solve_triangular(L, psi, lower=True), lower=True) / s2
-        e = (-0.5 * n * np.log(2 * np.pi) - np.sum(np.log(np.diag(LB))) - 0.5 * n * np.log(s2) - 0.5 * yy / s2
-             + 0.5 * c @ c - 0.5 * kappa / s2 + 0.5 * np.trace(W) / s2)
+        c = np.stack([sla.solve_triangular(LB, sla.solve_triangular(L, psi[:, p], lower=True), lower=True) / s2 for p in range(P)], axis=1)
+        e = sum(-0.5 * n * np.log(2 * np.pi) - np.sum(np.log(np.diag(LB))) - 0.5 * n * np.log(s2) - 0.5 * yy[p] / s2
+                + 0.5 * c[:, p] @ c[:, p] - 0.5 * kappa / s2 + 0.5 * np.trace(W) / s2 for p in range(P))       # one bound per output
         return float(e), (L, LB, c)
 
     def sgpr_elbo(self, desc, noise_var, jitter=1e-6):
         e, self._post = self._elbo(desc.spec, float(noise_var), jitter)
+        self._sel = 0
         return e
 
     def grad_len(self, desc):
@@ -140,14 +155,14 @@ class FakeContext:
 
     def sgpr_alpha(self, M):
         L, LB, c = self._post
-        return np.linalg.solve(L.T, np.linalg.solve(LB.T, c))
+        return np.linalg.solve(L.T, np.linalg.solve(LB.T, c[:, self._sel]))
 
     def sgpr_predict(self, desc, Xs):
         L, LB, c = self._post
         Kus = o.oak_K(desc.spec, self.Z, Xs)
         t1 = sla.solve_triangular(L, Kus, lower=True)
         t2 = sla.solve_triangular(LB, t1, lower=True)
-        return t2.T @ c, o.oak_K_diag(desc.spec, Xs) + np.sum(t2 * t2, 0) - np.sum(t1 * t1, 0)
+        return t2.T @ c[:, self._sel], o.oak_K_diag(desc.spec, Xs) + np.sum(t2 * t2, 0) - np.sum(t1 * t1, 0)
 
     def sgpr_last_terms(self):
         return {}

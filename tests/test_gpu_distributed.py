@@ -496,3 +496,43 @@ def test_allgatherv_refuses_blocks_for_ranks_it_cannot_reach():
     with pytest.raises(_capi.OakHipError):
         ctx.comm_allgatherv(np.arange(3.0), [3, 3, 3])
     ctx.close()
+
+
+def test_several_output_columns_under_a_two_rank_communicator():
+    """Row shards + extra target columns: each rank forms [Kuf y_p | y_p^T y_p] of its rows for every output, the library sums
+    them next to the packed statistics, and bound / gradient of the P-column model equal the one-context evaluation on both
+    ranks (bit-identical between the ranks)."""
+    import threading
+    X, y, Z = o.synthetic_problem(5001, 5, 96, seed=5)
+    rng = np.random.default_rng(2)
+    Y = np.concatenate([y, rng.standard_normal((len(X), 3)) + y], axis=1)
+    spec = o.make_spec(5, 2, lengthscales=[0.9, 1.1, 1.3, 0.8, 1.0])
+    d = _capi.KernelDesc(spec)
+    ref = _capi.HipContext(0)
+    ref.sgpr_set_data(X, Y[:, 0]); ref.sgpr_set_extra_targets(Y[:, 1:]); ref.sgpr_set_inducing(Z); ref.sgpr_set_route("phi")
+    e_ref, g_ref = ref.sgpr_elbo_grad(d, 0.05)
+    assert abs(e_ref - o.sgpr_elbo(spec, X, Y, Z, 0.05)) <= 1e-10 * abs(e_ref)
+    cb0, cb1 = _two_party_callbacks()
+    cuts = [(0, 2000), (2000, len(X))]
+    ranks = [_capi.HipContext(0), _capi.HipContext(0)]
+    for r, (lo, hi) in enumerate(cuts):
+        ranks[r].sgpr_set_data(X[lo:hi], Y[lo:hi, 0]); ranks[r].sgpr_set_extra_targets(Y[lo:hi, 1:])
+        ranks[r].sgpr_set_inducing(Z); ranks[r].sgpr_set_route("phi"); ranks[r].sgpr_set_global_rows(len(X))
+    ranks[0].comm_init_host(2, 0, cb0); ranks[1].comm_init_host(2, 1, cb1)
+    res = {}
+
+    def run(r):
+        res[r] = ranks[r].sgpr_elbo_grad(d, 0.05)
+        ranks[r].sgpr_select_output(3)
+        res[("alpha", r)] = ranks[r].sgpr_alpha(96)
+    th = [threading.Thread(target=run, args=(r,)) for r in (0, 1)]
+    [t.start() for t in th]; [t.join(120) for t in th]
+    assert not any(t.is_alive() for t in th) and 0 in res and 1 in res
+    for r in (0, 1):
+        assert abs(res[r][0] - e_ref) <= 1e-12 * abs(e_ref)
+        np.testing.assert_allclose(res[r][1], g_ref, rtol=1e-9, atol=1e-9 * np.abs(g_ref).max())
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[("alpha", 0)], res[("alpha", 1)])
+    ref.sgpr_select_output(3)
+    np.testing.assert_allclose(res[("alpha", 0)], ref.sgpr_alpha(96), rtol=1e-8, atol=1e-10)
+    for c in ranks + [ref]:
+        c.close()
