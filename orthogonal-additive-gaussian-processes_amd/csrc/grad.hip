@@ -1209,7 +1209,12 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
         }
         OAK_CHECK(copy_d2d(ctx, dPT, dLinvT, sizeof(double) * (size_t)M * M));
         OAK_CHECK(trsm_rows(ctx, dLB, M, M, dPT, M, M, 0));                         // rows = columns of LB^-1 L^-1
+        // On the whitened route -- chosen because Kuu is ill-conditioned -- a comes from the two transposed triangular solves, the
+        // arithmetic of oak_sgpr_alpha / predict: multiplying by the explicit (LB^-1 L^-1)^T loses ~cond(Kuu) ulps there (the forward
+        // tail records 8e-9 on such a problem), and the gradient's a would no longer be the posterior's.  0.6 ms of a ~95 ms evaluation.
+        const bool exact_a = ctx->stats_whitened;
         if (ctx->have_alpha) OAK_CHECK(copy_d2d(ctx, da, peek_buf(ctx, "alpha"), sizeof(double) * (size_t)M));
+        else if (exact_a) { OAK_CHECK(sgpr_ensure_alpha(ctx)); OAK_CHECK(copy_d2d(ctx, da, peek_buf(ctx, "alpha"), sizeof(double) * (size_t)M)); }
         else OAK_CHECK(gemv_rows(ctx, dPT, M, M, M, (const double*)peek_buf(ctx, "c"), da));         // a = (LB^-1 L^-1)^T c
         // LinvT (rows = columns of L^-1) and PT are upper triangular, L lower: the products below skip the zero k ranges and
         // slice k over gridDim.z (gemm_tail)
@@ -1224,7 +1229,13 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
         if (nx > 0) {                      // a_p = (LB^-1 L^-1)^T c_p for the other outputs: one product with the matrix at hand
             OAK_CHECK(get_buf_t(ctx, "g_ax", (size_t)nx * M, &d_ax));
             const double* d_cx = (const double*)peek_buf(ctx, "c_all") + M;
-            OAK_CHECK(gemm_nt(ctx, d_cx, dPT, d_ax, nx, M, M, M, M, M, 1.0, 0.0, 0));
+            if (exact_a) {
+                OAK_CHECK(copy_d2d(ctx, d_ax, d_cx, sizeof(double) * (size_t)nx * M));
+                OAK_CHECK(trsm_rows(ctx, dLB, M, M, d_ax, nx, M, 1));
+                OAK_CHECK(trsm_rows(ctx, dL, M, M, d_ax, nx, M, 1));
+            } else {
+                OAK_CHECK(gemm_nt(ctx, d_cx, dPT, d_ax, nx, M, M, M, M, M, 1.0, 0.0, 0));
+            }
         }
         combine_h_kernel<<<grid, 256, 0, ctx->stream>>>(dKinv, dSinv, da, dKWK, s2, M, dH, dGuu, d_ax, nx);
         OAK_HIP_CHECK(hipGetLastError());

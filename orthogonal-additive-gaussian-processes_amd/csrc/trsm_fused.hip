@@ -27,7 +27,11 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 
 constexpr int TF_NB = 128;                  // column block
 constexpr int TF_KC = 16;                   // k per stage
-constexpr int TF_ROWS = 64;                 // panel rows per workgroup (16 per wave)
+#ifndef OAK_TF_NW
+#define OAK_TF_NW 4
+#endif
+constexpr int TF_NW = OAK_TF_NW;            // waves per workgroup (4: two workgroups per CU; 8: one, the pack tile shared by twice the rows)
+constexpr int TF_ROWS = 16 * TF_NW;         // panel rows per workgroup (16 per wave)
 constexpr int TF_TILE = TF_NB * TF_KC;      // doubles per stage tile
 
 __host__ __device__ inline int64_t tf_stages_before(int64_t j) { return 4 * j * (j + 1); }   // block j has 8 j + 8 stages
@@ -141,7 +145,7 @@ constexpr int TF_GRP = 4;
 constexpr int TF_XT = TF_ROWS * TF_KC;       // doubles per X stage tile
 
 template <bool REV>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(64 * TF_NW, TF_NW <= 4 ? 2 : 1)
 trsm_fused_kernel(const double* __restrict__ pack, const double* Bin, double* Xout, double* scratch, int64_t nrhs, int64_t ldin,
                   int64_t ldout, int nb) {
     // REV: logical column c of the panels is memory column 128 nb - 1 - c (see trsm_pack_kernel): column offsets are subtracted
@@ -179,10 +183,11 @@ trsm_fused_kernel(const double* __restrict__ pack, const double* Bin, double* Xo
     int64_t s = 0;                                  // stage; its tile sits in slot s & 1
     auto glds_pack = [&](int64_t t) {              // tile t (clamped) -> slot t & 1; four 1 KiB pieces per wave
         const int64_t tc = t < nst ? t : nst - 1;
-        const double* src = pack + tc * TF_TILE + wave * 512 + lane * 2;
-        double* dst = Ls + (t & 1) * TF_TILE + wave * 512;
+        constexpr int PER_WAVE = TF_TILE / TF_NW;          // doubles of the tile each wave brings (1 KiB pieces)
+        const double* src = pack + tc * TF_TILE + wave * PER_WAVE + lane * 2;
+        double* dst = Ls + (t & 1) * TF_TILE + wave * PER_WAVE;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < PER_WAVE / 128; ++q)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + q * 128),
                                              (__attribute__((address_space(3))) void*)(dst + q * 128), 16, 0, 0);
     };
@@ -325,8 +330,8 @@ int trsm_rows_fused(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, cons
     double* dScratch = nullptr;                       // where the lanes of rows past the end read and write
     OAK_CHECK(get_buf_t(ctx, "trsm_scratch_row", (size_t)npad + 64, &dScratch));
     OAK_CHECK(fill_zero(ctx, dScratch, sizeof(double) * ((size_t)npad + 64)));
-    if (transposed) trsm_fused_kernel<true><<<grid, 256, 0, ctx->stream>>>(dPack, dBin, dXout, dScratch, nrhs, ldin, ldout, nb);
-    else trsm_fused_kernel<false><<<grid, 256, 0, ctx->stream>>>(dPack, dBin, dXout, dScratch, nrhs, ldin, ldout, nb);
+    if (transposed) trsm_fused_kernel<true><<<grid, 64 * TF_NW, 0, ctx->stream>>>(dPack, dBin, dXout, dScratch, nrhs, ldin, ldout, nb);
+    else trsm_fused_kernel<false><<<grid, 64 * TF_NW, 0, ctx->stream>>>(dPack, dBin, dXout, dScratch, nrhs, ldin, ldout, nb);
     OAK_HIP_CHECK(hipGetLastError());
     return OAK_OK;
 }

@@ -73,11 +73,15 @@ def choose_route(n_total: int, M: int) -> str:
 # ---------------------------------------------------------------------------------------------------------------------
 # control plane
 # ---------------------------------------------------------------------------------------------------------------------
+MAX_FRAME = 1 << 33          # 8 GiB: no collective of this package moves more (a length prefix beyond it is a protocol error, not an allocation)
+HELLO_MAGIC = b"OAKP"
+
+
 def _send(sock: socket.socket, payload: bytes):
     sock.sendall(struct.pack("<Q", len(payload)) + payload)
 
 
-def _recv(sock: socket.socket) -> bytes:
+def _recv(sock: socket.socket, limit: int = MAX_FRAME) -> bytes:
     def exactly(n):
         chunks, got = [], 0
         while got < n:
@@ -87,7 +91,19 @@ def _recv(sock: socket.socket) -> bytes:
             chunks.append(c); got += len(c)
         return b"".join(chunks)
     (n,) = struct.unpack("<Q", exactly(8))
+    if n > limit:
+        raise ConnectionError(f"control plane: frame of {n} bytes exceeds the limit of {limit}")
     return exactly(n)
+
+
+def _job_token(world: int, port: int) -> bytes:
+    """What a peer must present in its hello frame: $OAK_JOB_TOKEN if the launcher exported one (any shared secret), else a
+    value derived from what every rank of THIS job already agrees on (run id, world size, port).  It keeps a stray or stale
+    process that happens to hit the port from being taken for a rank; it is not an authentication scheme (the plane binds to
+    the loopback interface unless told otherwise)."""
+    import hashlib
+    secret = os.environ.get("OAK_JOB_TOKEN") or "|".join([os.environ.get("TORCHELASTIC_RUN_ID", ""), str(world), str(port)])
+    return hashlib.sha256(secret.encode()).digest()[:16]
 
 
 class HostPlane:
@@ -95,7 +111,12 @@ class HostPlane:
 
     Collectives are two hops through rank 0 (gather, combine, scatter back): fine for a control plane -- a 128-byte id, a
     few scalars, a barrier -- and for the debug / single-GPU ``"host"`` data exchange; the production exchange is RCCL.
-    Every rank receives the bytes rank 0 computed, so the results are bit-identical everywhere."""
+    Every rank receives the bytes rank 0 computed, so the results are bit-identical everywhere.
+
+    Handshake: a peer sends ``OAKP | job token (16 bytes) | rank``; rank 0 keeps ONE deadline for the whole rendezvous, gives
+    every accepted connection the remaining time to say hello, and drops (without failing the job) connections that send
+    nothing, a wrong token, or a rank that is out of range or already taken.  Rank 0 binds the address it is given
+    (MASTER_ADDR; 127.0.0.1 for a one-node job)."""
 
     def __init__(self, rank: int, world: int, addr: str = "127.0.0.1", port: int = 29533, timeout: float = 120.0):
         self.rank, self.world = int(rank), int(world)
@@ -103,21 +124,40 @@ class HostPlane:
         self._root: Optional[socket.socket] = None
         if self.world == 1:
             return
+        token = _job_token(self.world, port)
         if self.rank == 0:
             srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind((addr, port))
-            srv.listen(self.world)
-            srv.settimeout(timeout)
-            for _ in range(self.world - 1):
-                conn, _a = srv.accept()
-                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-                conn.settimeout(None)
-                (r,) = struct.unpack("<I", _recv(conn))
-                if not (0 < r < self.world) or self._peers[r] is not None:
-                    raise ConnectionError(f"control plane: unexpected rank {r}")
-                self._peers[r] = conn
-            srv.close()
+            srv.listen(self.world + 8)
+            deadline = time.time() + timeout
+            missing = self.world - 1
+            try:
+                while missing > 0:
+                    left = deadline - time.time()
+                    if left <= 0:
+                        raise TimeoutError(f"control plane: {missing} of {self.world - 1} ranks did not join within {timeout:.0f} s")
+                    srv.settimeout(left)
+                    try:
+                        conn, _a = srv.accept()
+                    except socket.timeout:
+                        continue
+                    try:
+                        conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                        conn.settimeout(max(0.05, min(10.0, deadline - time.time())))      # a silent connection cannot stall the rendezvous
+                        hello = _recv(conn, limit=64)
+                        ok = len(hello) == 24 and hello[:4] == HELLO_MAGIC and hello[4:20] == token
+                        r = struct.unpack("<I", hello[20:24])[0] if ok else -1
+                        if not ok or not (0 < r < self.world) or self._peers[r] is not None:
+                            raise ConnectionError("not a rank of this job")
+                    except (OSError, ConnectionError, struct.error):
+                        conn.close()                                                       # dropped; keep waiting for the real ranks
+                        continue
+                    conn.settimeout(None)
+                    self._peers[r] = conn
+                    missing -= 1
+            finally:
+                srv.close()
         else:
             deadline = time.time() + timeout
             while True:
@@ -130,7 +170,7 @@ class HostPlane:
                     time.sleep(0.05)
             s.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             s.settimeout(None)
-            _send(s, struct.pack("<I", self.rank))
+            _send(s, HELLO_MAGIC + token + struct.pack("<I", self.rank))
             self._root = s
 
     # -- primitives ------------------------------------------------------------------------------------------------

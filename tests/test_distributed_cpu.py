@@ -293,3 +293,61 @@ def test_full_gpr_under_a_multi_rank_job_evaluates_sobol_replicated(tmp_path):
     assert len(ref) == 21 and (ref > 0).all()
     for r in range(2):
         np.testing.assert_array_equal(np.load(tmp_path / f"g2_{r}.npz")["sobol"], ref)
+
+
+def _worker_plane_with_strays(rank, world, port, out_dir):
+    sys.path.insert(0, str(ROOT / "orthogonal-additive-gaussian-processes_amd"))
+    from oak import distributed as D
+    pl = D.HostPlane(rank, world, "127.0.0.1", port, timeout=60.0)
+    a = pl.allreduce_sum(np.array([float(rank + 1)]))
+    np.savez(Path(out_dir) / f"s{rank}.npz", a=a)
+    pl.close()
+
+
+def test_host_plane_rendezvous_ignores_connections_that_are_not_ranks(tmp_path):
+    """Round-3 advisor finding: a peer that connects and says nothing, or claims a rank without the job's token, or claims a
+    rank that does not exist, must neither stall the handshake nor become a rank.  Three such connections are opened against
+    rank 0's port while the real ranks join; a frame longer than the cap is refused."""
+    import socket, struct, threading, time
+    sys.path.insert(0, str(ROOT / "orthogonal-additive-gaussian-processes_amd"))
+    from oak import distributed as D
+    world, port = 2, _free_port()
+    strays = []
+
+    def pester():
+        deadline = time.time() + 30
+        while time.time() < deadline:
+            try:
+                silent = socket.create_connection(("127.0.0.1", port), timeout=1.0)
+                break
+            except OSError:
+                time.sleep(0.02)
+        else:
+            return
+        strays.append(silent)                                                   # says nothing at all
+        wrong = socket.create_connection(("127.0.0.1", port), timeout=1.0)
+        D._send(wrong, D.HELLO_MAGIC + b"\x00" * 16 + struct.pack("<I", 1))     # right shape, wrong token
+        strays.append(wrong)
+        bad = socket.create_connection(("127.0.0.1", port), timeout=1.0)
+        D._send(bad, D.HELLO_MAGIC + D._job_token(world, port) + struct.pack("<I", 7))   # right token, rank out of range
+        strays.append(bad)
+    th = threading.Thread(target=pester)
+    th.start()
+    ctx = mp.get_context("spawn")
+    root = ctx.Process(target=_worker_plane_with_strays, args=(0, world, port, str(tmp_path)))
+    root.start()
+    th.join(40)
+    peer = ctx.Process(target=_worker_plane_with_strays, args=(1, world, port, str(tmp_path)))
+    peer.start()
+    root.join(120); peer.join(120)
+    for s_ in strays:
+        s_.close()
+    assert root.exitcode == 0 and peer.exitcode == 0
+    for r in range(world):
+        np.testing.assert_array_equal(np.load(tmp_path / f"s{r}.npz")["a"], [3.0])
+    # the frame cap
+    a, b = socket.socketpair()
+    a.sendall(struct.pack("<Q", D.MAX_FRAME + 1))
+    with pytest.raises(ConnectionError):
+        D._recv(b)
+    a.close(); b.close()

@@ -437,3 +437,42 @@ def test_mixed_kernel_gradient_is_bitwise_repeatable(hip):
     for _ in range(40):
         e, g = hip.sgpr_elbo_grad(d, 0.2)
         assert e == e0 and np.array_equal(g, g0)
+
+
+def test_whitened_gradient_on_an_ill_conditioned_kuu_uses_the_posteriors_alpha(hip):
+    """Inducing points that nearly coincide in pairs (cond(Kuu + jitter I) ~ 1e8-1e9): on the whitened route the backward pass
+    takes a = L^-T LB^-T c from the two transposed triangular solves -- the same vector oak_sgpr_alpha returns -- and the
+    gradient matches central differences of the whitened bound (round-3 advisor finding: the explicit (LB^-1 L^-1)^T loses
+    ~cond(Kuu) ulps on exactly the problems this route exists for)."""
+    import copy
+    rng = np.random.default_rng(12)
+    N, D, M = 2500, 3, 64
+    X = rng.standard_normal((N, D))
+    Zh = rng.standard_normal((M // 2, D))
+    Z = np.concatenate([Zh, Zh + 2e-4 * rng.standard_normal(Zh.shape)])
+    y = (np.sin(X[:, 0]) + 0.3 * X[:, 1] * X[:, 2] + 0.1 * rng.standard_normal(N)).reshape(-1, 1)
+    spec = o.make_spec(D, 2, lengthscales=[1.2, 0.9, 1.5], order_variances=[0.5, 1.0, 0.7])
+    Kuu = o.oak_K(spec, Z) + 1e-6 * np.eye(M)
+    assert np.linalg.cond(Kuu) > 1e7
+    d = _capi.KernelDesc(spec)
+    ctx = _capi.HipContext(0)
+    try:
+        ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("whitened")
+        e, g = ctx.sgpr_elbo_grad(d, 0.05)
+        assert abs(e - o.sgpr_elbo(spec, X, y, Z, 0.05)) <= 1e-9 * abs(e)
+        alpha = ctx.sgpr_alpha(M)
+        ref_alpha = o.sgpr_alpha(spec, X, y, Z, 0.05)[:, 0]
+        np.testing.assert_allclose(alpha, ref_alpha, rtol=0, atol=1e-6 * np.abs(ref_alpha).max())
+
+        def bound(mod):
+            s = copy.deepcopy(spec); mod(s)
+            return ctx.sgpr_elbo(_capi.KernelDesc(s), 0.05)
+        for i in range(D):
+            h = 1e-4
+            fd = (bound(lambda s: s["dims"][i].__setitem__("lengthscale", spec["dims"][i]["lengthscale"] + h))
+                  - bound(lambda s: s["dims"][i].__setitem__("lengthscale", spec["dims"][i]["lengthscale"] - h))) / (2 * h)
+            assert abs(g[i] - fd) <= 2e-5 * max(1.0, abs(fd)), (i, g[i], fd)
+        fdn = (ctx.sgpr_elbo(d, 0.05 + 1e-5) - ctx.sgpr_elbo(d, 0.05 - 1e-5)) / 2e-5
+        assert abs(g[-1] - fdn) <= 2e-5 * abs(fdn), (g[-1], fdn)
+    finally:
+        ctx.close()
