@@ -399,7 +399,14 @@ static bool sobol_make_plan_budgeted(const int32_t* subsets, const int32_t* off,
 
 // modelled cost [s] of the two evaluations (fitted to MI355X runs: the terms kernel streams the stacked L_d at ~7.5 TB/s out of
 // L2 / Infinity Cache, the SYRK sustains ~55 TFLOP/s on panels this narrow and the builder ~3 TB/s of panel writes)
-static double sobol_cost_terms(int64_t total_len, int64_t n) { return 8.0 * (double)total_len * (double)n * (double)n / 7.5e12 + 20e-6; }
+// (a lone workgroup of the terms kernel streams its matrices at only ~4.5 GB/s -- an index division per element -- so a few
+// hundred terms, which leave most CUs idle, are bound by one workgroup's time, not by the aggregate rate: 136 terms at n = 1024
+// take 3.5 ms there against 0.8 ms through the Gram of products)
+static double sobol_cost_terms(int64_t total_len, int64_t n, int maxlen) {
+    const double nn = (double)n * (double)n;
+    const double aggregate = 8.0 * (double)total_len * nn / 7.5e12, one_wg = 8.0 * (double)maxlen * nn / 4.5e9;
+    return (aggregate > one_wg ? aggregate : one_wg) + 20e-6;
+}
 static double sobol_cost_gram(int nc, int64_t n) {
     const double Mp = (double)(((nc + 127) / 128) * 128), R = 0.5 * (double)n * (double)(n + 1);
     return R * Mp * (Mp + 128.0) / 55e12 + 8.0 * R * Mp / 3e12 + 150e-6;
@@ -514,7 +521,7 @@ static int sobol_run(oak_ctx* ctx, const oak_kernel_desc* desc, const double* Xc
     bool use_gram = false;
     if (ctx->sobol_path != 1 && sobol_make_plan_budgeted(subsets, subset_off, n_subsets, slot, nslot, &plan)) {
         const int nc = (int)plan.cols.size();
-        use_gram = ctx->sobol_path == 2 || (nc <= 16384 && sobol_cost_gram(nc, n) < sobol_cost_terms(total, n));
+        use_gram = ctx->sobol_path == 2 || (nc <= 16384 && sobol_cost_gram(nc, n) < sobol_cost_terms(total, n, plan.maxlen));
     }
     OAK_REQUIRE(ctx->sobol_path != 2 || use_gram, "oak_sobol: the Gram-of-products evaluation needs subsets of 1..6 distinct dims");
 

@@ -131,8 +131,8 @@ def test_c5_full_size_in_fp32_as_baseline_config_5_states_it():
     """BASELINE.json configs[4] literally: N = 262 144, D = 32 mixed (20 RBF + 8 binary + 4 categorical), M = 2048, depth 4,
     fp32.  The fp32 statistics mode must be honoured at that size (well-conditioned Kuu) and stay within its stated
     tolerance of the fp64 path -- ELBO and every kernel-dependent term <= 1e-5 relative, Phi <= 1e-5 of max|Phi| -- while a
-    16 384-row sample ties the fp64 path itself to the oracle at the full M (1e-10), so the fp32 numbers are anchored to
-    the restated reference through it.  Sobol indices computed from the fp32-statistics posterior still sum to one."""
+    16 384-row sample ties the fp64 path itself to the oracle at the full M (1e-10) and the fp32 mode to the oracle directly
+    (bound and every term <= 1e-5).  Sobol indices computed from the fp32-statistics posterior still sum to one."""
     import bench
     N5, D5, M5, R5 = 262144, 32, 2048, 4
     X, y, Z = bench.synthetic(N5, D5, M5, mixed=True)
@@ -157,6 +157,15 @@ def test_c5_full_size_in_fp32_as_baseline_config_5_states_it():
     e = ctx.sgpr_elbo(d, 0.01)
     er, parts = c_oracle.sgpr_elbo_chunked(spec, X[:ns], y[:ns], Z, 0.01, 1e-6, chunk=4096, return_parts=True)
     assert abs(e - er) <= 1e-10 * abs(er)
+    # ... and the fp32 statistics mode DIRECTLY against the oracle on the same sample (not only through the fp64 path): the bound
+    # and every kernel-dependent term within the mode's stated 1e-5
+    ctx.sgpr_set_precision("fp32")
+    e32s = ctx.sgpr_elbo(d, 0.01)
+    assert ctx.sgpr_stats_precision() == "fp32"
+    assert abs(e32s - er) <= 1e-5 * abs(er), (e32s, er)
+    t32s = ctx.sgpr_last_terms(); t32s.pop("cond_estimate", None)
+    cases.assert_terms_match(t32s, parts["terms"], rtol=1e-5, what="C5 sample, fp32 statistics vs oracle:")
+    ctx.sgpr_set_precision("fp64")
     # Sobol path from the fp32-statistics posterior: all 41 448 terms, normalised
     subsets = [list(s) for s in o.list_representation(D5, R5)[1:]]
     sob = ctx.sobol(d, Z, alpha32, subsets)
