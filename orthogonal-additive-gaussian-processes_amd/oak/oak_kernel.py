@@ -8,7 +8,7 @@ matrices nor the Newton-Girard intermediates.
 from __future__ import annotations
 
 import itertools
-from typing import List, Optional, Tuple, Type
+from typing import List, Optional, Tuple, Type, Sequence
 
 import numpy as np
 
@@ -206,18 +206,38 @@ class KernelComponenent(gpflow.Kernel):
         return TensorLike(ctx.gram_component_diag(self.oak_kernel._desc(), self._subset(), bool(self.share_var_across_orders), X))
 
 
+class _ComponentList(Sequence):
+    """``kernel_list`` of get_list_representation: the KernelComponenent of term i, built when it is asked for.  A depth-4 kernel
+    over 32 inputs has 41 449 terms; the Sobol pass wants their index subsets, not 41 449 Python objects (0.4 s to build, against
+    15 ms for all the indices on the device)."""
+
+    def __init__(self, kernel, subsets, share_var_across_orders):
+        self._kernel, self._subsets, self._share0 = kernel, subsets, share_var_across_orders
+
+    def __len__(self):
+        return len(self._subsets)
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError(i)
+        # as in the reference (:362) only the constant component takes ``share_var_across_orders`` from the caller
+        return KernelComponenent(self._kernel, self._subsets[i], share_var_across_orders=self._share0) if i == 0 \
+            else KernelComponenent(self._kernel, self._subsets[i])
+
+
 def get_list_representation(kernel: OAKKernel, num_dims: int, share_var_across_orders: Optional[bool] = True
-                            ) -> Tuple[List[List[int]], List[KernelComponenent]]:
+                            ) -> Tuple[List[List[int]], Sequence]:
     """All interaction subsets up to the kernel's depth, constant term first (oak/oak_kernel.py:338-364).
     As in the reference (:362) non-constant components ignore ``share_var_across_orders``."""
     assert isinstance(kernel, OAKKernel)
     selected_dims: List[List[int]] = [[]]
-    kernel_list = [KernelComponenent(kernel, [], share_var_across_orders=share_var_across_orders)]
     for order in range(1, kernel.max_interaction_depth + 1):
-        for combo in itertools.combinations(np.arange(num_dims), order):
-            selected_dims.append(list(combo))
-            kernel_list.append(KernelComponenent(kernel, list(combo)))
-    return selected_dims, kernel_list
+        selected_dims.extend(list(combo) for combo in itertools.combinations(range(num_dims), order))
+    return selected_dims, _ComponentList(kernel, selected_dims, share_var_across_orders)
 
 
 # --------------------------------------------------------------------------------------------------------
