@@ -127,6 +127,10 @@ int oak_gram(oak_ctx* ctx, const oak_kernel_desc* desc,
    "identical to the reference" can be shown entry by entry and the two deliberate deviations quantified
    (tests/test_gpu_gram.py).  A debug aid: one thread per entry, not a fast path. */
 int oak_set_gram_form(oak_ctx* ctx, int32_t form);
+/* out[n1 x n2] (float) = the fp32 Kuf panel that the opt-in fp32 statistics mode (oak_sgpr_set_precision) builds and feeds to
+   its fp32-MFMA SYRK: exposed so that the mode's Gram can be checked against the reference arithmetic (<= 1e-5 of max|K|). */
+int oak_gram_f32(oak_ctx* ctx, const oak_kernel_desc* desc, const double* X1, int64_t n1, const double* X2, int64_t n2,
+                 int32_t ldx, float* out);
 int oak_gram_diag(oak_ctx* ctx, const oak_kernel_desc* desc,
                   const double* X, int64_t n, int32_t ldx, double* out);
 /* KernelComponenent.K (oak_kernel.py:300-320): sigma2_{|S|} * prod_{d in S} k_d; subset = indices

@@ -711,6 +711,35 @@ int oak_gram(oak_ctx* ctx, const oak_kernel_desc* desc, const double* X1, int64_
     return gram_to_host(ctx, pk, X1, n1, X2, n2, ldx, out);
 }
 
+// The fp32 Kuf panel of the fp32 statistics mode (gram32.hip), as the SYRK of that mode consumes it: for parity checks of the mode.
+int oak_gram_f32(oak_ctx* ctx, const oak_kernel_desc* desc, const double* X1, int64_t n1, const double* X2, int64_t n2, int32_t ldx, float* out) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(X1 && X2 && out && n1 >= 1 && n2 >= 1 && ldx >= 1, "oak_gram_f32: bad arguments");
+    PreparedKernel pk;
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    OAK_REQUIRE(pk.dd.R <= 16, "oak_gram_f32: the fp32 Gram kernel is instantiated to an effective depth of 16");
+    double *dX1 = nullptr, *dX2 = nullptr;
+    OAK_CHECK(HostUpload::run(ctx, "gX1", X1, (size_t)n1 * ldx, &dX1));
+    OAK_CHECK(HostUpload::run(ctx, "gX2", X2, (size_t)n2 * ldx, &dX2));
+    Feat FA, FB;
+    OAK_CHECK(featurize(ctx, pk, dX1, n1, ldx, "gF1", &FA));
+    OAK_CHECK(featurize(ctx, pk, dX2, n2, ldx, "gF2", &FB));
+    const int64_t ld = pad128(n2);                      // the panel layout of the statistics pass: stride = n2 rounded up to 128, zero padded
+    int64_t chunk = (int64_t)((size_t)1 << 30) / ld;
+    if (chunk < 16) chunk = 16;
+    if (chunk > n1) chunk = n1;
+    float* dK = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "gK32", (size_t)chunk * ld, &dK));
+    for (int64_t a0 = 0; a0 < n1; a0 += chunk) {
+        const int64_t na = (a0 + chunk <= n1) ? chunk : n1 - a0;
+        OAK_CHECK(gram_f32(ctx, pk, FA, a0, na, FB, dK, ld, nullptr, nullptr, ld));
+        OAK_HIP_CHECK(hipMemcpy2DAsync(out + a0 * n2, sizeof(float) * (size_t)n2, dK, sizeof(float) * (size_t)ld, sizeof(float) * (size_t)n2, (size_t)na,
+                                       hipMemcpyDeviceToHost, ctx->stream));
+        OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+    return OAK_OK;
+}
+
 int oak_set_gram_form(oak_ctx* ctx, int32_t form) {
     OAK_CHECK(guard(ctx));
     OAK_REQUIRE(form == 0 || form == 1, "gram form must be 0 (native arithmetic) or 1 (the reference's arithmetic)");

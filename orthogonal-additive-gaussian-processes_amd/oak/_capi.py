@@ -70,6 +70,7 @@ SIGNATURES = {
     "oak_gram": (C.c_int, [_CTX, _DESC, _D, C.c_int64, _D, C.c_int64, C.c_int32, _D]),
     "oak_gram_diag": (C.c_int, [_CTX, _DESC, _D, C.c_int64, C.c_int32, _D]),
     "oak_set_gram_form": (C.c_int, [_CTX, C.c_int32]),
+    "oak_gram_f32": (C.c_int, [_CTX, _DESC, _D, C.c_int64, _D, C.c_int64, C.c_int32, C.POINTER(C.c_float)]),
     "oak_gram_component": (C.c_int, [_CTX, _DESC, _I, C.c_int32, C.c_int32, _D, C.c_int64, _D, C.c_int64, C.c_int32, _D]),
     "oak_gram_component_diag": (C.c_int, [_CTX, _DESC, _I, C.c_int32, C.c_int32, _D, C.c_int64, C.c_int32, _D]),
     "oak_sgpr_set_data": (C.c_int, [_CTX, _D, _D, C.c_int64, C.c_int32]),
@@ -672,6 +673,15 @@ class HipContext:
         _check(self._lib.oak_sobol_last_info(self._h, _dp(info)))
         return dict(path={1: "terms", 2: "gram"}.get(int(info[0]), "none"), columns=int(info[1]), pairing_disagreement=float(info[2]),
                     pair_rows=int(info[3]))
+
+    def gram_f32(self, desc: KernelDesc, X1, X2) -> np.ndarray:
+        """The fp32 Kuf panel of the fp32 statistics mode (parity checks of that mode)."""
+        X1, X2 = _f64(X1, 2), _f64(X2, 2)
+        self._check_cols(desc, X1); self._check_cols(desc, X2)
+        out = np.empty((X1.shape[0], X2.shape[0]), dtype=np.float32)
+        _check(self._lib.oak_gram_f32(self._h, desc.ref, _dp(X1), X1.shape[0], _dp(X2), X2.shape[0], X1.shape[1],
+                                      out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
 
     def sobol_L(self, desc: KernelDesc, dim: int, v: float, delta: float, mu: float, Xc) -> np.ndarray:
         Xc = _f64(Xc, 2)

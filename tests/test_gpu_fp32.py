@@ -166,6 +166,10 @@ def test_c5_full_size_in_fp32_as_baseline_config_5_states_it():
     t32s = ctx.sgpr_last_terms(); t32s.pop("cond_estimate", None)
     cases.assert_terms_match(t32s, parts["terms"], rtol=1e-5, what="C5 sample, fp32 statistics vs oracle:")
     ctx.sgpr_set_precision("fp64")
+    # the fp32 Kuf panel itself (all three sub-kernel types, depth 4) against the oracle on sampled rows
+    rows = np.random.default_rng(3).choice(N5, 512, replace=False)
+    K32, Kr = ctx.gram_f32(d, X[rows], Z), c_oracle.gram(spec, X[rows], Z)
+    assert K32.dtype == np.float32 and np.abs(K32 - Kr).max() <= 1e-5 * np.abs(Kr).max()
     # Sobol path from the fp32-statistics posterior: all 41 448 terms, normalised
     subsets = [list(s) for s in o.list_representation(D5, R5)[1:]]
     sob = ctx.sobol(d, Z, alpha32, subsets)
