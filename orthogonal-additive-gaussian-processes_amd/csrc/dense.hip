@@ -132,10 +132,14 @@ __device__ __forceinline__ void syrk_diag_body(const double* __restrict__ P, int
             }
 }
 
-template <int SY_KB>
+// TWO: the panel holds two row sets back to back -- rows [0, rowsA) served by splits [0, nsplitA), rows [rowsA, nrows) by the
+// others -- each split still writing its own partial: two independent Gram matrices from ONE launch (one ramp-up and one ragged
+// end instead of two; the Sobol pass's positive- and negative-weight pair rows).  The <KB, false> instantiation is the kernel as
+// it always was.
+template <int SY_KB, bool TWO = false>
 __global__ void __launch_bounds__(256, 2)
 syrk_kernel(const double* __restrict__ P, int64_t ldp, int64_t nrows, const int* __restrict__ desc, int nwg, int nsplit,
-            int64_t rows_per_split, double* __restrict__ part, int64_t Mp, int accumulate, int xcd_map) {
+            int64_t rows_per_split, double* __restrict__ part, int64_t Mp, int accumulate, int xcd_map, int nsplitA = 0, int64_t rowsA = 0) {
     __shared__ __attribute__((aligned(16))) double S[2][SY_KB * SY_LD];      // [Q0 | Q1] and [Q2 | Q3]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -155,9 +159,14 @@ syrk_kernel(const double* __restrict__ P, int64_t ldp, int64_t nrows, const int*
         split = blockIdx.x - unit * nsplit;
     }
     const int* dsc = desc + unit * SY_DESC;
+    int64_t row_lo = (int64_t)split * rows_per_split, row_end = nrows;
+    if constexpr (TWO) {
+        if (split < nsplitA) row_end = rowsA;
+        else row_lo = rowsA + (int64_t)(split - nsplitA) * rows_per_split;
+    }
     if ((dsc[4] >> 5) & 1) {            // workgroup-uniform: a pair of diagonal tiles
-        const int64_t q0 = (int64_t)split * rows_per_split;
-        const int64_t q1 = (q0 + rows_per_split < nrows) ? q0 + rows_per_split : nrows;
+        const int64_t q0 = row_lo;
+        const int64_t q1 = (q0 + rows_per_split < row_end) ? q0 + rows_per_split : row_end;
         syrk_diag_body<SY_KB, SY_KB>(P, ldp, dsc, q0, q1, part + (int64_t)split * Mp * Mp, Mp, accumulate, S);
         return;
     }
@@ -165,9 +174,9 @@ syrk_kernel(const double* __restrict__ P, int64_t ldp, int64_t nrows, const int*
     const int ia = wcode & 3, ib = (wcode >> 2) & 3, wstore = (wcode >> 4) & 1;
     const double* Sa = S[ia >> 1] + 64 * (ia & 1);
     const double* Sb = S[ib >> 1] + 64 * (ib & 1);
-    const int64_t r0 = (int64_t)split * rows_per_split;
+    const int64_t r0 = row_lo;
     int64_t r1 = r0 + rows_per_split;
-    if (r1 > nrows) r1 = nrows;
+    if (r1 > row_end) r1 = row_end;
 
     double4_t acc[4][4];
 #pragma unroll
@@ -412,6 +421,25 @@ int syrk_panel(oak_ctx* ctx, const double* d_panel, int64_t ldp, int64_t nrows, 
     if (kb == 8) syrk_kernel<8><<<grid, 256, 0, ctx->stream>>>(d_panel, ldp, nrows, d_desc, npairs, nsplit, rps, d_part, Mp, accumulate ? 1 : 0, xm);
     else if (kb == 32) syrk_kernel<32><<<grid, 256, 0, ctx->stream>>>(d_panel, ldp, nrows, d_desc, npairs, nsplit, rps, d_part, Mp, accumulate ? 1 : 0, xm);
     else syrk_kernel<16><<<grid, 256, 0, ctx->stream>>>(d_panel, ldp, nrows, d_desc, npairs, nsplit, rps, d_part, Mp, accumulate ? 1 : 0, xm);
+    OAK_HIP_CHECK(hipGetLastError());
+    return OAK_OK;
+}
+
+// Two Gram matrices from one launch: rows [0, rowsA) of the panel into the partials of splits [0, nsA), rows [rowsA, rowsA + rowsB)
+// into those of splits [nsA, nsA + nsB) (nsA, nsB multiples of 8; reduce each range with syrk_reduce on its part of d_part).
+int syrk_panel_two(oak_ctx* ctx, const double* d_panel, int64_t ldp, int64_t rowsA, int64_t rowsB, int64_t M, double* d_part, int nsA, int nsB,
+                   int64_t rows_per_split) {
+    const int ntile = (int)((M + SY_T - 1) / SY_T);
+    const int64_t Mp = (int64_t)ntile * SY_T;
+    OAK_REQUIRE(ldp == Mp && nsA % 8 == 0 && nsB % 8 == 0 && nsA + nsB >= 8 && rows_per_split % SY_KB_DEFAULT == 0 &&
+                    (int64_t)nsA * rows_per_split >= rowsA && (int64_t)nsB * rows_per_split >= rowsB,
+                "syrk_panel_two: bad split plan");
+    int* d_desc = nullptr;
+    int npairs = 0;
+    OAK_CHECK(syrk_descriptor_table(ctx, ntile, &d_desc, &npairs, true));
+    const int nsplit = nsA + nsB;
+    syrk_kernel<32, true><<<(unsigned)(npairs * nsplit), 256, 0, ctx->stream>>>(d_panel, ldp, rowsA + rowsB, d_desc, npairs, nsplit, rows_per_split,
+                                                                               d_part, Mp, 0, 1, nsA, rowsA);
     OAK_HIP_CHECK(hipGetLastError());
     return OAK_OK;
 }

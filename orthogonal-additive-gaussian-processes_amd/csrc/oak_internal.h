@@ -208,6 +208,8 @@ int gram_generic(oak_ctx* ctx, const PreparedKernel& pk, int form, const double*
 int syrk_panel(oak_ctx* ctx, const double* d_panel, int64_t ldp, int64_t nrows, int64_t M, double* d_part,
                int nsplit, bool accumulate);
 int syrk_plan_splits(oak_ctx* ctx, int64_t M, int64_t nrows);
+int syrk_panel_two(oak_ctx* ctx, const double* d_panel, int64_t ldp, int64_t rowsA, int64_t rowsB, int64_t M, double* d_part, int nsA, int nsB,
+                   int64_t rows_per_split);
 int syrk_descriptor_table(oak_ctx* ctx, int ntile, int** d_desc_out, int* npairs_out, bool diag_pairs);
 // fp32 statistics variant (gram32.hip): fp32 Kfu panel and fp32-MFMA partials, everything downstream fp64
 int gram_f32(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int64_t na, const Feat& B, float* d_out, int64_t ldo,

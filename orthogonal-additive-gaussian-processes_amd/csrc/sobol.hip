@@ -143,6 +143,128 @@ static int sobol_L_dim(oak_ctx* ctx, const oak_kernel_desc* desc, const Prepared
     return OAK_OK;
 }
 
+// ---- all L_d of a Sobol pass in one launch -----------------------------------------------------------------------------------
+// (the per-dimension kernels above serve oak_sobol_L, one matrix as the reference's helpers return it, in the reference's own
+// arithmetic).  For the Gaussian closed form only f1 depends on the pair:
+//     f2(x, y) = g2(x) h(y),  f3(x, y) = g2(y) h(x),  f4(x, y) = c4 h(x) h(y),   h(t) = exp(-(t - mu)^2 / (2 (l^2 + delta^2))),
+// g2 = the x-dependent factors of eq. (45); with g2 and h tabulated per point an entry costs ONE exponential (f1's two merged)
+// instead of nine -- 80 -> ~15 us per 2048 x 2048 matrix, and the 32 launches of a 32-input model become one.
+struct SobolSlotDev {
+    int type;                    // OAK_DIM_RBF (Gaussian closed form) / OAK_DIM_BINARY / OAK_DIM_CATEGORICAL; -1: filled elsewhere (empirical measure)
+    int col, trunc, C, tab_off;
+    double l, p0;
+};
+
+__global__ void __launch_bounds__(256) sobol_slots_prep_kernel(const double* __restrict__ X, int64_t n, int ldx, const int* __restrict__ perm,
+                                                               const SobolSlotDev* __restrict__ slots, double delta, double mu,
+                                                               double* __restrict__ xs, double* __restrict__ g2, double* __restrict__ hh) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int s = blockIdx.y;
+    if (i >= n) return;
+    const SobolSlotDev sl = slots[s];
+    if (sl.type < 0) return;
+    const int64_t src = perm ? perm[i] : i;
+    double x = X[src * ldx + sl.col];
+    if (sl.trunc) x = trunc(x);
+    xs[(int64_t)s * n + i] = x;
+    if (sl.type == OAK_DIM_RBF) {
+        const double l = sl.l, l2 = l * l, d2 = delta * delta;
+        const double Mt = 1.0 / l2 + 1.0 / (l2 + d2);
+        const double m = (mu / (l2 + d2) + x / l2) / Mt;
+        const double C = x * x / l2 + mu * mu / (l2 + d2) - m * m * Mt;
+        g2[(int64_t)s * n + i] = l * sqrt((l2 + 2.0 * d2) / (d2 * Mt + 1.0)) * exp(-0.5 * C) / (l2 + d2) *
+                                 exp(-((m - mu) * (m - mu)) / (2.0 * (1.0 / Mt + d2)));
+        hh[(int64_t)s * n + i] = exp(-((x - mu) * (x - mu)) / (2.0 * (l2 + d2)));
+    }
+}
+
+// grid (ceil(n / 256), n, nslot); upper_only: entries left of the diagonal are not written (the Gram of products reads pairs p <= q only)
+__global__ void __launch_bounds__(256) sobol_L_all_kernel(const SobolSlotDev* __restrict__ slots, const double* __restrict__ xs,
+                                                          const double* __restrict__ g2, const double* __restrict__ hh, int64_t n, double delta,
+                                                          double mu, const double* __restrict__ meas, int upper_only, double* __restrict__ Ls) {
+    const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = blockIdx.y;
+    const int s = blockIdx.z;
+    if (upper_only && (int64_t)blockIdx.x * 256 + 255 < i) return;
+    if (k >= n) return;
+    const SobolSlotDev sl = slots[s];
+    if (sl.type < 0) return;
+    const double* x = xs + (int64_t)s * n;
+    const double xi = x[i], yk = x[k];
+    double v;
+    if (sl.type == OAK_DIM_RBF) {
+        const double l = sl.l, l2 = l * l, d2 = delta * delta;
+        const double* g = g2 + (int64_t)s * n;
+        const double* h = hh + (int64_t)s * n;
+        const double dm = mu - 0.5 * (xi + yk);
+        const double f1 = l / sqrt(l2 + 2.0 * d2) * exp(-((xi - yk) * (xi - yk)) / (4.0 * l2) - (dm * dm) / (2.0 * d2 + l2));
+        const double c4 = l2 * (l2 + 2.0 * d2) * sqrt((l2 + d2) / (l2 + 3.0 * d2)) / ((l2 + d2) * (l2 + d2));
+        v = f1 - g[i] * h[k] - g[k] * h[i] + c4 * (h[i] * h[k]);
+    } else if (sl.type == OAK_DIM_BINARY) {
+        const double p0 = sl.p0, p1 = 1.0 - p0;
+        v = p0 * (p1 * p1 * (1.0 - xi) - p0 * p1 * xi) * (p1 * p1 * (1.0 - yk) - p0 * p1 * yk) +
+            p1 * (-p0 * p1 * (1.0 - xi) + p0 * p0 * xi) * (-p0 * p1 * (1.0 - yk) + p0 * p0 * yk);
+    } else {
+        const int C = sl.C;
+        const double* B = meas + sl.tab_off;
+        const double* p = B + C * C;
+        int ci = (int)xi, ck = (int)yk;
+        ci = ci < 0 ? 0 : (ci > C - 1 ? C - 1 : ci);
+        ck = ck < 0 ? 0 : (ck > C - 1 ? C - 1 : ck);
+        double acc = 0.0;
+        for (int c = 0; c < C; ++c) acc += B[c * C + ci] * (B[c * C + ck] * p[c]);
+        v = acc;
+    }
+    Ls[(int64_t)s * n * n + i * n + k] = v;
+}
+
+// every used dim's L into dLs[slot]; vexp[d] as sobol_L_dim reports it
+static int sobol_L_slots(oak_ctx* ctx, const oak_kernel_desc* desc, const PreparedKernel& pk, const std::vector<int>& slot, int nslot,
+                         const double* dXc, int64_t n, int32_t ldx, double delta, double mu, double* dLs, std::vector<int>& vexp,
+                         const int* d_perm, bool upper_only) {
+    const int D = desc->num_dims;
+    std::vector<SobolSlotDev> h((size_t)nslot);
+    bool any_batched = false;
+    for (int d = 0; d < D; ++d) {
+        if (slot[d] < 0) continue;
+        SobolSlotDev& sl = h[(size_t)slot[d]];
+        sl = SobolSlotDev{-1, desc->active_col[d], 0, 0, 0, 1.0, 0.5};
+        const int type = desc->dim_type[d];
+        if (type == OAK_DIM_RBF) {
+            vexp[d] = 2;
+            const int meas = desc->measure[d];
+            if (meas == OAK_MEAS_GAUSSIAN || meas == OAK_MEAS_NONE || meas == OAK_MEAS_UNIFORM) { sl.type = OAK_DIM_RBF; sl.l = desc->lengthscale[d]; }
+            else if (meas != OAK_MEAS_EMPIRICAL) { set_error("Sobol indices are not implemented for the MOG measure (oak/utils.py:413-414)"); return OAK_E_ARG; }
+        } else if (type == OAK_DIM_BINARY) {
+            vexp[d] = 1; sl.type = OAK_DIM_BINARY; sl.trunc = 1; sl.p0 = desc->meas_p0[d];
+        } else {
+            vexp[d] = 2; sl.type = OAK_DIM_CATEGORICAL; sl.trunc = 1; sl.C = desc->meas_k[d]; sl.tab_off = desc->meas_off[d];
+        }
+        any_batched = any_batched || sl.type >= 0;
+    }
+    if (any_batched) {
+        SobolSlotDev* d_slots = nullptr;
+        double *d_xs, *d_g2, *d_hh;
+        OAK_CHECK(get_buf_t(ctx, "sobol_slots", (size_t)nslot, &d_slots));
+        OAK_CHECK(get_buf_t(ctx, "sobol_xs", (size_t)nslot * n, &d_xs));
+        OAK_CHECK(get_buf_t(ctx, "sobol_g2", (size_t)nslot * n, &d_g2));
+        OAK_CHECK(get_buf_t(ctx, "sobol_hh", (size_t)nslot * n, &d_hh));
+        OAK_HIP_CHECK(hipMemcpyAsync(d_slots, h.data(), sizeof(SobolSlotDev) * (size_t)nslot, hipMemcpyHostToDevice, ctx->stream));
+        OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));                  // h goes out of scope
+        sobol_slots_prep_kernel<<<dim3((unsigned)((n + 255) / 256), (unsigned)nslot), 256, 0, ctx->stream>>>(dXc, n, ldx, d_perm, d_slots, delta, mu,
+                                                                                                           d_xs, d_g2, d_hh);
+        OAK_HIP_CHECK(hipGetLastError());
+        OAK_REQUIRE(n <= 65535 && nslot <= 65535, "oak_sobol: at most 65535 points");
+        sobol_L_all_kernel<<<dim3((unsigned)((n + 255) / 256), (unsigned)n, (unsigned)nslot), 256, 0, ctx->stream>>>(
+            d_slots, d_xs, d_g2, d_hh, n, delta, mu, pk.d_meas, upper_only ? 1 : 0, dLs);
+        OAK_HIP_CHECK(hipGetLastError());
+    }
+    for (int d = 0; d < D; ++d)            // empirical-measure dims: Kxu^T diag(w) Kxu through the Gram kernel, one at a time
+        if (slot[d] >= 0 && h[(size_t)slot[d]].type < 0)
+            OAK_CHECK(sobol_L_dim(ctx, desc, pk, d, dXc, n, ldx, delta, mu, dLs + (int64_t)slot[d] * n * n, &vexp[d], d_perm));
+    return OAK_OK;
+}
+
 // one workgroup per subset: out[s] = mult[s] * sum_{i,k} alpha_i alpha_k prod_{d in S} L_d[i,k]
 __global__ void __launch_bounds__(256) sobol_terms_kernel(const double* __restrict__ Ls, int64_t n, const double* __restrict__ alpha,
                                                           const int* __restrict__ subsets, const int* __restrict__ off,
@@ -278,8 +400,10 @@ __global__ void __launch_bounds__(256) sobol_quadform_rows_kernel(const double* 
     const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
     const double* row = Ls + (int64_t)slots[blockIdx.y] * n * n + i * n;
+    // only the entries on or right of the diagonal are read (the Gram of products generates no others): L is symmetric, so
+    // alpha^T L alpha = sum_i alpha_i (L_ii alpha_i + 2 sum_{k > i} L_ik alpha_k)
     double acc = 0.0;
-    for (int64_t k = lane; k < n; k += 64) acc = __builtin_fma(row[k], alpha[k], acc);
+    for (int64_t k = i + lane; k < n; k += 64) acc = __builtin_fma(k == i ? row[k] : 2.0 * row[k], alpha[k], acc);
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if (lane == 0) rowsum[(int64_t)blockIdx.y * n + i] = alpha[i] * acc;
 }
@@ -558,8 +682,11 @@ static int sobol_run(oak_ctx* ctx, const oak_kernel_desc* desc, const double* Xc
         OAK_HIP_CHECK(hipMemcpyAsync(dalpha, alpha, sizeof(double) * (size_t)n, hipMemcpyHostToDevice, ctx->stream));
     }
     std::vector<int> vexp(D, 2);
-    for (int d = 0; d < D; ++d)
-        if (slot[d] >= 0) OAK_CHECK(sobol_L_dim(ctx, desc, pk, d, dX, n, ldx, delta, mu, dLs + (int64_t)slot[d] * n * n, &vexp[d], dperm));
+    {
+        PhaseTimer tl(ctx, "sobol_L");
+        OAK_CHECK(sobol_L_slots(ctx, desc, pk, slot, nslot, dX, n, ldx, delta, mu, dLs, vexp, dperm, use_gram));
+        tl.stop();
+    }
     // per-term scalar: the reference gives the first factor v = sigma2_{|S|} and the others v = 1 when variances are shared
     // (utils.py:376-380), else v = base variance of each factor (:382); v enters squared except for binary factors (:266)
     std::vector<double> mult(n_subsets, 1.0);
@@ -612,12 +739,52 @@ static int sobol_run(oak_ctx* ctx, const oak_kernel_desc* desc, const double* Xc
             const int64_t per = (rows_set[m] + nranks - 1) / nranks;
             if (per > rows_mine_max) rows_mine_max = per;
         }
+        // Both sign sets in ONE launch when their panels fit one buffer (<= 16 GiB; C5: 8.6 GB): the matrix is only a few tiles
+        // wide, so a launch per set pays its ramp-up and ragged end twice (M = 512: 53.4 TFLOP/s for 1M rows, 55.7 for 2M).
+        {
+            int64_t lo2[2], hi2[2];
+            for (int m = 0; m < 2; ++m) {
+                const int64_t per = (rows_set[m] + nranks - 1) / nranks;
+                lo2[m] = std::min<int64_t>(rows_set[m], per * rank); hi2[m] = std::min<int64_t>(rows_set[m], lo2[m] + per);
+            }
+            const int64_t rA = hi2[0] - lo2[0], rB = hi2[1] - lo2[1];
+            const bool forced_chunks = getenv("OAK_SOBOL_CHUNK_ROWS") != nullptr;
+            if (!forced_chunks && rA + rB > 0 && (double)(rA + rB) * (double)Mp * 8.0 <= 16.0 * 1024 * 1024 * 1024) {
+                const int nsplit_t = std::max(16, 2 * syrk_plan_splits(ctx, nc, (rA + rB + 1) / 2));
+                int64_t rps = ((rA + rB) + nsplit_t - 1) / nsplit_t;
+                rps = ((rps + 31) / 32) * 32;
+                const int nsA = rA > 0 ? (int)(((rA + rps - 1) / rps + 7) / 8) * 8 : 0;
+                const int nsB = rB > 0 ? (int)(((rB + rps - 1) / rps + 7) / 8) * 8 : 0;
+                double *dpanel2, *dpart2;
+                OAK_CHECK(get_buf_t(ctx, "sobol_panel", (size_t)(rA + rB) * Mp, &dpanel2));
+                OAK_CHECK(get_buf_t(ctx, "sobol_part", (size_t)(nsA + nsB) * Mp * Mp, &dpart2));
+                {
+                    PhaseTimer tp(ctx, "sobol_panel");
+                    for (int m = 0; m < 2; ++m) {
+                        const int64_t nr = hi2[m] - lo2[m];
+                        if (nr <= 0) continue;
+                        sobol_panel_kernel<<<(unsigned)((nr + SB_ROWS - 1) / SB_ROWS), 256, 0, ctx->stream>>>(
+                            dLs, n, nslot, dalpha, m, npos, nneg, lo2[m], nr, dcols, nc, (int)Mp, dpanel2 + (m == 0 ? 0 : rA) * Mp);
+                        OAK_HIP_CHECK(hipGetLastError());
+                    }
+                    tp.stop();
+                }
+                {
+                    PhaseTimer ts(ctx, "sobol_syrk");
+                    OAK_CHECK(syrk_panel_two(ctx, dpanel2, Mp, rA, rB, nc, dpart2, nsA, nsB, rps));
+                    ts.stop();
+                }
+                if (nsA > 0) OAK_CHECK(syrk_reduce(ctx, dpart2, nsA, nc, dG, false));
+                if (nsB > 0) OAK_CHECK(syrk_reduce(ctx, dpart2 + (size_t)nsA * Mp * Mp, nsB, nc, dG + (size_t)nc * nc, false));
+                rows_mine_max = -1;                  // done: skip the chunked loop below
+            }
+        }
         const int64_t chunk_rows = rows_mine_max < chunk_cap ? (rows_mine_max > 0 ? rows_mine_max : 1) : chunk_cap;
         const int nsplit = syrk_plan_splits(ctx, nc, chunk_rows);
         double *dpanel, *dpart;
         OAK_CHECK(get_buf_t(ctx, "sobol_panel", (size_t)chunk_rows * Mp, &dpanel));
         OAK_CHECK(get_buf_t(ctx, "sobol_part", (size_t)nsplit * Mp * Mp, &dpart));
-        for (int m = 0; m < 2; ++m) {
+        for (int m = 0; m < 2 && rows_mine_max >= 0; ++m) {
             // this rank's contiguous share of the set's rows
             const int64_t per = (rows_set[m] + nranks - 1) / nranks;
             const int64_t lo = std::min<int64_t>(rows_set[m], per * rank), hi = std::min<int64_t>(rows_set[m], lo + per);

@@ -30,13 +30,13 @@ for path in paths:
         ctx.sobol(d, Z, alpha, subsets)
     wall = (time.perf_counter() - t0) / reps * 1e3
     info = ctx.sobol_last_info()
-    ph = {k: ctx.timing(k) for k in ("sobol", "sobol_panel", "sobol_syrk")}
+    ph = {k: ctx.timing(k) for k in ("sobol", "sobol_panel", "sobol_syrk", "sobol_L")}
     nc = info["columns"]
     Mp = -(-nc // 128) * 128 if nc else 0
     flop = Mp * (Mp + 1) * info["pair_rows"] if nc else 0
     syrk_ms = ph["sobol_syrk"][0] / reps
     print(f"path={info['path']}: {len(subsets)} terms, M={M}, D={D}, depth={R}: wall {wall:.2f} ms/call, device {ph['sobol'][0]/reps:.2f} ms "
-          f"(panel {ph['sobol_panel'][0]/reps:.2f}, syrk {syrk_ms:.2f}"
+          f"(L {ph['sobol_L'][0]/reps:.2f}, panel {ph['sobol_panel'][0]/reps:.2f}, syrk {syrk_ms:.2f}"
           + (f" = {flop/syrk_ms/1e9:.1f} TFLOP/s padded" if syrk_ms > 0 else "") + f"), columns {nc}, pairing disagreement {info['pairing_disagreement']:.2e}",
           flush=True)
 ctx.sobol_set_path("auto")
