@@ -243,6 +243,7 @@ static int sobol_L_slots(oak_ctx* ctx, const oak_kernel_desc* desc, const Prepar
         any_batched = any_batched || sl.type >= 0;
     }
     if (any_batched) {
+        OAK_REQUIRE(n <= 65535, "oak_sobol: at most 65535 points (one grid row per point)");
         SobolSlotDev* d_slots = nullptr;
         double *d_xs, *d_g2, *d_hh;
         OAK_CHECK(get_buf_t(ctx, "sobol_slots", (size_t)nslot, &d_slots));
@@ -254,7 +255,6 @@ static int sobol_L_slots(oak_ctx* ctx, const oak_kernel_desc* desc, const Prepar
         sobol_slots_prep_kernel<<<dim3((unsigned)((n + 255) / 256), (unsigned)nslot), 256, 0, ctx->stream>>>(dXc, n, ldx, d_perm, d_slots, delta, mu,
                                                                                                            d_xs, d_g2, d_hh);
         OAK_HIP_CHECK(hipGetLastError());
-        OAK_REQUIRE(n <= 65535 && nslot <= 65535, "oak_sobol: at most 65535 points");
         sobol_L_all_kernel<<<dim3((unsigned)((n + 255) / 256), (unsigned)n, (unsigned)nslot), 256, 0, ctx->stream>>>(
             d_slots, d_xs, d_g2, d_hh, n, delta, mu, pk.d_meas, upper_only ? 1 : 0, dLs);
         OAK_HIP_CHECK(hipGetLastError());
