@@ -116,7 +116,7 @@ static int check_route_counts(double nwhite, double nparts, bool expect_whitened
 // (the Gram kernel's fused partial sums serve output 0).  Workgroup w owns XP_ROWS panel rows and every column; a thread keeps
 // XP_G accumulators for each of its columns (coalesced panel reads, the target values are wave-uniform scalar loads), more than
 // XP_G extra outputs are served in groups.  Partials [workgroup][output][column] are summed in a fixed order afterwards.
-constexpr int XP_ROWS = 1024, XP_G = 8;
+constexpr int XP_ROWS = 4096, XP_G = 8;
 __global__ void __launch_bounds__(256) extra_psi_kernel(const double* __restrict__ panel, int64_t ldp, int64_t na, int64_t M,
                                                         const double* __restrict__ Yx, int64_t ldy, int p0, int np, int n_extra,
                                                         double* __restrict__ part, int accumulate) {
@@ -154,12 +154,18 @@ __global__ void __launch_bounds__(256) extra_psi_kernel(const double* __restrict
             *dst = accumulate ? (*dst + acc[q]) : acc[q];
         }
 }
+// out[e] = sum over the row blocks w of part[w][e], in a fixed order: lane group g (of four) sums the blocks w = g, g + 4, ..., the four
+// group sums are added ((s0 + s1) + s2) + s3.  64 elements per workgroup, coalesced 512-byte reads.
 __global__ void __launch_bounds__(256) extra_psi_reduce_kernel(const double* __restrict__ part, int nwg, int64_t len, double* __restrict__ out) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= len) return;
+    __shared__ double sh[4][64];
+    const int el = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int64_t e = (int64_t)blockIdx.x * 64 + el;
     double s = 0.0;
-    for (int w = 0; w < nwg; ++w) s += part[(int64_t)w * len + e];
-    out[e] = s;
+    if (e < len)
+        for (int w = g; w < nwg; w += 4) s += part[(int64_t)w * len + e];
+    sh[g][el] = s;
+    __syncthreads();
+    if (g == 0 && e < len) out[e] = ((sh[0][el] + sh[1][el]) + sh[2][el]) + sh[3][el];
 }
 
 int sgpr_extra_psi(oak_ctx* ctx, const double* d_panel, int64_t ldp, int64_t a0, int64_t na, bool first_chunk) {
@@ -186,7 +192,7 @@ int sgpr_extra_psi_finish(oak_ctx* ctx) {
     double* d_psix = nullptr;
     OAK_CHECK(get_buf_t(ctx, "psix", (size_t)nx * M + nx, &d_psix));
     const int nwg = ctx->psix_nwg;
-    extra_psi_reduce_kernel<<<(unsigned)((nx * M + 255) / 256), 256, 0, ctx->stream>>>((const double*)peek_buf(ctx, "psix_part"), nwg,
+    extra_psi_reduce_kernel<<<(unsigned)((nx * M + 63) / 64), 256, 0, ctx->stream>>>((const double*)peek_buf(ctx, "psix_part"), nwg,
                                                                                        (int64_t)nx * M, d_psix);
     OAK_HIP_CHECK(hipGetLastError());
     OAK_CHECK(copy_d2d(ctx, d_psix + (int64_t)nx * M, peek_buf(ctx, "yyx"), sizeof(double) * (size_t)nx));
@@ -292,7 +298,11 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
             else OAK_CHECK(gram(ctx, pk, FX, a0, na, FZ, dPanel, Mp, dY, st.psi, Mp));
             t.stop();
         }
-        if (ctx->n_extra > 0) {                  // the other outputs' Kuf y from the raw panel (before any whitening in place)
+        // the other outputs' Kuf y from the RAW panel: on a whitening evaluation before the solve overwrites it (the lazy auto route
+        // has not decided yet: before, to be safe); on the phi route behind the SYRK, which otherwise starts 0.4 ms slower on a
+        // panel the psi pass has just streamed through the caches
+        const bool psi_first = ctx->n_extra > 0 && (whiten || ctx->auto_pending || use32);
+        if (psi_first) {
             PhaseTimer t(ctx, "extra_psi");
             OAK_CHECK(sgpr_extra_psi(ctx, dPanel, Mp, a0, na, chunk_idx == 0));
             t.stop();
@@ -343,6 +353,11 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
             PhaseTimer t(ctx, "syrk");
             if (use32) OAK_CHECK(syrk_panel_f32(ctx, dPanel32, Mp, na, M, dPart, nsplit, chunk_idx > 0));
             else OAK_CHECK(syrk_panel(ctx, dSy, Mp, na, M, dPart, nsplit, chunk_idx > 0));
+            t.stop();
+        }
+        if (ctx->n_extra > 0 && !psi_first) {
+            PhaseTimer t(ctx, "extra_psi");
+            OAK_CHECK(sgpr_extra_psi(ctx, dPanel, Mp, a0, na, chunk_idx == 0));
             t.stop();
         }
     }
@@ -561,9 +576,13 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     OAK_CHECK(stats_view(ctx, &st));
     double *dL, *dT1, *dT2, *dLB, *dv1, *dc, *dscal;
     OAK_CHECK(get_buf_t(ctx, "L", (size_t)2 * M * M, &dL));
-    OAK_CHECK(get_buf_t(ctx, "T1", (size_t)(M + 1) * M, &dT1));
-    OAK_CHECK(get_buf_t(ctx, "T2", (size_t)(M + 1) * M, &dT2));
-    OAK_CHECK(get_buf_t(ctx, "LB", (size_t)(M + 1) * M, &dLB));
+    const int nx = ctx->n_extra;            // extra target columns: their right-hand sides ride next to output 0's (rows M + 1 ..)
+    OAK_CHECK(get_buf_t(ctx, "T1", (size_t)(M + 1 + nx) * M, &dT1));
+    OAK_CHECK(get_buf_t(ctx, "T2", (size_t)(M + 1 + nx) * M, &dT2));
+    OAK_CHECK(get_buf_t(ctx, "LB", (size_t)(M + 1 + nx) * M, &dLB));
+    if (nx > 0) OAK_REQUIRE(peek_buf(ctx, "psix") != nullptr, "SGPR tail: the statistics of the extra target columns are missing (they are formed by "
+                                                              "oak_sgpr_elbo / oak_sgpr_elbo_grad / oak_sgpr_local_stats, not by oak_sgpr_set_stats)");
+    const double* d_psix_in = nx > 0 ? (const double*)peek_buf(ctx, "psix") : nullptr;
     OAK_CHECK(get_buf_t(ctx, "v1", (size_t)M, &dv1));
     OAK_CHECK(get_buf_t(ctx, "c", (size_t)M, &dc));
     OAK_CHECK(get_buf_t(ctx, "scal", 16, &dscal));
@@ -592,6 +611,15 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
         // exactly those problems.)
         if (ctx->have_linv && M % 128 == 0 && M <= 8192) OAK_CHECK(trsv_lower_blockinv(ctx, dL, M, M, (const double*)peek_buf(ctx, "Linv"), M, dv));
         else OAK_CHECK(trsm_rows(ctx, dL, M, M, dv, 1, M, 0));
+        if (nx > 0 && aug_b) {              // the other outputs' L^-1 psi_p, rows M + 1 .. of the array chol(B) will carry
+            double* dvx = dT2 + (M + 1) * M;
+            OAK_CHECK(copy_d2d(ctx, dvx, d_psix_in, sizeof(double) * (size_t)nx * M));
+            if (nx <= 2 && ctx->have_linv && M % 128 == 0 && M <= 8192) {
+                for (int p = 0; p < nx; ++p) OAK_CHECK(trsv_lower_blockinv(ctx, dL, M, M, (const double*)peek_buf(ctx, "Linv"), M, dvx + (int64_t)p * M));
+            } else {
+                OAK_CHECK(trsm_rows(ctx, dL, M, M, dvx, nx, M, 0));
+            }
+        }
     } else if (aug) {
         // S = L^-1 Phi (rows 0..M-1 of T1; Phi is symmetric, so gemm_nt against it is the plain product), row M = psi^T;
         // [W ; (L^-1 psi)^T] = T1 L^-T in one (M+1) x M x M GEMM
@@ -600,7 +628,8 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
         // sliced over gridDim.z (the (M/64)^2 tiles alone leave most CUs idle)
         OAK_CHECK(gemm_tail(ctx, 1, dLinv, st.phi, dT1, M, M, M, M, M, M, 1.0, 0.0, OAK_TRI_A_LOWER));
         OAK_CHECK(copy_d2d(ctx, dT1 + M * M, st.psi, sizeof(double) * (size_t)M));
-        OAK_CHECK(gemm_tail(ctx, 1, dT1, dLinv, dT2, M + 1, M, M, M, M, M, 1.0, 0.0, OAK_TRI_B_LOWER));
+        if (nx > 0) OAK_CHECK(copy_d2d(ctx, dT1 + (M + 1) * M, d_psix_in, sizeof(double) * (size_t)nx * M));     // rows M + 1 ..: psi_p^T
+        OAK_CHECK(gemm_tail(ctx, 1, dT1, dLinv, dT2, M + 1 + nx, M, M, M, M, M, 1.0, 0.0, OAK_TRI_B_LOWER));
     } else {
         // rows 0..M-1 of T1 = Phi (symmetric), row M = psi: one blocked solve gives (L^-1 Phi)^T and L^-1 psi together
         OAK_CHECK(copy_d2d(ctx, dT1, st.phi, sizeof(double) * (size_t)(M * M + M)));
@@ -613,8 +642,8 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     // Aerr = L^-1 psi / sigma, c = LB^-1 Aerr / sigma).  Status is read with the scalars below: one host sync per tail.
     if (aug || (ctx->stats_whitened && aug_b)) {
         // row M of the (M+1) x M arrays = (L^-1 psi)^T, carried over unscaled: the panel solves turn it into (LB^-1 L^-1 psi)^T
-        OAK_CHECK(scale_add_eye(ctx, dT2, M, 1.0 / noise_var, dLB, 1));
-        OAK_CHECK(potrf_lower(ctx, dLB, M, M, false, M + 1));
+        OAK_CHECK(scale_add_eye(ctx, dT2, M, 1.0 / noise_var, dLB, 1 + nx));
+        OAK_CHECK(potrf_lower(ctx, dLB, M, M, false, M + 1 + nx));
         OAK_CHECK(scaled_copy(ctx, 1.0 / noise_var, dLB + M * M, dc, M));
     } else {
         OAK_CHECK(scale_add_eye(ctx, dT2, M, 1.0 / noise_var, dLB));
@@ -627,21 +656,23 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     tail_scalars_kernel<<<1, 256, 0, ctx->stream>>>(dLB, dc, dT2, dL, M, st.kappa, dscal);
     OAK_HIP_CHECK(hipGetLastError());
     // The other outputs share everything above (Kuu, Phi, L, LB); what differs is c_p = LB^-1 L^-1 psi_p / sigma^2 and y_p^T y_p.
-    const int nx = ctx->n_extra;
     std::vector<double> hx((size_t)2 * nx);
     double* d_call = nullptr;
     if (nx > 0) {
-        OAK_REQUIRE(peek_buf(ctx, "psix") != nullptr, "SGPR tail: the statistics of the extra target columns are missing (they are formed by "
-                                                      "oak_sgpr_elbo / oak_sgpr_elbo_grad / oak_sgpr_local_stats, not by oak_sgpr_set_stats)");
         double *d_psix = (double*)peek_buf(ctx, "psix"), *d_sq = nullptr;
         OAK_CHECK(get_buf_t(ctx, "c_all", (size_t)(1 + nx) * M, &d_call));
         OAK_CHECK(get_buf_t(ctx, "cx_sq", (size_t)2 * nx, &d_sq));
         OAK_CHECK(copy_d2d(ctx, d_call, dc, sizeof(double) * (size_t)M));
         double* d_cx = d_call + M;
-        OAK_CHECK(copy_d2d(ctx, d_cx, d_psix, sizeof(double) * (size_t)nx * M));
-        OAK_CHECK(trsm_rows(ctx, dL, M, M, d_cx, nx, M, 0));
-        OAK_CHECK(trsm_rows(ctx, dLB, M, M, d_cx, nx, M, 0));
-        OAK_CHECK(scale_vec(ctx, 1.0 / noise_var, d_cx, (int64_t)nx * M));
+        if (aug || (ctx->stats_whitened && aug_b)) {
+            // rows M + 1 .. of LB: (LB^-1 L^-1 psi_p)^T, carried through the panel solves of chol(B) like output 0's row M
+            OAK_CHECK(scaled_copy(ctx, 1.0 / noise_var, dLB + (M + 1) * M, d_cx, (int64_t)nx * M));
+        } else {
+            OAK_CHECK(copy_d2d(ctx, d_cx, d_psix, sizeof(double) * (size_t)nx * M));
+            OAK_CHECK(trsm_rows(ctx, dL, M, M, d_cx, nx, M, 0));
+            OAK_CHECK(trsm_rows(ctx, dLB, M, M, d_cx, nx, M, 0));
+            OAK_CHECK(scale_vec(ctx, 1.0 / noise_var, d_cx, (int64_t)nx * M));
+        }
         OAK_CHECK(row_sumsq(ctx, d_cx, nx, M, M, d_sq));
         OAK_CHECK(copy_d2d(ctx, d_sq + nx, d_psix + (int64_t)nx * M, sizeof(double) * (size_t)nx));
         OAK_HIP_CHECK(hipMemcpyAsync(hx.data(), d_sq, sizeof(double) * (size_t)2 * nx, hipMemcpyDeviceToHost, ctx->stream));
