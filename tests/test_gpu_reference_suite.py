@@ -389,3 +389,92 @@ def test_oak_gmm_applied_without_flows(binary_5D_data):
     assert oak.estimated_gmm_measures[:-1] == [None] * 4 and isinstance(oak.estimated_gmm_measures[-1], MOGMeasure)
     assert np.allclose(np.sort(oak.estimated_gmm_measures[-1].means), np.array([0, 1.0]))
     assert oak.input_flows[-1] is None and sum(f is not None for f in oak.input_flows[:-1]) == 4
+
+
+# ---- tests/test_orthogonality.py:79-149: a GP draw with the constrained kernel has zero mean under the input measure ----------------
+def _draw_mean(K, rng, weights=None):
+    K = np.asarray(K)
+    f = rng.multivariate_normal(np.zeros(len(K)), K + 1e-12 * np.eye(len(K)), size=1)
+    return float((f @ weights).mean()) if weights is not None else float(f.mean())
+
+
+def test_GaussianMeasure_draws_have_zero_mean():
+    """tests/test_orthogonality.py:83-89 (2 decimals)."""
+    rng = np.random.default_rng(0)
+    k = OrthogonalRBFKernel(gpflow.kernels.RBF(lengthscales=10), GaussianMeasure(0, 1))
+    xx = rng.normal(0, 1, (1000, 1))
+    np.testing.assert_almost_equal(_draw_mean(k.K(xx), rng), 0.0, decimal=2)
+
+
+def test_UniformMeasure_draws_have_zero_mean():
+    """tests/test_orthogonality.py:92-98."""
+    rng = np.random.default_rng(1)
+    k = OrthogonalRBFKernel(gpflow.kernels.RBF(lengthscales=10), UniformMeasure(0, 1))
+    xx = rng.uniform(0, 1, (1000, 1))
+    np.testing.assert_almost_equal(_draw_mean(k.K(xx), rng), 0.0, decimal=2)
+
+
+def test_EmpiricalMeasure_draws_have_zero_mean():
+    """tests/test_orthogonality.py:101-126: equal weights, then signed weights that sum to one."""
+    rng = np.random.default_rng(2)
+    location = np.linspace(0, 1, 1000).reshape(-1, 1)
+    k = OrthogonalRBFKernel(gpflow.kernels.RBF(lengthscales=10), EmpiricalMeasure(location))
+    np.testing.assert_almost_equal(_draw_mean(k.K(location), rng), 0.0, decimal=2)
+    # ... exactly: K(x, loc) w = 0 for every x, not only on average
+    np.testing.assert_allclose(np.asarray(k.K(rng.normal(size=(7, 1)), location)).mean(axis=1), 0.0, atol=1e-13)
+    # signed weights: the reference's own random sequence (global generator seeded with 44, draw included)
+    np.random.seed(44)
+    loc10 = np.linspace(0, 1, 10).reshape(-1, 1)
+    w = np.random.randn(10, 1); w /= w.sum()
+    kw = OrthogonalRBFKernel(gpflow.kernels.RBF(lengthscales=10), EmpiricalMeasure(loc10, w))
+    f = np.random.multivariate_normal(np.zeros(10), np.asarray(kw.K(loc10)), size=1)
+    np.testing.assert_almost_equal(np.dot(f, w).mean(), 0.0, decimal=2)
+    np.testing.assert_allclose(np.asarray(kw.K(rng.normal(size=(5, 1)), loc10)) @ w, 0.0, atol=1e-12)
+
+
+def test_MOGMeasure_draws_have_zero_mean():
+    """tests/test_orthogonality.py:129-149, with the reference's own random sequence (ten points: the outcome depends on it)."""
+    np.random.seed(44)
+    K, N = 5, 10
+    means, weights = np.random.randn(K), np.random.rand(K)
+    weights /= weights.sum()
+    variances = np.random.rand(K) + 0.1
+    k = OrthogonalRBFKernel(gpflow.kernels.RBF(lengthscales=10), MOGMeasure(means, variances, weights))
+    xx = np.random.randn(N, K) * np.sqrt(variances) + means
+    index = np.random.multinomial(1, weights, N).argmax(1)
+    xx = xx[np.arange(N), index]
+    f = np.random.multivariate_normal(np.zeros(N), np.asarray(k.K(xx.reshape(-1, 1))), size=1)
+    np.testing.assert_almost_equal(f.mean(), 0.0, decimal=2)
+
+
+@pytest.mark.parametrize("kind", ["gaussian", "uniform", "mog"])
+@pytest.mark.parametrize("lengthscale", [0.4, 1.3, 10.0])
+def test_constrained_kernel_integrates_to_zero_by_quadrature(kind, lengthscale):
+    """What the sampled tests above estimate to two decimals, to 1e-10 through the DEVICE Gram: int k(x, s) p(s) ds = 0 for every x,
+    by Gauss-Legendre / Gauss-Hermite quadrature of the kernel the HIP library returns (the orthogonality constraint of
+    ortho_rbf_kernel.py:157-177 for the three continuous measures)."""
+    def composite(a, b, panels=400, order=16):          # Gauss-Legendre on `panels` equal pieces of [a, b]
+        t, w = np.polynomial.legendre.leggauss(order)
+        edges = np.linspace(a, b, panels + 1)
+        h = 0.5 * (edges[1:] - edges[:-1])
+        return (0.5 * (edges[1:] + edges[:-1])[:, None] + h[:, None] * t[None, :]).reshape(-1), (h[:, None] * w[None, :]).reshape(-1)
+
+    def normal_pdf(s_, m, v):
+        return np.exp(-0.5 * (s_ - m) ** 2 / v) / np.sqrt(2 * np.pi * v)
+    if kind == "gaussian":
+        measure = GaussianMeasure(0.3, 2.0)
+        nodes, dx = composite(0.3 - 14 * np.sqrt(2.0), 0.3 + 14 * np.sqrt(2.0))
+        wts = dx * normal_pdf(nodes, 0.3, 2.0)
+    elif kind == "uniform":
+        measure = UniformMeasure(-1.0, 2.5)
+        nodes, dx = composite(-1.0, 2.5)
+        wts = dx / 3.5
+    else:
+        mu, var, pi = np.array([-1.0, 0.8]), np.array([0.6, 1.7]), np.array([0.35, 0.65])
+        measure = MOGMeasure(mu, var, pi)
+        nodes, dx = composite(-20.0, 20.0)
+        wts = dx * sum(p * normal_pdf(nodes, m, v) for p, m, v in zip(pi, mu, var))
+    k = OrthogonalRBFKernel(gpflow.kernels.RBF(lengthscales=lengthscale, variance=1.7), measure)
+    x = np.linspace(-2.0, 2.5, 23).reshape(-1, 1)
+    Kxs = np.asarray(k.K(x, nodes.reshape(-1, 1)))
+    np.testing.assert_allclose(Kxs @ wts, 0.0, atol=1e-10 * np.abs(Kxs).max())
