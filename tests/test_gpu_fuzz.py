@@ -130,6 +130,46 @@ def test_random_kernels_sobol_and_components(hip, seed):
 
 
 @pytest.mark.parametrize("seed", range(12))
+def test_random_subset_lists_through_both_sobol_evaluations(hip, seed):
+    """Random term lists -- any order, any mix of sizes 1..6, occasionally a size-7 subset or a repeated dim (which must fall back
+    to the per-term kernel) -- through the Gram of products and the per-term kernel: each against the oracle (1e-9 of the largest
+    term), the column budget and the direct order-1 terms included whenever the plan takes them."""
+    rng = np.random.default_rng(SEED0 + 12000 + seed)
+    D = int(rng.integers(3, 11))
+    depth = int(rng.integers(1, 5))
+    share = bool(rng.integers(0, 2))
+    kinds = tuple(rng.choice(("gaussian", "binary", "categorical", "gauss2"), size=D))
+    spec = cases.random_spec(rng, D, depth, kinds, share=share)
+    n = int(rng.integers(5, 200))
+    Z = cases.random_inputs(rng, spec, n)
+    alpha = rng.standard_normal(n) * rng.uniform(0.05, 3.0, n)
+    if seed % 4 == 0:
+        alpha = np.abs(alpha)                                   # one sign set empty
+    max_len = min(D, depth if share else 6)                     # with shared variances a term's order needs an order variance
+    subsets = []
+    for _ in range(int(rng.integers(1, 400))):
+        k = int(rng.integers(1, max_len + 1))
+        subsets.append([int(v) for v in rng.permutation(D)[:k]])
+    d = _capi.KernelDesc(spec)
+    ref = np.array(o.compute_sobol_oak(spec, Z, alpha.reshape(-1, 1), share_var_across_orders=share, subsets=subsets, L_cache={})[1])
+    scale = max(np.abs(ref).max(), 1e-300)
+    try:
+        for path in ("gram", "terms", "auto"):
+            hip.sobol_set_path(path)
+            got = hip.sobol(d, Z, alpha, subsets, use_order_var=share)
+            np.testing.assert_allclose(got, ref, rtol=1e-8, atol=1e-10 * scale, err_msg=path)
+        if not share and D >= 7:
+            big = [int(v) for v in rng.permutation(D)[:7]]
+            hip.sobol_set_path("auto")
+            got = hip.sobol(d, Z, alpha, subsets + [big], use_order_var=False)
+            assert hip.sobol_last_info()["path"] == "terms"
+            ref_big = o.compute_sobol_oak(spec, Z, alpha.reshape(-1, 1), share_var_across_orders=False, subsets=[big], L_cache={})[1][0]
+            np.testing.assert_allclose(got[-1], ref_big, rtol=1e-8, atol=1e-10 * scale)
+    finally:
+        hip.sobol_set_path("auto")
+
+
+@pytest.mark.parametrize("seed", range(12))
 def test_random_svgp_problems(hip, seed):
     """SVGP ELBO, predictions and the q_mu / q_sqrt gradients of random kernels and variational parameters against the
     oracle: ELBO 1e-10, mean / var / log density 1e-9, gradients 1e-6 of their largest entry vs central differences along
