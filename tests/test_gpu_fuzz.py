@@ -169,6 +169,51 @@ def test_random_subset_lists_through_both_sobol_evaluations(hip, seed):
         hip.sobol_set_path("auto")
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_random_multi_output_problems(seed):
+    """Random P-column targets, kernels, routes, panel chunkings and inducing counts (multiples of 32 and not: the right-hand sides
+    ride through chol(B) or take the explicit solves): bound and alpha against the oracle's N x P formulas, gradient against the
+    sum of the single-output gradients."""
+    rng = np.random.default_rng(SEED0 + 15000 + seed)
+    D = int(rng.integers(2, 7))
+    R = int(rng.integers(1, min(D, 3) + 1))
+    kinds = tuple(rng.choice(("gaussian", "binary", "categorical", "uniform"), size=D))
+    spec = cases.random_spec(rng, D, R, kinds, share=bool(rng.integers(0, 2)))
+    N = int(rng.integers(300, 2500))
+    M = int(rng.choice([24, 32, 50, 64, 96, 128, 130]))
+    P = int(rng.integers(2, 12))
+    X, Z = cases.random_inputs(rng, spec, N), cases.random_inputs(rng, spec, M)
+    Y = rng.standard_normal((N, P)) + np.sin(X[:, :1])
+    s2 = float(rng.uniform(0.05, 0.5))
+    route = ("phi", "whitened", "auto")[seed % 3]
+    d = _capi.KernelDesc(spec)
+    ctx = _capi.HipContext(0)
+    try:
+        ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route(route)
+        ctx.sgpr_set_panel_rows(0 if seed % 2 else int(rng.integers(64, N)))
+        g_sum, e_sum = 0.0, 0.0
+        for p in range(P):
+            ctx.sgpr_set_data(X, Y[:, p])
+            e, g = ctx.sgpr_elbo_grad(d, s2)
+            e_sum, g_sum = e_sum + e, g_sum + g
+        ctx.sgpr_set_data(X, Y[:, 0]); ctx.sgpr_set_extra_targets(Y[:, 1:])
+        e, g = ctx.sgpr_elbo_grad(d, s2)
+        er = o.sgpr_elbo(spec, X, Y, Z, s2)
+        assert abs(e - er) <= 1e-9 * abs(er) and abs(e - e_sum) <= 1e-10 * abs(e_sum), (e, er, e_sum)
+        np.testing.assert_allclose(g, g_sum, rtol=1e-7, atol=1e-8 * np.abs(g_sum).max())
+        # posterior of single outputs: the predictive mean (alpha itself is cond(Kuu)-sensitive with random inducing inputs: its
+        # agreement with the oracle is no better for ONE output)
+        Xs = cases.random_inputs(rng, spec, 40)
+        mr, vr = o.sgpr_predict_f(spec, X, Y, Z, s2, Xs)
+        for p in (P - 1, 0):
+            ctx.sgpr_select_output(p)
+            mean, var = ctx.sgpr_predict(d, Xs)
+            np.testing.assert_allclose(mean, mr[:, p], rtol=1e-6, atol=1e-7 * np.abs(mr).max())
+            np.testing.assert_allclose(var, vr[:, p], rtol=1e-6, atol=1e-8)
+    finally:
+        ctx.close()
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_random_svgp_problems(hip, seed):
     """SVGP ELBO, predictions and the q_mu / q_sqrt gradients of random kernels and variational parameters against the
