@@ -63,3 +63,30 @@ def test_every_row_of_a_large_solve(hip, trans):
     for rep in range(2):
         Xr, _ = hip.bench_trsm(L, B, trans=trans, reps=1)
         assert np.array_equal(Xr, X0), f"run {rep + 2} differs from run 1 in {int((Xr != X0).any(axis=1).sum())} rows"
+
+
+@pytest.mark.parametrize("n", [31, 97, 128, 160, 577, 1030, 2050, 4100])
+def test_cholesky_factor_itself(n):
+    """The two-level blocked Cholesky (32-column panels in 128-column blocks: every pending depth 0 / 32 / 64 / 96 / 128, partial last
+    panels and blocks, one to 33 outer blocks) through the full GP, whose entry point returns the factor: L against NumPy's on the
+    oracle's Gram matrix, and L L^T against the matrix, entry by entry."""
+    from oak import _capi
+    from oracle import oak_oracle as o
+    rng = np.random.default_rng(n)
+    D = 3
+    X = rng.standard_normal((n, D))
+    y = rng.standard_normal((n, 1))
+    spec = o.make_spec(D, 2, lengthscales=[0.7, 1.1, 1.6])
+    s2 = 0.05
+    ctx = _capi.HipContext(0)
+    try:
+        ctx.gpr_set_data(X, y)
+        ctx.gpr_log_marginal(_capi.KernelDesc(spec), s2)
+        L = ctx.gpr_chol(n)
+    finally:
+        ctx.close()
+    A = o.oak_K(spec, X) + s2 * np.eye(n)
+    assert np.all(np.triu(L, 1) == 0.0)
+    np.testing.assert_allclose(L @ L.T, A, rtol=0, atol=1e-12 * np.abs(A).max())
+    Lr = np.linalg.cholesky(A)
+    np.testing.assert_allclose(L, Lr, rtol=0, atol=1e-9 * np.abs(Lr).max())     # forward error ~ cond(A) eps; cond(A) <= 1e5 here
