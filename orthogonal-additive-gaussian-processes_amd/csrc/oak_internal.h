@@ -153,6 +153,7 @@ struct oak_ctx {
     // share kernel, inducing points and noise.  Buffers: "Yx" [n_extra x N], "yyx" [n_extra] (y^T y of this rank's rows),
     // "psix" [n_extra x M | n_extra] (Kuf y per column, then the y^T y), "c_all" [(1 + n_extra) x M] (c of every output).
     int n_extra = 0;
+    bool psix_valid = false;         // "psix" belongs to the statistics in "stats" (false once oak_sgpr_set_stats replaced those from outside)
     int psix_nwg = 0;                // row blocks whose partial sums "psix_part" holds (set by the first panel chunk)
     int out_sel = 0;                 // the output whose c sits in buffer "c" (alpha / predict): oak_sgpr_select_output
     int sobol_path = 0;              // 0 automatic (cost model), 1 one workgroup per term, 2 Gram of products (oak_sobol_set_path)

@@ -196,6 +196,7 @@ int sgpr_extra_psi_finish(oak_ctx* ctx) {
                                                                                        (int64_t)nx * M, d_psix);
     OAK_HIP_CHECK(hipGetLastError());
     OAK_CHECK(copy_d2d(ctx, d_psix + (int64_t)nx * M, peek_buf(ctx, "yyx"), sizeof(double) * (size_t)nx));
+    ctx->psix_valid = true;
     return OAK_OK;
 }
 
@@ -580,8 +581,14 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     OAK_CHECK(get_buf_t(ctx, "T1", (size_t)(M + 1 + nx) * M, &dT1));
     OAK_CHECK(get_buf_t(ctx, "T2", (size_t)(M + 1 + nx) * M, &dT2));
     OAK_CHECK(get_buf_t(ctx, "LB", (size_t)(M + 1 + nx) * M, &dLB));
-    if (nx > 0) OAK_REQUIRE(peek_buf(ctx, "psix") != nullptr, "SGPR tail: the statistics of the extra target columns are missing (they are formed by "
-                                                              "oak_sgpr_elbo / oak_sgpr_elbo_grad / oak_sgpr_local_stats, not by oak_sgpr_set_stats)");
+    if (nx > 0 && !(peek_buf(ctx, "psix") != nullptr && ctx->psix_valid)) {
+        // e.g. statistics summed over shards OUTSIDE the library (get_stats -> reduce -> set_stats): the extra outputs' Kuf y were
+        // not part of that sum, and a tail on them would be silently wrong
+        set_error("SGPR tail: the statistics of the extra target columns do not belong to the packed statistics in place (they are formed by "
+                  "oak_sgpr_elbo / oak_sgpr_elbo_grad / oak_sgpr_local_stats and summed over ranks only through the context's communicator, "
+                  "not by oak_sgpr_set_stats)");
+        return OAK_E_STATE;
+    }
     const double* d_psix_in = nx > 0 ? (const double*)peek_buf(ctx, "psix") : nullptr;
     OAK_CHECK(get_buf_t(ctx, "v1", (size_t)M, &dv1));
     OAK_CHECK(get_buf_t(ctx, "c", (size_t)M, &dc));
@@ -853,7 +860,7 @@ int oak_sgpr_set_extra_targets(oak_ctx* ctx, const double* Yt, int64_t N, int32_
     OAK_CHECK(get_buf_t(ctx, "yyx", (size_t)n_extra, &dyyx));
     for (int p = 0; p < n_extra; ++p) OAK_CHECK(reduce_sum(ctx, dYx + (int64_t)p * N, N, dyyx + p, 1, 1));
     OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    ctx->n_extra = n_extra; ctx->have_stats = false; ctx->have_post = false;
+    ctx->n_extra = n_extra; ctx->have_stats = false; ctx->have_post = false; ctx->psix_valid = false;
     return OAK_OK;
 }
 
@@ -952,6 +959,7 @@ int oak_sgpr_set_stats(oak_ctx* ctx, const double* packed, int32_t whitened) {
     OAK_HIP_CHECK(hipMemcpyAsync(st.phi, packed, sizeof(double) * (size_t)st.len, hipMemcpyHostToDevice, ctx->stream));
     OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ctx->have_stats = true; ctx->stats_whitened = whitened != 0; ctx->have_post = false;
+    ctx->psix_valid = false;               // whatever "psix" holds was formed for other statistics
     return OAK_OK;
 }
 

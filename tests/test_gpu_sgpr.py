@@ -601,3 +601,29 @@ def test_shared_statistics_for_several_outputs_at_the_c_abi(hip, route, P, panel
             ctx.sgpr_set_extra_targets(Y[:, 1:])              # row count of another data set
     finally:
         ctx.close()
+
+
+def test_extra_targets_refuse_statistics_reduced_outside_the_library(hip):
+    """get_stats -> (a sum over shards somewhere else) -> set_stats -> tail is a supported way to exchange the packed statistics, but
+    the extra outputs' Kuf y are not in that vector: with extra target columns set the tail must refuse, not return a bound whose
+    extra outputs saw one shard only."""
+    X, y, Z = o.synthetic_problem(2000, 4, 64, seed=8)
+    Y2 = np.concatenate([y, y[::-1]], axis=1)
+    d = _capi.KernelDesc(o.make_spec(4, 2))
+    ctx = _capi.HipContext(0)
+    try:
+        ctx.sgpr_set_data(X, Y2[:, 0]); ctx.sgpr_set_extra_targets(Y2[:, 1:]); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("phi")
+        ctx.sgpr_local_stats(d)
+        e, _ = ctx.sgpr_tail(d, 0.1)                                 # local statistics, untouched: fine
+        assert rel(e, o.sgpr_elbo(o.make_spec(4, 2), X, Y2, Z, 0.1)) <= 1e-10
+        st = ctx.sgpr_get_stats()
+        ctx.sgpr_set_stats(st, False)
+        with pytest.raises(_capi.OakHipError) as ei:
+            ctx.sgpr_tail(d, 0.1)
+        assert ei.value.status == _capi.OAK_E_STATE
+        ctx.sgpr_set_extra_targets(None)
+        ctx.sgpr_set_stats(st, False)
+        e1, _ = ctx.sgpr_tail(d, 0.1)                                # single-output statistics from outside: fine
+        assert rel(e1, o.sgpr_elbo(o.make_spec(4, 2), X, Y2[:, :1], Z, 0.1)) <= 1e-10
+    finally:
+        ctx.close()
