@@ -161,11 +161,16 @@ constexpr int G2_LPR = G2_K / 2;            // lanes per row chunk (16 B each)
 constexpr int G2_RPL = 64 / G2_LPR;          // rows per wave-load
 constexpr int G2_NQ = G2_T / (4 * G2_RPL);   // loads per thread per matrix
 
-template <bool TAIL>     // TAIL: triangular k ranges + split-k partials (M x M products); false: the N-sized products, unchanged
+// RANKP (only with TAIL = false): the epilogue adds  sum_p Yx[p][row] * ax[p][col]  to the tile before it is stored -- the rank-one
+// adjoints y_p a_p^T of the extra output columns of a multi-output model (grad.hip), 64 * nx FMAs per thread against the tile's
+// 2^21 MFMA flops per wave, instead of a read-modify-write pass over the finished 8.6 GB panel.  The other instantiations are
+// the kernels as they were.
+template <bool TAIL, bool RANKP = false>     // TAIL: triangular k ranges + split-k partials (M x M products); false: the N-sized products, unchanged
 __global__ void __launch_bounds__(256, 2)
 gemm128_nt_kernel(const double* A, const double* __restrict__ B, double* C /* may alias A: trsm_rows runs the diagonal-block product in place */, int64_t m, int64_t n,
                   int64_t k, int64_t lda, int64_t ldb, int64_t ldc, double alpha, double beta, int ntn,
-                  int tri /* GM_TRI_* */, int nsplitk /* gridDim.y slices of each tile's k range -> part[z][m][n] */, double* __restrict__ part) {
+                  int tri /* GM_TRI_* */, int nsplitk /* gridDim.y slices of each tile's k range -> part[z][m][n] */, double* __restrict__ part,
+                  const double* __restrict__ Yx = nullptr, int64_t ldy = 0, const double* __restrict__ ax = nullptr, int nx = 0) {
     __shared__ __attribute__((aligned(16))) double As[G2_T * G2_P];
     __shared__ __attribute__((aligned(16))) double Bs[G2_T * G2_P];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -238,6 +243,26 @@ gemm128_nt_kernel(const double* A, const double* __restrict__ B, double* C /* ma
                 for (int h = 0; h < 4; ++h) acc[g][h] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[g], b[h], acc[g][h], 0, 0, 0);
         }
         __syncthreads();
+    }
+    if constexpr (RANKP) {
+        // per output p: this thread's 16 row values and 4 column values (20 loads), 64 FMAs into the accumulators (alpha = 1 here)
+        for (int p = 0; p < nx; ++p) {
+            double av[4];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int64_t col = c0 + 64 * wc + 16 * h + fi;
+                av[h] = ax[(int64_t)p * n + (col < n ? col : n - 1)];
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int reg = 0; reg < 4; ++reg) {
+                    const int64_t row = r0 + 64 * wr + 16 * g + 4 * reg + fk;
+                    const double yv = Yx[(int64_t)p * ldy + (row < m ? row : m - 1)];
+#pragma unroll
+                    for (int h = 0; h < 4; ++h) acc[g][h][reg] = __builtin_fma(yv, av[h], acc[g][h][reg]);
+                }
+        }
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g)
@@ -321,6 +346,20 @@ int gemm_tail(oak_ctx* ctx, int bt, const double* dA, const double* dB, double* 
 static bool gemm128_eligible(const double* dA, const double* dB, int64_t m, int64_t n, int64_t k, int64_t lda, int64_t ldb, int lower_only) {
     const bool aligned = ((lda | ldb) & 1) == 0 && (((uintptr_t)dA | (uintptr_t)dB) & 15) == 0 && k >= 2 && (k & 1) == 0;
     return !lower_only && aligned && m >= 2048 && n >= 128 && m > 0 && n > 0;
+}
+// C = A B^T + sum_p Yx[p][:]^T ax[p][:]   (Yx [nx x ldy] indexed by C's rows, ax [nx x n]); false when the shape does not take
+// the 128 x 128 kernel (the caller then adds the rank-nx term in a pass of its own)
+bool gemm_nt_rankp(oak_ctx* ctx, const double* dA, const double* dB, double* dC, int64_t m, int64_t n, int64_t k, int64_t lda, int64_t ldb,
+                   int64_t ldc, const double* dYx, int64_t ldy, const double* d_ax, int nx, int* status) {
+    *status = OAK_OK;
+    if (!gemm128_eligible(dA, dB, m, n, k, lda, ldb, 0)) return false;
+    const int ntn = (int)((n + G2_T - 1) / G2_T);
+    const int64_t nrb = (m + G2_T - 1) / G2_T;
+    const int64_t ngrp = (nrb + 7) / 8;
+    gemm128_nt_kernel<false, true><<<(unsigned)(ngrp * 8 * ntn), 256, 0, ctx->stream>>>(dA, dB, dC, m, n, k, lda, ldb, ldc, 1.0, 0.0, ntn, 0, 1, nullptr,
+                                                                                       dYx, ldy, d_ax, nx);
+    if (hipGetLastError() != hipSuccess) { set_error("gemm128_nt_kernel<false, true> launch failed"); *status = OAK_E_HIP; }
+    return true;
 }
 int gemm_nt(oak_ctx* ctx, const double* dA, const double* dB, double* dC, int64_t m, int64_t n, int64_t k, int64_t lda,
             int64_t ldb, int64_t ldc, double alpha, double beta, int lower_only) {

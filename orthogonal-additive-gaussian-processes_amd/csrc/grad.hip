@@ -1303,11 +1303,16 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
         }
         {
             PhaseTimer t(ctx, "bwd_gemm");      // Gfu = Kfu H   (scaled by 1/s2 inside the pair kernel)
-            OAK_CHECK(gemm_nt(ctx, dPanel, dH, dG, na, M, M, Mp, M, Mp, 1.0, 0.0, 0));
-            if (nx > 0) {
-                rank_add_kernel<<<dim3((unsigned)((M + 255) / 256), (unsigned)((na + 15) / 16)), 256, 0, ctx->stream>>>(
-                    dG, Mp, na, M, (const double*)peek_buf(ctx, "Yx") + a0, N, d_ax, nx);
-                OAK_HIP_CHECK(hipGetLastError());
+            int rs = OAK_OK;
+            if (nx > 0 && gemm_nt_rankp(ctx, dPanel, dH, dG, na, M, M, Mp, M, Mp, (const double*)peek_buf(ctx, "Yx") + a0, N, d_ax, nx, &rs)) {
+                OAK_CHECK(rs);                  // the other outputs' y_p a_p^T went in with the GEMM's epilogue
+            } else {
+                OAK_CHECK(gemm_nt(ctx, dPanel, dH, dG, na, M, M, Mp, M, Mp, 1.0, 0.0, 0));
+                if (nx > 0) {                   // small shapes (the 64 x 64 GEMM): a pass of its own over the adjoint panel
+                    rank_add_kernel<<<dim3((unsigned)((M + 255) / 256), (unsigned)((na + 15) / 16)), 256, 0, ctx->stream>>>(
+                        dG, Mp, na, M, (const double*)peek_buf(ctx, "Yx") + a0, N, d_ax, nx);
+                    OAK_HIP_CHECK(hipGetLastError());
+                }
             }
             t.stop();
         }

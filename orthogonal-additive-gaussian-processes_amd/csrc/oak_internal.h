@@ -257,6 +257,8 @@ int gemm_nn(oak_ctx* ctx, const double* dA, const double* dB, double* dC, int64_
             int64_t lda, int64_t ldb, int64_t ldc, double alpha, double beta);   // C = alpha A B + beta C (row-major)
 int gemm_nt(oak_ctx* ctx, const double* dA, const double* dB, double* dC, int64_t m, int64_t n, int64_t k,
             int64_t lda, int64_t ldb, int64_t ldc, double alpha, double beta, int lower_only);   // C = alpha A B^T + beta C
+bool gemm_nt_rankp(oak_ctx* ctx, const double* dA, const double* dB, double* dC, int64_t m, int64_t n, int64_t k, int64_t lda, int64_t ldb,
+                   int64_t ldc, const double* dYx, int64_t ldy, const double* d_ax, int nx, int* status);   // factor.hip
 // M x M products of the O(M^3) tail: split-k over gridDim.z + fixed-order reduce, and triangular operands declared so that a
 // tile only walks the k range where both are non-zero.  bt = 1: C = alpha A B^T + beta C (B indexed [n][k]); bt = 0: A B.
 constexpr int OAK_TRI_A_LOWER = 1, OAK_TRI_A_UPPER = 2, OAK_TRI_B_LOWER = 4, OAK_TRI_B_UPPER = 8;
