@@ -985,12 +985,13 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
 }
 
 // d_gz[nb][dmax] += column-side contraction of G (+ optional rank-1 yA avec^T) with dK/dz over the pairs (A rows a0.., B);
-// d_dzb = featurize_dx of the B points.  Supported for 1 <= R <= 4 and D <= 32 (the register-resident pair walk).
+// d_dzb = featurize_dx of the B points.  Supported for 1 <= R <= 4 with D <= 32 and for 5 <= R <= 8 with D <= 16 (the register-resident pair walk).
 int gram_bwd_z(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int64_t na, const Feat& B, const double* d_dzb,
                const double* d_G, int64_t ldg, double g_scale, const double* d_yA, const double* d_avec, double* d_gz, int dmax) {
     if (na <= 0 || B.n <= 0) return OAK_OK;
     const int D = pk.dd.D, R = pk.dd.R;
-    OAK_REQUIRE(R >= 1 && R <= 4 && D <= 32, "gradient w.r.t. inducing inputs needs 1 <= max_interaction_depth <= 4 and <= 32 dims (got %d, %d)", R, D);
+    OAK_REQUIRE(R >= 1 && D <= 32 && (R <= 4 || (R <= 8 && D <= 16)),
+                "gradient w.r.t. inducing inputs needs an effective depth <= 4 with <= 32 dims or <= 8 with <= 16 dims (got depth %d, %d dims)", R, D);
     OAK_REQUIRE(A.xs32 != nullptr && B.xs32 != nullptr, "gram_bwd_z: features were not prepared for the backward pass");
     bool allrbf = true, unitbv = true;
     for (int d = 0; d < D; ++d) {
@@ -1025,6 +1026,10 @@ int gram_bwd_z(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0
         case 208: OAK_BZ(2, 8) break;   case 216: OAK_BZ(2, 16) break;   case 232: OAK_BZ(2, 32) break;
         case 308: OAK_BZ(3, 8) break;   case 316: OAK_BZ(3, 16) break;   case 332: OAK_BZ(3, 32) break;
         case 408: OAK_BZ(4, 8) break;   case 416: OAK_BZ(4, 16) break;   case 432: OAK_BZ(4, 32) break;
+        case 508: OAK_BZ(5, 8) break;   case 516: OAK_BZ(5, 16) break;
+        case 608: OAK_BZ(6, 8) break;   case 616: OAK_BZ(6, 16) break;
+        case 708: OAK_BZ(7, 8) break;   case 716: OAK_BZ(7, 16) break;
+        case 808: OAK_BZ(8, 8) break;   case 816: OAK_BZ(8, 16) break;
         default: set_error("gram_bwd_z: unsupported configuration"); return OAK_E_ARG;
     }
 #undef OAK_BZ

@@ -266,7 +266,9 @@ def test_fit_with_bfgs_improves_the_objective():
 @pytest.mark.parametrize("route", ["phi", "whitened"])
 @pytest.mark.parametrize("kinds,D,R,share", [(("gaussian",), 4, 2, True), (("gaussian", "uniform", "mog", "none", "gauss2"), 5, 3, False),
                                             (("gaussian", "binary", "categorical", "uniform"), 6, 2, True),
-                                            (("gaussian",), 20, 2, True)])
+                                            (("gaussian",), 20, 2, True),
+                                            (("gaussian", "uniform", "binary"), 6, 5, True), (("gaussian", "gauss2"), 10, 8, False),
+                                            (("gaussian", "categorical", "mog"), 16, 6, True)])
 def test_gradient_wrt_inducing_inputs(hip, route, kinds, D, R, share):
     """oak_sgpr_elbo_grad_z against central differences of the oracle ELBO, entry by entry of Z (every measure type; discrete
     columns get exactly 0), in both routes; the hyper-parameter gradient it returns alongside is unchanged."""
