@@ -85,8 +85,9 @@ typedef struct oak_kernel_desc {
     /* Grouped sub-kernels (OAKKernel(active_dims=[[0, 1], [2]]), oak_kernel.py:74-82,199-210: an unconstrained RBF over several
        columns with one lengthscale, i.e. the product of its one-column RBFs).  extra_col_off [D + 1] / extra_cols: the columns
        of sub-kernel d BEYOND active_col[d] are extra_cols[extra_col_off[d] .. extra_col_off[d + 1]).  Both NULL = every
-       sub-kernel reads one column.  Evaluated by the explicit Gram entry points (oak_gram / oak_gram_diag) only; the fused
-       model paths refuse a grouped description. */
+       sub-kernel reads one column.  Taken by oak_gram*, the SGPR / GPR / SVGP objectives, their hyper-parameter gradients,
+       predictions and components; the inducing-input gradient (gradZ_out != NULL), oak_sobol* and oak_gram_f32 refuse a
+       grouped description (OAK_E_ARG), the fp32 statistics mode falls back to fp64 for it. */
     const int32_t* extra_col_off;
     const int32_t* extra_cols;
 } oak_kernel_desc;

@@ -273,7 +273,12 @@ def component_K(spec, subset, X, X2=None, share_var_across_orders=True):
         return spec["order_variances"][0] * np.ones((X.shape[0], n2))
     mats = []
     for d in subset:
-        c = active_col(spec, d)
+        c = active_cols(spec, d)
+        if len(c) > 1:      # a grouped sub-kernel: the unconstrained RBF over the group's columns, as in oak_K
+            dim = spec["dims"][d]
+            mats.append(rbf_K(X[:, c], None if X2 is None else np.asarray(X2, dtype=np.float64)[:, c], dim["lengthscale"], dim["variance"]))
+            continue
+        c = c[0]
         mats.append(base_K(X[:, c:c + 1], None if X2 is None else np.asarray(X2, dtype=np.float64)[:, c:c + 1],
                            spec["dims"][d]))
     vn = spec["order_variances"][len(subset)] if share_var_across_orders else 1.0

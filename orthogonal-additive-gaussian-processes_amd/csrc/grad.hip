@@ -68,7 +68,7 @@ gram_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
                 int64_t a0, int64_t na, const double* __restrict__ Bxs, const double* __restrict__ Bcn,
                 const double* __restrict__ Bdcn, int64_t b_ld, int64_t nb, const double* __restrict__ G, int64_t ldg,
                 const double* __restrict__ yA, const double* __restrict__ avec, double g_scale, int rows_per_wg,
-                double* __restrict__ partial) {
+                double* __restrict__ partial, const double* __restrict__ Axx, const double* __restrict__ Bxx, int nx) {
     constexpr int TJ = 64 * CPT;
     constexpr int RT = 2, RS = 4 * RT;
     constexpr int RR = R > 0 ? R : 1;
@@ -86,6 +86,8 @@ gram_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
     double* accL = Tab + 64;            // [4][D]
     double* accK = accL + 4 * D;        // [4][D]
     double* accT = accK + 4 * D;        // [4][tablen]: one copy per wave (see accTw)
+    double* Bq = accT + 4 * tablen;     // [nx][TJ]  further columns of grouped RBF dims (DevDesc::xrow / nxc, Feat::xx)
+    double* Aq = Bq + nx * TJ;          // [nx][RS]
     const int tid = threadIdx.x, tx = tid & 63;
     const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int64_t jb = (int64_t)blockIdx.x * TJ;
@@ -98,6 +100,10 @@ gram_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
         Bx[idx] = ok ? Bxs[(int64_t)d * b_ld + gj] : 0.0;
         Bc[idx] = ok ? Bcn[(int64_t)d * b_ld + gj] : 0.0;
         Bd[idx] = ok ? Bdcn[(int64_t)d * b_ld + gj] : 0.0;
+    }
+    for (int idx = tid; idx < nx * TJ; idx += 256) {
+        const int q = idx / TJ, j = idx - q * TJ;
+        Bq[idx] = (jb + j < nb) ? Bxx[(int64_t)q * b_ld + jb + j] : 0.0;
     }
     for (int j = tid; j < TJ; j += 256) Av[j] = (avec != nullptr && jb + j < nb) ? avec[jb + j] : 0.0;
     if (tid < 64) Tab[tid] = c_exp2_table_g[tid];
@@ -124,6 +130,10 @@ gram_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
             Ad[idx] = ok ? Adcn[(int64_t)d * a_ld + a0 + gi] : 0.0;
         }
         if (tid < RS) Ay[tid] = (yA != nullptr && i0 + tid < iend) ? yA[a0 + i0 + tid] : 0.0;
+        for (int idx = tid; idx < nx * RS; idx += 256) {
+            const int q = idx / RS, r = idx - q * RS;
+            Aq[idx] = (i0 + r < iend) ? Axx[(int64_t)q * a_ld + a0 + i0 + r] : 0.0;
+        }
         __syncthreads();
         // adjoint of K for this lane's RT x CPT pairs
         double g[RT][CPT];
@@ -155,7 +165,12 @@ gram_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
                         double k;
                         if (rbf) {
                             const double u = xa - xb;
-                            const double E = exp2_neg_tab(__builtin_fma(-u, u, dd.log2bv[d]), Tab);
+                            double t = __builtin_fma(-u, u, dd.log2bv[d]);
+                            for (int q = dd.xrow[d]; q < dd.xrow[d] + dd.nxc[d]; ++q) {      // grouped dim: the other columns' share of the exponent
+                                const double uq = Aq[q * RS + ty * RT + r] - Bq[q * TJ + CPT * tx + c];
+                                t = __builtin_fma(-uq, uq, t);
+                            }
+                            const double E = exp2_neg_tab(t, Tab);
                             k = __builtin_fma(-Ac[d * RS + ty * RT + r], Bc[d * TJ + CPT * tx + c], E);
                         } else {
                             k = tables[dd.tab_off[d] + (int)xa * dd.ncat[d] + (int)xb];
@@ -188,7 +203,11 @@ gram_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
                         int tidx = 0;
                         if (rbf) {
                             const double u = xa - xb;
-                            const double u2 = u * u;
+                            double u2 = u * u;
+                            for (int q = dd.xrow[d]; q < dd.xrow[d] + dd.nxc[d]; ++q) {
+                                const double uq = Aq[q * RS + ty * RT + r] - Bq[q * TJ + CPT * tx + c];
+                                u2 = __builtin_fma(uq, uq, u2);
+                            }
                             const double E = exp2_neg_tab(dd.log2bv[d] - u2, Tab);
                             const double ca = Ac[d * RS + ty * RT + r], cb = Bc[d * TJ + CPT * tx + c];
                             k = __builtin_fma(-ca, cb, E);
@@ -904,7 +923,9 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     const int D = pk.dd.D, R = pk.dd.R;
     const int tablen = (int)pk.tables.size();
     OAK_REQUIRE(tablen <= 1024, "gradient: discrete tables too large (%d doubles; four per-wave copies are kept in LDS)", tablen);
-    const bool fast = (R >= 1 && R <= 4 && D <= 32 && getenv("OAK_BWD_GENERIC") == nullptr);
+    const int nx = pk.grouped ? A.nx : 0;       // grouped sub-kernels go through the general kernel
+    if (pk.grouped) OAK_REQUIRE(A.xx != nullptr && B.xx != nullptr && A.nx == B.nx, "gram_bwd: features lack the grouped sub-kernels' further columns");
+    const bool fast = (R >= 1 && R <= 4 && D <= 32 && nx == 0 && getenv("OAK_BWD_GENERIC") == nullptr);
     bool allrbf = true;
     for (int d = 0; d < D; ++d) allrbf = allrbf && pk.dd.type[d] == OAK_DIM_RBF;
     const int dmax = D <= 8 ? 8 : (D <= 16 ? 16 : 32);
@@ -913,7 +934,7 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     bool unitbv = true;
     for (int d = 0; d < D; ++d) unitbv = unitbv && (pk.dd.type[d] != OAK_DIM_RBF || pk.dd.bv[d] == 1.0);
     const size_t lds = fast ? sizeof(double) * ((size_t)3 * dmax * TJ + TJ + EW_N + (unitbv ? 0 : 2 * dmax) + 5 * tablen + (allrbf ? 0 : dmax))
-                            : sizeof(double) * ((size_t)3 * D * TJ + (size_t)3 * D * RS + RS + TJ + 64 + 8 * D + 4 * tablen + 64);
+                            : sizeof(double) * ((size_t)3 * D * TJ + (size_t)3 * D * RS + RS + TJ + 64 + 8 * D + 4 * tablen + 64 + (size_t)nx * (TJ + RS));
     OAK_REQUIRE(lds <= 160 * 1024, "gram_bwd: LDS request %zu exceeds 160 KiB", lds);
     const int64_t nb = B.n;
     const int64_t ncb = (nb + TJ - 1) / TJ;
@@ -942,7 +963,7 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
         auto kern = gram_bwd_kernel<RR, CP>;                                                                                     \
         if (lds > 64 * 1024) OAK_CHECK(ensure_max_dynamic_lds((const void*)kern)); \
         kern<<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen, A.xs, A.cn, A.dcn, A.ld, a0, na, B.xs, B.cn, B.dcn,  \
-                                              B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part);                     \
+                                              B.ld, nb, d_G, ldg, d_yA, d_avec, g_scale, (int)rows, d_part, A.xx, B.xx, nx);    \
     }
 #define OAK_BWD_FAST_K(RR, DM, AR, GK, UB)                                                                                         \
     {                                                                                                                             \
@@ -990,6 +1011,7 @@ int gram_bwd_z(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0
                const double* d_G, int64_t ldg, double g_scale, const double* d_yA, const double* d_avec, double* d_gz, int dmax) {
     if (na <= 0 || B.n <= 0) return OAK_OK;
     const int D = pk.dd.D, R = pk.dd.R;
+    OAK_REQUIRE(!pk.grouped, "gradient w.r.t. inducing inputs: a sub-kernel over several columns is not supported");
     OAK_REQUIRE(R >= 1 && D <= 32 && (R <= 4 || (R <= 8 && D <= 16)),
                 "gradient w.r.t. inducing inputs needs an effective depth <= 4 with <= 32 dims or <= 8 with <= 16 dims (got depth %d, %d dims)", R, D);
     OAK_REQUIRE(A.xs32 != nullptr && B.xs32 != nullptr, "gram_bwd_z: features were not prepared for the backward pass");
@@ -1170,7 +1192,7 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
     OAK_REQUIRE(grad_out != nullptr, "grad_out is NULL");
     OAK_REQUIRE(ctx->have_data && ctx->have_Z, "SGPR: set_data and set_inducing must be called first");
     PreparedKernel pk;
-    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk, PK_GROUPED));
     PhaseTimer ttot(ctx, "total");
     // ---- forward ------------------------------------------------------------------------------------------
     double elbo = 0.0, terms[8];
@@ -1383,7 +1405,7 @@ int oak_gpr_log_marginal_grad(oak_ctx* ctx, const oak_kernel_desc* desc, double 
     double logml = 0.0;
     OAK_CHECK(oak_gpr_log_marginal(ctx, desc, noise_var, &logml));
     PreparedKernel pk;
-    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk, PK_GROUPED));
     const int64_t N = ctx->gN;
     double* dL = (double*)peek_buf(ctx, "gprL");
     double* dalpha = (double*)peek_buf(ctx, "gpralpha");

@@ -40,12 +40,15 @@ __device__ __forceinline__ double esp_combine(const double (&e)[R > 0 ? R : 1], 
 //   CPT == 2: columns jb + 2*tx + {0,1}
 // The B-side (column) features of all D dims stay in LDS for the whole workgroup; A-side (row) features are
 // restaged per row-step.  Dynamic LDS = (EW_N + D*TJ*2 + D*4*RT*2 + 4*RT) doubles.
-template <int R, int RT, int CPT, bool ALLRBF, int TB>
+// GRP: some RBF dims read further columns (DevDesc::xrow / nxc, Feat::xx): their squared differences join the exponent before
+// the one exponential of the dim.  A separate instantiation, so the kernels of ordinary descriptions compile as before.
+template <int R, int RT, int CPT, bool ALLRBF, int TB, bool GRP = false>
 __global__ void __launch_bounds__(256)
 gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* __restrict__ Axs,
             const double* __restrict__ Acn, int64_t a_ld, int64_t a0, int64_t na, const double* __restrict__ Bxs,
             const double* __restrict__ Bcn, int64_t b_ld, int64_t nb, double* __restrict__ out, int64_t ldo,
-            int rows_per_wg, const double* __restrict__ yA, double* __restrict__ psi_part, int64_t zero_pad_to) {
+            int rows_per_wg, const double* __restrict__ yA, double* __restrict__ psi_part, int64_t zero_pad_to,
+            const double* __restrict__ Axx = nullptr, const double* __restrict__ Bxx = nullptr, int nx = 0) {
     constexpr int TJ = 64 * CPT;
     constexpr int RS = 4 * RT;   // rows per row-step
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -57,6 +60,8 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
     double* Ax = Bc + D * TJ;          // [D][RS]
     double* Ac = Ax + D * RS;          // [D][RS]
     double* Ay = Ac + D * RS;          // [RS]
+    double* Bq = Ay + RS;              // [nx][TJ]  further columns of grouped dims (GRP), pre-scaled like Bx
+    double* Aq = Bq + (GRP ? nx : 0) * TJ;   // [nx][RS]
     const int tid = threadIdx.x;
     const int tx = tid & 63;
     const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,6 +77,12 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
         const double pre = (ALLRBF || dd.type[d] == OAK_DIM_RBF) ? 0.03125 : 1.0;
         Bx[idx] = ok ? Bxs[(int64_t)d * b_ld + gj] * pre : 0.0;
         Bc[idx] = ok ? Bcn[(int64_t)d * b_ld + gj] : 0.0;
+    }
+    if constexpr (GRP) {
+        for (int idx = tid; idx < nx * TJ; idx += 256) {
+            const int q = idx / TJ, j = idx - q * TJ;
+            Bq[idx] = (jb + j < nb) ? Bxx[(int64_t)q * b_ld + jb + j] * 0.03125 : 0.0;
+        }
     }
     for (int j = tid; j < TABN; j += 256) Tab[j] = biased_table_entry<TB>(j);
     double psi[CPT];
@@ -89,6 +100,12 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
             Ac[idx] = ok ? Acn[(int64_t)d * a_ld + a0 + gi] : 0.0;
         }
         if (yA != nullptr && tid < RS) Ay[tid] = (i0 + tid < iend) ? yA[a0 + i0 + tid] : 0.0;
+        if constexpr (GRP) {
+            for (int idx = tid; idx < nx * RS; idx += 256) {
+                const int q = idx / RS, r = idx - q * RS;
+                Aq[idx] = (i0 + r < iend) ? Axx[(int64_t)q * a_ld + a0 + i0 + r] * 0.03125 : 0.0;
+            }
+        }
         __syncthreads();
 
         double e[RT][CPT][R > 0 ? R : 1];
@@ -126,6 +143,16 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
                         for (int c = 0; c < CPT; ++c) {
                             const double u = xa[r] - xb[c];
                             w[c] = fma_clamp01(u, u, woff);
+                        }
+                        if constexpr (GRP) {
+                            for (int q = dd.xrow[d]; q < dd.xrow[d] + dd.nxc[d]; ++q) {
+                                const double qa = Aq[q * RS + ty * RT + r];
+#pragma unroll
+                                for (int c = 0; c < CPT; ++c) {
+                                    const double u = qa - Bq[q * TJ + (c >> 1) * 128 + 2 * tx + (c & 1)];
+                                    w[c] = fma_clamp01(u, u, w[c]);     // clamp01(clamp01(a) + b) = clamp01(a + b) for a, b >= 0
+                                }
+                            }
                         }
                         double mg[CPT];
 #pragma unroll
@@ -257,7 +284,9 @@ static int launch_gram_t(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, 
     constexpr int RS = 4 * RT;
     const int D = pk.dd.D;
     // 1024-entry exp2 table unless its extra 4 KiB would lower the number of workgroups a CU holds (D = 32 at TJ = 128)
-    const size_t lds_body = sizeof(double) * ((size_t)D * TJ * 2 + (size_t)D * RS * 2 + RS);
+    const int nx = pk.grouped ? A.nx : 0;
+    if (pk.grouped) OAK_REQUIRE(A.xx != nullptr && B.xx != nullptr && A.nx == B.nx, "gram: features lack the grouped sub-kernels' further columns");
+    const size_t lds_body = sizeof(double) * ((size_t)D * TJ * 2 + (size_t)D * RS * 2 + RS + (size_t)nx * (TJ + RS));
     const size_t cu_lds = 160 * 1024;
     const bool big_table = cu_lds / (lds_body + sizeof(double) * 1024) == cu_lds / (lds_body + sizeof(double) * 512);
     size_t lds = lds_body + sizeof(double) * (big_table ? 1024 : 512);
@@ -284,10 +313,11 @@ static int launch_gram_t(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, 
     for (int d = 0; d < D; ++d) all_rbf = all_rbf && pk.dd.type[d] == OAK_DIM_RBF;
     auto kern = big_table ? (all_rbf ? gram_kernel<R, RT, CPT, true, 10> : gram_kernel<R, RT, CPT, false, 10>)
                           : (all_rbf ? gram_kernel<R, RT, CPT, true, 9> : gram_kernel<R, RT, CPT, false, 9>);
+    if (nx > 0) kern = gram_kernel<R, RT, CPT, false, 9, true>;      // grouped sub-kernels: one instantiation per shape (512-entry table)
     if (lds > 64 * 1024) OAK_CHECK(ensure_max_dynamic_lds((const void*)kern));
     dim3 grid((unsigned)ncb, (unsigned)nrb);
     kern<<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, A.xs, A.cn, A.ld, a0, na, B.xs, B.cn, B.ld, nb, d_out, ldo,
-                                          (int)rows, d_yA, d_part, zero_pad_to);
+                                          (int)rows, d_yA, d_part, zero_pad_to, A.xx, B.xx, nx);
     OAK_HIP_CHECK(hipGetLastError());
     if (d_yA != nullptr) {
         colsum_accum_kernel<<<(unsigned)((nb + 31) / 32), 256, 0, ctx->stream>>>(d_part, nrb, nb, d_psi);
@@ -357,7 +387,7 @@ struct GenericDims {
     short col[OAK_MAX_DIMS];
     int ncat[OAK_MAX_DIMS], tab_off[OAK_MAX_DIMS];
     double ls[OAK_MAX_DIMS], bv[OAK_MAX_DIMS];
-    short xoff[OAK_MAX_DIMS + 1];       // grouped sub-kernels: further columns of dim d are xcols[xoff[d] .. xoff[d + 1])
+    short xrow[OAK_MAX_DIMS]; unsigned char nxc[OAK_MAX_DIMS];   // grouped sub-kernels: further columns of dim d are xcols[xrow[d] .. xrow[d] + nxc[d])
 };
 
 template <int FORM, bool DIAG>
@@ -381,11 +411,11 @@ gram_generic_kernel(const GenericDims g, const double* __restrict__ w, const int
             } else {
                 const double ux = Xa[i * ldx + g.col[d]] / g.ls[d], uz = Xb[j * ldx + g.col[d]] / g.ls[d];
                 double r2;
-                if (g.xoff[d + 1] > g.xoff[d]) {
+                if (g.nxc[d] > 0) {
                     // a sub-kernel over several columns: one RBF of the group's squared distance (oak_kernel.py:199-210)
                     if (FORM == 1) {                                               // gpflow: -2 X X2^T + |X|^2 + |X2|^2, sums over columns
                         double xz = ux * uz, xx = ux * ux, zz = uz * uz;
-                        for (int q = g.xoff[d]; q < g.xoff[d + 1]; ++q) {
+                        for (int q = g.xrow[d]; q < g.xrow[d] + g.nxc[d]; ++q) {
                             const double vx = Xa[i * ldx + xcols[q]] / g.ls[d], vz = Xb[j * ldx + xcols[q]] / g.ls[d];
                             xz += vx * vz; xx += vx * vx; zz += vz * vz;
                         }
@@ -393,7 +423,7 @@ gram_generic_kernel(const GenericDims g, const double* __restrict__ w, const int
                     } else {
                         const double dz0 = ux - uz;
                         r2 = dz0 * dz0;
-                        for (int q = g.xoff[d]; q < g.xoff[d + 1]; ++q) {
+                        for (int q = g.xrow[d]; q < g.xrow[d] + g.nxc[d]; ++q) {
                             const double dz = Xa[i * ldx + xcols[q]] / g.ls[d] - Xb[j * ldx + xcols[q]] / g.ls[d];
                             r2 += dz * dz;
                         }
@@ -443,7 +473,7 @@ int gram_generic(oak_ctx* ctx, const PreparedKernel& pk, int form, const double*
         g.type[d] = pk.dd.type[d]; g.col[d] = pk.dd.col[d]; g.ncat[d] = pk.dd.ncat[d]; g.tab_off[d] = pk.dd.tab_off[d];
         g.ls[d] = pk.dm.ls[d]; g.bv[d] = pk.dd.bv[d];
     }
-    for (int d = 0; d <= g.D; ++d) g.xoff[d] = (short)pk.extra_off[d];
+    for (int d = 0; d < g.D; ++d) { g.xrow[d] = pk.dd.xrow[d]; g.nxc[d] = pk.dd.nxc[d]; }      // (a component description renumbers its dims)
     double* d_w = nullptr;
     int* d_xc = nullptr;
     OAK_CHECK(get_buf_t(ctx, "gram_generic_w", (size_t)OAK_MAX_DIMS + 1, &d_w));

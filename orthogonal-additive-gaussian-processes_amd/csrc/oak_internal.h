@@ -50,6 +50,11 @@ struct DevDesc {
     // pair-kernel exponent form (exp2w.h): log2(bv) = n - 1024 woff, n = max(ceil(log2 bv), 0)
     double woff[OAK_MAX_DIMS];     // (n - log2 bv) / 1024 >= 0
     double magic[OAK_MAX_DIMS];    // 1.5 * 2^32 + n / 1024 (EW_MAGIC + n/1024, exp2w.h)
+    // Grouped sub-kernels (an unconstrained RBF over several columns, oak/oak_kernel.py:74-82,199-210): dim d reads nxc[d] further
+    // columns; their scaled values are rows xrow[d] .. xrow[d] + nxc[d] - 1 of Feat::xx and their squared differences add to
+    // the exponent of dim d's one exponential (a product of one-column RBFs with a shared lengthscale).
+    short xrow[OAK_MAX_DIMS];
+    unsigned char nxc[OAK_MAX_DIMS];
 };
 
 // measure parameters used only by the featurize kernels
@@ -72,6 +77,8 @@ struct Feat {
     double* dcn = nullptr;     // d cn / d lengthscale_d (only when featurized for the backward pass)
     double* xs32 = nullptr;    // backward pass only: xs / 32 (RBF dims; category index otherwise) and dcn / 1024, the
     double* dcs = nullptr;     //   pre-scaled forms the fast backward kernel consumes (exp2w.h) without a multiply
+    double* xx = nullptr;      // grouped sub-kernels: xx[q*ld + i] = x[i, extra column q] * scale of the owning dim (nx rows)
+    int nx = 0;
     int64_t n = 0;
     int64_t ld = 0;
 };
@@ -93,8 +100,9 @@ struct PreparedKernel {
     int R_desc = 0;
     bool deep = false;
     std::vector<double> w_full;      // weights of e_0..e_{min(R, D)} (always filled)
-    bool grouped = false;            // some sub-kernel reads more than one column (explicit Gram entry points only)
+    bool grouped = false;            // some sub-kernel reads more than one column (an unconstrained RBF over a group)
     std::vector<int> extra_off, extra_cols;   // columns beyond dd.col[d]: extra_cols[extra_off[d] .. extra_off[d + 1])
+    std::vector<double> extra_scale;          // dd.scale of the dim that owns extra column q
     std::vector<double> tables;      // host copy of the discrete tables
     double* d_tables = nullptr;      // device (ctx scratch "tables")
     double* d_meas = nullptr;        // device (ctx scratch "meas")
@@ -181,7 +189,11 @@ void debug_mark(oak_ctx* ctx, const char* literal);      // breadcrumb: the last
 // kernel description ----------------------------------------------------------------------------
 // template depth a kernel of effective depth R is run with (zero weights above R): 0..8 exact, then 12, 16, 24, 32
 inline int template_depth(int R) { return R <= 8 ? R : (R <= 12 ? 12 : (R <= 16 ? 16 : (R <= 24 ? 24 : 32))); }
-int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk, bool allow_deep = false);
+// allow: what the caller's kernels can evaluate beyond the fused pair kernels' common ground
+constexpr int PK_DEEP = 1;       // effective depth > OAK_MAX_DEPTH (the explicit Gram entry points' generic kernel)
+constexpr int PK_GROUPED = 2;    // sub-kernels over several columns (gram / gram_diag / gram_bwd / diag_bwd take them; the fp32, inducing-input
+                                 // gradient and Sobol kernels do not)
+int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk, int allow = 0);
 // component (single subset) description derived from a full one
 int prepare_component(oak_ctx* ctx, const oak_kernel_desc* desc, const int32_t* subset, int32_t len,
                       int32_t apply_order_var, PreparedKernel* pk);

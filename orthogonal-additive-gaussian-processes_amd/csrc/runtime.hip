@@ -301,7 +301,7 @@ static double host_var_s(int kind, double l, double bv, double p0, double p1, co
     }
 }
 
-int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk, bool allow_deep) {
+int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk, int allow) {
     OAK_REQUIRE(desc != nullptr, "kernel description is NULL");
     const int D = desc->num_dims, Rd = desc->max_depth;
     OAK_REQUIRE(D >= 1 && D <= OAK_MAX_DIMS, "num_dims=%d outside [1,%d]", D, OAK_MAX_DIMS);
@@ -312,7 +312,7 @@ int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk
     const int R = Rd < D ? Rd : D;
     pk->R_desc = Rd;
     pk->deep = R > OAK_MAX_DEPTH;
-    if (pk->deep && !allow_deep) {
+    if (pk->deep && !(allow & PK_DEEP)) {
         set_error("effective interaction depth min(max_interaction_depth, num_dims) = %d exceeds the %d of the fused kernels "
                   "(only the explicit Gram entry points K / K_diag go deeper)", R, OAK_MAX_DEPTH);
         return OAK_E_ARG;
@@ -337,11 +337,13 @@ int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk
             pk->extra_off[d + 1] = (int)pk->extra_cols.size();
         }
     }
-    if (pk->grouped && !allow_deep) {
-        set_error("a sub-kernel over several columns (OAKKernel(active_dims=[[0, 1], ...])) is evaluated by the explicit Gram entry "
-                  "points K / K_diag only; the fused model paths take one column per sub-kernel");
+    if (pk->grouped && !(allow & PK_GROUPED)) {
+        set_error("a sub-kernel over several columns (OAKKernel(active_dims=[[0, 1], ...])) is not evaluated by this entry point "
+                  "(K / K_diag, the SGPR / GPR / SVGP objectives, their hyper-parameter gradients and predictions are; the "
+                  "inducing-input gradient, the Sobol pass and the fp32 Gram take one column per sub-kernel)");
         return OAK_E_ARG;
     }
+    OAK_REQUIRE(pk->extra_cols.size() <= 64, "grouped sub-kernels: %zu extra columns (at most 64)", pk->extra_cols.size());
     DevDesc& dd = pk->dd;
     DevMeasure& dm = pk->dm;
     memset(&dd, 0, sizeof(dd));
@@ -350,6 +352,8 @@ int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk
     pk->w_full.assign((size_t)R + 1, 0.0);
     for (int r = 0; r <= R; ++r) pk->w_full[r] = desc->share_var ? desc->order_var[r] : (r == 0 ? desc->order_var[0] : 1.0);
     for (int r = 0; r <= dd.R && r <= R; ++r) dd.w[r] = pk->w_full[r];
+    for (int d = 0; d < D; ++d) { dd.xrow[d] = (short)pk->extra_off[d]; dd.nxc[d] = (unsigned char)(pk->extra_off[d + 1] - pk->extra_off[d]); }
+    pk->extra_scale.assign(pk->extra_cols.size(), 0.0);
     pk->tables.clear();
     // upload measure data first (needed by the empirical variance kernel)
     double* d_meas = nullptr;
@@ -369,6 +373,7 @@ int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk
             const double l = desc->lengthscale[d];
             OAK_REQUIRE(l > 0.0 && bv > 0.0, "dim %d: lengthscale and variance must be positive", d);
             dd.scale[d] = std::sqrt(0.5 * 1.4426950408889634074) / l;   // (x s - z s)^2 = (x-z)^2 log2(e) / (2 l^2)
+            for (int q = pk->extra_off[d]; q < pk->extra_off[d + 1]; ++q) pk->extra_scale[q] = dd.scale[d];
             dd.log2bv[d] = std::log2(bv);
             {
                 // n >= 0: the clamp w <= 1 bounds the exponent at n - 1024 and the biased table (x4) keeps the exponent field
@@ -446,7 +451,7 @@ int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk
 
 int prepare_component(oak_ctx* ctx, const oak_kernel_desc* desc, const int32_t* subset, int32_t len,
                       int32_t apply_order_var, PreparedKernel* pk) {
-    OAK_CHECK(prepare_kernel(ctx, desc, pk));
+    OAK_CHECK(prepare_kernel(ctx, desc, pk, PK_GROUPED));
     OAK_REQUIRE(len >= 0 && len <= desc->num_dims, "subset length %d invalid", len);
     // Build a description whose D sub-kernels are the subset and whose only non-zero ESP weight is e_len:
     //   K_S = sigma2_{|S|} * prod_{d in S} k_d = w_len * e_len(k_S)   (oak/oak_kernel.py:300-320)
@@ -462,6 +467,8 @@ int prepare_component(oak_ctx* ctx, const oak_kernel_desc* desc, const int32_t* 
     for (int r = 0; r <= OAK_MAX_DEPTH; ++r) dd.w[r] = 0.0;
     dd.w[len] = wv;
     dd.R = len;
+    pk->w_full.assign((size_t)len + 1, 0.0);        // the generic kernel (reference arithmetic, grouped sub-kernels) reads its weights here
+    pk->w_full[len] = wv;
     if (len == 0) { dd.D = 1; return OAK_OK; }   // constant term: R = 0 -> K = w0 regardless of dims
     dd.D = len;
     for (int q = 0; q < len; ++q) {
@@ -470,10 +477,21 @@ int prepare_component(oak_ctx* ctx, const oak_kernel_desc* desc, const int32_t* 
         dd.type[q] = full.dd.type[s]; dd.col[q] = full.dd.col[s]; dd.ncat[q] = full.dd.ncat[s];
         dd.tab_off[q] = full.dd.tab_off[s]; dd.scale[q] = full.dd.scale[s]; dd.log2bv[q] = full.dd.log2bv[s];
         dd.bv[q] = full.dd.bv[s]; dd.woff[q] = full.dd.woff[s]; dd.magic[q] = full.dd.magic[s];
+        dd.xrow[q] = full.dd.xrow[s]; dd.nxc[q] = full.dd.nxc[s];      // rows of Feat::xx, which always holds every extra column
         dm.kind[q] = full.dm.kind[s]; dm.k[q] = full.dm.k[s]; dm.off[q] = full.dm.off[s]; dm.p0[q] = full.dm.p0[s];
         dm.p1[q] = full.dm.p1[s]; dm.ls[q] = full.dm.ls[s]; dm.inv_sqrt_v[q] = full.dm.inv_sqrt_v[s]; dm.dlogv[q] = full.dm.dlogv[s];
     }
     return OAK_OK;
+}
+
+// further columns of grouped sub-kernels, scaled like the owning dim's first column (zero past n, like xs)
+struct ExtraCols { short col[64]; double scale[64]; };
+__global__ void __launch_bounds__(256) featurize_extra_kernel(ExtraCols ec, const double* __restrict__ X, int64_t n, int ldx, int64_t ld,
+                                                              double* __restrict__ xx) {
+    const int q = blockIdx.y;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ld) return;
+    xx[(int64_t)q * ld + i] = i < n ? X[i * ldx + ec.col[q]] * ec.scale[q] : 0.0;
 }
 
 int featurize(oak_ctx* ctx, const PreparedKernel& pk, const double* dX, int64_t n, int32_t ldx, const char* bufname, Feat* out,
@@ -482,8 +500,16 @@ int featurize(oak_ctx* ctx, const PreparedKernel& pk, const double* dX, int64_t 
     const int D = pk.dd.D;
     const int64_t ld = ((n + 63) / 64) * 64 + 64;   // padded so tile loads never run past the array
     double* base = nullptr;
-    OAK_CHECK(get_buf_t(ctx, bufname, (size_t)((with_grad ? 5 : 2) * D * ld), &base));
+    const int nx = (int)pk.extra_cols.size();
+    OAK_CHECK(get_buf_t(ctx, bufname, (size_t)((with_grad ? 5 : 2) * D + nx) * ld, &base));
     out->xs = base; out->cn = base + (size_t)D * ld; out->n = n; out->ld = ld;
+    out->nx = nx; out->xx = nx > 0 ? base + (size_t)(with_grad ? 5 : 2) * D * ld : nullptr;
+    if (nx > 0) {
+        ExtraCols ec;
+        for (int q = 0; q < nx; ++q) { ec.col[q] = (short)pk.extra_cols[q]; ec.scale[q] = pk.extra_scale[q]; }
+        featurize_extra_kernel<<<dim3((unsigned)((ld + 255) / 256), (unsigned)nx), 256, 0, ctx->stream>>>(ec, dX, n, ldx, ld, out->xx);
+        OAK_HIP_CHECK(hipGetLastError());
+    }
     out->dcn = with_grad ? base + (size_t)2 * D * ld : nullptr;
     out->xs32 = with_grad ? base + (size_t)3 * D * ld : nullptr;
     out->dcs = with_grad ? base + (size_t)4 * D * ld : nullptr;

@@ -269,7 +269,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     }
     const bool lazy = ctx->auto_pending;
     bool whiten = lazy ? false : sgpr_route_whitened(ctx);
-    const bool use32 = want32 && !whiten && pk.dd.R <= 16;       // the fp32 Gram kernel is instantiated to depth 16
+    const bool use32 = want32 && !whiten && pk.dd.R <= 16 && !pk.grouped;       // the fp32 Gram kernel is instantiated to depth 16
     float* dPanel32 = nullptr;
     if (use32) OAK_CHECK(get_buf_t(ctx, "panel_f32", (size_t)rows * Mp, &dPanel32));
     double *dLw = nullptr, *dLinvw = nullptr;      // whitened route: L and (when it exists) the explicit L^-1 whose diagonal blocks the solve applies
@@ -745,7 +745,7 @@ int oak_gram(oak_ctx* ctx, const oak_kernel_desc* desc, const double* X1, int64_
     OAK_REQUIRE(X1 && out && n1 >= 0 && ldx >= 1, "oak_gram: bad arguments");
     if (n1 == 0 || (X2 && n2 == 0)) return OAK_OK;
     PreparedKernel pk;
-    OAK_CHECK(prepare_kernel(ctx, desc, &pk, true));
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk, PK_DEEP | PK_GROUPED));
     return gram_to_host(ctx, pk, X1, n1, X2, n2, ldx, out);
 }
 
@@ -790,7 +790,7 @@ int oak_gram_diag(oak_ctx* ctx, const oak_kernel_desc* desc, const double* X, in
     OAK_REQUIRE(X && out && n >= 0 && ldx >= 1, "oak_gram_diag: bad arguments");
     if (n == 0) return OAK_OK;
     PreparedKernel pk;
-    OAK_CHECK(prepare_kernel(ctx, desc, &pk, true));
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk, PK_DEEP | PK_GROUPED));
     return gram_diag_to_host(ctx, pk, X, n, ldx, out);
 }
 
@@ -906,7 +906,7 @@ int oak_sgpr_set_panel_rows(oak_ctx* ctx, int64_t rows) {
 int oak_sgpr_local_stats(oak_ctx* ctx, const oak_kernel_desc* desc, double jitter) {
     OAK_CHECK(guard(ctx));
     PreparedKernel pk;
-    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk, PK_GROUPED));
     return sgpr_local_stats(ctx, pk, jitter);
 }
 
@@ -966,14 +966,14 @@ int oak_sgpr_set_stats(oak_ctx* ctx, const double* packed, int32_t whitened) {
 int oak_sgpr_tail(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, double jitter, double* elbo_out, double* terms_out) {
     OAK_CHECK(guard(ctx));
     PreparedKernel pk;
-    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk, PK_GROUPED));
     return sgpr_tail(ctx, pk, noise_var, jitter, elbo_out, terms_out);
 }
 
 int oak_sgpr_elbo(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, double jitter, double* elbo_out) {
     OAK_CHECK(guard(ctx));
     PreparedKernel pk;
-    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk, PK_GROUPED));
     PhaseTimer t(ctx, "total");
     OAK_CHECK(sgpr_forward(ctx, pk, noise_var, jitter, elbo_out, nullptr));
     t.stop();
@@ -1004,7 +1004,7 @@ int oak_sgpr_predict(oak_ctx* ctx, const oak_kernel_desc* desc, const double* Xs
     if (!ctx->have_post) { set_error("SGPR posterior not available: call oak_sgpr_elbo/oak_sgpr_tail first"); return OAK_E_STATE; }
     if (Ns == 0) return OAK_OK;
     PreparedKernel pk;
-    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk, PK_GROUPED));
     const int64_t M = ctx->M;
     double* dL = (double*)peek_buf(ctx, "L");
     double* dLB = (double*)peek_buf(ctx, "LB");
@@ -1077,7 +1077,7 @@ int oak_gpr_log_marginal(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
     OAK_REQUIRE(ctx->g_have_data, "GPR: set_data must be called first");
     OAK_REQUIRE(noise_var > 0.0, "noise variance must be positive");
     PreparedKernel pk;
-    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk, PK_GROUPED));
     const int64_t N = ctx->gN;
     Feat FX;
     OAK_CHECK(featurize(ctx, pk, (double*)peek_buf(ctx, "gprX"), N, ctx->gldx, "gprF", &FX));
@@ -1156,7 +1156,7 @@ int oak_gpr_predict(oak_ctx* ctx, const oak_kernel_desc* desc, const double* Xs,
     if (!ctx->g_have_post) { set_error("GPR posterior not available: call oak_gpr_log_marginal first"); return OAK_E_STATE; }
     if (Ns == 0) return OAK_OK;
     PreparedKernel pk;
-    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk, PK_GROUPED));
     const int64_t N = ctx->gN;
     double* dL = (double*)peek_buf(ctx, "gprL");
     double* dalpha = (double*)peek_buf(ctx, "gpralpha");

@@ -273,7 +273,7 @@ int oak_svgp_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, const double* 
     SvQuad quad;
     OAK_CHECK(sv_quad(gh_x, gh_w, n_gh, link, link_eps, &quad));
     PreparedKernel pk;
-    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk, PK_GROUPED));
     const int64_t N = ctx->N, M = ctx->M, Mp = ((M + 127) / 128) * 128;
     OAK_REQUIRE((double)N * (double)Mp * 8.0 * 3.0 <= 160e9, "SVGP: N x M = %lld x %lld does not fit the unchunked path", (long long)N, (long long)M);
     PhaseTimer ttot(ctx, "total");
@@ -440,7 +440,7 @@ int oak_svgp_predict(oak_ctx* ctx, const oak_kernel_desc* desc, const double* q_
     if (Ys != nullptr) OAK_CHECK(sv_quad(gh_x, gh_w, n_gh, link, link_eps, &quad));
     if (Ns == 0) return OAK_OK;
     PreparedKernel pk;
-    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk, PK_GROUPED));
     const int64_t M = ctx->M;
     Feat FZ, FS;
     double *dL, *dqmu, *ds2m1;
@@ -482,7 +482,7 @@ int oak_svgp_posterior(oak_ctx* ctx, const oak_kernel_desc* desc, const double* 
     OAK_REQUIRE(desc && q_mu && q_sqrt && alpha_out, "oak_svgp_posterior: bad arguments");
     OAK_REQUIRE(ctx->have_Z, "SVGP: oak_sgpr_set_inducing must be called first");
     PreparedKernel pk;
-    OAK_CHECK(prepare_kernel(ctx, desc, &pk));
+    OAK_CHECK(prepare_kernel(ctx, desc, &pk, PK_GROUPED));
     const int64_t M = ctx->M;
     if (L_out != nullptr) {
         for (int64_t j = 0; j < M; ++j)

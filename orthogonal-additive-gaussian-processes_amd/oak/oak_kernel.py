@@ -58,7 +58,7 @@ def _sub_kernel_spec(k, col: int) -> dict:
         out = dict(type="rbf", lengthscale=float(ls[0]), variance=float(np.asarray(_as_value(k.variance)).reshape(-1)[0]),
                    measure=None, active_dim=col)
         if len(_columns(k)) > 1:
-            out["active_dims"] = _columns(k)        # one RBF over the group's columns: explicit Gram entry points only
+            out["active_dims"] = _columns(k)        # one RBF over the group's columns
         return out
     raise NotImplementedError(f"no HIP description for sub-kernel {type(k).__name__}")
 

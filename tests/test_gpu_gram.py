@@ -457,7 +457,7 @@ def test_grouped_active_dims_are_one_rbf_over_the_group(hip):
     """OAKKernel(active_dims=[[0, 1], [2], [4, 3, 5]], constrain_orthogonal=False): the reference evaluates each group as ONE
     base kernel over the group's columns (oak/oak_kernel.py:74-82,199-210) -- for the RBF a product of one-column RBFs with a
     shared lengthscale.  K and K_diag through the host mirror against the oracle (rbf_K on the group's columns), in the
-    native and in the reference arithmetic; the fused model paths refuse a grouped kernel loudly."""
+    native and in the reference arithmetic."""
     from oak import gpflow_lite as gpflow
     from oak.oak_kernel import OAKKernel, kernel_to_spec
     groups = [[0, 1], [2], [4, 3, 5]]
@@ -487,10 +487,9 @@ def test_grouped_active_dims_are_one_rbf_over_the_group(hip):
         assert np.abs(hip.gram(_capi.KernelDesc(spec), X, X2) - ref).max() <= 1e-13 * np.abs(ref).max()
     finally:
         hip.set_gram_form("native")
-    ctx = _capi.HipContext(0)
+    ctx = _capi.HipContext(0)     # the model paths take the grouped description too (tests/test_gpu_grouped.py)
     ctx.sgpr_set_data(X, X[:, :1]); ctx.sgpr_set_inducing(X2)
-    with pytest.raises(ValueError, match="several columns"):
-        ctx.sgpr_elbo(_capi.KernelDesc(spec), 0.1)
+    np.testing.assert_allclose(ctx.sgpr_elbo(_capi.KernelDesc(spec), 0.1), o.sgpr_elbo(spec, X, X[:, :1], X2, 0.1), rtol=1e-9)
     ctx.close()
     # a constrained kernel is one-dimensional in the reference too (ortho_rbf_kernel.py:50,83)
     with pytest.raises(NotImplementedError):
