@@ -86,8 +86,8 @@ typedef struct oak_kernel_desc {
        columns with one lengthscale, i.e. the product of its one-column RBFs).  extra_col_off [D + 1] / extra_cols: the columns
        of sub-kernel d BEYOND active_col[d] are extra_cols[extra_col_off[d] .. extra_col_off[d + 1]).  Both NULL = every
        sub-kernel reads one column.  Taken by oak_gram*, the SGPR / GPR / SVGP objectives, their hyper-parameter gradients,
-       predictions and components; the inducing-input gradient (gradZ_out != NULL), oak_sobol* and oak_gram_f32 refuse a
-       grouped description (OAK_E_ARG), the fp32 statistics mode falls back to fp64 for it. */
+       predictions, components and the inducing-input gradient (every column of a group gets its entry of gradZ_out);
+       oak_sobol* and oak_gram_f32 refuse a grouped description (OAK_E_ARG), the fp32 statistics mode falls back to fp64. */
     const int32_t* extra_col_off;
     const int32_t* extra_cols;
 } oak_kernel_desc;
@@ -234,7 +234,8 @@ int oak_sgpr_elbo_grad(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_v
 /* Same, plus the gradient with respect to the inducing inputs (create_model_oak(zfixed=False),
    oak/model_utils.py:156-157; TensorFlow autodiff through Kuf and Kuu in the reference).  gradZ_out is M x ldx
    row-major like Z; columns that no RBF sub-kernel reads, and binary / categorical columns, get 0.  Costs one more
-   pass over the N x M pairs; supported for 1 <= max_depth <= 4 and num_dims <= 32.  gradZ_out may be NULL. */
+   pass over the N x M pairs (register-resident kernels for an effective depth <= 4 with <= 32 sub-kernels or <= 8 with <= 16,
+   a general kernel -- about 4-5x slower -- for every other shape, incl. grouped sub-kernels).  gradZ_out may be NULL. */
 int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, double jitter,
                          double* elbo_out, double* grad_out, double* gradZ_out);
 

@@ -781,6 +781,113 @@ gram_bwd_z_kernel(const DevDesc dd, const double* __restrict__ tables, const dou
         if (jb + idx / DMAX < nb) out[idx] = accum[idx];
 }
 
+// General form of the inducing-input gradient: any depth the backward pass is instantiated for, up to OAK_MAX_DIMS sub-kernels,
+// grouped sub-kernels (the further columns of a group get their own output slots D .. D + nx - 1).  64 columns (inducing points)
+// per workgroup, one per lane; the waves of a workgroup take the rows in turn and keep their own accumulators [zd][64] in LDS
+// (as many waves as fit, merged in wave order at the end: deterministic).  Two passes per pair like gram_bwd_kernel -- e_1..e_R,
+// then the leave-one-out coefficient of every sub-kernel -- with the row features read as wave-uniform scalars.  Same output
+// scaling as the fast kernel: slot value = sum g dK/dk_d (E u / 32 - cn_d(x) dzb), times 64 ln2 s_d on the host.
+template <int R>
+__global__ void __launch_bounds__(256)
+gram_bwd_z_general_kernel(const DevDesc dd, const double* __restrict__ tables, const double* __restrict__ Axs, const double* __restrict__ Acn,
+                          const double* __restrict__ Axx, int64_t a_ld, int64_t a0, int64_t na, const double* __restrict__ Bxs,
+                          const double* __restrict__ Bcn, const double* __restrict__ Bdz, const double* __restrict__ Bxx, int64_t b_ld, int64_t nb,
+                          const double* __restrict__ G, int64_t ldg, const double* __restrict__ yA, const double* __restrict__ avec, double g_scale,
+                          int rows_per_wg, int nx, double* __restrict__ partial) {
+    constexpr int TJ = 64;
+    constexpr int RR = R > 0 ? R : 1;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int D = dd.D, zd = D + nx;
+    const int nw = blockDim.x >> 6;
+    double* Bx = smem;                  // [D][64]
+    double* Bc = Bx + D * TJ;
+    double* Bd = Bc + D * TJ;
+    double* Bq = Bd + D * TJ;           // [nx][64]
+    double* Tab = Bq + nx * TJ;         // [64]
+    double* acc = Tab + 64;             // [nw][zd][64]
+    const int tid = threadIdx.x, tx = tid & 63;
+    const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t jb = (int64_t)blockIdx.x * TJ;
+    const int64_t ib = (int64_t)blockIdx.y * rows_per_wg;
+    const int64_t iend = (ib + rows_per_wg < na) ? ib + rows_per_wg : na;
+    for (int idx = tid; idx < D * TJ; idx += blockDim.x) {
+        const int d = idx / TJ, j = idx - d * TJ;
+        const bool ok = jb + j < nb;
+        Bx[idx] = ok ? Bxs[(int64_t)d * b_ld + jb + j] : 0.0;
+        Bc[idx] = ok ? Bcn[(int64_t)d * b_ld + jb + j] : 0.0;
+        Bd[idx] = ok ? Bdz[(int64_t)d * b_ld + jb + j] : 0.0;
+    }
+    for (int idx = tid; idx < nx * TJ; idx += blockDim.x) {
+        const int q = idx / TJ, j = idx - q * TJ;
+        Bq[idx] = (jb + j < nb) ? Bxx[(int64_t)q * b_ld + jb + j] : 0.0;
+    }
+    if (tid < 64) Tab[tid] = c_exp2_table_g[tid];
+    for (int idx = tid; idx < nw * zd * TJ; idx += blockDim.x) acc[idx] = 0.0;
+    __syncthreads();
+    double* my = acc + (size_t)ty * zd * TJ + tx;
+    const int64_t col = jb + tx;
+    const double av = (avec != nullptr && col < nb) ? avec[col] : 0.0;
+    for (int64_t i = ib + ty; i < iend; i += nw) {
+        const int64_t gi = a0 + i;
+        double g = 0.0;
+        if (col < nb) g = g_scale * G[i * ldg + col] + (yA != nullptr ? yA[gi] * av : 0.0);
+        double e[RR];
+#pragma unroll
+        for (int q = 0; q < RR; ++q) e[q] = 0.0;
+        auto pair_k = [&](int d, double& E, double& u) -> double {     // k_d of this pair; E and u of the dim's first column
+            const double xa = Axs[(int64_t)d * a_ld + gi];
+            if (dd.type[d] == OAK_DIM_RBF) {
+                u = xa - Bx[d * TJ + tx];
+                double t = __builtin_fma(-u, u, dd.log2bv[d]);
+                for (int q = dd.xrow[d]; q < dd.xrow[d] + dd.nxc[d]; ++q) {
+                    const double uq = Axx[(int64_t)q * a_ld + gi] - Bq[q * TJ + tx];
+                    t = __builtin_fma(-uq, uq, t);
+                }
+                E = exp2_neg_tab(t, Tab);
+                return __builtin_fma(-Acn[(int64_t)d * a_ld + gi], Bc[d * TJ + tx], E);
+            }
+            E = 0.0; u = 0.0;
+            return tables[dd.tab_off[d] + (int)xa * dd.ncat[d] + (int)Bx[d * TJ + tx]];
+        };
+        if constexpr (R > 0) {
+            for (int d = 0; d < D; ++d) {
+                double E, u;
+                const double k = pair_k(d, E, u);
+#pragma unroll
+                for (int q = R - 1; q >= 1; --q) e[q] = __builtin_fma(k, e[q - 1], e[q]);
+                e[0] += k;
+            }
+            for (int d = 0; d < D; ++d) {
+                if (dd.type[d] != OAK_DIM_RBF) continue;
+                double E, u;
+                const double k = pair_k(d, E, u);
+                double f = 1.0, coef = dd.w[1];
+#pragma unroll
+                for (int q = 1; q < R; ++q) {
+                    f = __builtin_fma(-k, f, e[q - 1]);
+                    coef = __builtin_fma(dd.w[q + 1], f, coef);
+                }
+                const double gc = g * coef;
+                const double zc = __builtin_fma(-Acn[(int64_t)d * a_ld + gi], Bd[d * TJ + tx], E * (u * 0.03125));
+                my[d * TJ] = __builtin_fma(gc, zc, my[d * TJ]);
+                for (int q = dd.xrow[d]; q < dd.xrow[d] + dd.nxc[d]; ++q) {
+                    const double uq = Axx[(int64_t)q * a_ld + gi] - Bq[q * TJ + tx];
+                    my[(D + q) * TJ] = __builtin_fma(gc, E * (uq * 0.03125), my[(D + q) * TJ]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    double* out = partial + ((int64_t)blockIdx.y * nb + jb) * zd;
+    for (int idx = tid; idx < TJ * zd; idx += blockDim.x) {
+        const int j = idx / zd, slot = idx - j * zd;
+        if (jb + j >= nb) continue;
+        double v = acc[(size_t)slot * TJ + j];
+        for (int w = 1; w < nw; ++w) v += acc[((size_t)w * zd + slot) * TJ + j];
+        out[idx] = v;
+    }
+}
+
 // gz[m][d] += sum over row blocks (fixed order)
 __global__ void __launch_bounds__(256) reduce_gz_kernel(const double* __restrict__ partial, int64_t nrb, int64_t len, double* __restrict__ gz) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -1005,15 +1112,63 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     return OAK_OK;
 }
 
+// stride of the inducing-input gradient buffer: the fast kernels' padded dim count, or one slot per column a sub-kernel reads
+bool gram_bwd_z_fast(const PreparedKernel& pk) {
+    const int D = pk.dd.D, R = pk.dd.R;
+    return !pk.grouped && R >= 1 && D <= 32 && (R <= 4 || (R <= 8 && D <= 16)) && getenv("OAK_BWDZ_GENERAL") == nullptr;
+}
+int gram_bwd_z_stride(const PreparedKernel& pk) {
+    if (gram_bwd_z_fast(pk)) return pk.dd.D <= 8 ? 8 : (pk.dd.D <= 16 ? 16 : 32);
+    return pk.dd.D + (pk.grouped ? (int)pk.extra_cols.size() : 0);
+}
+
+static int gram_bwd_z_general(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int64_t na, const Feat& B, const double* d_dzb,
+                              const double* d_G, int64_t ldg, double g_scale, const double* d_yA, const double* d_avec, double* d_gz) {
+    const int D = pk.dd.D, R = pk.dd.R;
+    if (R < 1) return OAK_OK;                                   // a constant kernel does not depend on the inducing inputs
+    const int nx = pk.grouped ? A.nx : 0, zd = D + nx;
+    if (pk.grouped) OAK_REQUIRE(A.xx != nullptr && B.xx != nullptr && A.nx == B.nx, "gram_bwd_z: features lack the grouped sub-kernels' further columns");
+    int nw = 4;
+    auto lds_for = [&](int w) { return sizeof(double) * ((size_t)(3 * D + nx) * 64 + 64 + (size_t)w * zd * 64); };
+    while (nw > 1 && lds_for(nw) > 160 * 1024) nw >>= 1;
+    const size_t lds = lds_for(nw);
+    OAK_REQUIRE(lds <= 160 * 1024, "gradient w.r.t. inducing inputs: %d sub-kernels with %d further columns need %zu bytes of LDS", D, nx, lds);
+    const int64_t nb = B.n, ncb = (nb + 63) / 64;
+    int64_t nrb = ((int64_t)ctx->num_cu * 4 + ncb - 1) / ncb;
+    int64_t rows = (na + nrb - 1) / nrb;
+    if (rows < 4) rows = 4;
+    nrb = (na + rows - 1) / rows;
+    if (nrb > 65535) { rows = (na + 65534) / 65535; nrb = (na + rows - 1) / rows; }
+    double* d_part = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "bwdz_part", (size_t)nrb * nb * zd, &d_part));
+    dim3 grid((unsigned)ncb, (unsigned)nrb);
+#define OAK_BZG(RR) case RR: {                                                                                                        \
+        auto kern = gram_bwd_z_general_kernel<RR>;                                                                                        \
+        if (lds > 64 * 1024) OAK_CHECK(ensure_max_dynamic_lds((const void*)kern));                                                        \
+        kern<<<grid, 64 * nw, lds, ctx->stream>>>(pk.dd, pk.d_tables, A.xs, A.cn, A.xx, A.ld, a0, na, B.xs, B.cn, d_dzb, B.xx, B.ld, nb,  \
+                                                  d_G, ldg, d_yA, d_avec, g_scale, (int)rows, nx, d_part);                                \
+    } break;
+    switch (template_depth(R)) {
+        OAK_BZG(1) OAK_BZG(2) OAK_BZG(3) OAK_BZG(4) OAK_BZG(5) OAK_BZG(6) OAK_BZG(7) OAK_BZG(8) OAK_BZG(12) OAK_BZG(16) OAK_BZG(24) OAK_BZG(32)
+        default: set_error("gram_bwd_z: unsupported depth %d", R); return OAK_E_ARG;
+    }
+#undef OAK_BZG
+    OAK_HIP_CHECK(hipGetLastError());
+    const int64_t len = nb * zd;
+    reduce_gz_kernel<<<(unsigned)((len + 255) / 256), 256, 0, ctx->stream>>>(d_part, nrb, len, d_gz);
+    OAK_HIP_CHECK(hipGetLastError());
+    return OAK_OK;
+}
+
 // d_gz[nb][dmax] += column-side contraction of G (+ optional rank-1 yA avec^T) with dK/dz over the pairs (A rows a0.., B);
-// d_dzb = featurize_dx of the B points.  Supported for 1 <= R <= 4 with D <= 32 and for 5 <= R <= 8 with D <= 16 (the register-resident pair walk).
+// d_dzb = featurize_dx of the B points, dmax = gram_bwd_z_stride(pk).  Depth <= 4 with <= 32 dims and depth <= 8 with <= 16 take the
+// register-resident pair walk; everything else (deeper, wider, grouped sub-kernels) the general kernel above.
 int gram_bwd_z(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int64_t na, const Feat& B, const double* d_dzb,
                const double* d_G, int64_t ldg, double g_scale, const double* d_yA, const double* d_avec, double* d_gz, int dmax) {
     if (na <= 0 || B.n <= 0) return OAK_OK;
     const int D = pk.dd.D, R = pk.dd.R;
-    OAK_REQUIRE(!pk.grouped, "gradient w.r.t. inducing inputs: a sub-kernel over several columns is not supported");
-    OAK_REQUIRE(R >= 1 && D <= 32 && (R <= 4 || (R <= 8 && D <= 16)),
-                "gradient w.r.t. inducing inputs needs an effective depth <= 4 with <= 32 dims or <= 8 with <= 16 dims (got depth %d, %d dims)", R, D);
+    OAK_REQUIRE(dmax == gram_bwd_z_stride(pk), "gram_bwd_z: buffer stride %d does not match the kernel description", dmax);
+    if (!gram_bwd_z_fast(pk)) return gram_bwd_z_general(ctx, pk, A, a0, na, B, d_dzb, d_G, ldg, g_scale, d_yA, d_avec, d_gz);
     OAK_REQUIRE(A.xs32 != nullptr && B.xs32 != nullptr, "gram_bwd_z: features were not prepared for the backward pass");
     bool allrbf = true, unitbv = true;
     for (int d = 0; d < D; ++d) {
@@ -1299,7 +1454,7 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
         OAK_CHECK(featurize(ctx, pk, (double*)peek_buf(ctx, "X"), N, ctx->ldx, "featXg", &FX, true));
     }
     // optional: gradient w.r.t. the inducing inputs (second pair pass, column-side accumulators)
-    const int zdmax = pk.dd.D <= 8 ? 8 : (pk.dd.D <= 16 ? 16 : 32);
+    const int zdmax = gram_bwd_z_stride(pk);
     double *d_dzb = nullptr, *d_gz = nullptr;
     if (gradZ_out != nullptr) {
         OAK_CHECK(get_buf_t(ctx, "featZ_dx", (size_t)pk.dd.D * FZ.ld, &d_dzb));
@@ -1392,6 +1547,8 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
             if (pk.dd.type[d] != OAK_DIM_RBF) continue;                       // discrete inputs have no derivative
             const double cd = 64.0 * 0.6931471805599453094 * pk.dd.scale[d];  // divided out in featurize_dx_kernel / the pair kernel
             for (int64_t m = 0; m < M; ++m) gradZ_out[m * ldz + pk.dd.col[d]] += cd * gz[(size_t)m * zdmax + d];
+            for (int q = pk.dd.xrow[d]; q < pk.dd.xrow[d] + pk.dd.nxc[d]; ++q)          // a group's further columns (general kernel: slots D + q)
+                for (int64_t m = 0; m < M; ++m) gradZ_out[m * ldz + pk.extra_cols[q]] += cd * gz[(size_t)m * zdmax + pk.dd.D + q];
         }
     }
     if (elbo_out) *elbo_out = elbo;

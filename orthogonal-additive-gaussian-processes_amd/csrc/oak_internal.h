@@ -191,8 +191,8 @@ void debug_mark(oak_ctx* ctx, const char* literal);      // breadcrumb: the last
 inline int template_depth(int R) { return R <= 8 ? R : (R <= 12 ? 12 : (R <= 16 ? 16 : (R <= 24 ? 24 : 32))); }
 // allow: what the caller's kernels can evaluate beyond the fused pair kernels' common ground
 constexpr int PK_DEEP = 1;       // effective depth > OAK_MAX_DEPTH (the explicit Gram entry points' generic kernel)
-constexpr int PK_GROUPED = 2;    // sub-kernels over several columns (gram / gram_diag / gram_bwd / diag_bwd take them; the fp32, inducing-input
-                                 // gradient and Sobol kernels do not)
+constexpr int PK_GROUPED = 2;    // sub-kernels over several columns (gram / gram_diag / gram_bwd / gram_bwd_z / diag_bwd take them; the fp32
+                                 // and Sobol kernels do not)
 int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk, int allow = 0);
 // component (single subset) description derived from a full one
 int prepare_component(oak_ctx* ctx, const oak_kernel_desc* desc, const int32_t* subset, int32_t len,

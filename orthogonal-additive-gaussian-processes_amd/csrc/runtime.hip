@@ -339,8 +339,8 @@ int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk
     }
     if (pk->grouped && !(allow & PK_GROUPED)) {
         set_error("a sub-kernel over several columns (OAKKernel(active_dims=[[0, 1], ...])) is not evaluated by this entry point "
-                  "(K / K_diag, the SGPR / GPR / SVGP objectives, their hyper-parameter gradients and predictions are; the "
-                  "inducing-input gradient, the Sobol pass and the fp32 Gram take one column per sub-kernel)");
+                  "(K / K_diag, the SGPR / GPR / SVGP objectives, their gradients and predictions are; the Sobol pass and "
+                  "the fp32 Gram take one column per sub-kernel)");
         return OAK_E_ARG;
     }
     OAK_REQUIRE(pk->extra_cols.size() <= 64, "grouped sub-kernels: %zu extra columns (at most 64)", pk->extra_cols.size());

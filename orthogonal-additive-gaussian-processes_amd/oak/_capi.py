@@ -193,7 +193,7 @@ class KernelDesc:
     ("uniform", a, b) | ("empirical", loc, w) | ("mog", means, vars, w), "active_dim": col (optional)},
     {"type": "binary", "p0", "variance"}, {"type": "categorical", "p", "W", "kappa", "variance"}.
     An unconstrained rbf dim may carry "active_dims": [c0, c1, ...] instead of "active_dim": one RBF over those columns
-    (OAKKernel(active_dims=[[0, 1], ...]), oak_kernel.py:74-82); every model path takes it except the inducing-input gradient and Sobol.
+    (OAKKernel(active_dims=[[0, 1], ...]), oak_kernel.py:74-82); every model path takes it except Sobol (undefined for unconstrained kernels).
     """
 
     def __init__(self, spec: dict):

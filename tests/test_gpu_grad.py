@@ -297,6 +297,60 @@ def test_gradient_wrt_inducing_inputs(hip, route, kinds, D, R, share):
         assert abs(gz[m, c] - fd) <= 2e-5 * max(1.0, abs(fd)), f"Z[{m},{c}] ({spec['dims'][c].get('measure')}): {gz[m, c]} vs {fd}"
 
 
+@pytest.mark.parametrize("kinds,D,R,share", [(("gaussian", "uniform"), 12, 10, True), (("gaussian", "binary", "mog"), 20, 6, True),
+                                            (("gaussian", "categorical", "none"), 36, 3, False), (("gaussian",), 40, 2, True),
+                                            (("gaussian", "gauss2"), 18, 18, True)])
+def test_gradient_wrt_inducing_inputs_beyond_the_register_resident_shapes(hip, kinds, D, R, share):
+    """Depth > 8, or > 16 dims above depth 4, or > 32 dims: the general inducing-input kernel (one column per lane, per-wave LDS
+    accumulators).  Entries of Z against central differences of the oracle; discrete columns exactly 0."""
+    rng = np.random.default_rng(D * 11 + R)
+    spec = cases.random_spec(rng, D, R, kinds, share=share)
+    N, M = 140, 70                       # two column blocks of 64, the second one ragged
+    X = cases.random_inputs(rng, spec, N)
+    Z = cases.random_inputs(rng, spec, M)
+    y = rng.standard_normal((N, 1))
+    s2 = 0.2
+    d = _capi.KernelDesc(spec)
+    hip.sgpr_set_data(X, y); hip.sgpr_set_inducing(Z); hip.sgpr_set_route("whitened")
+    e0, g0 = hip.sgpr_elbo_grad(d, s2)
+    e, g, gz = hip.sgpr_elbo_grad_z(d, s2, M, D)
+    assert e == e0 and gz.shape == (M, D)
+    np.testing.assert_allclose(g, g0, rtol=1e-12, atol=1e-12 * np.abs(g0).max())
+    for (m, c) in [(m, c) for m in (0, 63, 64, M - 1) for c in (0, 1, 2, D // 2, D - 1)]:
+        if spec["dims"][c]["type"] != "rbf":
+            assert gz[m, c] == 0.0
+            continue
+        h = 1e-5
+        Zp, Zm = Z.copy(), Z.copy()
+        Zp[m, c] += h; Zm[m, c] -= h
+        fd = (o.sgpr_elbo(spec, X, y, Zp, s2) - o.sgpr_elbo(spec, X, y, Zm, s2)) / (2 * h)
+        assert abs(gz[m, c] - fd) <= 3e-5 * max(1.0, abs(fd)), f"Z[{m},{c}]: {gz[m, c]} vs {fd}"
+
+
+def test_general_and_register_resident_inducing_input_kernels_agree(monkeypatch):
+    """OAK_BWDZ_GENERAL=1 sends a shape the fast kernels cover through the general one: same gradient to rounding, at a size
+    with several row blocks and every sub-kernel type."""
+    rng = np.random.default_rng(77)
+    spec = cases.random_spec(rng, 7, 3, ("gaussian", "binary", "uniform", "categorical", "mog", "none", "gauss2"), share=False)
+    N, M = 3000, 150
+    X = cases.random_inputs(rng, spec, N)
+    Z = cases.random_inputs(rng, spec, M)
+    y = rng.standard_normal((N, 1))
+    d = _capi.KernelDesc(spec)
+    out = {}
+    for mode in ("fast", "general"):
+        if mode == "general":
+            monkeypatch.setenv("OAK_BWDZ_GENERAL", "1")
+        ctx = _capi.HipContext(0)
+        ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("whitened")
+        out[mode] = ctx.sgpr_elbo_grad_z(d, 0.1, M, 7)
+        ctx.close()
+    assert out["fast"][0] == out["general"][0]
+    np.testing.assert_array_equal(out["fast"][1], out["general"][1])
+    scale = np.abs(out["fast"][2]).max()
+    np.testing.assert_allclose(out["general"][2], out["fast"][2], rtol=0, atol=1e-11 * scale)
+
+
 def test_trainable_inducing_inputs_through_the_model_api():
     """create_model_oak(zfixed=False) (oak/model_utils.py:156-157): Z joins the trainable variables, the model-level loss
     gradient matches central differences of the loss in a few Z entries, and BFGS moves the inducing points while improving

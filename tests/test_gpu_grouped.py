@@ -162,9 +162,7 @@ def test_predictions_gpr_and_what_stays_refused(hip):
     rm, rv = o.gpr_predict_f(spec, X, y, s2, Xs)
     np.testing.assert_allclose(gm, rm.ravel(), rtol=1e-8, atol=1e-9)
     np.testing.assert_allclose(gv, rv.ravel(), rtol=1e-7, atol=1e-9)
-    # the inducing-input gradient and the Sobol pass keep one column per sub-kernel, and say so
-    with pytest.raises(ValueError, match="several columns"):
-        hip.sgpr_elbo_grad_z(desc, s2, len(Z), 6)
+    # the Sobol pass keeps one column per sub-kernel (the reference defines no Sobol index for an unconstrained kernel), and says so
     with pytest.raises(ValueError, match="several columns"):
         hip.sobol(desc, Z, np.ones(len(Z)), [[0], [0, 1]])
     # the fp32 statistics mode is not taken for a grouped kernel: same numbers as fp64
@@ -268,3 +266,28 @@ def test_components_of_a_grouped_kernel(hip):
             np.testing.assert_allclose(hip.gram_component(_capi.KernelDesc(specB), S, True, XB, XB[:17]), ref, rtol=0, atol=1e-13 * np.abs(ref).max())
     finally:
         hip.set_gram_form("native")
+
+
+@pytest.mark.parametrize("route", ["phi", "whitened"])
+def test_gradient_wrt_the_inducing_inputs_of_a_grouped_kernel(hip, route):
+    """Every column of a group is an input of the model: dF/dZ[m, c] for the group's first AND further columns against central
+    differences of the oracle (general inducing-input kernel: slot D + q for further column q)."""
+    rng = np.random.default_rng(31)
+    groups = [[0, 1], [2], [4, 3, 5], [6]]
+    spec = grouped_spec(rng, groups, 3, binary_at=3)
+    X, y, Z = problem(rng, 200, 70, 7, binary_col=6)
+    s2 = 0.12
+    desc = _capi.KernelDesc(spec)
+    hip.sgpr_set_data(X, y); hip.sgpr_set_inducing(Z); hip.sgpr_set_route(route)
+    e0, g0 = hip.sgpr_elbo_grad(desc, s2)
+    e, g, gz = hip.sgpr_elbo_grad_z(desc, s2, len(Z), 7)
+    assert e == e0 and gz.shape == (70, 7)
+    np.testing.assert_allclose(g, g0, rtol=1e-12, atol=1e-12 * np.abs(g0).max())
+    assert np.all(gz[:, 6] == 0.0)                     # the binary column
+    for m in (0, 33, 64, 69):
+        for c in range(6):
+            h = 1e-5
+            Zp, Zm = Z.copy(), Z.copy()
+            Zp[m, c] += h; Zm[m, c] -= h
+            ref = (o.sgpr_elbo(spec, X, y, Zp, s2) - o.sgpr_elbo(spec, X, y, Zm, s2)) / (2 * h)
+            assert abs(gz[m, c] - ref) <= 3e-5 * max(1.0, abs(ref)), f"Z[{m},{c}]: {gz[m, c]} vs {ref}"
