@@ -199,7 +199,9 @@ def test_random_multi_output_problems(seed):
         ctx.sgpr_set_data(X, Y[:, 0]); ctx.sgpr_set_extra_targets(Y[:, 1:])
         e, g = ctx.sgpr_elbo_grad(d, s2)
         er = o.sgpr_elbo(spec, X, Y, Z, s2)
-        assert abs(e - er) <= 1e-9 * abs(er) and abs(e - e_sum) <= 1e-10 * abs(e_sum), (e, er, e_sum)
+        # against the oracle: the phi route's error grows with cond(Kuu) (random inducing inputs over discrete columns repeat
+        # rows; the single-output tests allow it 1e-8 too); against the P single-output evaluations of the same route: 1e-10
+        assert abs(e - er) <= (1e-8 if route == "phi" else 1e-9) * abs(er) and abs(e - e_sum) <= 1e-10 * abs(e_sum), (e, er, e_sum)
         np.testing.assert_allclose(g, g_sum, rtol=1e-7, atol=1e-8 * np.abs(g_sum).max())
         # posterior of single outputs: the predictive mean (alpha itself is cond(Kuu)-sensitive with random inducing inputs: its
         # agreement with the oracle is no better for ONE output)
