@@ -291,3 +291,41 @@ def test_gradient_wrt_the_inducing_inputs_of_a_grouped_kernel(hip, route):
             Zp[m, c] += h; Zm[m, c] -= h
             ref = (o.sgpr_elbo(spec, X, y, Zp, s2) - o.sgpr_elbo(spec, X, y, Zm, s2)) / (2 * h)
             assert abs(gz[m, c] - ref) <= 3e-5 * max(1.0, abs(ref)), f"Z[{m},{c}]: {gz[m, c]} vs {ref}"
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_grouped_problems(hip, seed):
+    """Random groupings of 3..14 columns (groups of 1..4, shuffled), depth, route, sizes and variances: the bound against the
+    oracle, two hyper-parameter entries and two inducing-input entries against its differences.  OAK_FUZZ_SEED0 shifts the streams."""
+    import os
+    rng = np.random.default_rng(int(os.environ.get("OAK_FUZZ_SEED0", "0")) + 21000 + seed)
+    ncol = int(rng.integers(3, 15))
+    cols = [int(c) for c in rng.permutation(ncol)]
+    groups, i = [], 0
+    while i < ncol:
+        k = min(int(rng.integers(1, 5)), ncol - i)
+        groups.append(cols[i:i + k]); i += k
+    D = len(groups)
+    R = int(rng.integers(1, min(D, 5) + 1))
+    share = bool(rng.integers(0, 2))
+    spec = grouped_spec(rng, groups, R, share=share)
+    N, M = int(rng.integers(100, 900)), int(rng.choice([20, 33, 64, 70]))
+    X, y, Z = problem(rng, N, M, ncol)
+    s2 = float(rng.uniform(0.05, 0.4))
+    route = ("whitened", "phi")[seed % 2]
+    desc = _capi.KernelDesc(spec)
+    hip.sgpr_set_data(X, y); hip.sgpr_set_inducing(Z); hip.sgpr_set_route(route)
+    e, g, gz = hip.sgpr_elbo_grad_z(desc, s2, M, ncol)
+    np.testing.assert_allclose(e, o.sgpr_elbo(spec, X, y, Z, s2), rtol=1e-10 if route == "whitened" else 1e-8)
+    for d in rng.choice(D, size=min(2, D), replace=False):
+        def f(h, d=int(d)):
+            s = copy.deepcopy(spec); s["dims"][d]["lengthscale"] += h
+            return o.sgpr_elbo(s, X, y, Z, s2)
+        check(g[int(d)], fd(f), rtol=1e-4)
+    for _ in range(2):
+        m, c = int(rng.integers(0, M)), int(rng.integers(0, ncol))
+        def fz(h):
+            Zs = Z.copy(); Zs[m, c] += h
+            return o.sgpr_elbo(spec, X, y, Zs, s2)
+        ref = fd(fz)
+        assert abs(gz[m, c] - ref) <= 5e-5 * max(1.0, abs(ref)), f"seed {seed}: Z[{m},{c}] {gz[m, c]} vs {ref} (groups {groups}, depth {R}, {route})"
