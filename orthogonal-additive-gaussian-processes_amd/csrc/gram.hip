@@ -48,7 +48,7 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
             const double* __restrict__ Acn, int64_t a_ld, int64_t a0, int64_t na, const double* __restrict__ Bxs,
             const double* __restrict__ Bcn, int64_t b_ld, int64_t nb, double* __restrict__ out, int64_t ldo,
             int rows_per_wg, const double* __restrict__ yA, double* __restrict__ psi_part, int64_t zero_pad_to,
-            const double* __restrict__ Axx = nullptr, const double* __restrict__ Bxx = nullptr, int nx = 0) {
+            const double* __restrict__ Axx = nullptr, const double* __restrict__ Bxx = nullptr, int nx = 0, int tablen = 0) {
     constexpr int TJ = 64 * CPT;
     constexpr int RS = 4 * RT;   // rows per row-step
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -62,6 +62,7 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
     double* Ay = Ac + D * RS;          // [RS]
     double* Bq = Ay + RS;              // [nx][TJ]  further columns of grouped dims (GRP), pre-scaled like Bx
     double* Aq = Bq + (GRP ? nx : 0) * TJ;   // [nx][RS]
+    double* Tl = Aq + (GRP ? nx : 0) * RS;   // [tablen] discrete tables (mixed kernels; tablen = 0: they stay in global memory)
     const int tid = threadIdx.x;
     const int tx = tid & 63;
     const int ty = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -85,6 +86,9 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
         }
     }
     for (int j = tid; j < TABN; j += 256) Tab[j] = biased_table_entry<TB>(j);
+    if constexpr (!ALLRBF) {
+        for (int j = tid; j < tablen; j += 256) Tl[j] = tables[j];
+    }
     double psi[CPT];
 #pragma unroll
     for (int c = 0; c < CPT; ++c) psi[c] = 0.0;
@@ -162,12 +166,32 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
                         for (int c = 0; c < CPT; ++c) kk[r][c] = __builtin_fma(-ca[r], cb[c], E[c]);
                     }
                 } else {
+                    // a gather from the (tiny) table: out of LDS -- from global memory each dimension waited ~600 cycles on eight
+                    // dependent loads per lane and a binary input cost as much as an exponential one (C5: 0.30 ms per dimension)
+                    if (dd.type[d] == OAK_DIM_BINARY) {          // rank one: the factors ride in the cn slot (featurize_point)
+#pragma unroll
+                        for (int r = 0; r < RT; ++r)
+#pragma unroll
+                            for (int c = 0; c < CPT; ++c) kk[r][c] = ca[r] * cb[c];
+                    } else {
                     const int C = dd.ncat[d];
-                    const double* tab = tables + dd.tab_off[d];
+                    int ia[RT], ib[CPT];
 #pragma unroll
-                    for (int r = 0; r < RT; ++r)
+                    for (int r = 0; r < RT; ++r) ia[r] = dd.tab_off[d] + (int)xa[r] * C;
 #pragma unroll
-                        for (int c = 0; c < CPT; ++c) kk[r][c] = tab[(int)xa[r] * C + (int)xb[c]];
+                    for (int c = 0; c < CPT; ++c) ib[c] = (int)xb[c];
+                    if (tablen > 0) {
+#pragma unroll
+                        for (int r = 0; r < RT; ++r)
+#pragma unroll
+                            for (int c = 0; c < CPT; ++c) kk[r][c] = Tl[ia[r] + ib[c]];
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < RT; ++r)
+#pragma unroll
+                            for (int c = 0; c < CPT; ++c) kk[r][c] = tables[ia[r] + ib[c]];
+                    }
+                    }
                 }
 #pragma unroll
                 for (int r = 0; r < RT; ++r)
@@ -286,7 +310,10 @@ static int launch_gram_t(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, 
     // 1024-entry exp2 table unless its extra 4 KiB would lower the number of workgroups a CU holds (D = 32 at TJ = 128)
     const int nx = pk.grouped ? A.nx : 0;
     if (pk.grouped) OAK_REQUIRE(A.xx != nullptr && B.xx != nullptr && A.nx == B.nx, "gram: features lack the grouped sub-kernels' further columns");
-    const size_t lds_body = sizeof(double) * ((size_t)D * TJ * 2 + (size_t)D * RS * 2 + RS + (size_t)nx * (TJ + RS));
+    bool all_rbf = true;
+    for (int d = 0; d < D; ++d) all_rbf = all_rbf && pk.dd.type[d] == OAK_DIM_RBF;
+    const int tablen = (!all_rbf && pk.tables.size() <= 1024) ? (int)pk.tables.size() : 0;      // discrete tables ride in LDS up to 8 KiB
+    const size_t lds_body = sizeof(double) * ((size_t)D * TJ * 2 + (size_t)D * RS * 2 + RS + (size_t)nx * (TJ + RS) + (size_t)tablen);
     const size_t cu_lds = 160 * 1024;
     const bool big_table = cu_lds / (lds_body + sizeof(double) * 1024) == cu_lds / (lds_body + sizeof(double) * 512);
     size_t lds = lds_body + sizeof(double) * (big_table ? 1024 : 512);
@@ -309,15 +336,13 @@ static int launch_gram_t(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, 
     if (nrb > 65535) { rows = ((na + 65534) / 65535 + RS - 1) / RS * RS; nrb = (na + rows - 1) / rows; }
     double* d_part = nullptr;
     if (d_yA != nullptr) OAK_CHECK(get_buf_t(ctx, "psi_part", (size_t)(nrb * nb), &d_part));
-    bool all_rbf = true;
-    for (int d = 0; d < D; ++d) all_rbf = all_rbf && pk.dd.type[d] == OAK_DIM_RBF;
     auto kern = big_table ? (all_rbf ? gram_kernel<R, RT, CPT, true, 10> : gram_kernel<R, RT, CPT, false, 10>)
                           : (all_rbf ? gram_kernel<R, RT, CPT, true, 9> : gram_kernel<R, RT, CPT, false, 9>);
     if (nx > 0) kern = gram_kernel<R, RT, CPT, false, 9, true>;      // grouped sub-kernels: one instantiation per shape (512-entry table)
     if (lds > 64 * 1024) OAK_CHECK(ensure_max_dynamic_lds((const void*)kern));
     dim3 grid((unsigned)ncb, (unsigned)nrb);
     kern<<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, A.xs, A.cn, A.ld, a0, na, B.xs, B.cn, B.ld, nb, d_out, ldo,
-                                          (int)rows, d_yA, d_part, zero_pad_to, A.xx, B.xx, nx);
+                                          (int)rows, d_yA, d_part, zero_pad_to, A.xx, B.xx, nx, tablen);
     OAK_HIP_CHECK(hipGetLastError());
     if (d_yA != nullptr) {
         colsum_accum_kernel<<<(unsigned)((nb + 31) / 32), 256, 0, ctx->stream>>>(d_part, nrb, nb, d_psi);

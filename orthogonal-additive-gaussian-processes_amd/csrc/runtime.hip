@@ -170,6 +170,10 @@ __device__ __forceinline__ void featurize_point(const DevDesc& dd, const DevMeas
         const double hi = (double)(dd.ncat[d] - 1);
         t = t < 0.0 ? 0.0 : (t > hi ? hi : t);
         vx = t; vc = 0.0;
+        // the orthogonal binary kernel is rank one, bv * a(x) a(z) with a = (1 - p0, -p0) (ortho_binary_kernel.py:29-38): a(x) sqrt(bv) rides
+        // in the cn slot and the forward pair kernel multiplies instead of gathering from the table (same products as the table's entries
+        // when bv = 1)
+        if (dd.type[d] == OAK_DIM_BINARY) vc = (t == 0.0 ? 1.0 - dm.p0[d] : -dm.p0[d]) * dm.p1[d];
     }
 }
 
@@ -421,6 +425,7 @@ int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk
             }
         } else if (t == OAK_DIM_BINARY) {     // oak/ortho_binary_kernel.py:29-38
             const double p0 = desc->meas_p0[d], p1 = 1.0 - p0;
+            dm.p0[d] = p0; dm.p1[d] = std::sqrt(bv);          // featurize: the rank-one factor a(x) sqrt(bv)
             dd.ncat[d] = 2;
             dd.tab_off[d] = (int)pk->tables.size();
             const double tab[6] = {p1 * p1 * bv, -p0 * p1 * bv, -p0 * p1 * bv, p0 * p0 * bv, p1 * p1 * bv, p0 * p0 * bv};
