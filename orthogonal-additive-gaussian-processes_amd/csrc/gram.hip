@@ -14,6 +14,10 @@
 #include "exp2w.h"
 #include <cstdlib>
 
+#ifndef OAK_GRAM_PREFETCH
+#define OAK_GRAM_PREFETCH 1
+#endif
+
 namespace oak {
 
 template <int R>
@@ -93,8 +97,44 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
 #pragma unroll
     for (int c = 0; c < CPT; ++c) psi[c] = 0.0;
 
+#if OAK_GRAM_PREFETCH
+    // Row-side features of the NEXT row step are fetched into registers while the current one is computed (D * RS <= 1024 values per
+    // array: at most four per thread), raw and from clamped addresses; mask and pre-scale are applied when they go to LDS.  Without
+    // this the global loads sat between the two barriers of a step: every wave of the workgroup waited out an HBM latency per 16 rows.
+    // (the launcher pairs CPT = 4 and RT < 4 with D <= 16 and RT = 1 with RS = 4: one value per thread there; RT = 4, CPT = 2 goes to 64 dims)
+    constexpr int NS = (RT == 4 && CPT == 2) ? 4 : 1;
+    double rx[NS], rc[NS], ry = 0.0;
+    auto fetch_rows = [&](int64_t i0n) {
+#pragma unroll
+        for (int s4 = 0; s4 < NS; ++s4) {
+            const int idx = tid + 256 * s4;
+            const int d = idx / RS, r = idx - d * RS;
+            int64_t gi = i0n + r;
+            gi = gi < iend ? gi : iend - 1;
+            const bool in = idx < D * RS;
+            rx[s4] = in ? Axs[(int64_t)d * a_ld + a0 + gi] : 0.0;
+            rc[s4] = in ? Acn[(int64_t)d * a_ld + a0 + gi] : 0.0;
+        }
+        if (yA != nullptr && tid < RS) { const int64_t gi = i0n + tid; ry = yA[a0 + (gi < iend ? gi : iend - 1)]; }
+    };
+    if (ib < iend) fetch_rows(ib);
+#endif
     for (int64_t i0 = ib; i0 < iend; i0 += RS) {
         __syncthreads();   // previous step's readers done (and B-side staged on first pass)
+#if OAK_GRAM_PREFETCH
+#pragma unroll
+        for (int s4 = 0; s4 < NS; ++s4) {
+            const int idx = tid + 256 * s4;
+            if (idx < D * RS) {
+                const int d = idx / RS, r = idx - d * RS;
+                const bool ok = i0 + r < iend;
+                const double pre = (ALLRBF || dd.type[d] == OAK_DIM_RBF) ? 0.03125 : 1.0;
+                Ax[idx] = ok ? rx[s4] * pre : 0.0;
+                Ac[idx] = ok ? rc[s4] : 0.0;
+            }
+        }
+        if (yA != nullptr && tid < RS) Ay[tid] = (i0 + tid < iend) ? ry : 0.0;
+#else
         for (int idx = tid; idx < D * RS; idx += 256) {
             const int d = idx / RS, r = idx - d * RS;
             const int64_t gi = i0 + r;
@@ -104,6 +144,7 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
             Ac[idx] = ok ? Acn[(int64_t)d * a_ld + a0 + gi] : 0.0;
         }
         if (yA != nullptr && tid < RS) Ay[tid] = (i0 + tid < iend) ? yA[a0 + i0 + tid] : 0.0;
+#endif
         if constexpr (GRP) {
             for (int idx = tid; idx < nx * RS; idx += 256) {
                 const int q = idx / RS, r = idx - q * RS;
@@ -111,6 +152,9 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
             }
         }
         __syncthreads();
+#if OAK_GRAM_PREFETCH
+        if (i0 + RS < iend) fetch_rows(i0 + RS);
+#endif
 
         double e[RT][CPT][R > 0 ? R : 1];
 #pragma unroll
@@ -307,6 +351,7 @@ static int launch_gram_t(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, 
     constexpr int TJ = 64 * CPT;
     constexpr int RS = 4 * RT;
     const int D = pk.dd.D;
+    OAK_REQUIRE(D * RS <= ((RT == 4 && CPT == 2) ? 1024 : 256), "gram: %d sub-kernels do not fit this tile shape's row staging", D);
     // 1024-entry exp2 table unless its extra 4 KiB would lower the number of workgroups a CU holds (D = 32 at TJ = 128)
     const int nx = pk.grouped ? A.nx : 0;
     if (pk.grouped) OAK_REQUIRE(A.xx != nullptr && B.xx != nullptr && A.nx == B.nx, "gram: features lack the grouped sub-kernels' further columns");
