@@ -614,10 +614,17 @@ int oak_ctx_create(int device, oak_ctx** out) {
     }
     if (device < 0 || device >= n) { oak::set_error("device %d out of range [0,%d)", device, n); return OAK_E_ARG; }
     OAK_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    OAK_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    // The library holds gfx950 code objects only, and several kernels are sized for the 160 KiB of LDS of an MI355X CU (fused
+    // triangular solve, blocked Cholesky, Gram tiles at 32+ sub-kernels): say so here instead of failing inside an evaluation.
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        oak::set_error("device %d is %s: this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+        return OAK_E_HIP;
+    }
     oak_ctx* ctx = new oak_ctx();
     ctx->device = device;
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cu = prop.multiProcessorCount;
+    ctx->num_cu = prop.multiProcessorCount;
     // both streams are non-blocking: no implicit coupling to the legacy NULL stream, hence none between contexts
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || oak::create_side_stream(&ctx->side) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev0, hipEventDisableTiming) != hipSuccess ||
