@@ -53,7 +53,7 @@ static int gram_to_host(oak_ctx* ctx, const PreparedKernel& pk, const double* X1
     if (chunk > n1) chunk = n1;
     double* dK = nullptr;
     OAK_CHECK(get_buf_t(ctx, "gK", (size_t)chunk * n2, &dK));
-    const bool generic = pk.deep || pk.grouped || ctx->gram_form != 0;      // beyond depth 16, multi-column sub-kernels, or the reference-arithmetic A/B form
+    const bool generic = pk.deep || ctx->gram_form != 0;      // beyond the fused kernels' depth, or the reference-arithmetic A/B form (grouped sub-kernels: fused since r04)
     if (generic) OAK_REQUIRE(n1 <= 65535, "the generic Gram kernel (depth > %d or oak_set_gram_form) takes at most 65535 rows per call", OAK_MAX_DEPTH);
     for (int64_t a0 = 0; a0 < n1; a0 += chunk) {
         const int64_t na = (a0 + chunk <= n1) ? chunk : n1 - a0;
@@ -76,7 +76,7 @@ static int gram_diag_to_host(oak_ctx* ctx, const PreparedKernel& pk, const doubl
     OAK_CHECK(featurize(ctx, pk, dX, n, ldx, "gF1", &FA));
     double* dD = nullptr;
     OAK_CHECK(get_buf_t(ctx, "gD", (size_t)n, &dD));
-    if (pk.deep || pk.grouped || ctx->gram_form != 0) OAK_CHECK(gram_generic(ctx, pk, ctx->gram_form, dX, FA, n, nullptr, FA, n, ldx, dD, 0, true));
+    if (pk.deep || ctx->gram_form != 0) OAK_CHECK(gram_generic(ctx, pk, ctx->gram_form, dX, FA, n, nullptr, FA, n, ldx, dD, 0, true));
     else
     OAK_CHECK(gram_diag(ctx, pk, FA, dD, nullptr));
     OAK_HIP_CHECK(hipMemcpyAsync(out, dD, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, ctx->stream));

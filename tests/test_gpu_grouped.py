@@ -131,7 +131,7 @@ def test_kernel_shape_variants_at_a_size_that_tiles(hip, ncol, R):
             s = copy.deepcopy(spec); s["dims"][d]["lengthscale"] += h
             return o.sgpr_elbo(s, X, y, Z, s2)
         check(g[d], fd(f), rtol=1e-4)
-    # the explicit Gram entry point (generic kernel, one thread per entry) and the fused pair kernel agree on Kuf
+    # the explicit Gram entry point (the same fused pair kernel, no statistics around it) against the oracle, entry by entry
     K = hip.gram(desc, X[:300], Z)
     np.testing.assert_allclose(K, o.oak_K(spec, X[:300], Z), rtol=0, atol=1e-12 * np.abs(K).max())
 
