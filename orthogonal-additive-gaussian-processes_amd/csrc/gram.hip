@@ -101,8 +101,8 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
     // Row-side features of the NEXT row step are fetched into registers while the current one is computed (D * RS <= 1024 values per
     // array: at most four per thread), raw and from clamped addresses; mask and pre-scale are applied when they go to LDS.  Without
     // this the global loads sat between the two barriers of a step: every wave of the workgroup waited out an HBM latency per 16 rows.
-    // (the launcher pairs CPT = 4 and RT < 4 with D <= 16 and RT = 1 with RS = 4: one value per thread there; RT = 4, CPT = 2 goes to 64 dims)
-    constexpr int NS = (RT == 4 && CPT == 2) ? 4 : 1;
+    // (the launcher pairs CPT = 4 with <= 16 sub-kernels: one value per thread there; CPT = 2 goes to 64)
+    constexpr int NS = (CPT == 4) ? 1 : RS / 4;       // values per array per thread: 16 sub-kernels x RS rows, or 64 x RS, over 256 threads
     double rx[NS], rc[NS], ry = 0.0;
     auto fetch_rows = [&](int64_t i0n) {
 #pragma unroll
@@ -351,7 +351,7 @@ static int launch_gram_t(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, 
     constexpr int TJ = 64 * CPT;
     constexpr int RS = 4 * RT;
     const int D = pk.dd.D;
-    OAK_REQUIRE(D * RS <= ((RT == 4 && CPT == 2) ? 1024 : 256), "gram: %d sub-kernels do not fit this tile shape's row staging", D);
+    OAK_REQUIRE(D * RS <= 256 * ((CPT == 4) ? 1 : RS / 4), "gram: %d sub-kernels do not fit this tile shape's row staging", D);
     // 1024-entry exp2 table unless its extra 4 KiB would lower the number of workgroups a CU holds (D = 32 at TJ = 128)
     const int nx = pk.grouped ? A.nx : 0;
     if (pk.grouped) OAK_REQUIRE(A.xx != nullptr && B.xx != nullptr && A.nx == B.nx, "gram: features lack the grouped sub-kernels' further columns");
@@ -400,18 +400,26 @@ template <int R>
 static int launch_gram_r(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int64_t na, const Feat& B,
                          double* d_out, int64_t ldo, const double* d_yA, double* d_psi, int64_t zero_pad_to) {
     const int D = pk.dd.D;
-    // register blocking: 16 pairs/lane for R<=2, 8 for R<=4, 4 above; halve the column tile when D*TJ*16 B > 64 KiB
+    // register blocking: 16 pairs/lane for R<=4 (8 beyond 16 sub-kernels), 4 above; halve the column tile when D*TJ*16 B > 64 KiB
     if constexpr (R <= 2) {
         if (D <= 16) return launch_gram_t<R, 4, 4>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
         return launch_gram_t<R, 4, 2>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
     } else if constexpr (R <= 4) {
-        if (D <= 16) return launch_gram_t<R, 2, 4>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+        // 16 pairs per lane here too (r04: depth 4 at 16 dims 11.2 -> 10.3 ms, depth 3 10.05 -> 9.7; 8 dims: 2 % / none)
+        if (D <= 16) return launch_gram_t<R, 4, 4>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
         return launch_gram_t<R, 4, 2>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
     } else if constexpr (R <= 16) {
+        if constexpr (R <= 8) {      // depth 5..8: 8 pairs per lane (r04: 3-7 % over 4 at 10 and 16 sub-kernels)
+            if (D <= 16) return launch_gram_t<R, 2, 4>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+            return launch_gram_t<R, 4, 2>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);     // 8 pairs here too: 13-34 % over 2 (20..64 sub-kernels)
+        }
+        // depth 9..16: 4 pairs per lane (2 x 4 at <= 16 sub-kernels measured WORSE than 1 x 4: 8.8 vs 6.7 ms at depth 12 of 13;
+        // 2 x 2 beyond 16 sub-kernels against 1 x 2: 11.6 vs 13.1 ms at depth 12 of 24, 16.8 vs 21.7 at 16 of 32)
         if (D <= 16) return launch_gram_t<R, 1, 4>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
-        return launch_gram_t<R, 1, 2>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
+        return launch_gram_t<R, 2, 2>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
     } else {
         // effective depth > 16 means more than 16 sub-kernels: two pairs per lane, R + 1 polynomials each
+        // (2 x 2 here: 30.0 vs 24.7 ms at depth 20 of 32 -- the 4 x 25 polynomials no longer fit two waves per SIMD)
         return launch_gram_t<R, 1, 2>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to);
     }
 }

@@ -8,11 +8,12 @@ sys.path.insert(0, str(ROOT / "orthogonal-additive-gaussian-processes_amd")); sy
 from oak import _capi
 import bench
 cfg = bench.CONFIGS[os.environ.get("CONFIG", "headline")]
-N, D, M, R = cfg["N"], cfg["D"], cfg["M"], cfg["R"]
-X, y, Z = bench.synthetic(N, D, M, mixed=cfg.get("mixed", False))
+N, D, M, R = cfg["N"], int(os.environ.get("D", cfg["D"])), cfg["M"], int(os.environ.get("R", cfg["R"]))     # D= / R= override the config
+mixed = cfg.get("mixed", False) and D == cfg["D"]
+X, y, Z = bench.synthetic(N, D, M, mixed=mixed)
 ctx = _capi.HipContext(0)
 ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z)
-desc = _capi.KernelDesc(bench.make_spec(D, R, mixed=cfg.get("mixed", False)))
+desc = _capi.KernelDesc(bench.make_spec(D, R, mixed=mixed))
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 ctx.bench_gram_resident(desc)
 ts = []
