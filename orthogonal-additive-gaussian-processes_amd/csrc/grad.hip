@@ -304,7 +304,8 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const double* __restrict
 // per-dimension code on its own half.  Lane h of a pair takes the staged dimensions 2*step + h.  Row features are lane-dependent
 // then: vector loads (L1-resident) from rows packed [half][chunk of four steps][feature][step] by pack_rows_kernel(split = 2).
 template <int R, int DMAX, int CPT, bool ALLRBF, bool WANT_GK, bool UNITBV, int SPLIT = 1>
-__global__ void __launch_bounds__(256, (DMAX <= 16 ? 2 : 1))      // <= 16 dims per lane: hold the register budget at two waves per SIMD
+__global__ void __launch_bounds__(256, ((DMAX <= 16 && !(SPLIT == 2 && R > 4)) ? 2 : 1))      // <= 16 dims per lane: hold the register budget at two waves per SIMD
+                                                                            // (lane pairs at depth 5..8: one wave, 370 registers -- at 256 it spilled 452 B: 65 vs 25 ms)
 gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
                      const double* __restrict__ Apack, int64_t a0, int64_t na, const double* __restrict__ Bxs,
                      const double* __restrict__ Bcn, const double* __restrict__ Bdcn, int64_t b_ld, int64_t nb,
@@ -1032,14 +1033,22 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     OAK_REQUIRE(tablen <= 1024, "gradient: discrete tables too large (%d doubles; four per-wave copies are kept in LDS)", tablen);
     const int nx = pk.grouped ? A.nx : 0;       // grouped sub-kernels go through the general kernel
     if (pk.grouped) OAK_REQUIRE(A.xx != nullptr && B.xx != nullptr && A.nx == B.nx, "gram_bwd: features lack the grouped sub-kernels' further columns");
-    const bool fast = (R >= 1 && R <= 4 && D <= 32 && nx == 0 && getenv("OAK_BWD_GENERIC") == nullptr);
+    // register-resident pair walk: depth <= 8 with <= 32 sub-kernels (r04: depth 5..8 too -- one instantiation per shape, the mixed / any-variance /
+    // base-variance-gradient form; the general two-pass kernel took 3.5x (depth 8 of 16) to 6x (8 of 32) as long)
+    const bool fast = (R >= 1 && R <= 8 && D <= 32 && nx == 0 && getenv("OAK_BWD_GENERIC") == nullptr);
     bool allrbf = true;
     for (int d = 0; d < D; ++d) allrbf = allrbf && pk.dd.type[d] == OAK_DIM_RBF;
-    const int dmax = D <= 8 ? 8 : (D <= 16 ? 16 : 32);
-    const int cpt = fast ? (dmax <= 16 ? 2 : 1) : ((D <= 40 && R <= 16) ? 2 : 1);     // depth > 16: 2 pairs x (R + 1) polynomials per lane
-    const int TJ = 64 * cpt, RS = 8;
     bool unitbv = true;
     for (int d = 0; d < D; ++d) unitbv = unitbv && (pk.dd.type[d] != OAK_DIM_RBF || pk.dd.bv[d] == 1.0);
+    // depth 5..8: two forms per shape -- all-continuous / unit base variances / no base-variance sums (the reference's default model), and the
+    // mixed / any-variance / base-variance-gradient form, which evaluates everything else (lane pairs, > 16 sub-kernels: only the latter)
+    const bool plain58 = fast && R > 4 && allrbf && unitbv && !want_gk && D <= 16;
+    if (fast && R > 4 && !plain58) { allrbf = false; unitbv = false; want_gk = true; }
+    const int dmax = D <= 8 ? 8 : (D <= 16 ? 16 : 32);
+    // general kernel: two columns per lane while two workgroups still fit a CU's LDS (<= 24 sub-kernels) and the depth leaves registers (<= 16)
+    int cpt = fast ? (dmax <= 16 ? 2 : 1) : ((D <= 24 && R <= 16) ? 2 : 1);
+    if (const char* e = getenv("OAK_BWD_CPT")) { if (!fast && (e[0] == '1' || e[0] == '2')) cpt = e[0] - '0'; }      // tuning knob
+    const int TJ = 64 * cpt, RS = 8;
     const size_t lds = fast ? sizeof(double) * ((size_t)3 * dmax * TJ + TJ + EW_N + (unitbv ? 0 : 2 * dmax) + 5 * tablen + (allrbf ? 0 : dmax))
                             : sizeof(double) * ((size_t)3 * D * TJ + (size_t)3 * D * RS + RS + TJ + 64 + 8 * D + 4 * tablen + 64 + (size_t)nx * (TJ + RS));
     OAK_REQUIRE(lds <= 160 * 1024, "gram_bwd: LDS request %zu exceeds 160 KiB", lds);
@@ -1091,6 +1100,18 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
             case 408: OAK_BWD_FAST(4, 8) break;   case 416: OAK_BWD_FAST(4, 16) break;
             case 132: OAK_BWD_FAST(1, 32) break;  case 232: OAK_BWD_FAST(2, 32) break;
             case 332: OAK_BWD_FAST(3, 32) break;  case 432: OAK_BWD_FAST(4, 32) break;
+            case 508: if (plain58) OAK_BWD_FAST_K(5, 8, true, false, true) else OAK_BWD_FAST_K(5, 8, false, true, false) break;
+            case 516: if (plain58) OAK_BWD_FAST_K(5, 16, true, false, true) else OAK_BWD_FAST_K(5, 16, false, true, false) break;
+              case 532: OAK_BWD_FAST_K(5, 32, false, true, false) break;
+            case 608: if (plain58) OAK_BWD_FAST_K(6, 8, true, false, true) else OAK_BWD_FAST_K(6, 8, false, true, false) break;
+            case 616: if (plain58) OAK_BWD_FAST_K(6, 16, true, false, true) else OAK_BWD_FAST_K(6, 16, false, true, false) break;
+              case 632: OAK_BWD_FAST_K(6, 32, false, true, false) break;
+            case 708: if (plain58) OAK_BWD_FAST_K(7, 8, true, false, true) else OAK_BWD_FAST_K(7, 8, false, true, false) break;
+            case 716: if (plain58) OAK_BWD_FAST_K(7, 16, true, false, true) else OAK_BWD_FAST_K(7, 16, false, true, false) break;
+              case 732: OAK_BWD_FAST_K(7, 32, false, true, false) break;
+            case 808: if (plain58) OAK_BWD_FAST_K(8, 8, true, false, true) else OAK_BWD_FAST_K(8, 8, false, true, false) break;
+            case 816: if (plain58) OAK_BWD_FAST_K(8, 16, true, false, true) else OAK_BWD_FAST_K(8, 16, false, true, false) break;
+              case 832: OAK_BWD_FAST_K(8, 32, false, true, false) break;
         }
     } else
     switch (template_depth(R)) {      // depths 9..32: the next larger instantiation, zero weights above R

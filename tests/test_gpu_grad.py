@@ -53,11 +53,11 @@ def test_sgpr_gradient_continuous(hip, route, R):
     check(g[2 * D + R + 1], fd(lambda h: o.sgpr_elbo(spec, X, y, Z, s2 + h), h=1e-6))
 
 
-@pytest.mark.parametrize("D,R", [(12, 2), (16, 3), (20, 2), (32, 4), (33, 2), (9, 5)])
+@pytest.mark.parametrize("D,R", [(12, 2), (16, 3), (20, 2), (32, 4), (33, 2), (9, 5), (16, 8), (8, 7), (24, 6), (32, 8), (40, 3), (13, 13)])
 def test_sgpr_gradient_kernel_variants(hip, D, R):
-    """D <= 8 / <= 16 / <= 32 take the register-resident fast backward kernel (one column per lane above 16), larger D or
-    R > 4 the generic two-pass kernel: all must agree with finite differences of the oracle (a subset of parameters is
-    probed)."""
+    """D <= 8 / <= 16 / <= 32 at depth <= 8 take the register-resident fast backward kernel (lane pairs above 16 sub-kernels; depth
+    5..8 since r04), wider or deeper kernels the general two-pass kernel: all must agree with finite differences of the oracle
+    (a subset of parameters is probed)."""
     rng = np.random.default_rng(D * 10 + R)
     N, M = 260, 20
     X, y, Z = o.synthetic_problem(N, D, M, seed=D)
@@ -77,10 +77,13 @@ def test_sgpr_gradient_kernel_variants(hip, D, R):
         check(g[2 * D + r], fd(f), rtol=5e-5)
 
 
-def test_sgpr_gradient_all_kernel_types(hip):
-    """Every sub-kernel type / measure, base variances trainable (share_var_across_orders=False), categorical table."""
+@pytest.mark.parametrize("depth", [3, 5, 6])
+def test_sgpr_gradient_all_kernel_types(hip, depth):
+    """Every sub-kernel type / measure, base variances trainable (share_var_across_orders=False), categorical table; depth 3
+    (fast kernel, mixed form), 5 and 6 (its depth-5..8 form with base-variance sums and per-dimension exponent offsets)."""
     spec, X, y, Z, s2 = cases.case_B()
     spec = copy.deepcopy(spec)
+    spec["max_interaction_depth"] = depth
     spec["share_var_across_orders"] = False
     spec["order_variances"] = [0.6]
     for i, dim in enumerate(spec["dims"]):
@@ -325,6 +328,36 @@ def test_gradient_wrt_inducing_inputs_beyond_the_register_resident_shapes(hip, k
         Zp[m, c] += h; Zm[m, c] -= h
         fd = (o.sgpr_elbo(spec, X, y, Zp, s2) - o.sgpr_elbo(spec, X, y, Zm, s2)) / (2 * h)
         assert abs(gz[m, c] - fd) <= 3e-5 * max(1.0, abs(fd)), f"Z[{m},{c}]: {gz[m, c]} vs {fd}"
+
+
+@pytest.mark.parametrize("D,R,kinds,share", [(7, 6, ("gaussian", "binary", "uniform", "categorical", "mog", "none", "gauss2"), False),
+                                              (20, 5, ("gaussian",), True), (12, 8, ("gaussian", "gauss2"), True),
+                                              (30, 7, ("gaussian", "binary", "categorical"), True)])
+def test_fast_and_general_backward_kernels_agree_at_depth_5_to_8(monkeypatch, D, R, kinds, share):
+    """OAK_BWD_GENERIC=1 sends the depth-5..8 shapes back through the general two-pass kernel they used before r04: the whole
+    gradient record (lengthscales, base variances, order variances, categorical table sums) agrees to rounding at a size with
+    several row and column blocks."""
+    rng = np.random.default_rng(D * 100 + R)
+    spec = cases.random_spec(rng, D, R, kinds, share=share)
+    N, M = 2500, 150
+    X = cases.random_inputs(rng, spec, N)
+    Z = cases.random_inputs(rng, spec, M)
+    y = rng.standard_normal((N, 1))
+    d = _capi.KernelDesc(spec)
+    out = {}
+    for mode in ("fast", "general"):
+        if mode == "general":
+            monkeypatch.setenv("OAK_BWD_GENERIC", "1")
+        ctx = _capi.HipContext(0)
+        ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("whitened")
+        out[mode] = ctx.sgpr_elbo_grad(d, 0.1)
+        ctx.close()
+    assert out["fast"][0] == out["general"][0]
+    gf, gg = out["fast"][1].copy(), out["general"][1].copy()
+    if not d.struct.grad_base_var:         # base variances are constants then: their slots are not part of the result (the general kernel
+        gf[D:2 * D] = gg[D:2 * D] = 0.0    # fills them anyway, the plain fast form leaves zeros)
+    scale = np.abs(gg).max()
+    np.testing.assert_allclose(gf, gg, rtol=1e-9, atol=1e-11 * scale)
 
 
 def test_general_and_register_resident_inducing_input_kernels_agree(monkeypatch):
