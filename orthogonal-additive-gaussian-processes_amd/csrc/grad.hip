@@ -1047,7 +1047,7 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     const int dmax = D <= 8 ? 8 : (D <= 16 ? 16 : 32);
     // general kernel: two columns per lane while two workgroups still fit a CU's LDS (<= 24 sub-kernels) and the depth leaves registers (<= 16)
     int cpt = fast ? (dmax <= 16 ? 2 : 1) : ((D <= 24 && R <= 16) ? 2 : 1);
-    if (const char* e = getenv("OAK_BWD_CPT")) { if (!fast && (e[0] == '1' || e[0] == '2')) cpt = e[0] - '0'; }      // tuning knob
+    if (const char* e = getenv("OAK_BWD_CPT")) { if (!fast && R <= 16 && (e[0] == '1' || e[0] == '2')) cpt = e[0] - '0'; }      // tuning knob (depth > 16 is instantiated for one column only)
     const int TJ = 64 * cpt, RS = 8;
     const size_t lds = fast ? sizeof(double) * ((size_t)3 * dmax * TJ + TJ + EW_N + (unitbv ? 0 : 2 * dmax) + 5 * tablen + (allrbf ? 0 : dmax))
                             : sizeof(double) * ((size_t)3 * D * TJ + (size_t)3 * D * RS + RS + TJ + 64 + 8 * D + 4 * tablen + 64 + (size_t)nx * (TJ + RS));
