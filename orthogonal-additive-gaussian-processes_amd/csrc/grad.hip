@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const double* __restrict
 // per-dimension code on its own half.  Lane h of a pair takes the staged dimensions 2*step + h.  Row features are lane-dependent
 // then: vector loads (L1-resident) from rows packed [half][chunk of four steps][feature][step] by pack_rows_kernel(split = 2).
 template <int R, int DMAX, int CPT, bool ALLRBF, bool WANT_GK, bool UNITBV, int SPLIT = 1>
-__global__ void __launch_bounds__(256, ((DMAX <= 16 && !(SPLIT == 2 && R > 4)) ? 2 : 1))      // <= 16 dims per lane: hold the register budget at two waves per SIMD
+__global__ void __launch_bounds__(256, ((DMAX <= 16 && !(SPLIT == 2 && R > 4) && R <= 8) ? 2 : 1))      // <= 16 dims per lane: hold the register budget at two waves per SIMD
                                                                             // (lane pairs at depth 5..8: one wave, 370 registers -- at 256 it spilled 452 B: 65 vs 25 ms)
 gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
                      const double* __restrict__ Apack, int64_t a0, int64_t na, const double* __restrict__ Bxs,
@@ -562,13 +562,14 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
         }
     }
     __syncthreads();
-    const int64_t reclen = 2 * D + (R + 1) + tablen;
+    const int RA = dd.R;                                  // actual depth <= R (depth 9..16 runs the R = 12 / 16 instantiations, zero weights above)
+    const int64_t reclen = 2 * D + (RA + 1) + tablen;
     double* rec = partial + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * reclen;
     auto sum4 = [&](int j) { return ((red[j] + red[NACC + j]) + red[2 * NACC + j]) + red[3 * NACC + j]; };
     for (int d = tid; d < D; d += 256) { rec[d] = sum4(d) * 1024.0; rec[D + d] = sum4(DT + d); }
-    if (tid <= R) rec[2 * D + tid] = sum4(2 * DT + tid);
+    if (tid <= RA) rec[2 * D + tid] = sum4(2 * DT + tid);
     for (int idx = tid; idx < tablen; idx += 256)
-        rec[2 * D + (R + 1) + idx] = ((accT[idx] + accT[tablen + idx]) + accT[2 * tablen + idx]) + accT[3 * tablen + idx];
+        rec[2 * D + (RA + 1) + idx] = ((accT[idx] + accT[tablen + idx]) + accT[2 * tablen + idx]) + accT[3 * tablen + idx];
 }
 #undef OAK_SD
 
@@ -1035,7 +1036,8 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     if (pk.grouped) OAK_REQUIRE(A.xx != nullptr && B.xx != nullptr && A.nx == B.nx, "gram_bwd: features lack the grouped sub-kernels' further columns");
     // register-resident pair walk: depth <= 8 with <= 32 sub-kernels (r04: depth 5..8 too -- one instantiation per shape, the mixed / any-variance /
     // base-variance-gradient form; the general two-pass kernel took 3.5x (depth 8 of 16) to 6x (8 of 32) as long)
-    const bool fast = (R >= 1 && R <= 8 && D <= 32 && nx == 0 && getenv("OAK_BWD_GENERIC") == nullptr);
+    // (depth 9..16, which needs >= 9 sub-kernels: the R = 12 / 16 instantiations at <= 16 sub-kernels, one wave per SIMD)
+    const bool fast = (R >= 1 && (R <= 8 ? D <= 32 : (R <= 16 && D <= 16)) && nx == 0 && getenv("OAK_BWD_GENERIC") == nullptr);
     bool allrbf = true;
     for (int d = 0; d < D; ++d) allrbf = allrbf && pk.dd.type[d] == OAK_DIM_RBF;
     bool unitbv = true;
@@ -1093,7 +1095,9 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
 #define OAK_BWD_FAST(RR, DM) { if (allrbf) OAK_BWD_FAST_G(RR, DM, true) else OAK_BWD_FAST_G(RR, DM, false) }
 #define OAK_BWD_CASE(RR) case RR: if (cpt == 2) OAK_BWD_LAUNCH(RR, 2) else OAK_BWD_LAUNCH(RR, 1) break;
     if (fast) {
-        switch (R * 100 + dmax) {
+        switch ((R <= 8 ? R : template_depth(R)) * 100 + dmax) {
+            case 1216: if (plain58) OAK_BWD_FAST_K(12, 16, true, false, true) else OAK_BWD_FAST_K(12, 16, false, true, false) break;
+            case 1616: if (plain58) OAK_BWD_FAST_K(16, 16, true, false, true) else OAK_BWD_FAST_K(16, 16, false, true, false) break;
             case 108: OAK_BWD_FAST(1, 8) break;   case 116: OAK_BWD_FAST(1, 16) break;
             case 208: OAK_BWD_FAST(2, 8) break;   case 216: OAK_BWD_FAST(2, 16) break;
             case 308: OAK_BWD_FAST(3, 8) break;   case 316: OAK_BWD_FAST(3, 16) break;
