@@ -1037,7 +1037,7 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     // register-resident pair walk: depth <= 8 with <= 32 sub-kernels (r04: depth 5..8 too -- one instantiation per shape, the mixed / any-variance /
     // base-variance-gradient form; the general two-pass kernel took 3.5x (depth 8 of 16) to 6x (8 of 32) as long)
     // (depth 9..16, which needs >= 9 sub-kernels: the R = 12 / 16 instantiations at <= 16 sub-kernels, one wave per SIMD)
-    const bool fast = (R >= 1 && (R <= 8 ? D <= 32 : (R <= 16 && D <= 16)) && nx == 0 && getenv("OAK_BWD_GENERIC") == nullptr);
+    const bool fast = (R >= 1 && R <= 16 && D <= 32 && nx == 0 && getenv("OAK_BWD_GENERIC") == nullptr);
     bool allrbf = true;
     for (int d = 0; d < D; ++d) allrbf = allrbf && pk.dd.type[d] == OAK_DIM_RBF;
     bool unitbv = true;
@@ -1098,6 +1098,8 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
         switch ((R <= 8 ? R : template_depth(R)) * 100 + dmax) {
             case 1216: if (plain58) OAK_BWD_FAST_K(12, 16, true, false, true) else OAK_BWD_FAST_K(12, 16, false, true, false) break;
             case 1616: if (plain58) OAK_BWD_FAST_K(16, 16, true, false, true) else OAK_BWD_FAST_K(16, 16, false, true, false) break;
+            case 1232: OAK_BWD_FAST_K(12, 32, false, true, false) break;
+            case 1632: OAK_BWD_FAST_K(16, 32, false, true, false) break;
             case 108: OAK_BWD_FAST(1, 8) break;   case 116: OAK_BWD_FAST(1, 16) break;
             case 208: OAK_BWD_FAST(2, 8) break;   case 216: OAK_BWD_FAST(2, 16) break;
             case 308: OAK_BWD_FAST(3, 8) break;   case 316: OAK_BWD_FAST(3, 16) break;
