@@ -259,12 +259,13 @@ gram_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
 
 // Row-major pack of the backward features of rows a0 .. a0+na-1:  out[i][q][d],  q = (xs32, cn, dcs),  d < DP;
 // padding dimensions d >= D hold (-1, 0, 0) so that against the column-side padding (+1) the pair clamps to E = 2^-1024.
-// split = 2 (the lane-pair form of the fast kernel, DP = 32): lane h of a pair walks dimensions 2*step + h; its features are laid out
+// split = 2 / 4 (the lane-pair / lane-quad form of the fast kernel, DP = 32 / 64): lane h of a group walks dimensions split*step + h; its features are laid out
 // [h][chunk of four steps][q][step in chunk], so that a chunk's 12 values are contiguous (wide vector loads).
 __global__ void __launch_bounds__(256) pack_rows_kernel(const double* __restrict__ xs32, const double* __restrict__ cn,
                                                         const double* __restrict__ dcs, int64_t ld, int64_t a0, int64_t na, int D,
                                                         int DP, double* __restrict__ out, int split) {
-    __shared__ double tile[96][65];                               // 3 * DP <= 96
+    extern __shared__ double tile_mem[];                          // [3 * DP][65]: 3 * DP <= 192 (dynamic: 100 KB at DP = 64)
+    auto tile = [&](int j, int r) -> double& { return tile_mem[j * 65 + r]; };
     const int64_t i0 = (int64_t)blockIdx.x * 64;
     const int W = 3 * DP;
     for (int idx = threadIdx.x; idx < W * 64; idx += 256) {       // coalesced over rows
@@ -273,19 +274,26 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const double* __restrict
         const int64_t i = i0 + r;
         double v = (q == 0) ? -1.0 : 0.0;
         if (d < D && i < na) v = (q == 0 ? xs32 : (q == 1 ? cn : dcs))[(int64_t)d * ld + a0 + i];
-        tile[j][r] = v;
+        tile(j, r) = v;
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < W * 64; idx += 256) {       // coalesced over the packed row
         const int r = idx / W, j = idx - r * W;
         int src = j;
-        if (split == 2) {                                         // j = ((h * nch + c) * 3 + q) * 4 + v  <-  tile row q * DP + d
-            const int v = j & 3, q = (j >> 2) % 3, hc = (j >> 2) / 3, nch = DP / 8;
+        if (split >= 2) {                                         // j = ((h * nch + c) * 3 + q) * 4 + v  <-  tile row q * DP + d
+            const int v = j & 3, q = (j >> 2) % 3, hc = (j >> 2) / 3, nch = DP / (4 * split);
             const int h = hc / nch, c = hc - h * nch;
-            src = q * DP + 2 * (4 * c + v) + h;
+            src = q * DP + split * (4 * c + v) + h;
         }
-        if (i0 + r < na) out[(i0 + r) * W + j] = tile[src][r];
+        if (i0 + r < na) out[(i0 + r) * W + j] = tile(src, r);
     }
+}
+static int launch_pack_rows(oak_ctx* ctx, const Feat& A, int64_t a0, int64_t na, int D, int DP, double* d_pack, int split) {
+    const size_t lds = sizeof(double) * (size_t)3 * DP * 65;
+    if (lds > 64 * 1024) OAK_CHECK(ensure_max_dynamic_lds((const void*)pack_rows_kernel));
+    pack_rows_kernel<<<(unsigned)((na + 63) / 64), 256, lds, ctx->stream>>>(A.xs32, A.cn, A.dcs, A.ld, a0, na, D, DP, d_pack, split);
+    OAK_HIP_CHECK(hipGetLastError());
+    return OAK_OK;
 }
 
 // Fast path (1 <= R <= 4, D <= DMAX <= 16): one exp2 per pair per dimension.  Each lane walks its pairs one at a time,
@@ -304,7 +312,7 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const double* __restrict
 // per-dimension code on its own half.  Lane h of a pair takes the staged dimensions 2*step + h.  Row features are lane-dependent
 // then: vector loads (L1-resident) from rows packed [half][chunk of four steps][feature][step] by pack_rows_kernel(split = 2).
 template <int R, int DMAX, int CPT, bool ALLRBF, bool WANT_GK, bool UNITBV, int SPLIT = 1>
-__global__ void __launch_bounds__(256, ((DMAX <= 16 && !(SPLIT == 2 && R > 4) && R <= 8) ? 2 : 1))      // <= 16 dims per lane: hold the register budget at two waves per SIMD
+__global__ void __launch_bounds__(256, ((DMAX <= 16 && !(SPLIT >= 2 && R > 4) && R <= 8 && SPLIT < 4) ? 2 : 1))      // <= 16 dims per lane: hold the register budget at two waves per SIMD
                                                                             // (lane pairs at depth 5..8: one wave, 370 registers -- at 256 it spilled 452 B: 65 vs 25 ms)
 gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
                      const double* __restrict__ Apack, int64_t a0, int64_t na, const double* __restrict__ Bxs,
@@ -335,8 +343,8 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
     double* red = Bx;                   // [4][2*DT + R + 1], aliases the column features once the row loop is done
                                         // (54 272 B at DMAX = 16 without discrete tables: three workgroups per CU)
     const int tid = threadIdx.x, tx = tid & 63;
-    const int cl = (SPLIT == 2) ? (tx >> 1) : tx;           // column of the wave's pass this lane works on
-    const int half = (SPLIT == 2) ? (tx & 1) : 0;           // which of the pair's two lanes this is
+    const int cl = tx / SPLIT;                              // column of the wave's pass this lane works on
+    const int half = tx & (SPLIT - 1);                      // which of the group's SPLIT lanes this is (SPLIT = 4, r04: 33..64 sub-kernels)
     // lane (half, step d) works on staged dimension SPLIT * d + half: with the usual ordering of a mixed kernel (continuous
     // columns first) both lanes of a pair then meet the same kind of dimension at most steps, and whole chunks of four steps
     // are all-RBF or all-discrete -- decided by wave-uniform tests on the dimension mask, not per lane
@@ -365,19 +373,19 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
     for (int idx = tid; idx < 4 * tablen; idx += 256) accT[idx] = 0.0;
     for (int idx = tid; idx < tablen; idx += 256) Tbl[idx] = tables[idx];
     double* accTw = accT + ty * tablen;
-    unsigned rbf_mask = 0xffffffffu, cat_mask = 0u;
+    unsigned long long rbf_mask = ~0ull, cat_mask = 0ull;
     if constexpr (!ALLRBF) {
         if (tid < DT) meta[tid] = tid < D ? (dd.tab_off[tid] | (dd.ncat[tid] << 16)) : 0;      // tablen <= 1024
         for (int d = 0; d < D; ++d) {
-            if (dd.type[d] != OAK_DIM_RBF) rbf_mask &= ~(1u << d);
-            if (dd.type[d] == OAK_DIM_CATEGORICAL) cat_mask |= 1u << d;
+            if (dd.type[d] != OAK_DIM_RBF) rbf_mask &= ~(1ull << d);
+            if (dd.type[d] == OAK_DIM_CATEGORICAL) cat_mask |= 1ull << d;
         }
     }
     unsigned my_rbf = 0u, my_cat = 0u;          // bit d: this lane's dimension at step d (lane-dependent when SPLIT = 2)
 #pragma unroll
     for (int d = 0; d < DMAX; ++d) {
-        my_rbf |= ((rbf_mask >> OAK_SD(d)) & 1u) << d;
-        my_cat |= ((cat_mask >> OAK_SD(d)) & 1u) << d;
+        my_rbf |= (unsigned)((rbf_mask >> OAK_SD(d)) & 1ull) << d;
+        my_cat |= (unsigned)((cat_mask >> OAK_SD(d)) & 1ull) << d;
     }
     double gl[DMAX], gk[NGK], gw[R + 1];
 #pragma unroll
@@ -404,7 +412,7 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
             const int d = d0 + v;
-            if constexpr (SPLIT == 2) {        // [half][chunk][q][v]: 12 contiguous values per chunk (prow already points at this half)
+            if constexpr (SPLIT >= 2) {        // [half][chunk][q][v]: 12 contiguous values per chunk (prow already points at this half)
                 ch.xa[v] = prow[3 * d0 + v]; ch.ca[v] = prow[3 * d0 + 4 + v]; ch.ad[v] = prow[3 * d0 + 8 + v];
             } else {
                 ch.xa[v] = prow[d]; ch.ca[v] = prow[DT + d]; ch.ad[v] = prow[2 * DT + d];
@@ -440,7 +448,7 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
                 asm volatile("" ::: "memory");              // keep later chunks' loads below this point: bounds the live SGPRs
                 // the staged dimensions SPLIT*d0 .. SPLIT*(d0+4)-1 of this chunk: wave-uniform view of their types
                 constexpr unsigned CM = (1u << (4 * SPLIT)) - 1u;
-                const unsigned cbits = ALLRBF ? CM : ((rbf_mask >> (SPLIT * d0)) & CM);
+                const unsigned cbits = ALLRBF ? CM : (unsigned)((rbf_mask >> (SPLIT * d0)) & CM);
                 double kv4[4] = {0.0, 0.0, 0.0, 0.0}, dv4[4] = {0.0, 0.0, 0.0, 0.0};
                 if (ALLRBF || cbits != 0u) {                // some lane has an RBF dimension here: the exp2 path (all lanes)
                     double w[4], u2[4], mg[4], E[4];
@@ -492,22 +500,26 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
                 for (int q = R - 1; q >= 1; --q) e[q] = __builtin_fma(k[d], e[q - 1], e[q]);
                 e[0] += k[d];
             }
-            if constexpr (SPLIT == 2) {
-                // e holds this half's polynomials e_1..e_R; the partner lane holds the other half's.  Total: e_r = sum_{i+j=r} e_i e'_j
-                double eo[R], et[R];
+            if constexpr (SPLIT >= 2) {
+                // e holds this lane's polynomials e_1..e_R; the partner lane holds another part's.  Total: e_r = sum_{i+j=r} e_i e'_j
+                // (lane quads: pairs first, then the pairs of pairs -- the product of the parts' generating polynomials either way)
 #pragma unroll
-                for (int q = 0; q < R; ++q) eo[q] = __shfl_xor(e[q], 1, 64);
+                for (int stage = 1; stage < SPLIT; stage <<= 1) {
+                    double eo[R], et[R];
 #pragma unroll
-                for (int r = 1; r <= R; ++r) {
-                    double t = e[r - 1] + eo[r - 1];
+                    for (int q = 0; q < R; ++q) eo[q] = __shfl_xor(e[q], stage, 64);
 #pragma unroll
-                    for (int i = 1; i < r; ++i) t = __builtin_fma(e[i - 1], eo[r - i - 1], t);
-                    et[r - 1] = t;
+                    for (int r = 1; r <= R; ++r) {
+                        double t = e[r - 1] + eo[r - 1];
+#pragma unroll
+                        for (int i = 1; i < r; ++i) t = __builtin_fma(e[i - 1], eo[r - i - 1], t);
+                        et[r - 1] = t;
+                    }
+#pragma unroll
+                    for (int q = 0; q < R; ++q) e[q] = et[q];
                 }
-#pragma unroll
-                for (int q = 0; q < R; ++q) e[q] = et[q];
             }
-            const double gq = (SPLIT == 2 && half != 0) ? 0.0 : g;      // the order-variance sums count a pair once
+            const double gq = (SPLIT >= 2 && half != 0) ? 0.0 : g;      // the order-variance sums count a pair once
             gw[0] += gq;
 #pragma unroll
             for (int q = 1; q <= R; ++q) gw[q] = __builtin_fma(gq, e[q - 1], gw[q]);
@@ -530,10 +542,10 @@ gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int ta
                 gl[d] = __builtin_fma(gc, dk[d], gl[d]);
                 if constexpr (WANT_GK) gk[d] = __builtin_fma(gc, k[d], gk[d]);
                 if constexpr (!ALLRBF) {
-                    if ((cat_mask >> (SPLIT * d)) & ((1u << SPLIT) - 1u)) {       // wave-uniform: a categorical dimension at this step
+                    if ((cat_mask >> (SPLIT * d)) & ((1ull << SPLIT) - 1ull)) {       // wave-uniform: a categorical dimension at this step
                         if (((my_cat >> d) & 1u) && gc != 0.0) {
                             const int mt = meta[OAK_SD(d)];
-                            atomicAdd(&accTw[(mt & 0xffff) + (int)prow[SPLIT == 2 ? 3 * (d & ~3) + (d & 3) : d] * (mt >> 16) + (int)Bx[OAK_SD(d) * TJ + col]], gc);
+                            atomicAdd(&accTw[(mt & 0xffff) + (int)prow[SPLIT >= 2 ? 3 * (d & ~3) + (d & 3) : d] * (mt >> 16) + (int)Bx[OAK_SD(d) * TJ + col]], gc);
                         }
                     }
                 }
@@ -1037,7 +1049,8 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     // register-resident pair walk: depth <= 8 with <= 32 sub-kernels (r04: depth 5..8 too -- one instantiation per shape, the mixed / any-variance /
     // base-variance-gradient form; the general two-pass kernel took 3.5x (depth 8 of 16) to 6x (8 of 32) as long)
     // (depth 9..16, which needs >= 9 sub-kernels: the R = 12 / 16 instantiations at <= 16 sub-kernels, one wave per SIMD)
-    const bool fast = (R >= 1 && R <= 16 && D <= 32 && nx == 0 && getenv("OAK_BWD_GENERIC") == nullptr);
+    // (33..64 sub-kernels: lane QUADS, depth <= 8)
+    const bool fast = (R >= 1 && (D <= 32 ? R <= 16 : R <= 8) && nx == 0 && getenv("OAK_BWD_GENERIC") == nullptr);
     bool allrbf = true;
     for (int d = 0; d < D; ++d) allrbf = allrbf && pk.dd.type[d] == OAK_DIM_RBF;
     bool unitbv = true;
@@ -1045,12 +1058,12 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     // depth 5..8: two forms per shape -- all-continuous / unit base variances / no base-variance sums (the reference's default model), and the
     // mixed / any-variance / base-variance-gradient form, which evaluates everything else (lane pairs, > 16 sub-kernels: only the latter)
     const bool plain58 = fast && R > 4 && allrbf && unitbv && !want_gk && D <= 16;
-    if (fast && R > 4 && !plain58) { allrbf = false; unitbv = false; want_gk = true; }
-    const int dmax = D <= 8 ? 8 : (D <= 16 ? 16 : 32);
+    if (fast && (R > 4 || D > 32) && !plain58) { allrbf = false; unitbv = false; want_gk = true; }
+    const int dmax = D <= 8 ? 8 : (D <= 16 ? 16 : (D <= 32 ? 32 : 64));
     // general kernel: two columns per lane while two workgroups still fit a CU's LDS (<= 24 sub-kernels) and the depth leaves registers (<= 16)
     int cpt = fast ? (dmax <= 16 ? 2 : 1) : ((D <= 24 && R <= 16) ? 2 : 1);
     if (const char* e = getenv("OAK_BWD_CPT")) { if (!fast && R <= 16 && (e[0] == '1' || e[0] == '2')) cpt = e[0] - '0'; }      // tuning knob (depth > 16 is instantiated for one column only)
-    const int TJ = 64 * cpt, RS = 8;
+    const int TJ = (fast && dmax == 64) ? 32 : 64 * cpt, RS = 8;       // lane quads: 16 columns per wave pass, two passes
     const size_t lds = fast ? sizeof(double) * ((size_t)3 * dmax * TJ + TJ + EW_N + (unitbv ? 0 : 2 * dmax) + 5 * tablen + (allrbf ? 0 : dmax))
                             : sizeof(double) * ((size_t)3 * D * TJ + (size_t)3 * D * RS + RS + TJ + 64 + 8 * D + 4 * tablen + 64 + (size_t)nx * (TJ + RS));
     OAK_REQUIRE(lds <= 160 * 1024, "gram_bwd: LDS request %zu exceeds 160 KiB", lds);
@@ -1073,8 +1086,7 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     if (fast) {
         OAK_REQUIRE(A.xs32 != nullptr && B.xs32 != nullptr, "gram_bwd: features were not prepared for the backward pass");
         OAK_CHECK(get_buf_t(ctx, "bwd_pack", (size_t)na * 3 * dmax, &d_pack));
-        pack_rows_kernel<<<(unsigned)((na + 63) / 64), 256, 0, ctx->stream>>>(A.xs32, A.cn, A.dcs, A.ld, a0, na, D, dmax, d_pack, dmax > 16 ? 2 : 1);
-        OAK_HIP_CHECK(hipGetLastError());
+        OAK_CHECK(launch_pack_rows(ctx, A, a0, na, D, dmax, d_pack, dmax > 16 ? dmax / 16 : 1));
     }
 #define OAK_BWD_LAUNCH(RR, CP)                                                                                                   \
     {                                                                                                                            \
@@ -1085,7 +1097,7 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     }
 #define OAK_BWD_FAST_K(RR, DM, AR, GK, UB)                                                                                         \
     {                                                                                                                             \
-        auto kern = gram_bwd_fast_kernel<RR, (DM <= 16 ? DM : 16), 2, AR, GK, UB, (DM <= 16 ? 1 : 2)>;                            \
+        auto kern = gram_bwd_fast_kernel<RR, (DM <= 16 ? DM : 16), 2, AR, GK, UB, (DM <= 16 ? 1 : DM / 16)>;                       \
         if (lds > 64 * 1024) OAK_CHECK(ensure_max_dynamic_lds((const void*)kern)); \
         kern<<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, tablen, d_pack, a0, na, B.xs32, B.cn, B.dcs, B.ld, nb, d_G, ldg, \
                                               d_yA, d_avec, g_scale, (int)rows, d_part);                                          \
@@ -1098,6 +1110,10 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
         switch ((R <= 8 ? R : template_depth(R)) * 100 + dmax) {
             case 1216: if (plain58) OAK_BWD_FAST_K(12, 16, true, false, true) else OAK_BWD_FAST_K(12, 16, false, true, false) break;
             case 1616: if (plain58) OAK_BWD_FAST_K(16, 16, true, false, true) else OAK_BWD_FAST_K(16, 16, false, true, false) break;
+            case 164: OAK_BWD_FAST_K(1, 64, false, true, false) break;   case 264: OAK_BWD_FAST_K(2, 64, false, true, false) break;
+            case 364: OAK_BWD_FAST_K(3, 64, false, true, false) break;   case 464: OAK_BWD_FAST_K(4, 64, false, true, false) break;
+            case 564: OAK_BWD_FAST_K(5, 64, false, true, false) break;   case 664: OAK_BWD_FAST_K(6, 64, false, true, false) break;
+            case 764: OAK_BWD_FAST_K(7, 64, false, true, false) break;   case 864: OAK_BWD_FAST_K(8, 64, false, true, false) break;
             case 1232: OAK_BWD_FAST_K(12, 32, false, true, false) break;
             case 1632: OAK_BWD_FAST_K(16, 32, false, true, false) break;
             case 108: OAK_BWD_FAST(1, 8) break;   case 116: OAK_BWD_FAST(1, 16) break;
@@ -1217,8 +1233,7 @@ int gram_bwd_z(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0
     double *d_pack = nullptr, *d_part = nullptr;
     OAK_CHECK(get_buf_t(ctx, "bwd_pack", (size_t)na * 3 * dmax, &d_pack));
     OAK_CHECK(get_buf_t(ctx, "bwdz_part", (size_t)nrb * nb * dmax, &d_part));
-    pack_rows_kernel<<<(unsigned)((na + 63) / 64), 256, 0, ctx->stream>>>(A.xs32, A.cn, A.dcs, A.ld, a0, na, D, dmax, d_pack, 1);
-    OAK_HIP_CHECK(hipGetLastError());
+    OAK_CHECK(launch_pack_rows(ctx, A, a0, na, D, dmax, d_pack, 1));
     dim3 grid((unsigned)ncb, (unsigned)nrb);
 #define OAK_BZ_K(RR, DM, AR, UB)                                                                                                  \
     gram_bwd_z_kernel<RR, DM, (DM <= 16 ? 2 : 1), AR, UB><<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, d_pack, a0, na,   \

@@ -335,9 +335,11 @@ def test_gradient_wrt_inducing_inputs_beyond_the_register_resident_shapes(hip, k
                                               (30, 7, ("gaussian", "binary", "categorical"), True),
                                               (13, 11, ("gaussian",), True), (16, 16, ("gaussian", "binary", "mog", "categorical"), False),
                                               (14, 9, ("gaussian", "uniform"), True), (24, 12, ("gaussian",), True),
-                                              (32, 16, ("gaussian", "binary", "gauss2", "categorical"), True), (20, 9, ("gaussian", "mog"), False)])
+                                              (32, 16, ("gaussian", "binary", "gauss2", "categorical"), True), (20, 9, ("gaussian", "mog"), False),
+                                              (40, 3, ("gaussian",), True), (64, 2, ("gaussian", "binary", "categorical", "uniform"), False),
+                                              (50, 7, ("gaussian", "categorical", "gauss2"), True), (33, 1, ("gaussian", "binary"), True)])
 def test_fast_and_general_backward_kernels_agree_at_depth_5_to_8(monkeypatch, D, R, kinds, share):
-    """OAK_BWD_GENERIC=1 sends the depth-5..16 shapes back through the general two-pass kernel they used before r04: the whole
+    """OAK_BWD_GENERIC=1 sends the depth-5..16 shapes and the 33..64-sub-kernel shapes back through the general two-pass kernel they used before r04: the whole
     gradient record (lengthscales, base variances, order variances, categorical table sums) agrees to rounding at a size with
     several row and column blocks."""
     rng = np.random.default_rng(D * 100 + R)

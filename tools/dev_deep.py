@@ -8,7 +8,7 @@ import bench
 from oak import _capi
 ctx = _capi.default_context()
 N, M = 1 << 18, 1024
-for (D, R) in ((16, 2), (16, 4), (13, 5), (13, 13), (16, 8), (32, 4), (32, 8), (32, 32), (40, 3), (24, 12), (32, 16)):
+for (D, R) in ((16, 2), (16, 4), (13, 5), (13, 13), (16, 8), (32, 4), (32, 8), (32, 32), (40, 3), (24, 12), (32, 16), (64, 2), (48, 6)):
     X, y, Z = bench.synthetic(N, D, M)
     spec = bench.make_spec(D, R)
     ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("phi")
