@@ -312,7 +312,7 @@ static int launch_pack_rows(oak_ctx* ctx, const Feat& A, int64_t a0, int64_t na,
 // per-dimension code on its own half.  Lane h of a pair takes the staged dimensions 2*step + h.  Row features are lane-dependent
 // then: vector loads (L1-resident) from rows packed [half][chunk of four steps][feature][step] by pack_rows_kernel(split = 2).
 template <int R, int DMAX, int CPT, bool ALLRBF, bool WANT_GK, bool UNITBV, int SPLIT = 1>
-__global__ void __launch_bounds__(256, ((DMAX <= 16 && !(SPLIT >= 2 && R > 4) && R <= 8 && SPLIT < 4) ? 2 : 1))      // <= 16 dims per lane: hold the register budget at two waves per SIMD
+__global__ void __launch_bounds__(256, ((DMAX <= 16 && !(SPLIT >= 2 && R > 4) && R <= 8 && (SPLIT < 4 || (ALLRBF && UNITBV && !WANT_GK))) ? 2 : 1))      // <= 16 dims per lane: hold the register budget at two waves per SIMD
                                                                             // (lane pairs at depth 5..8: one wave, 370 registers -- at 256 it spilled 452 B: 65 vs 25 ms)
 gram_bwd_fast_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
                      const double* __restrict__ Apack, int64_t a0, int64_t na, const double* __restrict__ Bxs,
@@ -1057,7 +1057,7 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     for (int d = 0; d < D; ++d) unitbv = unitbv && (pk.dd.type[d] != OAK_DIM_RBF || pk.dd.bv[d] == 1.0);
     // depth 5..8: two forms per shape -- all-continuous / unit base variances / no base-variance sums (the reference's default model), and the
     // mixed / any-variance / base-variance-gradient form, which evaluates everything else (lane pairs, > 16 sub-kernels: only the latter)
-    const bool plain58 = fast && R > 4 && allrbf && unitbv && !want_gk && D <= 16;
+    const bool plain58 = fast && allrbf && unitbv && !want_gk && ((R > 4 && D <= 16) || (R <= 4 && D > 32));     // (also the plain lane-quad form at depth <= 4)
     if (fast && (R > 4 || D > 32) && !plain58) { allrbf = false; unitbv = false; want_gk = true; }
     const int dmax = D <= 8 ? 8 : (D <= 16 ? 16 : (D <= 32 ? 32 : 64));
     // general kernel: two columns per lane while two workgroups still fit a CU's LDS (<= 24 sub-kernels) and the depth leaves registers (<= 16)
@@ -1110,8 +1110,10 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
         switch ((R <= 8 ? R : template_depth(R)) * 100 + dmax) {
             case 1216: if (plain58) OAK_BWD_FAST_K(12, 16, true, false, true) else OAK_BWD_FAST_K(12, 16, false, true, false) break;
             case 1616: if (plain58) OAK_BWD_FAST_K(16, 16, true, false, true) else OAK_BWD_FAST_K(16, 16, false, true, false) break;
-            case 164: OAK_BWD_FAST_K(1, 64, false, true, false) break;   case 264: OAK_BWD_FAST_K(2, 64, false, true, false) break;
-            case 364: OAK_BWD_FAST_K(3, 64, false, true, false) break;   case 464: OAK_BWD_FAST_K(4, 64, false, true, false) break;
+            case 164: if (plain58) OAK_BWD_FAST_K(1, 64, true, false, true) else OAK_BWD_FAST_K(1, 64, false, true, false) break;
+            case 264: if (plain58) OAK_BWD_FAST_K(2, 64, true, false, true) else OAK_BWD_FAST_K(2, 64, false, true, false) break;
+            case 364: if (plain58) OAK_BWD_FAST_K(3, 64, true, false, true) else OAK_BWD_FAST_K(3, 64, false, true, false) break;
+            case 464: if (plain58) OAK_BWD_FAST_K(4, 64, true, false, true) else OAK_BWD_FAST_K(4, 64, false, true, false) break;
             case 564: OAK_BWD_FAST_K(5, 64, false, true, false) break;   case 664: OAK_BWD_FAST_K(6, 64, false, true, false) break;
             case 764: OAK_BWD_FAST_K(7, 64, false, true, false) break;   case 864: OAK_BWD_FAST_K(8, 64, false, true, false) break;
             case 1232: OAK_BWD_FAST_K(12, 32, false, true, false) break;
