@@ -1,4 +1,4 @@
-"""Generates tests/golden/reference_sobol_L.npz by EXECUTING THE REFERENCE'S OWN CODE (build container only).
+"""Generates tests/golden/reference_sobol_L.npz and tests/golden/reference_host_logic.npz by EXECUTING THE REFERENCE'S OWN CODE (build container only).
 
     python tests/golden/make_reference_golden.py          # needs /root/reference; nothing of it travels with the repo
 
@@ -10,7 +10,13 @@ attribute of a placeholder is another placeholder, calling one returns a placeho
 run to the end; a function that touched one would return a placeholder instead of numbers, so the generator
  * calls ONLY the six functions above, whose bodies use nothing but NumPy (read them: no ``tf.``, no ``gpflow.``), and
  * refuses to write anything that is not a plain float64 ndarray of the expected shape.
-Nothing else of the reference is pinned by this file: the ELBO scalar, predictive variance and the transforms stay
+Second fixture (r04, ``reference_host_logic.npz``): the data-preparation logic that is plain NumPy / scikit-learn in the reference --
+``oak.model_utils._calculate_features`` (oak/model_utils.py:703-750: feature-type index sets, p0 of binary and p of categorical columns),
+``oak.model_utils.get_kmeans_centers`` (:31-41) and ``oak.utils.initialize_kmeans_with_binary / _with_categorical`` (oak/utils.py:533-574), the
+last three running the installed scikit-learn's KMeans exactly as the reference calls it.  ``oak.model_utils`` needs a few more inert
+placeholders to load (tikzplotlib, gpflow.models.training_mixins, tensorflow_probability.distributions); the only placeholder call on these
+paths is ``tf.random.set_seed(44)`` in get_kmeans_centers, whose result is discarded.
+Nothing else of the reference is pinned by these files: the ELBO scalar, predictive variance and the transforms stay
 "parity unpinned" (DESIGN.md section 3).
 
 The fixture holds inputs and outputs only (a few KB of numbers).  It is labelled inside the file:
@@ -29,7 +35,9 @@ OUT = Path(__file__).resolve().parent / "reference_sobol_L.npz"
 LABEL = "reference-executed: f1-f4 / compute_L / compute_L_binary_kernel only"
 PLACEHOLDERS = ("tensorflow", "tensorflow_probability", "gpflow", "gpflow.config", "gpflow.covariances", "gpflow.covariances.dispatch",
                 "gpflow.models", "gpflow.base", "gpflow.utilities", "gpflow.kernels", "gpflow.inducing_variables", "tensorflow_probability.python",
-                "tensorflow_probability.python.bijectors")
+                "tensorflow_probability.python.bijectors", "gpflow.models.training_mixins", "tensorflow_probability.distributions", "tikzplotlib")
+OUT_HOST = Path(__file__).resolve().parent / "reference_host_logic.npz"
+LABEL_HOST = "reference-executed: _calculate_features / get_kmeans_centers / initialize_kmeans_with_binary / initialize_kmeans_with_categorical only"
 
 
 class Inert(types.ModuleType):
@@ -63,6 +71,15 @@ def load_reference_utils():
     return ref_utils
 
 
+def load_reference_model_utils():
+    load_reference_utils()
+    import matplotlib
+    matplotlib.use("Agg")
+    import oak.model_utils as ref_mu
+    assert Path(ref_mu.__file__).resolve().is_relative_to(REFERENCE), ref_mu.__file__
+    return ref_mu
+
+
 def plain(a, shape):
     if not isinstance(a, np.ndarray) or a.dtype != np.float64 or a.shape != shape or not np.isfinite(a).all():
         raise SystemExit(f"not a plain finite float64 array of shape {shape}: {type(a)} -- a placeholder was touched?")
@@ -93,6 +110,38 @@ def main():
     out["Lb"] = np.stack([plain(ref.compute_L_binary_kernel(Xb, p[0], p[1], int(p[2])), (19, 19)) for p in b_params])
     np.savez_compressed(OUT, **out)
     print(f"wrote {OUT} ({OUT.stat().st_size} bytes): {LABEL}")
+    host_logic(ref)
+
+
+def host_logic(ref_utils):
+    import contextlib, io, sklearn
+    mu = load_reference_model_utils()
+    rng = np.random.default_rng(20240602)
+    n = 240
+    X = rng.normal(size=(n, 6)) * np.array([1.0, 2.0, 0.5, 1.0, 1.0, 3.0]) + np.array([0.0, 1.0, -2.0, 0.0, 0.0, 0.5])
+    X[:, 1] = (rng.random(n) < 0.35).astype(float)                     # binary
+    X[:, 3] = rng.choice(4, size=n, p=[0.1, 0.2, 0.3, 0.4]).astype(float)   # categorical, 4 classes
+    X[:, 4] = (rng.random(n) < 0.6).astype(float)                      # binary
+    out = {"label": np.array(LABEL_HOST), "sklearn_version": np.array(sklearn.__version__), "X": X}
+    with contextlib.redirect_stdout(io.StringIO()):                    # the function prints its index lists
+        cont, binary, cat, p0, p = mu._calculate_features(X, categorical_feature=[3], binary_feature=[1, 4])
+        cont_all, bin_none, cat_none, p0_none, p_none = mu._calculate_features(X[:, [0, 2, 5]], None, None)
+    assert p0_none is None and p_none is None and bin_none == [] and cat_none == []
+    out["cf_continuous"], out["cf_binary"], out["cf_categorical"] = np.array(cont), np.array(binary), np.array(cat)
+    out["cf_all_continuous"] = np.array(cont_all)
+    out["cf_p0"] = np.array([np.nan if v is None else float(v) for v in p0])            # NaN stands for the reference's None
+    out["cf_p_col3"] = plain(np.asarray(p[3], dtype=np.float64), (4, 1))
+    assert all(v is None for i, v in enumerate(p) if i != 3)
+    K = 9
+    out["K"] = np.array(K)
+    out["kmeans_centers"] = plain(np.asarray(mu.get_kmeans_centers(X[:, [0, 2, 5]], K), dtype=np.float64), (K, 3))
+    out["init_binary"] = plain(np.asarray(ref_utils.initialize_kmeans_with_binary(X[:, [0, 1, 2, 4, 5]], binary_index=[1, 3], continuous_index=[0, 2, 4],
+                                                                                  n_clusters=2), dtype=np.float64), (2, 5))
+    out["init_categorical"] = plain(np.asarray(ref_utils.initialize_kmeans_with_categorical(X[:, [0, 3, 2, 5]], binary_index=[], categorical_index=[1],
+                                                                                            continuous_index=[0, 2, 3], n_clusters=4),
+                                               dtype=np.float64), (4, 4))
+    np.savez_compressed(OUT_HOST, **out)
+    print(f"wrote {OUT_HOST} ({OUT_HOST.stat().st_size} bytes): {LABEL_HOST}")
 
 
 if __name__ == "__main__":

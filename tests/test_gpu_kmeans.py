@@ -172,3 +172,25 @@ def test_kmeans_plusplus_properties_at_scale(hip):
     sub = X[rng.choice(N, 20000, replace=False)]
     pot = lambda C: ((sub[:, None, :] - C[None, :256, :]) ** 2).sum(-1).min(1).sum()
     assert pot(c) < pot(X[rng.choice(N, K, replace=False)]) * 1.02
+
+
+def test_inducing_point_initialisers_against_the_reference_executed_fixture():
+    """tests/golden/reference_host_logic.npz: outputs of the reference's OWN ``get_kmeans_centers`` (oak/model_utils.py:31-41) and
+    ``initialize_kmeans_with_binary / _with_categorical`` (oak/utils.py:533-574), executed from /root/reference in the build container
+    with the installed scikit-learn.  The mirrors run the continuous part on the device (k-means++ seeding in scikit-learn's order +
+    Lloyd): same centres in the same order to 1e-9, discrete columns exactly."""
+    from pathlib import Path
+    import sklearn
+    from oak.model_utils import get_kmeans_centers
+    from oak.utils import initialize_kmeans_with_binary, initialize_kmeans_with_categorical
+    fx = np.load(Path(__file__).resolve().parent / "golden" / "reference_host_logic.npz")
+    if str(fx["sklearn_version"]) != sklearn.__version__:
+        pytest.skip(f"fixture made with scikit-learn {fx['sklearn_version']}, this is {sklearn.__version__}")
+    X, K = fx["X"], int(fx["K"])
+    np.testing.assert_allclose(get_kmeans_centers(X[:, [0, 2, 5]], K), fx["kmeans_centers"], rtol=0, atol=1e-9)
+    Zb = initialize_kmeans_with_binary(X[:, [0, 1, 2, 4, 5]], binary_index=[1, 3], continuous_index=[0, 2, 4], n_clusters=2)
+    np.testing.assert_array_equal(Zb[:, [1, 3]], fx["init_binary"][:, [1, 3]])
+    np.testing.assert_allclose(Zb[:, [0, 2, 4]], fx["init_binary"][:, [0, 2, 4]], rtol=0, atol=1e-9)
+    Zc = initialize_kmeans_with_categorical(X[:, [0, 3, 2, 5]], binary_index=[], categorical_index=[1], continuous_index=[0, 2, 3], n_clusters=4)
+    np.testing.assert_array_equal(Zc[:, 1], fx["init_categorical"][:, 1])
+    np.testing.assert_allclose(Zc[:, [0, 2, 3]], fx["init_categorical"][:, [0, 2, 3]], rtol=0, atol=1e-9)

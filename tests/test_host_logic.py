@@ -256,3 +256,29 @@ def test_multi_output_sgpr_is_the_sum_over_columns():
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([str(root / "orthogonal-additive-gaussian-processes_amd"), str(root), str(root / "tests")]))
     r = subprocess.run([sys.executable, "-c", _MULTI_OUTPUT], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "multi-output ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_calculate_features_against_the_reference_executed_fixture():
+    """tests/golden/reference_host_logic.npz holds what the reference's OWN ``_calculate_features`` (oak/model_utils.py:703-750,
+    executed from /root/reference in the build container by tests/golden/make_reference_golden.py) returned for a 240 x 6 matrix
+    with two binary and one categorical column: the mirror must return the same index sets, p0 and p -- exactly."""
+    import contextlib, io
+    from pathlib import Path
+    from oak.model_utils import _calculate_features
+    fx = np.load(Path(__file__).resolve().parent / "golden" / "reference_host_logic.npz")
+    assert str(fx["label"]).startswith("reference-executed")
+    X = fx["X"]
+    with contextlib.redirect_stdout(io.StringIO()):
+        cont, binary, cat, p0, p = _calculate_features(X, categorical_feature=[3], binary_feature=[1, 4])
+        cont_all, b0, c0, p0_none, p_none = _calculate_features(X[:, [0, 2, 5]], None, None)
+    assert list(cont) == fx["cf_continuous"].tolist() and list(binary) == fx["cf_binary"].tolist() and list(cat) == fx["cf_categorical"].tolist()
+    assert list(cont_all) == fx["cf_all_continuous"].tolist() and b0 == [] and c0 == [] and p0_none is None and p_none is None
+    ref_p0 = fx["cf_p0"]
+    assert len(p0) == len(ref_p0) == 6
+    for j in range(6):
+        if np.isnan(ref_p0[j]):
+            assert p0[j] is None
+        else:
+            assert float(p0[j]) == float(ref_p0[j])
+    assert all(v is None for j, v in enumerate(p) if j != 3)
+    np.testing.assert_array_equal(np.asarray(p[3], dtype=np.float64), fx["cf_p_col3"])
