@@ -336,7 +336,9 @@ class oak_model:
         self.tuple_of_indices = selected_dims[1:]
         return self.normalised_sobols
 
-    def plot(self, *args, **kwargs):
+    def plot(self, transformer_y=None, X_columns=None, X_lists=None, top_n=None, likelihood_variance=False, semilogy=True, save_fig=None,
+             tikz_path=None, ylim=None, quantile_range=None, log_axis=(False, False), grid_range=None, log_bin=None, num_bin=100):
+        """Arguments as in the reference (oak/model_utils.py:526-545); the figures themselves are outside this build's scope."""
         raise NotImplementedError("plotting (oak/model_utils.py:526-700, plotting_utils.py) is outside this build's scope")
 
 

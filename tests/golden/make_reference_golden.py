@@ -16,6 +16,8 @@ Second fixture (r04, ``reference_host_logic.npz``): the data-preparation logic t
 last three running the installed scikit-learn's KMeans exactly as the reference calls it.  ``oak.model_utils`` needs a few more inert
 placeholders to load (tikzplotlib, gpflow.models.training_mixins, tensorflow_probability.distributions); the only placeholder call on these
 paths is ``tf.random.set_seed(44)`` in get_kmeans_centers, whose result is discarded.
+Third file (``reference_signatures.json``): ``inspect.signature`` of the reference's public callables on the path -- parameter names, kinds and
+plain defaults, no body executed -- against which tests/test_host_logic.py holds the mirrors' signatures.
 Nothing else of the reference is pinned by these files: the ELBO scalar, predictive variance and the transforms stay
 "parity unpinned" (DESIGN.md section 3).
 
@@ -142,6 +144,59 @@ def host_logic(ref_utils):
                                                dtype=np.float64), (4, 4))
     np.savez_compressed(OUT_HOST, **out)
     print(f"wrote {OUT_HOST} ({OUT_HOST.stat().st_size} bytes): {LABEL_HOST}")
+    signatures(ref_utils, mu)
+
+
+def signatures(ref_utils, ref_mu):
+    """Parameter names, kinds and defaults of the reference's public callables on the path, read with ``inspect.signature`` from the
+    imported reference modules (an interface description: no body is executed).  Defaults that are placeholders or other objects are
+    recorded by type name only."""
+    import inspect, json
+    import oak.oak_kernel as ok, oak.ortho_rbf_kernel as orb, oak.ortho_binary_kernel as ob, oak.ortho_categorical_kernel as oc
+    import oak.input_measures as im
+
+    def default(v):
+        if v is inspect.Parameter.empty:
+            return "<required>"
+        if v is None or isinstance(v, (bool, int, float, str)):
+            return v
+        if isinstance(v, (list, tuple)) and all(x is None or isinstance(x, (bool, int, float, str)) for x in v):
+            return list(v)
+        return f"<{type(v).__name__}>"
+
+    def sig(fn):
+        return [[p.name, p.kind.name, default(p.default)] for p in inspect.signature(fn).parameters.values()]
+
+    targets = {
+        "oak_model.__init__": ref_mu.oak_model.__init__, "oak_model.fit": ref_mu.oak_model.fit, "oak_model.optimise": ref_mu.oak_model.optimise,
+        "oak_model.predict": ref_mu.oak_model.predict, "oak_model.get_loglik": ref_mu.oak_model.get_loglik,
+        "oak_model.get_sobol": ref_mu.oak_model.get_sobol, "oak_model.plot": ref_mu.oak_model.plot,
+        "create_model_oak": ref_mu.create_model_oak, "get_kmeans_centers": ref_mu.get_kmeans_centers, "save_model": ref_mu.save_model,
+        "load_model": ref_mu.load_model, "_calculate_features": ref_mu._calculate_features,
+        "OAKKernel.__init__": ok.OAKKernel.__init__, "OAKKernel.compute_additive_terms": ok.OAKKernel.compute_additive_terms,
+        "OAKKernel.K": ok.OAKKernel.K, "OAKKernel.K_diag": ok.OAKKernel.K_diag, "KernelComponenent.__init__": ok.KernelComponenent.__init__,
+        "get_list_representation": ok.get_list_representation, "bounded_param": ok.bounded_param,
+        "OrthogonalRBFKernel.__init__": orb.OrthogonalRBFKernel.__init__, "OrthogonalBinary.__init__": ob.OrthogonalBinary.__init__,
+        "OrthogonalCategorical.__init__": oc.OrthogonalCategorical.__init__,
+        "UniformMeasure.__init__": im.UniformMeasure.__init__, "GaussianMeasure.__init__": im.GaussianMeasure.__init__,
+        "EmpiricalMeasure.__init__": im.EmpiricalMeasure.__init__, "MOGMeasure.__init__": im.MOGMeasure.__init__,
+        "compute_sobol_oak": ref_utils.compute_sobol_oak, "get_prediction_component": ref_utils.get_prediction_component,
+        "get_model_sufficient_statistics": ref_utils.get_model_sufficient_statistics, "compute_L": ref_utils.compute_L,
+        "compute_L_binary_kernel": ref_utils.compute_L_binary_kernel, "compute_L_categorical_kernel": ref_utils.compute_L_categorical_kernel,
+        "compute_L_empirical_measure": ref_utils.compute_L_empirical_measure, "f1": ref_utils.f1,
+        "initialize_kmeans_with_binary": ref_utils.initialize_kmeans_with_binary,
+        "initialize_kmeans_with_categorical": ref_utils.initialize_kmeans_with_categorical,
+    }
+    out = {"label": "reference-introspected: inspect.signature of the imported reference callables (names, kinds, plain defaults)",
+           "signatures": {}}
+    for name, fn in targets.items():
+        try:
+            out["signatures"][name] = sig(fn)
+        except (TypeError, ValueError) as e:          # e.g. a tf.function-wrapped callable that became a placeholder
+            out["signatures"][name] = f"<not introspectable: {type(e).__name__}>"
+    dst = Path(__file__).resolve().parent / "reference_signatures.json"
+    dst.write_text(json.dumps(out, indent=1, sort_keys=True) + "\n")
+    print(f"wrote {dst} ({dst.stat().st_size} bytes)")
 
 
 if __name__ == "__main__":

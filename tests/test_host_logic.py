@@ -282,3 +282,60 @@ def test_calculate_features_against_the_reference_executed_fixture():
             assert float(p0[j]) == float(ref_p0[j])
     assert all(v is None for j, v in enumerate(p) if j != 3)
     np.testing.assert_array_equal(np.asarray(p[3], dtype=np.float64), fx["cf_p_col3"])
+
+
+def test_public_signatures_match_the_introspected_reference():
+    """tests/golden/reference_signatures.json = ``inspect.signature`` of the reference's callables on the path, read from the
+    imported reference modules in the build container (tests/golden/make_reference_golden.py).  Every mirror must take the same
+    parameters, in the same order, with the same plain defaults; it may add keyword parameters with defaults AFTER the reference's
+    (extensions), nothing else."""
+    import inspect, json
+    from pathlib import Path
+    from oak import input_measures as im, model_utils as mu, oak_kernel as ok, utils as ut
+    from oak.ortho_binary_kernel import OrthogonalBinary
+    from oak.ortho_categorical_kernel import OrthogonalCategorical
+    from oak.ortho_rbf_kernel import OrthogonalRBFKernel
+    ref = json.loads((Path(__file__).resolve().parent / "golden" / "reference_signatures.json").read_text())["signatures"]
+    mine = {
+        "oak_model.__init__": mu.oak_model.__init__, "oak_model.fit": mu.oak_model.fit, "oak_model.optimise": mu.oak_model.optimise,
+        "oak_model.predict": mu.oak_model.predict, "oak_model.get_loglik": mu.oak_model.get_loglik, "oak_model.get_sobol": mu.oak_model.get_sobol,
+        "oak_model.plot": mu.oak_model.plot, "create_model_oak": mu.create_model_oak, "get_kmeans_centers": mu.get_kmeans_centers,
+        "save_model": mu.save_model, "load_model": mu.load_model, "_calculate_features": mu._calculate_features,
+        "OAKKernel.__init__": ok.OAKKernel.__init__, "OAKKernel.compute_additive_terms": ok.OAKKernel.compute_additive_terms,
+        "OAKKernel.K": ok.OAKKernel.K, "OAKKernel.K_diag": ok.OAKKernel.K_diag, "KernelComponenent.__init__": ok.KernelComponenent.__init__,
+        "get_list_representation": ok.get_list_representation, "bounded_param": ok.bounded_param,
+        "OrthogonalRBFKernel.__init__": OrthogonalRBFKernel.__init__, "OrthogonalBinary.__init__": OrthogonalBinary.__init__,
+        "OrthogonalCategorical.__init__": OrthogonalCategorical.__init__, "UniformMeasure.__init__": im.UniformMeasure.__init__,
+        "GaussianMeasure.__init__": im.GaussianMeasure.__init__, "EmpiricalMeasure.__init__": im.EmpiricalMeasure.__init__,
+        "MOGMeasure.__init__": im.MOGMeasure.__init__, "compute_sobol_oak": ut.compute_sobol_oak,
+        "get_prediction_component": ut.get_prediction_component, "get_model_sufficient_statistics": ut.get_model_sufficient_statistics,
+        "compute_L": ut.compute_L, "compute_L_binary_kernel": ut.compute_L_binary_kernel,
+        "compute_L_categorical_kernel": ut.compute_L_categorical_kernel, "f1": ut.f1,
+        "initialize_kmeans_with_binary": ut.initialize_kmeans_with_binary,
+        "initialize_kmeans_with_categorical": ut.initialize_kmeans_with_categorical,
+    }
+    checked, problems = 0, []
+    for name, rsig in ref.items():
+        if isinstance(rsig, str) or name not in mine:          # a tf.function wrapper that became a placeholder: nothing to compare
+            continue
+        params = list(inspect.signature(mine[name]).parameters.values())
+        for k, (pname, kind, default) in enumerate(rsig):
+            if k >= len(params):
+                problems.append(f"{name}: missing parameter {pname}")
+                break
+            p = params[k]
+            if p.name != pname:
+                problems.append(f"{name}: parameter {k} is {p.name!r}, the reference's is {pname!r}")
+                break
+            if default == "<required>":
+                if p.default is not inspect.Parameter.empty:
+                    problems.append(f"{name}.{pname}: has default {p.default!r}, required in the reference")
+            elif not (isinstance(default, str) and default.startswith("<")):
+                mine_default = list(p.default) if isinstance(p.default, (list, tuple)) else p.default
+                if mine_default != default or (p.default is inspect.Parameter.empty):
+                    problems.append(f"{name}.{pname}: default {p.default!r}, the reference's is {default!r}")
+        for p in params[len(rsig):]:
+            if p.default is inspect.Parameter.empty and p.kind not in (p.VAR_KEYWORD, p.VAR_POSITIONAL):
+                problems.append(f"{name}: extra parameter {p.name} without a default")
+        checked += 1
+    assert checked >= 30 and not problems, "\\n".join(problems)
