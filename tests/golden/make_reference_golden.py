@@ -194,6 +194,17 @@ def signatures(ref_utils, ref_mu):
             out["signatures"][name] = sig(fn)
         except (TypeError, ValueError) as e:          # e.g. a tf.function-wrapped callable that became a placeholder
             out["signatures"][name] = f"<not introspectable: {type(e).__name__}>"
+    # members the reference's classes define themselves, and the functions / classes its modules define (not what they import)
+    import oak.normalising_flow as nf
+    classes = {"oak_model": ref_mu.oak_model, "OAKKernel": ok.OAKKernel, "KernelComponenent": ok.KernelComponenent,
+               "OrthogonalRBFKernel": orb.OrthogonalRBFKernel, "OrthogonalBinary": ob.OrthogonalBinary, "OrthogonalCategorical": oc.OrthogonalCategorical,
+               "UniformMeasure": im.UniformMeasure, "GaussianMeasure": im.GaussianMeasure, "EmpiricalMeasure": im.EmpiricalMeasure,
+               "MOGMeasure": im.MOGMeasure, "Normalizer": nf.Normalizer}
+    out["class_members"] = {name: sorted(k for k, v in vars(cls).items() if callable(v) or isinstance(v, property)) for name, cls in classes.items()}
+    modules = {"oak.model_utils": ref_mu, "oak.utils": ref_utils, "oak.oak_kernel": ok, "oak.input_measures": im, "oak.normalising_flow": nf,
+               "oak.ortho_rbf_kernel": orb, "oak.ortho_binary_kernel": ob, "oak.ortho_categorical_kernel": oc}
+    out["module_members"] = {name: sorted(k for k, v in vars(mod).items() if (inspect.isfunction(v) or inspect.isclass(v)) and getattr(v, "__module__", None) == mod.__name__)
+                             for name, mod in modules.items()}
     dst = Path(__file__).resolve().parent / "reference_signatures.json"
     dst.write_text(json.dumps(out, indent=1, sort_keys=True) + "\n")
     print(f"wrote {dst} ({dst.stat().st_size} bytes)")
