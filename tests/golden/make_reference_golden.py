@@ -39,7 +39,7 @@ PLACEHOLDERS = ("tensorflow", "tensorflow_probability", "gpflow", "gpflow.config
                 "gpflow.models", "gpflow.base", "gpflow.utilities", "gpflow.kernels", "gpflow.inducing_variables", "tensorflow_probability.python",
                 "tensorflow_probability.python.bijectors", "gpflow.models.training_mixins", "tensorflow_probability.distributions", "tikzplotlib")
 OUT_HOST = Path(__file__).resolve().parent / "reference_host_logic.npz"
-LABEL_HOST = "reference-executed: _calculate_features / get_kmeans_centers / initialize_kmeans_with_binary / initialize_kmeans_with_categorical only"
+LABEL_HOST = "reference-executed: _calculate_features / get_kmeans_centers / initialize_kmeans_with_binary / _with_categorical / estimate_one_dim_gmm / oak_model.__init__ only"
 
 
 class Inert(types.ModuleType):
@@ -142,6 +142,20 @@ def host_logic(ref_utils):
     out["init_categorical"] = plain(np.asarray(ref_utils.initialize_kmeans_with_categorical(X[:, [0, 3, 2, 5]], binary_index=[], categorical_index=[1],
                                                                                             continuous_index=[0, 2, 3], n_clusters=4),
                                                dtype=np.float64), (4, 4))
+    # estimate_one_dim_gmm (oak/model_utils.py:753-770): scikit-learn's GaussianMixture as the reference configures it, wrapped in its MOGMeasure
+    xg = np.concatenate([rng.normal(-2.0, 0.5, 150), rng.normal(1.5, 1.0, 250)])
+    mog = mu.estimate_one_dim_gmm(3, xg)
+    out["gmm_x"] = xg
+    out["gmm_means"], out["gmm_variances"], out["gmm_weights"] = (plain(np.asarray(getattr(mog, k), dtype=np.float64), (3,)) for k in ("means", "variances", "weights"))
+    # the attributes an oak_model instance starts with (oak/model_utils.py:195-247): plain Python, names and default values
+    import json
+    def attrs(obj):
+        return {k: (v if v is None or isinstance(v, (bool, int, float, str, list)) else f"<{type(v).__name__}>") for k, v in vars(obj).items()}
+    out["oak_model_default_attrs"] = np.array(json.dumps(attrs(mu.oak_model()), sort_keys=True))
+    out["oak_model_custom_attrs"] = np.array(json.dumps(attrs(mu.oak_model(max_interaction_depth=3, num_inducing=50, lengthscale_bounds=[0.01, 10.0],
+                                                                             binary_feature=[1], categorical_feature=[2], empirical_measure=[0],
+                                                                             use_sparsity_prior=False, gmm_measure=[0, 2, 0], sparse=True,
+                                                                             use_normalising_flow=False, share_var_across_orders=False)), sort_keys=True))
     np.savez_compressed(OUT_HOST, **out)
     print(f"wrote {OUT_HOST} ({OUT_HOST.stat().st_size} bytes): {LABEL_HOST}")
     signatures(ref_utils, mu)

@@ -365,3 +365,27 @@ def test_members_of_the_introspected_reference_exist_in_the_mirror():
             members = [m for m in members if m != "KL_objective"]
         missing += [f"{cname}.{m}" for m in members if not hasattr(cls, m)]
     assert not missing, missing
+
+
+def test_model_defaults_and_gmm_estimate_against_the_reference_executed_fixture():
+    """Same fixture: the attributes a freshly constructed reference ``oak_model`` carries (defaults and a fully specified call) and
+    the mixture the reference's ``estimate_one_dim_gmm`` fits (scikit-learn GaussianMixture, spherical, random_state=0)."""
+    import json
+    from pathlib import Path
+    import sklearn
+    from oak.model_utils import estimate_one_dim_gmm, oak_model
+    fx = np.load(Path(__file__).resolve().parent / "golden" / "reference_host_logic.npz")
+    custom = dict(max_interaction_depth=3, num_inducing=50, lengthscale_bounds=[0.01, 10.0], binary_feature=[1], categorical_feature=[2],
+                  empirical_measure=[0], use_sparsity_prior=False, gmm_measure=[0, 2, 0], sparse=True, use_normalising_flow=False,
+                  share_var_across_orders=False)
+    for key, model in (("oak_model_default_attrs", oak_model()), ("oak_model_custom_attrs", oak_model(**custom))):
+        ref = json.loads(str(fx[key]))
+        mine = vars(model)
+        for name, value in ref.items():
+            assert name in mine, f"{key}: attribute {name} missing"
+            got = list(mine[name]) if isinstance(mine[name], tuple) else mine[name]
+            assert got == value, f"{key}: {name} = {got!r}, the reference's {value!r}"
+    if str(fx["sklearn_version"]) == sklearn.__version__:
+        mog = estimate_one_dim_gmm(3, fx["gmm_x"])
+        for name in ("means", "variances", "weights"):
+            np.testing.assert_array_equal(np.asarray(getattr(mog, name), dtype=np.float64).reshape(-1), fx[f"gmm_{name}"])
