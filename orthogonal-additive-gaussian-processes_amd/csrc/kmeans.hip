@@ -26,6 +26,9 @@
 
 namespace oak {
 
+#ifndef OAK_KM_TWO_CENTRES
+#define OAK_KM_TWO_CENTRES 1
+#endif
 static constexpr int KM_LDS_DOUBLES = 4096;   // 32 KiB of centres per LDS chunk
 
 template <int DMAX, int P>
@@ -54,7 +57,35 @@ kmeans_assign_kernel(const double* __restrict__ X, int64_t N, int D, int64_t ldx
         __syncthreads();
         for (int idx = tid; idx < kc * DMAX; idx += 256) sC[idx] = C[(int64_t)k0 * DMAX + idx];
         __syncthreads();
-        for (int kk = 0; kk < kc; ++kk) {
+        int kk = 0;
+#if OAK_KM_TWO_CENTRES
+        // two centres per trip: 2 P independent accumulation chains per lane instead of P (each chain is DMAX dependent FMAs)
+        for (; kk + 1 < kc; kk += 2) {
+            double da[P], db[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p) { da[p] = 0.0; db[p] = 0.0; }
+#pragma unroll
+            for (int d = 0; d < DMAX; d += 2) {
+                const double2 ca = *reinterpret_cast<const double2*>(&sC[kk * DMAX + d]);          // uniform addresses: LDS broadcast
+                const double2 cb = *reinterpret_cast<const double2*>(&sC[(kk + 1) * DMAX + d]);
+#pragma unroll
+                for (int p = 0; p < P; ++p) {
+                    const double a0 = x[p][d] - ca.x, b0 = x[p][d] - cb.x;
+                    da[p] = __builtin_fma(a0, a0, da[p]);
+                    db[p] = __builtin_fma(b0, b0, db[p]);
+                    const double a1 = x[p][d + 1] - ca.y, b1 = x[p][d + 1] - cb.y;
+                    da[p] = __builtin_fma(a1, a1, da[p]);
+                    db[p] = __builtin_fma(b1, b1, db[p]);
+                }
+            }
+#pragma unroll
+            for (int p = 0; p < P; ++p) {                       // in centre order, strict <: the first minimum wins
+                if (da[p] < best[p]) { best[p] = da[p]; bi[p] = k0 + kk; }
+                if (db[p] < best[p]) { best[p] = db[p]; bi[p] = k0 + kk + 1; }
+            }
+        }
+#endif
+        for (; kk < kc; ++kk) {
             double dist[P];
 #pragma unroll
             for (int p = 0; p < P; ++p) dist[p] = 0.0;
