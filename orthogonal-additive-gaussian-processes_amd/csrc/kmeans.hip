@@ -540,13 +540,16 @@ kpp_pick_kernel(const double* __restrict__ closest, const double* __restrict__ b
 
 // newmin[t][i] = min(closest_i, |x_i - x_cand_t|^2) and per-block sums part[t][block].  Each point is read once and
 // tested against all candidates (their coordinates sit in LDS, broadcast reads).
+// KPP_DT threads per workgroup: with one workgroup per 4096 points the row-strided loads need every wave a CU can hold to cover their latency
+// (256 threads: 178 us per selection step at N = 2^20; 1024: see tools/dev_kmeans.py)
+static constexpr int KPP_DT = 256;
 template <int DMAX>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(KPP_DT)
 kpp_dist_kernel(const double* __restrict__ X, int64_t N, int D, int64_t ldx, const int64_t* __restrict__ cand, int n_trials,
                 const double* __restrict__ closest, double* __restrict__ newmin, double* __restrict__ part) {
-    __shared__ double red[256];
+    __shared__ double red[KPP_DT];
     __shared__ double cs[KPP_MAXT][DMAX];
-    for (int idx = threadIdx.x; idx < n_trials * DMAX; idx += 256) {
+    for (int idx = threadIdx.x; idx < n_trials * DMAX; idx += KPP_DT) {
         const int t = idx / DMAX, d = idx - t * DMAX;
         cs[t][d] = d < D ? X[cand[t] * ldx + d] : 0.0;
     }
@@ -555,12 +558,23 @@ kpp_dist_kernel(const double* __restrict__ X, int64_t N, int D, int64_t ldx, con
     double s[KPP_MAXT];
 #pragma unroll
     for (int t = 0; t < KPP_MAXT; ++t) s[t] = 0.0;
-    for (int q = 0; q < KPP_BLOCK / 256; ++q) {
-        const int64_t i = b0 + (int64_t)q * 256 + threadIdx.x;
+    // The 256 rows of a trip come in as ONE contiguous, coalesced block and go through an LDS tile (odd pitch: conflict-free row reads);
+    // read row by row per thread, every load instruction touched 64 cache lines for 8 bytes each.  Arithmetic and order unchanged.
+    extern __shared__ double kpp_tile[];                     // [256][DMAX + 1]
+    for (int q = 0; q < KPP_BLOCK / KPP_DT; ++q) {
+        const int64_t r0 = b0 + (int64_t)q * KPP_DT;
+        __syncthreads();
+        const int64_t nel = (r0 + KPP_DT <= N ? KPP_DT : (r0 < N ? N - r0 : 0)) * ldx;
+        for (int64_t e = threadIdx.x; e < nel; e += KPP_DT) {
+            const int r = (int)(e / ldx), c = (int)(e - (int64_t)r * ldx);
+            if (c < D) kpp_tile[r * (DMAX + 1) + c] = X[r0 * ldx + e];
+        }
+        __syncthreads();
+        const int64_t i = r0 + threadIdx.x;
         if (i < N) {
             double x[DMAX];
 #pragma unroll
-            for (int d = 0; d < DMAX; ++d) x[d] = d < D ? X[i * ldx + d] : 0.0;
+            for (int d = 0; d < DMAX; ++d) x[d] = d < D ? kpp_tile[threadIdx.x * (DMAX + 1) + d] : 0.0;
             const double cl = closest[i];
 #pragma unroll
             for (int t = 0; t < KPP_MAXT; ++t) {
@@ -578,9 +592,15 @@ kpp_dist_kernel(const double* __restrict__ X, int64_t N, int D, int64_t ldx, con
 #pragma unroll
     for (int t = 0; t < KPP_MAXT; ++t) {
         if (t < n_trials) {
-            const double r = kpp_block_reduce(s[t], red);
-            if (threadIdx.x == 0) part[(int64_t)t * gridDim.x + blockIdx.x] = r;
+            const double ws = km_wave_sum(s[t]);        // fixed butterfly within the wave, then the waves in order: two barriers
+            if ((threadIdx.x & 63) == 0) red[t * (KPP_DT / 64) + (threadIdx.x >> 6)] = ws;      // for ALL trials instead of eight trees of eight
         }
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < n_trials) {
+        double r = red[threadIdx.x * (KPP_DT / 64)];
+        for (int w = 1; w < KPP_DT / 64; ++w) r += red[threadIdx.x * (KPP_DT / 64) + w];
+        part[(int64_t)threadIdx.x * gridDim.x + blockIdx.x] = r;
     }
 }
 
@@ -635,9 +655,11 @@ static int kpp_run(oak_ctx* ctx, const double* dX, int64_t N, int D, int64_t ldx
     OAK_HIP_CHECK(hipGetLastError());
     OAK_CHECK(reduce_sum(ctx, dBsum, nb, dState, 0, 1));                           // initial potential
     const size_t lds_pick = sizeof(double) * ((size_t)nb + 1 + 256);
+    const size_t lds_dist = sizeof(double) * (size_t)KPP_DT * (DMAX + 1);
+    if (lds_dist > 48 * 1024) OAK_CHECK(ensure_dynamic_lds((const void*)kpp_dist_kernel<DMAX>, lds_dist));      // next to ~10 KiB of static LDS
     for (int c = 1; c < K; ++c) {
         kpp_pick_kernel<<<1, 256, lds_pick, ctx->stream>>>(dClosest, dBsum, nb, N, dState, dU + (size_t)(c - 1) * n_trials, n_trials, dCand);
-        kpp_dist_kernel<DMAX><<<nb, 256, 0, ctx->stream>>>(dX, N, D, ldx, dCand, n_trials, dClosest, dNewmin, dPart);
+        kpp_dist_kernel<DMAX><<<nb, KPP_DT, lds_dist, ctx->stream>>>(dX, N, D, ldx, dCand, n_trials, dClosest, dNewmin, dPart);
         kpp_select_kernel<<<1, 256, 0, ctx->stream>>>(dPart, nb, n_trials, dCand, dState, dIdx, c);
         kpp_commit_kernel<<<nb, 256, 0, ctx->stream>>>(dNewmin, dPart, N, dState, dClosest, dBsum);
     }
