@@ -126,10 +126,11 @@ def spawn_ranks(world, argv):
 def sobol_record(ctx, desc, spec, Z, M, D, R):
     """All Sobol terms of the model (oak/utils.py:338-435) from the posterior of the last evaluation: the Gram-of-products pass
     (two fp64-MFMA SYRKs over the index-pair panel) timed with HIP events on the library's stream, against the fp64 matrix peak."""
-    from oracle import oak_oracle               # list_representation only (test-infrastructure helper; nothing is computed by it)
+    import itertools
     from oak import _capi
     alpha = ctx.sgpr_alpha(M)
-    subsets = oak_oracle.list_representation(D, R)[1:]
+    # the term list of oak.oak_kernel.get_list_representation (oak/oak_kernel.py:338-364) without its constant term
+    subsets = [list(c) for r in range(1, R + 1) for c in itertools.combinations(range(D), r)]
     packed = _capi.HipContext.pack_subsets(subsets)
     ctx.sobol(desc, Z, alpha, packed)             # warm-up (scratch buffers, descriptor tables)
     reps = 5
@@ -507,6 +508,8 @@ def main():
     gram_roofline["frac_of_algorithmic_floor"] = (floor_ipd * pair_dims / 64.0 / (gram_ms * 1e-3) / DP_ISSUE_PEAK) if gram_ms else None
     gram_roofline["in_step_frac_of_algorithmic_floor"] = (floor_ipd * pair_dims / 64.0 / (gram_step_ms * 1e-3) / DP_ISSUE_PEAK) if gram_step_ms else None
 
+    kernel_note = ("20 Gaussian-measure ortho-RBF + 8 orthogonal binary (p0=0.7) + 4 orthogonal categorical (C=5) sub-kernels"
+                   if cfg.get("mixed") else "Gaussian-measure ortho-RBF")
     out = {
         "metric": "ELBO steps/sec" + (" (forward+gradient)" if args.grad else " (forward)")
                   + (" [fp32 statistics mode: not the reference's fp64 arithmetic]" if precision_used == "fp32" else "")
@@ -516,7 +519,7 @@ def main():
         "dtype": "f64" if precision_used == "fp64" else "f32 panel + f32-MFMA partials, f64 sums / tail",
         "precision_requested": args.precision, "precision_used": precision_used,
         "data": "synthetic", "degraded": degraded,
-        "config": {"workload": f"{args.config}: SGPR ELBO, N={N} D={D} M={M} order={R}, Gaussian-measure ortho-RBF, "
+        "config": {"workload": f"{args.config}: SGPR ELBO, N={N} D={D} M={M} order={R}, {kernel_note}, "
                                f"Z=X[:M], noise=0.01, jitter=1e-6, route={args.route}, precision={precision_used}",
                    "N": N, "D": D, "M": M, "order": R, "rows_per_gpu": n_local, "parallelism": f"row-shard x{world}",
                    "exchange": exchange_note, "rccl": rccl_info},

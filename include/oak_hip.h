@@ -336,7 +336,9 @@ int oak_comm_init_host(oak_ctx* ctx, int32_t nranks, int32_t rank, oak_host_allr
    against), its ncclGetVersion and the header's NCCL_VERSION_CODE; a major-version mismatch is refused at load time. */
 int oak_comm_info(char* path_out, int64_t cap, int32_t* version_out, int32_t* header_version_out);
 int oak_comm_destroy(oak_ctx* ctx);
-int oak_comm_allreduce_stats(oak_ctx* ctx);                    /* in-place sum of packed stats */
+/* In-place sum over the ranks of the packed statistics AND, with extra target columns set (oak_sgpr_set_extra_targets), of their
+   [Kuf y_p | y_p^T y_p]: local_stats -> allreduce_stats -> tail exchanges exactly what oak_sgpr_elbo does. */
+int oak_comm_allreduce_stats(oak_ctx* ctx);
 int oak_comm_allreduce_host(oak_ctx* ctx, double* buf, int64_t n); /* small host vector (gradients) */
 /* All-gather of variable-sized blocks of a host vector: buf has sum(counts) doubles, rank r owns counts[r] of them at
    offset sum(counts[:r]); on return every rank holds all blocks (predictions are sharded with no other exchange).
@@ -386,19 +388,8 @@ int oak_kmeans_plusplus(oak_ctx* ctx, const double* X, int64_t N, int32_t D, int
                         int64_t first_index, const double* uniforms, int32_t n_trials, double* centres_out,
                         int64_t* indices_out);
 
-/* ---- device-resident benchmarking hooks (inputs already in HBM) ---------------------------- */
-/* Explicit Kuf panel for the rows set with oak_sgpr_set_data, written to a device buffer and not
-   copied back: the "Gram GB/s" workload.  bytes_out = algorithmic bytes 8*(N*M + N*D + M*D). */
-int oak_bench_gram_resident(oak_ctx* ctx, const oak_kernel_desc* desc, double* bytes_out);
-/* The Cholesky of the O(M^3) tail alone (tf.linalg.cholesky at oak/utils.py:188,193): factors an n x n SPD test matrix
-   (exponential kernel + 1e-3 I, built on the device) `reps` times; *ms_out = mean GPU time per factorisation (HIP events),
-   *logdet_out (may be NULL) = log det from the factor, for checking against a host Cholesky of the same matrix. */
-int oak_bench_potrf(oak_ctx* ctx, int64_t n, int32_t reps, double* ms_out, double* logdet_out);
-/* The many-right-hand-side triangular solve alone (tf.linalg.triangular_solve at oak/utils.py:189 and in predict_f): every row
-   b of B (host, nrhs x n row-major, overwritten) becomes the solution of L x = b (trans = 0) or L^T x = b (trans = 1) for the
-   lower-triangular host matrix L (n x n); *ms_out (may be NULL) = mean GPU time of `reps` solves.  For residual checks and
-   timing of the blocked solve the whitened route, the SVGP and large prediction batches run. */
-int oak_bench_trsm(oak_ctx* ctx, const double* L, int64_t n, double* B, int64_t nrhs, int32_t trans, int32_t reps, double* ms_out);
+/* Measurement hooks (oak_bench_*: resident Gram pass, the tail's Cholesky and the many-row triangular solve on their own) are not part
+   of the drop-in surface: include/oak_hip_bench.h. */
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,28 @@
+/* Measurement hooks of liboak_hip.so -- NOT part of the drop-in boundary (include/oak_hip.h): nothing in the reference binds to
+   these.  bench.py and tools/ time single kernels of the path through them with the inputs already resident in HBM. */
+#ifndef OAK_HIP_BENCH_H
+#define OAK_HIP_BENCH_H
+#include "oak_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- device-resident benchmarking hooks (inputs already in HBM) ---------------------------- */
+/* Explicit Kuf panel for the rows set with oak_sgpr_set_data, written to a device buffer and not
+   copied back: the "Gram GB/s" workload.  bytes_out = algorithmic bytes 8*(N*M + N*D + M*D). */
+int oak_bench_gram_resident(oak_ctx* ctx, const oak_kernel_desc* desc, double* bytes_out);
+/* The Cholesky of the O(M^3) tail alone (tf.linalg.cholesky at oak/utils.py:188,193): factors an n x n SPD test matrix
+   (exponential kernel + 1e-3 I, built on the device) `reps` times; *ms_out = mean GPU time per factorisation (HIP events),
+   *logdet_out (may be NULL) = log det from the factor, for checking against a host Cholesky of the same matrix. */
+int oak_bench_potrf(oak_ctx* ctx, int64_t n, int32_t reps, double* ms_out, double* logdet_out);
+/* The many-right-hand-side triangular solve alone (tf.linalg.triangular_solve at oak/utils.py:189 and in predict_f): every row
+   b of B (host, nrhs x n row-major, overwritten) becomes the solution of L x = b (trans = 0) or L^T x = b (trans = 1) for the
+   lower-triangular host matrix L (n x n); *ms_out (may be NULL) = mean GPU time of `reps` solves.  For residual checks and
+   timing of the blocked solve the whitened route, the SVGP and large prediction batches run. */
+int oak_bench_trsm(oak_ctx* ctx, const double* L, int64_t n, double* B, int64_t nrhs, int32_t trans, int32_t reps, double* ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OAK_HIP_BENCH_H */

@@ -230,6 +230,14 @@ int oak_comm_allreduce_stats(oak_ctx* ctx) {
     PhaseTimer t(ctx, "allreduce");
     // the two trailing slots (shards that whitened, shards summed) ride along: the tail rejects a mixed sum
     OAK_CHECK(comm_allreduce_dev(ctx, d_stats, oak_sgpr_stats_len(ctx)));
+    // extra target columns: [Kuf y_p | y_p^T y_p] is part of the same sum over the row shards -- reduced HERE, so that the documented
+    // local_stats -> allreduce_stats -> tail sequence and the fused entry points exchange the same things
+    if (ctx->n_extra > 0) {
+        double* d_psix = (double*)peek_buf(ctx, "psix");
+        OAK_REQUIRE(d_psix != nullptr && ctx->psix_valid, "oak_comm_allreduce_stats: the extra target columns' statistics are not those of the "
+                    "packed statistics in place (form both with oak_sgpr_local_stats on every rank)");
+        OAK_CHECK(comm_allreduce_dev(ctx, d_psix, (int64_t)ctx->n_extra * ctx->M + ctx->n_extra, "comm_stage_x"));
+    }
     t.stop();
     return OAK_OK;
 }

@@ -370,7 +370,9 @@ int syrk_plan_splits(oak_ctx* ctx, int64_t M, int64_t nrows) {
     // 34.6 ms, from 128-256, 17.4 ms); every 8 splits add M x M partials to the fixed-order reduction (~100 row-equivalents
     // at M <= 1024, growing with M^2).
     (void)per_cu;
-    const int cus_per_xcd = ctx->num_cu / 8 > 0 ? ctx->num_cu / 8 : 1;
+    // a partitioned forward pass whose SYRK stays on main_part has the side stream's compute units taken out of every XCD
+    const int cus_total = (ctx->part_active && !ctx->part_syrk_full && ctx->route != 2) ? ctx->num_cu - ctx->part_cus : ctx->num_cu;
+    const int cus_per_xcd = cus_total / 8 > 0 ? cus_total / 8 : 1;
     const double red_m2 = 100.0 * ((double)ntile * SY_T / 1024.0) * ((double)ntile * SY_T / 1024.0);
     const double red = red_m2 > 100.0 ? red_m2 : 100.0;
     int best_s = 1;

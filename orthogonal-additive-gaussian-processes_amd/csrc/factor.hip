@@ -967,6 +967,14 @@ __global__ void zero_upper_kernel(double* __restrict__ A, int64_t n, int64_t lda
 
 static const int PO_BIG = 0x7fffffff;
 
+// status word of a factorisation as a kernel left it in "potrf_info" (read by the caller together with its other results)
+int potrf_check_value(int info, int64_t n) {
+    if (info != PO_BIG) {
+        set_error("Cholesky decomposition was not successful: leading minor of order %d is not positive definite (n=%lld)", info, (long long)n);
+        return OAK_E_NOTPD;
+    }
+    return OAK_OK;
+}
 int potrf_check(oak_ctx* ctx, int slot, int64_t n) {
     int* d_info = (int*)peek_buf(ctx, "potrf_info");
     int info = 0;

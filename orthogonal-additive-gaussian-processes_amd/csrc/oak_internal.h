@@ -8,6 +8,7 @@
 #include <vector>
 #include <map>
 #include "oak_hip.h"
+#include "oak_hip_bench.h"
 
 namespace oak {
 
@@ -62,15 +63,19 @@ struct DevMeasure {
     unsigned char kind[OAK_MAX_DIMS];
     int k[OAK_MAX_DIMS];
     int off[OAK_MAX_DIMS];         // offset into device meas buffer
-    double p0[OAK_MAX_DIMS], p1[OAK_MAX_DIMS];
+    double p0[OAK_MAX_DIMS], p1[OAK_MAX_DIMS];   // continuous dims: measure parameters; binary dims: p0 and sqrt(base variance)
     double ls[OAK_MAX_DIMS];
     double inv_sqrt_v[OAK_MAX_DIMS];   // 1/sqrt(var_s)   (0 for unconstrained)
     double dlogv[OAK_MAX_DIMS];        // d log(var_s) / d lengthscale  (gradient path)
 };
 
 // Featurised point set, struct-of-arrays, dimension-major: xs[d*ld + i], cn[d*ld + i]
-//   RBF dim:      xs = x * scale_d ;  cn = cov_X_s(x)/sqrt(var_s)
-//   discrete dim: xs = category index (as double) ; cn = 0
+//   RBF dim:         xs = x * scale_d ;  cn = cov_X_s(x)/sqrt(var_s)
+//   categorical dim: xs = category index (as double) ; cn = 0
+//   binary dim:      xs = category index (as double) ; cn = a(x) * sqrt(bv), a = (1 - p0, -p0)[x]: the sub-kernel is the rank-one
+//                    product cn_a * cn_b (ortho_binary_kernel.py:29-38) and the forward Gram kernel evaluates it as that, NOT as
+//                    E - cn_a cn_b.  A kernel that walks every dim with the RBF form must branch on dd.type first (the backward,
+//                    fp32, diag and generic kernels read the table for discrete dims and ignore cn there).
 struct Feat {
     double* xs = nullptr;
     double* cn = nullptr;
@@ -81,6 +86,14 @@ struct Feat {
     int nx = 0;
     int64_t n = 0;
     int64_t ld = 0;
+};
+
+// the streams and events of one context (pooled per process, runtime.hip::acquire_streams)
+struct StreamSet {
+    int device = 0;
+    hipStream_t main = nullptr, side = nullptr, main_part = nullptr, side_part = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    int part_cus = 0, part_cus_req = 0;
 };
 
 struct DevBuf {
@@ -116,6 +129,18 @@ struct oak_ctx {
     hipStream_t stream = nullptr;
     hipStream_t side = nullptr;                  // side stream: Kuu factorisation overlapped with the N-sized stages
     hipEvent_t ev0 = nullptr, ev1 = nullptr;     // fork / join events for the side stream
+    // Spatial partition for SMALL evaluations (sgpr_forward): `side_part` owns part_cus compute units (the same
+    // ones in every XCD, hipExtStreamCreateWithCUMask), `main_part` the others.  The latency-bound chol(Kuu) chain then runs at
+    // its stand-alone speed NEXT to the first Gram panel instead of in front of it.  `stream` / `side` point at the unmasked pair
+    // (`main_full` / `side_full`) except inside a partitioned forward pass.
+    hipStream_t main_full = nullptr, side_full = nullptr, main_part = nullptr, side_part = nullptr;
+    hipEvent_t ev3 = nullptr;                    // main_part -> main_full hand-over
+    int part_cus = 0;                            // compute units of side_part (0: no partition streams)
+    int part_cus_req = 0;                        // what OAK_PART_CUS asked for when the streams were made (pool key)
+    bool part_active = false;                    // inside a partitioned forward pass
+    bool kuu_deferred = false;                   // ... whose side chain is enqueued by local_stats right behind its first Gram launch
+    bool part_syrk_full = false;                 // ... whose SYRK runs on the whole chip once the side chain has finished
+    double kuu_jitter = 0;                       // jitter of the deferred chain
     std::map<std::string, oak::DevBuf> bufs;     // named, grow-only device scratch
     std::map<std::string, oak::Timing> timings;
     std::vector<oak::PendingEvt> pending;       // harvested without blocking once it grows (PhaseTimer::stop), read by oak_last_timing
@@ -233,7 +258,8 @@ int syrk_reduce(oak_ctx* ctx, const double* d_part, int nsplit, int64_t M, doubl
 // (row r >= n ends up as  A[r, :n] L^-T,  i.e. the solution of L x = A[r, :n]^T: a right-hand side rides for free).
 int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, bool check = true, int64_t nrows = -1, bool identity_below = false);
 int set_identity(oak_ctx* ctx, double* dA, int64_t n);
-int potrf_check(oak_ctx* ctx, int slot, int64_t n);   // deferred status of a check=false factorisation (slot 1 = side stream)
+int potrf_check(oak_ctx* ctx, int slot, int64_t n);
+int potrf_check_value(int info, int64_t n);             // the same test on a status word the caller fetched itself   // deferred status of a check=false factorisation (slot 1 = side stream)
 // rows-trsm: each of the nrhs rows of BT (row stride ldb) is a right-hand side; solves L x = b (trans=0)
 // or L^T x = b (trans=1) in place.
 int trsm_rows(oak_ctx* ctx, const double* dL, int64_t n, int64_t ldl, double* dBT, int64_t nrhs, int64_t ldb, int trans);
@@ -284,7 +310,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter);
 int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out,
               int l_state = 0);
 bool sgpr_route_whitened(const oak_ctx* ctx);
-int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter, double* cond_out = nullptr);
+int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter, double* cond_out = nullptr, bool fork = true);
 int sgpr_forward(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out);
 int sgpr_ensure_alpha(oak_ctx* ctx);
 // psix[p][m] (+)= sum_r panel[r][m] * Yx[p][a0 + r] for the extra target columns, one pass over a raw Kfu panel chunk

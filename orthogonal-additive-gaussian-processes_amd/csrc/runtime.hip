@@ -601,6 +601,65 @@ static hipError_t create_side_stream(hipStream_t* s) {
         return hipSuccess;
     return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
 }
+// The partition pair.  Mask bit i stands for compute unit i / 8 of XCD i % 8 (tools/ubench/cumask_probe.hip: bits 0..15 = two CUs in
+// each of the eight XCDs; a mask that leaves an XCD empty is ignored by the driver), so both masks keep all XCDs with equal
+// shares and every XCD-aware workgroup mapping stays valid.  OAK_PART_CUS = 0 disables, 8 / 16 / 24 / 32 sets the side's share.
+static int requested_part_cus() {
+    int side_cus = 16;
+    if (const char* e = getenv("OAK_PART_CUS")) side_cus = atoi(e);
+    return (side_cus <= 0 || side_cus % 8 != 0 || side_cus > 64) ? 0 : side_cus;
+}
+static void create_partition_streams(StreamSet* ss, int num_cu) {
+    const int side_cus = requested_part_cus();
+    ss->part_cus_req = side_cus;
+    if (side_cus == 0 || num_cu != 256) return;
+    uint32_t ms[8], mm[8];
+    for (int w = 0; w < 8; ++w) { ms[w] = 0u; mm[w] = 0xffffffffu; }
+    for (int b = 0; b < side_cus; ++b) { ms[b >> 5] |= 1u << (b & 31); mm[b >> 5] &= ~(1u << (b & 31)); }
+    hipStream_t a = nullptr, b = nullptr;
+    if (hipExtStreamCreateWithCUMask(&a, 8, mm) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipExtStreamCreateWithCUMask(&b, 8, ms) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamDestroy(a); return; }
+    if (hipEventCreateWithFlags(&ss->ev3, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(a); (void)hipStreamDestroy(b); return; }
+    ss->main_part = a; ss->side_part = b; ss->part_cus = side_cus;
+}
+
+// Streams and events are POOLED per process and never destroyed.  hipStreamDestroy on this runtime (ROCm 7.2) can deadlock
+// against the HSA runtime's asynchronous-event thread while other host threads use the device: the destroying thread holds a
+// runtime lock while it tears the queue down, the event thread's completion callback waits for that lock, and the teardown does
+// not finish (native stacks of the stall: profiles/r05_stream_destroy_deadlock.txt; it is the intermittent suite stall of
+// rounds 2-4, reproduced in 10-80 iterations of tools/soak.py --only threads).  A context therefore hands its idle streams back
+// on destruction and the next context of that device takes them over.
+static std::mutex g_pool_mu;
+static std::vector<StreamSet> g_pool;
+static int acquire_streams(int device, int num_cu, StreamSet* out) {
+    {
+        std::lock_guard<std::mutex> lock(g_pool_mu);
+        const int want = requested_part_cus();
+        for (size_t i = 0; i < g_pool.size(); ++i)
+            if (g_pool[i].device == device && g_pool[i].part_cus_req == want) {
+                *out = g_pool[i];
+                g_pool.erase(g_pool.begin() + (long)i);
+                return OAK_OK;
+            }
+    }
+    StreamSet ss;
+    ss.device = device;
+    // both streams are non-blocking: no implicit coupling to the legacy NULL stream, hence none between contexts
+    if (hipStreamCreateWithFlags(&ss.main, hipStreamNonBlocking) != hipSuccess || create_side_stream(&ss.side) != hipSuccess ||
+        hipEventCreateWithFlags(&ss.ev0, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ss.ev1, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ss.ev2, hipEventDisableTiming) != hipSuccess) {
+        set_error("hipStreamCreate / hipEventCreate failed");
+        return OAK_E_HIP;
+    }
+    create_partition_streams(&ss, num_cu);
+    *out = ss;
+    return OAK_OK;
+}
+static void release_streams(const StreamSet& ss) {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    g_pool.push_back(ss);
+}
 }  // namespace oak
 
 int oak_ctx_create(int device, oak_ctx** out) {
@@ -625,13 +684,12 @@ int oak_ctx_create(int device, oak_ctx** out) {
     oak_ctx* ctx = new oak_ctx();
     ctx->device = device;
     ctx->num_cu = prop.multiProcessorCount;
-    // both streams are non-blocking: no implicit coupling to the legacy NULL stream, hence none between contexts
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess || oak::create_side_stream(&ctx->side) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev0, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev1, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev2, hipEventDisableTiming) != hipSuccess) {
-        delete ctx; oak::set_error("hipStreamCreate / hipEventCreate failed"); return OAK_E_HIP;
-    }
+    oak::StreamSet ss;
+    if (oak::acquire_streams(device, ctx->num_cu, &ss) != OAK_OK) { delete ctx; return OAK_E_HIP; }
+    ctx->stream = ctx->main_full = ss.main; ctx->side = ctx->side_full = ss.side;
+    ctx->ev0 = ss.ev0; ctx->ev1 = ss.ev1; ctx->ev2 = ss.ev2; ctx->ev3 = ss.ev3;
+    ctx->main_part = ss.main_part; ctx->side_part = ss.side_part; ctx->part_cus = ss.part_cus;
+    ctx->part_cus_req = ss.part_cus_req;
     { std::lock_guard<std::mutex> lock(oak::g_ctx_mu); oak::g_ctxs.insert(ctx); }
     *out = ctx;
     return OAK_OK;
@@ -670,16 +728,19 @@ int oak_ctx_destroy(oak_ctx* ctx) {
     if (!ctx) return OAK_OK;
     { std::lock_guard<std::mutex> lock(oak::g_ctx_mu); oak::g_ctxs.erase(ctx); }
     (void)hipSetDevice(ctx->device);
+    ctx->stream = ctx->main_full; ctx->side = ctx->side_full;
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipStreamSynchronize(ctx->side);
+    if (ctx->main_part) { (void)hipStreamSynchronize(ctx->main_part); (void)hipStreamSynchronize(ctx->side_part); }
     oak::reset_timings(ctx);
     oak_comm_destroy(ctx);
     for (auto& kv : ctx->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
-    (void)hipStreamDestroy(ctx->stream);
-    (void)hipStreamDestroy(ctx->side);
-    (void)hipEventDestroy(ctx->ev0);
-    (void)hipEventDestroy(ctx->ev1);
-    (void)hipEventDestroy(ctx->ev2);
+    {   // the (idle) streams and events go back to the pool: see acquire_streams for why they are never destroyed
+        oak::StreamSet ss;
+        ss.device = ctx->device; ss.main = ctx->main_full; ss.side = ctx->side_full; ss.main_part = ctx->main_part; ss.side_part = ctx->side_part;
+        ss.ev0 = ctx->ev0; ss.ev1 = ctx->ev1; ss.ev2 = ctx->ev2; ss.ev3 = ctx->ev3; ss.part_cus = ctx->part_cus; ss.part_cus_req = ctx->part_cus_req;
+        oak::release_streams(ss);
+    }
     delete ctx;
     return OAK_OK;
 }
@@ -688,6 +749,7 @@ int oak_sync(oak_ctx* ctx) {
     if (!ctx) { oak::set_error("ctx is NULL"); return OAK_E_ARG; }
     OAK_HIP_CHECK(hipSetDevice(ctx->device));
     OAK_HIP_CHECK(hipStreamSynchronize(ctx->side));          // this context's work only: other contexts are not waited for
+    if (ctx->main_part) { OAK_HIP_CHECK(hipStreamSynchronize(ctx->side_part)); OAK_HIP_CHECK(hipStreamSynchronize(ctx->main_part)); }
     OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return OAK_OK;
 }

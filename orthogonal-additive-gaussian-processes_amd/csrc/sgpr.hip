@@ -200,6 +200,8 @@ int sgpr_extra_psi_finish(oak_ctx* ctx) {
     return OAK_OK;
 }
 
+static int partition_to_full(oak_ctx* ctx);
+
 int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     OAK_REQUIRE(ctx->have_data && ctx->have_Z, "SGPR: set_data and set_inducing must be called first");
     const int64_t N = ctx->N, M = ctx->M, Mp = pad128(M);
@@ -283,7 +285,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
         OAK_CHECK(add_diag(ctx, dLw, M, M, jitter));
         OAK_CHECK(potrf_lower(ctx, dLw, M, M));
     }
-    if (whiten && ctx->kuu_async && !l_joined) {
+    if (whiten && ctx->kuu_async && !l_joined && !ctx->part_active) {
         // Route known up front: the solve needs L before anything else can follow the Gram, and next to the Gram kernel the
         // latency-bound factorisation chain both runs 4-5x slower and slows the Gram (shared DP pipe: 10.3 vs 9.6 ms at the
         // headline size) -- let the 0.45 ms chain run first, alone.
@@ -298,6 +300,12 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
             if (use32) OAK_CHECK(gram_f32(ctx, pk, FX, a0, na, FZ, dPanel32, Mp, dY, st.psi, Mp));
             else OAK_CHECK(gram(ctx, pk, FX, a0, na, FZ, dPanel, Mp, dY, st.psi, Mp));
             t.stop();
+        }
+        if (ctx->kuu_deferred) {
+            // partitioned pass: the factorisation chain is enqueued HERE, behind the first Gram launch, and runs next to it on its
+            // own compute units (sgpr_forward)
+            ctx->kuu_deferred = false;
+            OAK_CHECK(sgpr_factor_kuu_async(ctx, pk, ctx->kuu_jitter, ctx->cond_requested ? ctx->cond_mm : nullptr, false));
         }
         // the other outputs' Kuf y from the RAW panel: on a whitening evaluation before the solve overwrites it (the lazy auto route
         // has not decided yet: before, to be safe); on the phi route behind the SYRK, which otherwise starts 0.4 ms slower on a
@@ -322,6 +330,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
             ctx->auto_pending = false;
             whiten = ctx->auto_whiten > 0;
         }
+        if (ctx->part_active && (whiten || ctx->part_syrk_full)) OAK_CHECK(partition_to_full(ctx));
         if (whiten && ctx->kuu_async && dLw == nullptr) {
             // the side stream's L (and L^-1) serve; joined here, behind the first Gram panel, so that the factorisation chain ran
             // underneath it.  The solve stays GPflow's literal TRSM: applying the explicit L^-1 as one GEMM would be faster but
@@ -456,7 +465,8 @@ static int chol_with_inverse(oak_ctx* ctx, double* dL, int64_t M) {
 
 // L = chol(Kuu + jitter I) on the side stream.  It depends only on Z and the hyperparameters, so it runs concurrently
 // with the N-sized gram / SYRK stages; the tail joins on ev1 and reads the deferred Cholesky status (slot 1).
-int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter, double* cond_out /* [2] min, max diag L; may be NULL */) {
+int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter, double* cond_out /* [2] min, max diag L; may be NULL */,
+                          bool fork) {
     const int64_t M = ctx->M;
     const bool want_cond = cond_out != nullptr;
     double* dmm = nullptr;
@@ -468,8 +478,10 @@ int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter,
     int* d_info = nullptr;
     OAK_CHECK(get_buf_t(ctx, "potrf_info", 2, &d_info));
     double* dZ = (double*)peek_buf(ctx, "Z");
-    OAK_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));            // fork: Z / tables uploads are ordered before
-    OAK_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ev0, 0));
+    if (fork) {                                                      // a partitioned forward pass forked both of its streams already
+        OAK_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->stream));            // fork: Z / tables uploads are ordered before
+        OAK_HIP_CHECK(hipStreamWaitEvent(ctx->side, ctx->ev0, 0));
+    }
     hipStream_t main_stream = ctx->stream;
     ctx->stream = ctx->side;
     int rc = [&]() -> int {
@@ -495,6 +507,49 @@ int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter,
     return OAK_OK;
 }
 
+// ---- spatial partition of a small forward pass (oak_ctx::main_part / side_part) ---------------------------------------------------
+// One Kfu panel, and a Gram pass short enough that the chain's enqueue time (a few microseconds per launch, ~0.2 ms at M = 1024)
+// is worth more than the share of the chip the panel gives up (part_cus / 256 of its time).
+static bool partition_wanted(const oak_ctx* ctx, const PreparedKernel& pk) {
+    if (ctx->main_part == nullptr || ctx->stream != ctx->main_full || ctx->side != ctx->side_full) return false;
+    int mode = -1;
+    if (const char* e = getenv("OAK_PARTITION")) mode = atoi(e);       // 0 never, 1 whenever possible, otherwise the size rule
+    if (mode == 0) return false;
+    const int64_t Mp = pad128(ctx->M);
+    const int64_t rows = ctx->panel_rows > 0 ? ctx->panel_rows : (int64_t)(((size_t)16 << 30) / (sizeof(double) * (size_t)Mp));
+    if (ctx->N > rows || ctx->M % 32 != 0) return false;
+    if (mode == 1) return true;
+    return (double)ctx->N * (double)Mp * (double)pk.dd.D <= 4.4e9;     // Gram <= ~2.6 ms (a quarter of the headline's rows)
+}
+struct PartitionScope {
+    oak_ctx* ctx;
+    explicit PartitionScope(oak_ctx* c) : ctx(c) {}
+    void enter() { ctx->stream = ctx->main_part; ctx->side = ctx->side_part; ctx->part_active = true; }
+    // whatever main_part still holds is ordered before what follows on main_full; the side pointer stays on side_part until the
+    // evaluation ends (the tail joins ev1 of THAT stream and reads its Cholesky status slot)
+    int leave() {
+        if (ctx->part_active && ctx->stream == ctx->main_part) {
+            OAK_HIP_CHECK(hipEventRecord(ctx->ev3, ctx->main_part));
+            OAK_HIP_CHECK(hipStreamWaitEvent(ctx->main_full, ctx->ev3, 0));
+            ctx->stream = ctx->main_full;
+        }
+        return OAK_OK;
+    }
+    ~PartitionScope() {
+        if (ctx->part_active) { ctx->stream = ctx->main_full; ctx->side = ctx->side_full; ctx->part_active = false; ctx->kuu_deferred = false; }
+    }
+};
+// local_stats, partitioned pass: what follows needs the whole chip (N-sized solve, SYRK of a long panel) -- wait for the side chain
+// (whose compute units an unmasked kernel would otherwise flood) and continue on main_full
+static int partition_to_full(oak_ctx* ctx) {
+    if (!ctx->part_active || ctx->stream != ctx->main_part) return OAK_OK;
+    OAK_HIP_CHECK(hipEventRecord(ctx->ev3, ctx->main_part));
+    OAK_HIP_CHECK(hipStreamWaitEvent(ctx->main_full, ctx->ev3, 0));
+    OAK_HIP_CHECK(hipStreamWaitEvent(ctx->main_full, ctx->ev1, 0));
+    ctx->stream = ctx->main_full;
+    return OAK_OK;
+}
+
 // forward pass shared by oak_sgpr_elbo and oak_sgpr_elbo_grad
 int sgpr_forward(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out) {
     int l_state = 2;                                    // L = chol(Kuu + jitter I) and L^-1 come from the side stream on every route
@@ -512,15 +567,37 @@ int sgpr_forward(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, doubl
     ctx->auto_pending = false;
     ctx->cond_requested = false;
     ctx->cond_seen = false;
+    // Small evaluations (C2, the row shards of a multi-GPU job) run SPATIALLY PARTITIONED: the host enqueues the first Gram panel
+    // before the ~45 launches of the factorisation chain (which used to sit in front of it: 0.15-0.3 ms during which the GPU ran
+    // a 16-workgroup chain and nothing else), the chain runs on its own compute units (side_part) at its stand-alone speed, the
+    // Gram panel on the others (main_part).  Without the partition the two cannot share the chip: next to a kernel that fills
+    // every CU the chain's small launches are starved (one Cholesky step measured 1.2 ms beside the Gram kernel,
+    // tools/ubench/cumask_probe.hip: 44 ms against 1.3 ms for 40 small kernels) whatever the queue priority.
+    PartitionScope part(ctx);
+    const bool want_cond = auto_big || (ctx->precision == 1 && !ctx->keep_kfu && !sgpr_route_whitened(ctx));
+    if (partition_wanted(ctx, pk)) {
+        OAK_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->main_full));        // everything enqueued so far (uploads, the previous evaluation) is ordered before both
+        OAK_HIP_CHECK(hipStreamWaitEvent(ctx->main_part, ctx->ev0, 0));
+        OAK_HIP_CHECK(hipStreamWaitEvent(ctx->side_part, ctx->ev0, 0));
+        part.enter();
+        // the chain goes behind the first Gram launch -- unless the fp32 mode needs its conditioning estimate before that launch
+        ctx->kuu_deferred = !(ctx->precision == 1 && want_cond);
+        ctx->kuu_jitter = jitter;
+        // The SYRK always moves to the whole chip and therefore waits for the chain (its workgroup-to-XCD packing is built for 32
+        // CUs per XCD: on main_part's 30 it measured +19 %, and unmasked it would flood the chain's CUs).  With a Gram panel that
+        // outlasts the chain (N / 8 shards) the wait is free; with a shorter one (C2) the SYRK starts when the chain ends, which is
+        // still earlier than behind the chain's enqueue time plus the Gram.
+        ctx->part_syrk_full = true;
+        if (const char* e = getenv("OAK_PART_SYRK_FULL")) ctx->part_syrk_full = atoi(e) != 0;
+    }
     {
         // The factorisation depends only on Z and the hyperparameters: it runs on the side stream underneath the first Gram
         // panel whatever the route (the whitened route joins it before its N-sized solve, the phi route in the tail).
         // auto on a large problem: the side stream also reports min / max of diag L; local_stats decides under its first
         // Gram panel.  The fp32 statistics mode asks for the same estimate.
-        const bool want_cond = auto_big || (ctx->precision == 1 && !ctx->keep_kfu && !sgpr_route_whitened(ctx));
-        OAK_CHECK(sgpr_factor_kuu_async(ctx, pk, jitter, want_cond ? ctx->cond_mm : nullptr));
-        ctx->auto_pending = auto_big;
         ctx->cond_requested = want_cond;
+        if (!ctx->kuu_deferred) OAK_CHECK(sgpr_factor_kuu_async(ctx, pk, jitter, want_cond ? ctx->cond_mm : nullptr, !ctx->part_active));
+        ctx->auto_pending = auto_big;
         ctx->cond_seen = want_cond;
         ctx->kuu_async = true;
     }
@@ -528,20 +605,23 @@ int sgpr_forward(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, doubl
     ctx->auto_pending = false;
     ctx->cond_requested = false;
     ctx->kuu_async = false;
+    if (rc == OAK_OK) rc = part.leave();             // statistics finished on main_part: the rest of the evaluation runs unmasked
     if (rc == OAK_OK && ctx->comm != nullptr) rc = oak_comm_allreduce_stats(ctx);
-    if (rc == OAK_OK && ctx->comm != nullptr && ctx->n_extra > 0)         // the other outputs' [Kuf y | y^T y], summed over the row shards
-        rc = comm_allreduce_dev(ctx, (double*)peek_buf(ctx, "psix"), (int64_t)ctx->n_extra * ctx->M + ctx->n_extra, "comm_stage_x");
+    // (the other outputs' [Kuf y_p | y_p^T y_p] are summed over the row shards inside oak_comm_allreduce_stats)
     if (rc != OAK_OK) { if (l_state == 2) (void)hipStreamSynchronize(ctx->side); ctx->auto_whiten = -1; return rc; }
     rc = sgpr_tail(ctx, pk, noise_var, jitter, elbo_out, terms_out, l_state);
+    if (rc != OAK_OK && ctx->part_active) (void)hipStreamSynchronize(ctx->side);     // never leave a masked chain running behind an error
     ctx->auto_whiten = -1;              // the decision belongs to this evaluation only
     return rc;
 }
 
 // out[0] = sum log diag LB, out[1] = c^T c, out[2] = tr W, out[3..5] = (kappa, yy, nrows), out[6] = sum log diag L,
-// out[7..8] = (n_whitened, n_parts)
+// out[7..8] = (n_whitened, n_parts), out[9..10] = status words of the two factorisations (main / side stream slot): one
+// device-to-host copy and one host wait per tail instead of three
 __global__ void __launch_bounds__(256) tail_scalars_kernel(const double* __restrict__ LB, const double* __restrict__ c,
                                                            const double* __restrict__ W, const double* __restrict__ L, int64_t M,
-                                                           const double* __restrict__ kappa3, double* __restrict__ out) {
+                                                           const double* __restrict__ kappa3, const int* __restrict__ info,
+                                                           double* __restrict__ out) {
     __shared__ double red[4][256];
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     for (int64_t i = threadIdx.x; i < M; i += 256) {
@@ -564,6 +644,7 @@ __global__ void __launch_bounds__(256) tail_scalars_kernel(const double* __restr
         out[3] = kappa3[0]; out[4] = kappa3[1]; out[5] = kappa3[2];
         out[6] = red[3][0];
         out[7] = kappa3[3]; out[8] = kappa3[4];          // shards that whitened / shards summed
+        out[9] = (double)info[0]; out[10] = (double)info[1];
     }
 }
 
@@ -660,7 +741,7 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
         OAK_CHECK(scale_vec(ctx, 1.0 / noise_var, dc, M));
     }
     // scalars: sum log diag LB, c^T c, tr W, (kappa, yy, nrows), sum log diag L -- one small kernel, fixed reduction trees
-    tail_scalars_kernel<<<1, 256, 0, ctx->stream>>>(dLB, dc, dT2, dL, M, st.kappa, dscal);
+    tail_scalars_kernel<<<1, 256, 0, ctx->stream>>>(dLB, dc, dT2, dL, M, st.kappa, (const int*)peek_buf(ctx, "potrf_info"), dscal);
     OAK_HIP_CHECK(hipGetLastError());
     // The other outputs share everything above (Kuu, Phi, L, LB); what differs is c_p = LB^-1 L^-1 psi_p / sigma^2 and y_p^T y_p.
     std::vector<double> hx((size_t)2 * nx);
@@ -685,12 +766,12 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
         OAK_HIP_CHECK(hipMemcpyAsync(hx.data(), d_sq, sizeof(double) * (size_t)2 * nx, hipMemcpyDeviceToHost, ctx->stream));
     }
     ctx->out_sel = 0;
-    double h[9] = {0};
-    OAK_HIP_CHECK(hipMemcpyAsync(h, dscal, sizeof(double) * 9, hipMemcpyDeviceToHost, ctx->stream));
+    double h[11] = {0};
+    OAK_HIP_CHECK(hipMemcpyAsync(h, dscal, sizeof(double) * 11, hipMemcpyDeviceToHost, ctx->stream));
     OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     OAK_CHECK(check_route_counts(h[7], h[8], ctx->stats_whitened));   // a mixed-route sum explains any failure below: report it first
-    if (l_state == 2) OAK_CHECK(potrf_check(ctx, 1, M));      // Kuu (side stream) first: it is the upstream failure
-    OAK_CHECK(potrf_check(ctx, 0, M));                        // then B
+    if (l_state == 2) OAK_CHECK(potrf_check_value((int)h[10], M));    // Kuu (side stream) first: it is the upstream failure
+    OAK_CHECK(potrf_check_value((int)h[9], M));                       // then B
     t.stop();
     const double sumlogLB = h[0], cTc = h[1], trAAT = h[2] / noise_var, kappa = h[3], yy = h[4], nrows = h[5];
     // gpflow SGPR.elbo, P = 1

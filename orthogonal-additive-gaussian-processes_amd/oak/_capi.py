@@ -320,6 +320,17 @@ def categorical_table_unit(W, kappa, p):
     return np.ascontiguousarray(B), np.ascontiguousarray(p)
 
 
+class PackedSubsets(tuple):
+    """(flat int32 dim indices, int32 offsets[n + 1]) as ``HipContext.pack_subsets`` returns them; the type is the marker."""
+    __slots__ = ()
+
+    def __new__(cls, flat, off):
+        flat, off = np.ascontiguousarray(flat, np.int32), np.ascontiguousarray(off, np.int32)
+        if off.ndim != 1 or off.size < 1 or off[0] != 0 or np.any(np.diff(off) < 0) or (off.size > 1 and off[-1] > max(flat.size, 0)):
+            raise ValueError("PackedSubsets: offsets must start at 0, be non-decreasing and end within the index array")
+        return super().__new__(cls, (flat, off))
+
+
 class HipContext:
     """One device context (HIP stream + device scratch); mirrors ``oak_ctx``."""
 
@@ -638,8 +649,9 @@ class HipContext:
     @staticmethod
     def _pack_subsets(subsets):
         """(flat dim indices, offsets[len + 1]) of a list of subsets.  A caller that evaluates the same term list repeatedly
-        can pack once (``pack_subsets``) and pass the pair: walking 41 448 Python lists costs more than the device pass."""
-        if isinstance(subsets, tuple) and len(subsets) == 2 and isinstance(subsets[0], np.ndarray):
+        can pack once (``pack_subsets`` returns a ``PackedSubsets``) and pass that: walking 41 448 Python lists costs more than
+        the device pass.  Only a ``PackedSubsets`` is taken as already packed -- a plain tuple of two arrays is two subsets."""
+        if isinstance(subsets, PackedSubsets):
             return subsets
         n = len(subsets)
         lens = np.fromiter(map(len, subsets), dtype=np.int64, count=n)
@@ -647,7 +659,7 @@ class HipContext:
         np.cumsum(lens, out=off[1:])
         total = int(off[-1])
         flat = np.fromiter(itertools.chain.from_iterable(subsets), dtype=np.int32, count=total) if total else np.zeros(1, np.int32)
-        return np.ascontiguousarray(flat), off
+        return PackedSubsets(np.ascontiguousarray(flat), off)
 
     pack_subsets = _pack_subsets
 

@@ -206,31 +206,96 @@ class KernelComponenent(gpflow.Kernel):
         return TensorLike(ctx.gram_component_diag(self.oak_kernel._desc(), self._subset(), bool(self.share_var_across_orders), X))
 
 
-class _ComponentList(Sequence):
+class _ComponentList(list):
     """``kernel_list`` of get_list_representation: the KernelComponenent of term i, built when it is asked for.  A depth-4 kernel
     over 32 inputs has 41 449 terms; the Sobol pass wants their index subsets, not 41 449 Python objects (0.4 s to build, against
-    15 ms for all the indices on the device)."""
+    15 ms for all the indices on the device).  It IS a list, as in the reference (``isinstance(x, list)``, ``kernel_list + [...]``,
+    ``.append``): indexing builds and caches single components (``kernel_list[i] is kernel_list[i]``), anything that needs the whole
+    list (iteration, concatenation, mutation, comparison) fills the underlying list first."""
 
     def __init__(self, kernel, subsets, share_var_across_orders):
+        super().__init__()
         self._kernel, self._subsets, self._share0 = kernel, subsets, share_var_across_orders
+        self._cache, self._full = {}, False
+
+    def _component(self, i):
+        c = self._cache.get(i)
+        if c is None:
+            # as in the reference (:362) only the constant component takes ``share_var_across_orders`` from the caller
+            c = KernelComponenent(self._kernel, self._subsets[i], share_var_across_orders=self._share0) if i == 0 \
+                else KernelComponenent(self._kernel, self._subsets[i])
+            self._cache[i] = c
+        return c
+
+    def _fill(self):
+        if not self._full:
+            self._full = True
+            list.extend(self, (self._component(i) for i in range(len(self._subsets))))
+            self._cache = {}
+        return self
 
     def __len__(self):
-        return len(self._subsets)
+        return list.__len__(self) if self._full else len(self._subsets)
 
     def __getitem__(self, i):
-        if isinstance(i, slice):
-            return [self[j] for j in range(*i.indices(len(self)))]
-        if i < 0:
-            i += len(self)
-        if not 0 <= i < len(self):
-            raise IndexError(i)
-        # as in the reference (:362) only the constant component takes ``share_var_across_orders`` from the caller
-        return KernelComponenent(self._kernel, self._subsets[i], share_var_across_orders=self._share0) if i == 0 \
-            else KernelComponenent(self._kernel, self._subsets[i])
+        if self._full or isinstance(i, slice):
+            return list.__getitem__(self._fill(), i)
+        n = len(self._subsets)
+        j = i + n if i < 0 else i
+        if not 0 <= j < n:
+            raise IndexError("list index out of range")
+        return self._component(j)
+
+    def __iter__(self):
+        return list.__iter__(self._fill())
+
+    def __reversed__(self):
+        return list.__reversed__(self._fill())
+
+    def __contains__(self, x):
+        return list.__contains__(self._fill(), x)
+
+    def __add__(self, other):
+        return list(self._fill()) + list(other)
+
+    def __radd__(self, other):
+        return list(other) + list(self._fill())
+
+    def __mul__(self, k):
+        return list(self._fill()) * k
+
+    __rmul__ = __mul__
+
+    def __eq__(self, other):
+        return list.__eq__(self._fill(), other)
+
+    def __ne__(self, other):
+        return list.__ne__(self._fill(), other)
+
+    __hash__ = None
+
+    def __repr__(self):
+        return list.__repr__(self._fill())
+
+    def __reduce__(self):
+        return (list, (list(self._fill()),))
+
+
+def _fill_first(name):
+    def method(self, *a, **k):
+        return getattr(list, name)(self._fill(), *a, **k)
+    method.__name__ = name
+    return method
+
+
+for _n in ("append", "extend", "insert", "pop", "remove", "clear", "index", "count", "sort", "reverse", "copy",
+           "__setitem__", "__delitem__", "__iadd__", "__imul__"):
+    setattr(_ComponentList, _n, _fill_first(_n))
+del _n
 
 
 def get_list_representation(kernel: OAKKernel, num_dims: int, share_var_across_orders: Optional[bool] = True
-                            ) -> Tuple[List[List[int]], Sequence]:
+                            ) -> Tuple[List[List[int]], List]:
     """All interaction subsets up to the kernel's depth, constant term first (oak/oak_kernel.py:338-364).
     As in the reference (:362) non-constant components ignore ``share_var_across_orders``."""
     assert isinstance(kernel, OAKKernel)

@@ -9,11 +9,20 @@ from oak import _capi
 
 ROOT = Path(__file__).resolve().parent.parent
 HEADER = ROOT / "include" / "oak_hip.h"
+BENCH_HEADER = ROOT / "include" / "oak_hip_bench.h"          # measurement hooks: exported and bound, not part of the boundary
 
 
-def declared_functions():
-    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
-    return sorted(set(re.findall(r"\b(oak_[A-Za-z0-9_]+)\s*\(", text)))
+def declared_functions(headers=(HEADER, BENCH_HEADER)):
+    names = set()
+    for h in headers:
+        text = re.sub(r"/\*.*?\*/", "", h.read_text(), flags=re.S)
+        names.update(re.findall(r"\b(oak_[A-Za-z0-9_]+)\s*\(", text))
+    return sorted(names)
+
+
+def test_measurement_hooks_live_in_their_own_header():
+    assert not [n for n in declared_functions((HEADER,)) if n.startswith("oak_bench_")]
+    assert all(n.startswith("oak_bench_") for n in declared_functions((BENCH_HEADER,)))
 
 
 def test_header_declares_the_expected_entry_points():

@@ -536,3 +536,31 @@ def test_several_output_columns_under_a_two_rank_communicator():
     np.testing.assert_allclose(res[("alpha", 0)], ref.sgpr_alpha(96), rtol=1e-8, atol=1e-10)
     for c in ranks + [ref]:
         c.close()
+
+
+@pytest.mark.parametrize("route", ["phi", "whitened"])
+def test_three_call_sequence_with_extra_outputs_under_a_loopback_communicator(route):
+    """oak_hip.h documents oak_sgpr_elbo as local_stats -> allreduce_stats -> tail.  With extra target columns the three calls must
+    exchange what the fused entry point does: [Kuf y_p | y_p^T y_p] of the extra outputs is summed next to the packed statistics
+    (it used to be summed inside oak_sgpr_elbo only, so the hand-written sequence paired summed Phi / psi with per-shard psi_p)."""
+    X, y, Z = o.synthetic_problem(3000, 4, 64, seed=13)
+    rng = np.random.default_rng(4)
+    Y = np.concatenate([y, rng.standard_normal((len(X), 2)) + 0.5 * y], axis=1)
+    spec = o.make_spec(4, 2, lengthscales=[0.9, 1.1, 1.3, 0.8])
+    d = _capi.KernelDesc(spec)
+    world = 2
+    ctx = _capi.HipContext(0)
+    try:
+        ctx.sgpr_set_data(X, Y[:, 0]); ctx.sgpr_set_extra_targets(Y[:, 1:]); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route(route)
+        ctx.comm_init_loopback(world)
+        e_fused = ctx.sgpr_elbo(d, 0.07)
+        ctx.sgpr_local_stats(d)
+        ctx.comm_allreduce_stats()
+        e_seq, _ = ctx.sgpr_tail(d, 0.07)
+        Xs, Ys = np.tile(X, (world, 1)), np.tile(Y, (world, 1))
+        e_ref = o.sgpr_elbo(spec, Xs, Ys, Z, 0.07)
+        assert abs(e_fused - e_ref) <= 1e-10 * abs(e_ref)
+        assert abs(e_seq - e_ref) <= 1e-10 * abs(e_ref)
+        assert abs(e_seq - e_fused) <= 1e-13 * abs(e_ref)
+    finally:
+        ctx.close()

@@ -34,6 +34,20 @@ def say(msg):
     log.write(msg + "\n"); log.flush()
 
 
+def native_backtraces():
+    """Every thread's C-level stack through a debugger started as a CHILD process (never an exec of this one): where inside the
+    HIP runtime a wedged call sits.  The child may attach because this process names it as its tracer (Yama ptrace_scope = 1)."""
+    import ctypes, shutil, subprocess
+    gdb = shutil.which("rocgdb") or shutil.which("gdb") or "/opt/rocm/bin/rocgdb"
+    try:
+        ctypes.CDLL(None).prctl(0x59616d61, ctypes.c_ulong(-1 & 0xffffffffffffffff), 0, 0, 0)      # PR_SET_PTRACER, PR_SET_PTRACER_ANY
+        r = subprocess.run([gdb, "-p", str(os.getpid()), "-batch", "-ex", "set pagination off", "-ex", "info sharedlibrary", "-ex", "thread apply all bt 25"],
+                           capture_output=True, text=True, timeout=90)
+        return r.stdout[-60000:] + "\n" + r.stderr[-3000:]
+    except Exception as ex:                       # noqa: BLE001
+        return f"(no native backtrace: {ex!r})"
+
+
 def stalled(what):
     say(f"STALL: {what} exceeded {args.limit:.0f} s")
     try:
@@ -42,6 +56,7 @@ def stalled(what):
         say(f"(no library state: {ex!r})")
     faulthandler.dump_traceback(file=log, all_threads=True)
     log.flush()
+    say(native_backtraces())
     os._exit(3)
 
 
