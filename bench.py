@@ -209,6 +209,7 @@ def bounded_fit(X, y, M, R, maxiter):
             "setup_seconds": t_setup, "optimise_seconds": t_opt, "bfgs_iterations": int(getattr(res, "nit", -1)),
             "gradient_evaluations": len(evals), "whitened_evaluations": nw, "phi_evaluations": len(evals) - nw,
             "ms_per_evaluation_mean": float(np.mean(ms)) if ms else None,
+            "ms_each_evaluation": [round(v, 2) for v in ms], "routes": "".join("w" if w else "p" for _, w in evals),
             "ms_per_whitened_evaluation": float(np.mean([m_ for m_, (_, w) in zip(ms, evals) if w])) if nw else None,
             "ms_per_phi_evaluation": float(np.mean([m_ for m_, (_, w) in zip(ms, evals) if not w])) if nw < len(evals) else None,
             "loss_before": loss0, "loss_after": float(res.fun), "cond_estimate_last": float(hip.sgpr_last_terms().get("cond_estimate", 0.0))}

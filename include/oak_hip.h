@@ -100,6 +100,11 @@ const char* oak_version(void);
 int oak_device_count(int* count);
 int oak_ctx_create(int device, oak_ctx** out);
 int oak_ctx_destroy(oak_ctx* ctx);
+/* Streams and events of destroyed contexts are kept in a per-process pool and handed to the next context (hipStreamDestroy can
+   deadlock against the runtime's event thread while other host threads use the device: DESIGN section 9).  This call destroys
+   the pooled ones; call it once at the end of the process, after every context has been destroyed and while no other thread
+   uses the device (the Python binding does so at interpreter exit).  Optional: an ordinary process may simply exit. */
+int oak_runtime_shutdown(void);
 int oak_sync(oak_ctx* ctx);
 /* Post-mortem aid for a stalled process: one text record per live context -- whether its two streams have drained, its
    communicator, and the last 16 phases / collectives it enqueued with their age.  Call it from ANOTHER host thread than the

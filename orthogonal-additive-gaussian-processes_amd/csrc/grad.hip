@@ -263,7 +263,7 @@ gram_bwd_kernel(const DevDesc dd, const double* __restrict__ tables, int tablen,
 // [h][chunk of four steps][q][step in chunk], so that a chunk's 12 values are contiguous (wide vector loads).
 __global__ void __launch_bounds__(256) pack_rows_kernel(const double* __restrict__ xs32, const double* __restrict__ cn,
                                                         const double* __restrict__ dcs, int64_t ld, int64_t a0, int64_t na, int D,
-                                                        int DP, double* __restrict__ out, int split) {
+                                                        int DP, double* __restrict__ out, int split, double xpad) {
     extern __shared__ double tile_mem[];                          // [3 * DP][65]: 3 * DP <= 192 (dynamic: 100 KB at DP = 64)
     auto tile = [&](int j, int r) -> double& { return tile_mem[j * 65 + r]; };
     const int64_t i0 = (int64_t)blockIdx.x * 64;
@@ -272,7 +272,7 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const double* __restrict
         const int j = idx >> 6, r = idx & 63;
         const int q = j / DP, d = j - q * DP;
         const int64_t i = i0 + r;
-        double v = (q == 0) ? -1.0 : 0.0;
+        double v = (q == 0) ? xpad : 0.0;              // padding dims: -1 on the row side, +1 on the column side (w clamps to 1)
         if (d < D && i < na) v = (q == 0 ? xs32 : (q == 1 ? cn : dcs))[(int64_t)d * ld + a0 + i];
         tile(j, r) = v;
     }
@@ -288,10 +288,10 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const double* __restrict
         if (i0 + r < na) out[(i0 + r) * W + j] = tile(src, r);
     }
 }
-static int launch_pack_rows(oak_ctx* ctx, const Feat& A, int64_t a0, int64_t na, int D, int DP, double* d_pack, int split) {
+static int launch_pack_rows(oak_ctx* ctx, const Feat& A, int64_t a0, int64_t na, int D, int DP, double* d_pack, int split, double xpad = -1.0) {
     const size_t lds = sizeof(double) * (size_t)3 * DP * 65;
     if (lds > 64 * 1024) OAK_CHECK(ensure_max_dynamic_lds((const void*)pack_rows_kernel));
-    pack_rows_kernel<<<(unsigned)((na + 63) / 64), 256, lds, ctx->stream>>>(A.xs32, A.cn, A.dcs, A.ld, a0, na, D, DP, d_pack, split);
+    pack_rows_kernel<<<(unsigned)((na + 63) / 64), 256, lds, ctx->stream>>>(A.xs32, A.cn, A.dcs, A.ld, a0, na, D, DP, d_pack, split, xpad);
     OAK_HIP_CHECK(hipGetLastError());
     return OAK_OK;
 }
@@ -1080,6 +1080,27 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     if (nrb > 65535) { rows = (((na + 65534) / 65535 + RS - 1) / RS) * RS; nrb = (na + rows - 1) / rows; }
     const int64_t reclen = record_len(pk);
     double* d_part = nullptr;
+    // r05: rows in lanes for the reference's default continuous model (grad_rows.hip) -- the column features are scalar loads, the
+    // row's live in registers; three LDS reads per pair-dimension fewer.  Large row counts only: a workgroup owns 256 rows.
+    bool rows_form = fast && allrbf && unitbv && !want_gk && tablen == 0 && dmax <= 16 && R <= (dmax == 16 ? 3 : 4) && na >= 16384;
+    if (const char* e = getenv("OAK_BWD_ROWS")) rows_form = rows_form && atoi(e) != 0;
+    if (rows_form) {
+        OAK_REQUIRE(A.xs32 != nullptr && B.xs32 != nullptr, "gram_bwd: features were not prepared for the backward pass");
+        int cols_per_wg = 256;
+        if (const char* e = getenv("OAK_BWD_ROWS_COLS")) { int v = atoi(e); if (v >= 16 && v % 16 == 0) cols_per_wg = v; }
+        const int64_t ncb_r = (nb + cols_per_wg - 1) / cols_per_wg, nrb_r = (na + 255) / 256;
+        double *d_apack = nullptr, *d_bpack = nullptr;
+        OAK_CHECK(get_buf_t(ctx, "bwd_part", (size_t)(nrb_r * ncb_r * reclen), &d_part));
+        OAK_CHECK(get_buf_t(ctx, "bwd_pack", (size_t)na * 3 * dmax, &d_apack));
+        OAK_CHECK(get_buf_t(ctx, "bwd_pack_cols", (size_t)nb * 3 * dmax, &d_bpack));
+        OAK_CHECK(launch_pack_rows(ctx, A, a0, na, D, dmax, d_apack, 1, -1.0));
+        OAK_CHECK(launch_pack_rows(ctx, B, 0, nb, D, dmax, d_bpack, 1, 1.0));
+        int64_t nrec = 0;
+        OAK_CHECK(gram_bwd_rows_launch(ctx, pk, dmax, d_apack, a0, na, d_bpack, nb, d_G, ldg, d_yA, d_avec, g_scale, cols_per_wg, d_part, &nrec));
+        reduce_records_kernel<<<(unsigned)reclen, 256, 0, ctx->stream>>>(d_part, nrec, reclen, d_rec);
+        OAK_HIP_CHECK(hipGetLastError());
+        return OAK_OK;
+    }
     OAK_CHECK(get_buf_t(ctx, "bwd_part", (size_t)(nrb * ncb * reclen), &d_part));
     dim3 grid((unsigned)ncb, (unsigned)nrb);
     double* d_pack = nullptr;

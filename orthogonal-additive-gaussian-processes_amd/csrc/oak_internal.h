@@ -310,7 +310,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter);
 int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out,
               int l_state = 0);
 bool sgpr_route_whitened(const oak_ctx* ctx);
-int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter, double* cond_out = nullptr, bool fork = true);
+int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter, double* cond_out = nullptr, bool fork = true, int phase = 0);
 int sgpr_forward(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double jitter, double* elbo_out, double* terms_out);
 int sgpr_ensure_alpha(oak_ctx* ctx);
 // psix[p][m] (+)= sum_r panel[r][m] * Yx[p][a0 + r] for the extra target columns, one pass over a raw Kfu panel chunk
@@ -324,6 +324,10 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
              int64_t ldg, double g_scale, const double* d_yA, const double* d_avec, double* d_rec, bool want_gk = true);
 // d_rec += sum_n gconst * (d_gvec ? d_gvec[n] : 1) * dKdiag_n/dtheta
 int diag_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, double gconst, double* d_rec, const double* d_gvec = nullptr);
+// rows-in-lanes form of the backward pair kernel (grad_rows.hip): all-continuous, unit base variances, depth <= 4, <= 16 sub-kernels
+int gram_bwd_rows_launch(oak_ctx* ctx, const PreparedKernel& pk, int dmax, const double* d_apack, int64_t a0, int64_t na, const double* d_bpack,
+                         int64_t nb, const double* d_G, int64_t ldg, const double* d_yA, const double* d_avec, double g_scale, int cols_per_wg,
+                         double* d_part, int64_t* nrec_out);
 void scatter_record(const oak_kernel_desc* desc, const PreparedKernel& pk, const std::vector<double>& rec, double dnoise,
                     double* grad_out);
 

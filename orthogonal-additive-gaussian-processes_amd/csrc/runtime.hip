@@ -603,9 +603,9 @@ static hipError_t create_side_stream(hipStream_t* s) {
 }
 // The partition pair.  Mask bit i stands for compute unit i / 8 of XCD i % 8 (tools/ubench/cumask_probe.hip: bits 0..15 = two CUs in
 // each of the eight XCDs; a mask that leaves an XCD empty is ignored by the driver), so both masks keep all XCDs with equal
-// shares and every XCD-aware workgroup mapping stays valid.  OAK_PART_CUS = 0 disables, 8 / 16 / 24 / 32 sets the side's share.
+// shares and every XCD-aware workgroup mapping stays valid.  OAK_PART_CUS = 0 disables, 8 / 16 / ... / 64 sets the side's share (default 32).
 static int requested_part_cus() {
-    int side_cus = 16;
+    int side_cus = 32;          // 4 CUs in each XCD: N/16 shards gain with 32 and lose with 16, N/8 and N/4 measure the same with either
     if (const char* e = getenv("OAK_PART_CUS")) side_cus = atoi(e);
     return (side_cus <= 0 || side_cus % 8 != 0 || side_cus > 64) ? 0 : side_cus;
 }
@@ -631,6 +631,22 @@ static void create_partition_streams(StreamSet* ss, int num_cu) {
 // on destruction and the next context of that device takes them over.
 static std::mutex g_pool_mu;
 static std::vector<StreamSet> g_pool;
+// oak_runtime_shutdown: the idle (pooled) streams are synchronised and destroyed -- to be called by the host when no other
+// thread uses the device any more (oak/_capi.py does at interpreter exit, after closing its contexts).  Not from a C atexit
+// handler: under rocprofv3 the tool's per-thread state is gone by then and hipStreamDestroy aborts, while CU-masked queues
+// left alive make its finalisation crash.
+static int shutdown_pool() {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    for (const StreamSet& ss : g_pool) {
+        if (hipSetDevice(ss.device) != hipSuccess) continue;
+        for (hipStream_t st : {ss.main, ss.side, ss.main_part, ss.side_part})
+            if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+        for (hipEvent_t ev : {ss.ev0, ss.ev1, ss.ev2, ss.ev3})
+            if (ev) (void)hipEventDestroy(ev);
+    }
+    g_pool.clear();
+    return OAK_OK;
+}
 static int acquire_streams(int device, int num_cu, StreamSet* out) {
     {
         std::lock_guard<std::mutex> lock(g_pool_mu);
@@ -715,7 +731,7 @@ int oak_debug_state(char* buf, int64_t cap) {
         const unsigned n = c->mark_n;
         for (unsigned k = (n > 16 ? n - 16 : 0); k < n; ++k) {
             const char* m = c->marks[k & 15u];
-            snprintf(line, sizeof line, "    [%u] %-14s %.3f s ago\n", k, m ? m : "?", now - c->mark_t[k & 15u]);
+            snprintf(line, sizeof line, "    [%u] %-14s %.6f s ago\n", k, m ? m : "?", now - c->mark_t[k & 15u]);
             out += line;
         }
     }
@@ -744,6 +760,8 @@ int oak_ctx_destroy(oak_ctx* ctx) {
     delete ctx;
     return OAK_OK;
 }
+
+int oak_runtime_shutdown(void) { return oak::shutdown_pool(); }
 
 int oak_sync(oak_ctx* ctx) {
     if (!ctx) { oak::set_error("ctx is NULL"); return OAK_E_ARG; }

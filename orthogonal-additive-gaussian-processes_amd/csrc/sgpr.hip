@@ -305,7 +305,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
             // partitioned pass: the factorisation chain is enqueued HERE, behind the first Gram launch, and runs next to it on its
             // own compute units (sgpr_forward)
             ctx->kuu_deferred = false;
-            OAK_CHECK(sgpr_factor_kuu_async(ctx, pk, ctx->kuu_jitter, ctx->cond_requested ? ctx->cond_mm : nullptr, false));
+            OAK_CHECK(sgpr_factor_kuu_async(ctx, pk, ctx->kuu_jitter, ctx->cond_requested ? ctx->cond_mm : nullptr, false, 2));
         }
         // the other outputs' Kuf y from the RAW panel: on a whitening evaluation before the solve overwrites it (the lazy auto route
         // has not decided yet: before, to be safe); on the phi route behind the SYRK, which otherwise starts 0.4 ms slower on a
@@ -452,11 +452,11 @@ static int build_linv(oak_ctx* ctx, const double* dL, int64_t M) {
 // r >= n ends up as A[r, :n] L^-T), so when the factor is done those rows ARE L^-T -- the rows-TRSM of the identity that
 // build_linv runs as a second dependent chain (8 leaf solves + 7 GEMMs, ~560 us at M = 1024 against 372 us for the whole
 // factorisation) costs nothing on top.  M must be a multiple of 32 (the panel width); otherwise the caller uses build_linv.
-static int chol_with_inverse(oak_ctx* ctx, double* dL, int64_t M) {
+static int chol_with_inverse(oak_ctx* ctx, double* dL, int64_t M, bool identity_in_place = false) {
     double *dLinvT, *dLinv;
     OAK_CHECK(get_buf_t(ctx, "LinvT", (size_t)M * M, &dLinvT));
     OAK_CHECK(get_buf_t(ctx, "Linv", (size_t)M * M, &dLinv));
-    OAK_CHECK(set_identity(ctx, dL + M * M, M));
+    if (!identity_in_place) OAK_CHECK(set_identity(ctx, dL + M * M, M));
     OAK_CHECK(potrf_lower(ctx, dL, M, M, false, 2 * M, true));
     OAK_CHECK(copy_d2d(ctx, dLinvT, dL + M * M, sizeof(double) * (size_t)M * M));
     OAK_CHECK(transpose(ctx, dLinvT, M, M, M, dLinv, M));
@@ -465,8 +465,11 @@ static int chol_with_inverse(oak_ctx* ctx, double* dL, int64_t M) {
 
 // L = chol(Kuu + jitter I) on the side stream.  It depends only on Z and the hyperparameters, so it runs concurrently
 // with the N-sized gram / SYRK stages; the tail joins on ev1 and reads the deferred Cholesky status (slot 1).
+// phase: 0 = the whole chain; 1 = only its head (Kuu + jitter I and the identity block: five launches); 2 = the rest.  A
+// partitioned pass enqueues the head, then the main path's featurize + first Gram panel, then the rest: the side stream is busy
+// with the head while the host enqueues the main path, and the host runs ahead of the 10 us Cholesky steps from then on.
 int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter, double* cond_out /* [2] min, max diag L; may be NULL */,
-                          bool fork) {
+                          bool fork, int phase) {
     const int64_t M = ctx->M;
     const bool want_cond = cond_out != nullptr;
     double* dmm = nullptr;
@@ -484,13 +487,17 @@ int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter,
     }
     hipStream_t main_stream = ctx->stream;
     ctx->stream = ctx->side;
+    const bool fused_inverse = (M % 32) == 0;
     int rc = [&]() -> int {
-        Feat FZ;
-        OAK_CHECK(featurize(ctx, pk, dZ, M, ctx->ldx, "featZ_side", &FZ));
-        OAK_CHECK(gram(ctx, pk, FZ, 0, M, FZ, dL, M, nullptr, nullptr, 0));
-        OAK_CHECK(add_diag(ctx, dL, M, M, jitter));
-        const bool fused_inverse = (M % 32) == 0;
-        if (fused_inverse) OAK_CHECK(chol_with_inverse(ctx, dL, M));
+        if (phase != 2) {
+            Feat FZ;
+            OAK_CHECK(featurize(ctx, pk, dZ, M, ctx->ldx, "featZ_side", &FZ));
+            OAK_CHECK(gram(ctx, pk, FZ, 0, M, FZ, dL, M, nullptr, nullptr, 0));
+            OAK_CHECK(add_diag(ctx, dL, M, M, jitter));
+            if (fused_inverse) OAK_CHECK(set_identity(ctx, dL + M * M, M));
+        }
+        if (phase == 1) return OAK_OK;
+        if (fused_inverse) OAK_CHECK(chol_with_inverse(ctx, dL, M, true));
         else OAK_CHECK(potrf_lower(ctx, dL, M, M, false));
         if (want_cond) {
             diag_minmax_kernel<<<1, 256, 0, ctx->stream>>>(dL, M, dmm);
@@ -503,7 +510,7 @@ int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter,
     }();
     ctx->stream = main_stream;
     if (rc != OAK_OK) { (void)hipStreamSynchronize(ctx->side); return rc; }
-    OAK_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->side));
+    if (phase != 1) OAK_HIP_CHECK(hipEventRecord(ctx->ev1, ctx->side));
     return OAK_OK;
 }
 
@@ -519,7 +526,15 @@ static bool partition_wanted(const oak_ctx* ctx, const PreparedKernel& pk) {
     const int64_t rows = ctx->panel_rows > 0 ? ctx->panel_rows : (int64_t)(((size_t)16 << 30) / (sizeof(double) * (size_t)Mp));
     if (ctx->N > rows || ctx->M % 32 != 0) return false;
     if (mode == 1) return true;
-    return (double)ctx->N * (double)Mp * (double)pk.dd.D <= 4.4e9;     // Gram <= ~2.6 ms (a quarter of the headline's rows)
+    // Measured (tools/ab_partition.sh, profiles/r05_ab_partition.txt): the row shards N/4, N/8, N/16 of the headline problem gain
+    // 0.15-0.3 ms; C2 (Gram 0.2 ms, chain 0.3 ms) gains nothing -- its SYRK would wait for the chain, and without the partition
+    // the chain's enqueue time is already spent next to the chain's own execution.  So: the Gram panel must be about as long as
+    // the chain (estimates: 1.7e6 pair-dimensions per microsecond on the whole chip; 12 us per 32 columns + Kuu's own Gram on the
+    // side's share), and short enough that giving up part_cus / 256 of it costs less than the chain's enqueue time.
+    const double frac = (double)ctx->part_cus / (double)ctx->num_cu;
+    const double gram_us = (double)ctx->N * (double)Mp * (double)pk.dd.D / 1.7e6;
+    const double chain_us = 12.0 * (double)ctx->M / 32.0 + 80.0 + (double)Mp * (double)Mp * pk.dd.D / (1.7e6 * frac);
+    return gram_us >= 0.9 * chain_us && gram_us <= 2600.0;
 }
 struct PartitionScope {
     oak_ctx* ctx;
@@ -597,6 +612,7 @@ int sgpr_forward(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, doubl
         // Gram panel.  The fp32 statistics mode asks for the same estimate.
         ctx->cond_requested = want_cond;
         if (!ctx->kuu_deferred) OAK_CHECK(sgpr_factor_kuu_async(ctx, pk, jitter, want_cond ? ctx->cond_mm : nullptr, !ctx->part_active));
+        else OAK_CHECK(sgpr_factor_kuu_async(ctx, pk, jitter, nullptr, false, 1));      // the chain's head; local_stats enqueues the rest
         ctx->auto_pending = auto_big;
         ctx->cond_seen = want_cond;
         ctx->kuu_async = true;
@@ -768,7 +784,9 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     ctx->out_sel = 0;
     double h[11] = {0};
     OAK_HIP_CHECK(hipMemcpyAsync(h, dscal, sizeof(double) * 11, hipMemcpyDeviceToHost, ctx->stream));
+    debug_mark(ctx, "tail_wait");
     OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    debug_mark(ctx, "tail_done");
     OAK_CHECK(check_route_counts(h[7], h[8], ctx->stats_whitened));   // a mixed-route sum explains any failure below: report it first
     if (l_state == 2) OAK_CHECK(potrf_check_value((int)h[10], M));    // Kuu (side stream) first: it is the upstream failure
     OAK_CHECK(potrf_check_value((int)h[9], M));                       // then B
@@ -1053,6 +1071,7 @@ int oak_sgpr_tail(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, d
 
 int oak_sgpr_elbo(oak_ctx* ctx, const oak_kernel_desc* desc, double noise_var, double jitter, double* elbo_out) {
     OAK_CHECK(guard(ctx));
+    debug_mark(ctx, "elbo_enter");
     PreparedKernel pk;
     OAK_CHECK(prepare_kernel(ctx, desc, &pk, PK_GROUPED));
     PhaseTimer t(ctx, "total");

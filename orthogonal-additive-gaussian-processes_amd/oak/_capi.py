@@ -6,7 +6,9 @@ device is usable, the first compute call raises :class:`OakHipError`.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
+import weakref
 import itertools
 import os
 from pathlib import Path
@@ -125,6 +127,7 @@ SIGNATURES = {
     "oak_comm_init_host": (C.c_int, [_CTX, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "oak_comm_info": (C.c_int, [C.c_char_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "oak_comm_allgatherv": (C.c_int, [_CTX, _D, C.POINTER(C.c_int64), C.c_int32]),
+    "oak_runtime_shutdown": (C.c_int, []),
     "oak_bench_gram_resident": (C.c_int, [_CTX, _DESC, _D]),
     "oak_bench_potrf": (C.c_int, [_CTX, C.c_int64, C.c_int32, _D, _D]),
     "oak_bench_trsm": (C.c_int, [_CTX, _D, C.c_int64, _D, C.c_int64, C.c_int32, C.c_int32, _D]),
@@ -155,7 +158,28 @@ def load_library():
         fn.restype = res
         fn.argtypes = args
     _lib = lib
+    atexit.register(_shutdown_runtime)
     return lib
+
+
+_live_contexts = weakref.WeakSet()
+
+
+def _shutdown_runtime():
+    """Interpreter exit: close the contexts still alive, then let the library destroy its pooled streams (oak_runtime_shutdown) --
+    while the process is still whole (a C-level exit handler would run after a profiler's per-thread state is gone)."""
+    for ctx in list(_live_contexts):
+        try:
+            ctx.close()
+        except Exception:                       # noqa: BLE001
+            pass
+    global _default_ctx
+    _default_ctx = None
+    if _lib is not None:
+        try:
+            _lib.oak_runtime_shutdown()
+        except Exception:                       # noqa: BLE001
+            pass
 
 
 def _check(status: int):
@@ -339,6 +363,7 @@ class HipContext:
         h = _CTX()
         _check(self._lib.oak_ctx_create(int(device), C.byref(h)))
         self._h = h
+        _live_contexts.add(self)
         self.device = device
 
     def close(self):
