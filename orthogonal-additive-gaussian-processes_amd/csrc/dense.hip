@@ -386,6 +386,13 @@ int syrk_plan_splits(oak_ctx* ctx, int64_t M, int64_t nrows) {
         const double cost = ((double)rounds + 1.7) * (double)rps + 120.0 * rounds + red * sp;
         if (sp == 1 || cost < best_cost) { best_cost = cost; best_s = sp; }
     }
+    // Fabric traffic (r05, profiles/r05_syrk_traffic_vs_splits.txt): at 128 splits of >= 8192 rows the workgroups of a split drift
+    // ~1000 rows apart (the diagonal pairs run 12 % longer) and the rows between leader and laggard no longer fit the XCD's L2:
+    // 32.5 GB fetched for an 8.6 GB panel.  Shorter splits shrink the drift in bytes -- 28.2 GB at 192, 24.8 GB at 256 -- while the
+    // fixed-order reduction grows (0.125 / 0.19 / 0.24 ms) and the SYRK itself starts to lose (same box, whole step: 28.09-28.18 ms
+    // at 128, 28.13-28.27 at 192, 28.33-28.45 at 208, 28.5 at 256).  192 where the time model had hit its cap: -4.3 GB of fabric
+    // traffic for <= 0.1 ms of a 28 ms step; more is not free.
+    if (best_s == 16 && (nrows + 127) / 128 >= 8192 && part_bytes * 24 <= 4.0 * 1024 * 1024 * 1024) return 192;
     return 8 * best_s;
 }
 

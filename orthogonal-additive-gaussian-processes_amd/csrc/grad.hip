@@ -280,7 +280,10 @@ __global__ void __launch_bounds__(256) pack_rows_kernel(const double* __restrict
     for (int idx = threadIdx.x; idx < W * 64; idx += 256) {       // coalesced over the packed row
         const int r = idx / W, j = idx - r * W;
         int src = j;
-        if (split >= 2) {                                         // j = ((h * nch + c) * 3 + q) * 4 + v  <-  tile row q * DP + d
+        if (split < 0) {                                          // j = (c * 3 + q) * 4 + v  <-  tile row q * DP + 4 c + v   (rows-in-lanes kernel's column side)
+            const int v = j & 3, q = (j >> 2) % 3, c = (j >> 2) / 3;
+            src = q * DP + 4 * c + v;
+        } else if (split >= 2) {                                  // j = ((h * nch + c) * 3 + q) * 4 + v  <-  tile row q * DP + d
             const int v = j & 3, q = (j >> 2) % 3, hc = (j >> 2) / 3, nch = DP / (4 * split);
             const int h = hc / nch, c = hc - h * nch;
             src = q * DP + split * (4 * c + v) + h;
@@ -1081,9 +1084,11 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     const int64_t reclen = record_len(pk);
     double* d_part = nullptr;
     // r05: rows in lanes for the reference's default continuous model (grad_rows.hip) -- the column features are scalar loads, the
-    // row's live in registers; three LDS reads per pair-dimension fewer.  Large row counts only: a workgroup owns 256 rows.
+    // row's live in registers; three LDS reads per pair-dimension fewer.  OPT-IN (OAK_BWD_ROWS=1): built because the r04 verdict asked
+    // for it, it fits 256 VGPRs without scratch (253) and halves the LDS instructions, but measures 15.1-15.5 ms against 14.8 at the
+    // headline shape -- the wait cycles move from LDS to scalar / vector memory (profiles/r05_pmc_pair_kernels.json).
     bool rows_form = fast && allrbf && unitbv && !want_gk && tablen == 0 && dmax <= 16 && R <= (dmax == 16 ? 3 : 4) && na >= 16384;
-    if (const char* e = getenv("OAK_BWD_ROWS")) rows_form = rows_form && atoi(e) != 0;
+    { const char* e = getenv("OAK_BWD_ROWS"); rows_form = rows_form && e != nullptr && atoi(e) != 0; }
     if (rows_form) {
         OAK_REQUIRE(A.xs32 != nullptr && B.xs32 != nullptr, "gram_bwd: features were not prepared for the backward pass");
         int cols_per_wg = 256;
@@ -1094,7 +1099,7 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
         OAK_CHECK(get_buf_t(ctx, "bwd_pack", (size_t)na * 3 * dmax, &d_apack));
         OAK_CHECK(get_buf_t(ctx, "bwd_pack_cols", (size_t)nb * 3 * dmax, &d_bpack));
         OAK_CHECK(launch_pack_rows(ctx, A, a0, na, D, dmax, d_apack, 1, -1.0));
-        OAK_CHECK(launch_pack_rows(ctx, B, 0, nb, D, dmax, d_bpack, 1, 1.0));
+        OAK_CHECK(launch_pack_rows(ctx, B, 0, nb, D, dmax, d_bpack, -1, 1.0));      // [column][chunk of four dims][feature][dim in chunk]
         int64_t nrec = 0;
         OAK_CHECK(gram_bwd_rows_launch(ctx, pk, dmax, d_apack, a0, na, d_bpack, nb, d_G, ldg, d_yA, d_avec, g_scale, cols_per_wg, d_part, &nrec));
         reduce_records_kernel<<<(unsigned)reclen, 256, 0, ctx->stream>>>(d_part, nrec, reclen, d_rec);

@@ -20,7 +20,8 @@ __global__ void __launch_bounds__(256, 2)
 gram_bwd_rows_kernel(const DevDesc dd, const double* __restrict__ Apack, int64_t a0, int64_t na, const double* __restrict__ Bpack, int64_t nb,
                      const double* __restrict__ G, int64_t ldg, const double* __restrict__ yA, const double* __restrict__ avec,
                      double g_scale, int cols_per_wg, double* __restrict__ partial) {
-    // Apack: [na][3][DMAX] = (xs32 | cn | dcs) of rows a0.., padding dims (-1, 0, 0); Bpack: [nb][3][DMAX], padding dims (+1, 0, 0)
+    // Apack: [na][3][DMAX] = (xs32 | cn | dcs) of rows a0.., padding dims (-1, 0, 0); Bpack: [nb][DMAX / 4][3][4] -- a column's
+    // features chunk by chunk (12 contiguous doubles per chunk of four dimensions), padding dims (+1, 0, 0)
     extern __shared__ __attribute__((aligned(16))) double smem[];
     double* Tab = smem;                                   // [EW_N] biased exp2 table
     double* Gt = Tab + EW_N;                              // [4 waves][2 buffers][BR_GC][BR_LD]
@@ -71,10 +72,15 @@ gram_bwd_rows_kernel(const DevDesc dd, const double* __restrict__ Apack, int64_t
     struct Chunk { double xb[4], cb[4], bd[4]; };
     auto fetch = [&](const double* __restrict__ pc, int d0, Chunk& ch) {
 #pragma unroll
-        for (int v = 0; v < 4; ++v) { ch.xb[v] = pc[d0 + v]; ch.cb[v] = pc[DMAX + d0 + v]; ch.bd[v] = pc[2 * DMAX + d0 + v]; }
+        for (int v = 0; v < 4; ++v) { ch.xb[v] = pc[3 * d0 + v]; ch.cb[v] = pc[3 * d0 + 4 + v]; ch.bd[v] = pc[3 * d0 + 8 + v]; }
     };
+    auto col_ptr = [&](int64_t gj) -> const double* { return Bpack + (gj < jend ? gj : jend - 1) * (3 * DMAX); };
+    // The first chunk of a column is fetched while the PREVIOUS column is in its second phase (coefficients, Horner, accumulation:
+    // no scalar value is live there); the later chunks one chunk ahead, as in the columns-in-lanes kernel.
+    Chunk cur;
+    if (jb < jend) fetch(col_ptr(jb), 0, cur);
     int buf = 0;
-    double gnext = 0.0;
+    double gnext = 0.0, gprev = 0.0;
     for (int64_t j0 = jb; j0 < jend; j0 += BR_GC) {
         const double* Gcur = Gw + buf * (BR_GC * BR_LD);
         double* Gnxt = Gw + (buf ^ 1) * (BR_GC * BR_LD);
@@ -82,17 +88,17 @@ gram_bwd_rows_kernel(const DevDesc dd, const double* __restrict__ Apack, int64_t
 #pragma unroll 1
         for (int jj = 0; jj < BR_GC; ++jj) {
             const int64_t gj = j0 + jj;
-            // next tile's load jj goes out now and lands in LDS one column later: its latency hides under a whole pair
-            if (jj > 0 && more) Gnxt[tcol * BR_LD + 4 * (jj - 1) + trow] = gnext;
+            // next tile's load jj goes out now and lands in LDS two columns later: its latency hides under two whole pairs
+            if (jj > 1 && more) Gnxt[tcol * BR_LD + 4 * (jj - 2) + trow] = gprev;
+            gprev = gnext;
             if (more) gnext = g_load(j0 + BR_GC, jj);
             const int64_t gc_ = gj < jend ? gj : jend - 1;                  // uniform; columns past the end contribute g = 0
-            const double* __restrict__ pc = Bpack + gc_ * (3 * DMAX);
+            const double* __restrict__ pc = col_ptr(gj);
             const double av = avec != nullptr ? avec[gc_] : 0.0;
             const double graw = Gcur[jj * BR_LD + lane];
             const double g = (row_ok && gj < jend) ? __builtin_fma(g_scale, graw, yrow * av) : 0.0;
             double k[DMAX], dk[DMAX];
-            Chunk cur, nxt;
-            fetch(pc, 0, cur);
+            Chunk nxt;
 #pragma unroll
             for (int d0 = 0; d0 < DMAX; d0 += 4) {
                 if (d0 + 4 < DMAX) fetch(pc, d0 + 4, nxt);
@@ -111,6 +117,7 @@ gram_bwd_rows_kernel(const DevDesc dd, const double* __restrict__ Apack, int64_t
                 }
                 if (d0 + 4 < DMAX) cur = nxt;
             }
+            fetch(col_ptr(gj + 1), 0, cur);      // next column's first chunk (clamped address past the end: loaded, never used)
             double e[R];
 #pragma unroll
             for (int q = 0; q < R; ++q) e[q] = 0.0;
@@ -140,7 +147,7 @@ gram_bwd_rows_kernel(const DevDesc dd, const double* __restrict__ Apack, int64_t
                 gl[d] = __builtin_fma(gc, dk[d], gl[d]);
             }
         }
-        if (more) Gnxt[tcol * BR_LD + 4 * (BR_GC - 1) + trow] = gnext;
+        if (more) { Gnxt[tcol * BR_LD + 4 * (BR_GC - 2) + trow] = gprev; Gnxt[tcol * BR_LD + 4 * (BR_GC - 1) + trow] = gnext; }
         buf ^= 1;
     }
     // workgroup reduction of the register accumulators (fixed order: lanes by butterfly, then the four waves)

@@ -645,7 +645,18 @@ static int sobol_run(oak_ctx* ctx, const oak_kernel_desc* desc, const double* Xc
     bool use_gram = false;
     if (ctx->sobol_path != 1 && sobol_make_plan_budgeted(subsets, subset_off, n_subsets, slot, nslot, &plan)) {
         const int nc = (int)plan.cols.size();
-        use_gram = ctx->sobol_path == 2 || (nc <= 16384 && sobol_cost_gram(nc, n) < sobol_cost_terms(total, n, plan.maxlen));
+        // Device memory the Gram-of-products evaluation can ask for, bounded from the INPUTS alone (never from the free memory of
+        // this GPU: under a communicator every rank must take the same path, or one rank's allocation failure leaves the others
+        // waiting in the all-reduce): split partials (<= 256 splits of Mp x Mp), one panel launch (<= 16 GiB), the L_d stack.
+        const double mp = (double)(((nc + 127) / 128) * 128), pair_rows = 0.5 * (double)n * ((double)n + 1.0);
+        const double gram_bytes = 256.0 * mp * mp * 8.0 + std::min(16.0 * 1073741824.0, pair_rows * mp * 8.0) + (double)nslot * (double)n * (double)n * 8.0;
+        const bool gram_fits = gram_bytes <= 96.0 * 1073741824.0;            // a third of an MI355X's 288 GB
+        if (ctx->sobol_path == 2 && !gram_fits) {
+            set_error("oak_sobol: the Gram-of-products evaluation of %d product columns over %lld points would need up to %.0f GiB of device memory", nc,
+                      (long long)n, gram_bytes / 1073741824.0);
+            return OAK_E_ARG;
+        }
+        use_gram = ctx->sobol_path == 2 || (gram_fits && nc <= 16384 && sobol_cost_gram(nc, n) < sobol_cost_terms(total, n, plan.maxlen));
     }
     OAK_REQUIRE(ctx->sobol_path != 2 || use_gram, "oak_sobol: the Gram-of-products evaluation needs subsets of 1..6 distinct dims");
 

@@ -570,3 +570,21 @@ def test_whitened_gradient_on_an_ill_conditioned_kuu_uses_the_posteriors_alpha(h
         assert abs(g[-1] - fdn) <= 2e-5 * abs(fdn), (g[-1], fdn)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("R,D", [(1, 5), (2, 8), (2, 16), (3, 11), (4, 7)])
+def test_rows_in_lanes_backward_kernel_equals_the_columns_in_lanes_kernel(hip, R, D, monkeypatch):
+    """csrc/grad_rows.hip (a lane owns a ROW, the column features are scalar loads) is an opt-in alternative to the default
+    backward pair kernel for the reference's default model (continuous inputs, unit base variances, depth <= 4): same record,
+    different summation order -- the two gradients agree to rounding, and with a ragged row and column count."""
+    X, y, Z = o.synthetic_problem(16384 + 77, D, 200 + 13, seed=31)
+    spec = o.make_spec(D, R, lengthscales=list(np.linspace(0.7, 1.6, D)), order_variances=list(np.linspace(0.6, 1.3, R + 1)))
+    d = _capi.KernelDesc(spec)
+    hip.sgpr_set_data(X, y); hip.sgpr_set_inducing(Z); hip.sgpr_set_route("phi")
+    monkeypatch.setenv("OAK_BWD_ROWS", "0")
+    e0, g0 = hip.sgpr_elbo_grad(d, 0.05)
+    monkeypatch.setenv("OAK_BWD_ROWS", "1")
+    e1, g1 = hip.sgpr_elbo_grad(d, 0.05)
+    assert e0 == e1
+    np.testing.assert_allclose(g1, g0, rtol=1e-10, atol=1e-11 * np.abs(g0).max())
+    hip.sgpr_set_route("auto")

@@ -495,3 +495,27 @@ def test_grouped_active_dims_are_one_rbf_over_the_group(hip):
     with pytest.raises(NotImplementedError):
         _capi.KernelDesc(dict(dims=[dict(type="rbf", lengthscale=1.0, variance=1.0, measure=("gaussian", 0.0, 1.0), active_dims=[0, 1])],
                               order_variances=[1.0, 1.0], max_interaction_depth=1, share_var_across_orders=True))
+
+
+def test_binary_sub_kernel_with_a_non_unit_base_variance_in_every_gram_form(hip):
+    """The forward Gram kernel evaluates a binary sub-kernel as the rank-one product cn_a * cn_b with cn = a(x) sqrt(bv) riding in
+    the feature slot the continuous dims use for their constraint term (csrc/oak_internal.h, Feat); the generic kernel
+    (oak_set_gram_form, one thread per entry) and the diagonal kernel read the 2 x 2 table instead.  With bv != 1 the two only
+    agree if the sqrt(bv) factor and the table carry the same variance: fused == generic == oracle."""
+    rng = np.random.default_rng(5)
+    X = np.column_stack([rng.normal(size=300), (rng.random(300) < 0.35).astype(float), rng.normal(size=300), (rng.random(300) < 0.6).astype(float)])
+    X2 = X[:70].copy()
+    spec = o.make_spec(4, 3, p0=[None, 0.65, None, 0.4], lengthscales=[0.8, 1.0, 1.3, 1.0], base_variances=[1.0, 2.75, 0.6, 0.3],
+                       order_variances=[0.9, 1.1, 0.7, 1.4])
+    d = _capi.KernelDesc(spec)
+    ref = o.oak_K(spec, X, X2)
+    fused = hip.gram(d, X, X2)
+    close(fused, ref)
+    close(hip.gram_diag(d, X), o.oak_K_diag(spec, X))
+    try:
+        hip.set_gram_form("reference")
+        generic = hip.gram(d, X, X2)
+    finally:
+        hip.set_gram_form("native")
+    close(generic, ref, 1e-11)
+    close(generic, fused, 1e-11)

@@ -627,3 +627,28 @@ def test_extra_targets_refuse_statistics_reduced_outside_the_library(hip):
         assert rel(e1, o.sgpr_elbo(o.make_spec(4, 2), X, Y2[:, :1], Z, 0.1)) <= 1e-10
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("route", ["phi", "whitened", "auto"])
+def test_partitioned_forward_pass_is_bit_identical(hip, route, monkeypatch):
+    """Small evaluations run spatially partitioned (sgpr.hip: the Kuu chain on its own compute units next to the first Gram panel,
+    CU-masked streams).  Which stream a kernel runs on must not change a single bit of the bound, its terms, the gradient or the
+    predictions: the same context evaluates with the partition forced on and forced off."""
+    X, y, Z = o.synthetic_problem(20000, 5, 256, seed=21)
+    spec = o.make_spec(5, 2, lengthscales=[0.9, 1.1, 1.3, 0.8, 1.0])
+    d = _capi.KernelDesc(spec)
+    hip.sgpr_set_data(X, y); hip.sgpr_set_inducing(Z); hip.sgpr_set_route(route)
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("OAK_PARTITION", mode)
+        e = hip.sgpr_elbo(d, 0.05)
+        terms = hip.sgpr_last_terms()
+        eg, g = hip.sgpr_elbo_grad(d, 0.05)
+        m, v = hip.sgpr_predict(d, X[:64])
+        out[mode] = (e, terms, eg, g, m, v)
+    a, b = out["0"], out["1"]
+    assert a[0] == b[0] and a[2] == b[2] and a[1] == b[1]
+    assert np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4]) and np.array_equal(a[5], b[5])
+    # (the phi route's deviation from GPflow's op order grows with cond(Kuu): 256 inducing points drawn from 5-D data)
+    assert abs(a[0] - o.sgpr_elbo(spec, X, y, Z, 0.05)) <= (1e-10 if route == "whitened" else 2e-9) * abs(a[0])
+    hip.sgpr_set_route("auto")

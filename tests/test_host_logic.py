@@ -389,3 +389,39 @@ def test_model_defaults_and_gmm_estimate_against_the_reference_executed_fixture(
         mog = estimate_one_dim_gmm(3, fx["gmm_x"])
         for name in ("means", "variances", "weights"):
             np.testing.assert_array_equal(np.asarray(getattr(mog, name), dtype=np.float64).reshape(-1), fx[f"gmm_{name}"])
+
+
+def test_component_list_is_a_list_that_fills_itself():
+    """get_list_representation's kernel_list is built lazily (41 449 components at D = 32, depth 4) but must behave as the list the
+    reference returns (oak/oak_kernel.py:338-364): isinstance, identity of repeated indexing, concatenation from both sides,
+    append, slices, iteration, equality."""
+    k = OAKKernel([gpflow.RBF] * 3, num_dims=3, max_interaction_depth=2, constrain_orthogonal=True)
+    sel, comps = get_list_representation(k, num_dims=3)
+    assert isinstance(comps, list) and len(comps) == len(sel) == 7
+    assert comps[2] is comps[2] and comps[-1] is comps[6]
+    assert comps[2].iComponent_list == sel[2]
+    with pytest.raises(IndexError):
+        comps[7]
+    both = comps + ["x"]
+    assert type(both) is list and len(both) == 8 and both[2] is comps[2]
+    assert (["y"] + comps)[1] is comps[0]
+    assert [c.iComponent_list for c in comps] == sel
+    assert [c.iComponent_list for c in comps[1:3]] == sel[1:3]
+    comps.append("z")
+    assert len(comps) == 8 and comps[-1] == "z" and comps[2].iComponent_list == sel[2]
+    _, again = get_list_representation(k, num_dims=3)
+    assert comps[:7] != again[:]          # components compare by identity, as objects do
+
+
+def test_packed_subsets_are_told_apart_from_a_pair_of_arrays():
+    """HipContext.pack_subsets returns a PackedSubsets; only that type is taken as already packed -- two subsets passed as a tuple of
+    arrays must not be misread as (indices, offsets)."""
+    packed = _capi.HipContext.pack_subsets([[0], [1, 2], [0, 1, 2]])
+    assert isinstance(packed, _capi.PackedSubsets)
+    flat, off = packed
+    assert flat.tolist() == [0, 1, 2, 0, 1, 2] and off.tolist() == [0, 1, 3, 6]
+    assert _capi.HipContext.pack_subsets(packed) is packed
+    two = _capi.HipContext.pack_subsets((np.array([0]), np.array([1, 2])))
+    assert two[0].tolist() == [0, 1, 2] and two[1].tolist() == [0, 1, 3]
+    with pytest.raises(ValueError):
+        _capi.PackedSubsets(np.array([0, 1]), np.array([1, 2]))

@@ -1,0 +1,296 @@
+// Go / no-go probe (round-4 verdict, item 3): fp64 SYRK Phi = K^T K (oak/utils.py:189-192, M = 1024 inducing points, N = 2^20 rows)
+// EMULATED on the int8 matrix pipe by the modular ("Ozaki scheme II", CRT) construction:
+//   1. per column m a power-of-two scale 2^s_m so that |K[n, m]| 2^s_m < 2^B;   A'[n, m] = rint(K[n, m] 2^s_m)  (a B-bit integer)
+//   2. L pairwise coprime moduli p_i <= 256 with  prod p_i > 2 N 2^(2B);   residue planes R_i = A' mod p_i, symmetric, int8
+//   3. C_i = R_i^T R_i with int8 MFMA, int32 accumulation over row splits short enough to stay exact, summed and reduced mod p_i
+//   4. Garner / mixed-radix reconstruction of X = A'^T A' (exact integer) from (C_1 .. C_L), Phi[a, b] = X[a, b] 2^(-s_a - s_b)
+// Measured here: the conversion pass (fp64 panel -> L int8 planes), the int8 SYRK of one plane (a plain first kernel: direct
+// 16-byte fragment loads, 64 x 64 per wave, no LDS), the reconstruction, and the error of the reconstructed Phi against a
+// double-double reference next to the error of a plain fp64 accumulation -- on a synthetic panel with the value distribution of an
+// OAK Gram panel (second-order additive kernel over four inputs).  Build: hipcc --offload-arch=gfx950 -O3 -o ozaki2_syrk ozaki2_syrk.hip
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <algorithm>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s (line %d)\n", #x, hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+constexpr int MAXL = 20;
+struct Moduli { int L; int p[MAXL]; double inv[MAXL]; };
+
+// ---- synthetic panel: K[n][m] = 1 + e1 + e2 of four constrained-RBF-like factors ------------------------------------------------
+__device__ __forceinline__ double urand(uint64_t i) {
+    uint64_t z = i + 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+    return ((double)(z >> 11) + 0.5) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ double nrand(uint64_t i) { return sqrt(-2.0 * log(urand(2 * i))) * cos(6.283185307179586 * urand(2 * i + 1)); }
+__global__ void make_panel(double* K, int64_t N, int M) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * M) return;
+    const int64_t n = idx / M; const int m = (int)(idx % M);
+    double e1 = 0.0, e2 = 0.0;
+    for (int d = 0; d < 4; ++d) {
+        const double x = nrand(1000003ull * (uint64_t)n + d), z = nrand(77777777ull + 1000003ull * (uint64_t)m + d);
+        const double k = exp(-0.5 * (x - z) * (x - z)) - 0.7598 * exp(-0.25 * (x * x + z * z));     // RBF minus its constraint term
+        e2 += k * e1; e1 += k;
+    }
+    K[idx] = 1.0 + e1 + e2;
+}
+
+// ---- 1. column scales ------------------------------------------------------------------------------------------------------------
+__global__ void colmax_kernel(const double* __restrict__ K, int64_t N, int M, double* __restrict__ part) {     // grid (M/256, nblk)
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.y * 4096, r1 = r0 + 4096 < N ? r0 + 4096 : N;
+    double mx = 0.0;
+    for (int64_t n = r0; n < r1; ++n) mx = fmax(mx, fabs(K[n * M + m]));
+    part[(int64_t)blockIdx.y * M + m] = mx;
+}
+__global__ void colscale_kernel(const double* __restrict__ part, int nblk, int M, int B, int* __restrict__ sexp) {
+    const int m = blockIdx.x * 256 + threadIdx.x;
+    double mx = 0.0;
+    for (int b = 0; b < nblk; ++b) mx = fmax(mx, part[(int64_t)b * M + m]);
+    int e = 0; frexp(mx, &e);                          // mx < 2^e
+    sexp[m] = B - 1 - e;                               // |K| 2^s < 2^(B-1): one bit of head room for the rounding
+}
+
+// ---- 2. conversion: fp64 panel -> L residue planes, layout [plane][n / 16][m][n % 16] -------------------------------------------
+// thread = (16-row group, column): reads 16 doubles of its column (stride M: coalesced across the columns of a wave), writes 16 bytes
+// per plane.  a mod p through fp64: q = rint(a / p), r = a - q p (exact: |a| < 2^52), folded into [-p/2, p/2).
+__global__ void __launch_bounds__(256) convert_kernel(const double* __restrict__ K, int64_t N, int M, const int* __restrict__ sexp,
+                                                      Moduli md, int8_t* __restrict__ planes) {
+    const int m = blockIdx.y * 256 + threadIdx.x;
+    const int64_t g = blockIdx.x;
+    const double sc = ldexp(1.0, sexp[m]);
+    double a[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a[j] = rint(K[(g * 16 + j) * M + m] * sc);
+    const int64_t plane_bytes = N * (int64_t)M;
+    for (int i = 0; i < md.L; ++i) {
+        const double p = (double)md.p[i], ip = md.inv[i], hp = 0.5 * p;
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            double r = __builtin_fma(-rint(a[j] * ip), p, a[j]);
+            r = r >= hp ? r - p : (r < -hp ? r + p : r);
+            w[j >> 2] |= ((uint32_t)(int)r & 0xffu) << (8 * (j & 3));
+        }
+        *reinterpret_cast<uint4*>(planes + i * plane_bytes + (g * M + m) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// ---- 3. int8 SYRK of one plane ---------------------------------------------------------------------------------------------------
+// workgroup = one 128 x 128 tile (bi <= bj) of one row split; wave (wr, wc) its 64 x 64 quarter as 2 x 2 v_mfma_i32_32x32x32_i8.
+// Fragments are 16-byte loads straight from the plane: lane (h = l >> 5, c = l & 31) takes rows 16 h .. 16 h + 15 of a 32-row step of
+// column c -- the same k order for both operands, so the contraction is right whatever order the instruction assigns to the bytes.
+__global__ void __launch_bounds__(256) syrk_i8_kernel(const int8_t* __restrict__ plane, int64_t N, int M, int nt, int64_t rows_per_split,
+                                                      int* __restrict__ part) {
+    // XCD-aware decode (workgroup b runs on XCD b % 8): all tile pairs of a row split on ONE XCD, so that the split's rows stream
+    // through that XCD's L2 once instead of once per XCD
+    const int ntile = nt * (nt + 1) / 2;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int split = xcd + 8 * (jx / ntile);
+    int bi = 0, rem = jx % ntile;
+    while (rem >= nt - bi) { rem -= nt - bi; ++bi; }
+    const int bj = bi + rem;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wr = wave >> 1, wc = wave & 1;
+    const int h = lane >> 5, c = lane & 31;
+    const int64_t g0 = (int64_t)split * rows_per_split / 16, g1 = (((int64_t)(split + 1) * rows_per_split < N) ? (int64_t)(split + 1) * rows_per_split : N) / 16;
+    const int ca = bi * 128 + wr * 64 + c, cb = bj * 128 + wc * 64 + c;
+    const v4i* pa = reinterpret_cast<const v4i*>(plane) + ca;
+    const v4i* pb = reinterpret_cast<const v4i*>(plane) + cb;
+    v16i acc[2][2];
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0;
+    // register double-buffering: the fragments of step g + 2 and g + 4 are in flight under the MFMAs of step g
+    constexpr int PF = 3;
+    v4i fa0[PF], fa1[PF], fb0[PF], fb1[PF];
+    auto ld = [&](int64_t g, int s) {
+        const int64_t gg = g < g1 ? g : g1 - 2;
+        const int64_t o = (gg + h) * M;
+        fa0[s] = pa[o]; fa1[s] = pa[o + 32]; fb0[s] = pb[o]; fb1[s] = pb[o + 32];
+    };
+#pragma unroll
+    for (int s = 0; s < PF - 1; ++s) ld(g0 + 2 * s, s);
+    for (int64_t g = g0; g < g1; g += 2 * PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            ld(g + 2 * (s + PF - 1), (s + PF - 1) % PF);
+            if (g + 2 * s < g1) {
+                acc[0][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa0[s], fb0[s], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa0[s], fb1[s], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa1[s], fb0[s], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa1[s], fb1[s], acc[1][1], 0, 0, 0);
+            }
+        }
+    }
+    int* dst = part + (int64_t)split * M * M;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = bi * 128 + wr * 64 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int col = bj * 128 + wc * 64 + 32 * y + c;
+                dst[(int64_t)row * M + col] = acc[x][y][r];
+            }
+}
+// residues[i][a][b] = (sum over splits of part) mod p_i, symmetric range; only the upper block triangle is defined
+__global__ void reduce_mod_kernel(const int* __restrict__ part, int nsplit, int M, int p, int* __restrict__ res) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)M * M) return;
+    long long s = 0;
+    for (int sp = 0; sp < nsplit; ++sp) s += part[(int64_t)sp * M * M + e];
+    long long r = s % p; if (r < 0) r += p;
+    if (2 * r >= p) r -= p;
+    res[e] = (int)r;
+}
+
+// ---- 4. Garner reconstruction (symmetric mixed-radix digits), Horner in fp64 from the top --------------------------------------------
+struct Garner { int L; int p[MAXL]; int inv[MAXL][MAXL]; };       // inv[j][i] = (p_j)^-1 mod p_i  (j < i)
+__global__ void crt_kernel(const int* __restrict__ res, int M, Garner gr, const int* __restrict__ sexp, double* __restrict__ phi) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (int64_t)M * M) return;
+    const int a = (int)(e / M), b = (int)(e % M);
+    if ((a >> 7) > (b >> 7)) return;                  // lower block triangle: not computed
+    int v[MAXL];
+    for (int i = 0; i < gr.L; ++i) {
+        const int p = gr.p[i];
+        int t = res[(int64_t)i * M * M + e];
+        for (int j = 0; j < i; ++j) {                 // t = (t - v_j) / p_j  mod p_i
+            t = ((t - v[j]) % p) * gr.inv[j][i] % p;
+        }
+        t %= p; if (t < 0) t += p;
+        if (2 * t >= p) t -= p;
+        v[i] = t;
+    }
+    double x = 0.0;
+    for (int i = gr.L - 1; i >= 0; --i) x = __builtin_fma(x, (double)gr.p[i], (double)v[i]);
+    phi[e] = ldexp(x, -(sexp[a] + sexp[b]));
+}
+
+// ---- reference: sampled entries in double-double (two-sum / two-prod) and in plain fp64 ------------------------------------------------
+__global__ void ref_kernel(const double* __restrict__ K, int64_t N, int M, const int* __restrict__ ea, const int* __restrict__ eb, int ne,
+                           double* __restrict__ hi_out, double* __restrict__ lo_out, double* __restrict__ plain_out) {
+    __shared__ double sh[256], sl[256], sp[256];
+    const int e = blockIdx.x;
+    const int a = ea[e], b = eb[e];
+    double hi = 0.0, lo = 0.0, pl = 0.0;
+    for (int64_t n = threadIdx.x; n < N; n += 256) {
+        const double x = K[n * M + a], y = K[n * M + b];
+        const double p = x * y, pe = __builtin_fma(x, y, -p);
+        const double s = hi + p, bb = s - hi, err = (hi - (s - bb)) + (p - bb);
+        hi = s; lo += err + pe;
+        pl = __builtin_fma(x, y, pl);
+    }
+    sh[threadIdx.x] = hi; sl[threadIdx.x] = lo; sp[threadIdx.x] = pl;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double H = 0.0, Lo = 0.0, P = 0.0;
+        for (int t = 0; t < 256; ++t) {
+            const double s = H + sh[t], bb = s - H, err = (H - (s - bb)) + (sh[t] - bb);
+            H = s; Lo += err + sl[t]; P += sp[t];
+        }
+        hi_out[e] = H; lo_out[e] = Lo; plain_out[e] = P;
+    }
+}
+
+static int modinv(int a, int p) { a %= p; if (a < 0) a += p; for (int x = 1; x < p; ++x) if ((a * x) % p == 1) return x; return 0; }
+
+int main(int argc, char** argv) {
+    const int64_t N = argc > 1 ? atoll(argv[1]) : (1 << 20);
+    const int M = argc > 2 ? atoi(argv[2]) : 1024;
+    const int B = argc > 3 ? atoi(argv[3]) : 48;                 // bits of the scaled integers
+    const int nsplit = argc > 4 ? atoi(argv[4]) : 64;
+    // pairwise coprime moduli <= 256, largest first
+    const int cand[] = {256, 255, 253, 251, 247, 241, 239, 233, 229, 227, 223, 217, 211, 199, 197, 193, 191, 181, 179, 173, 167, 163};
+    const double need_bits = 2.0 * B + log2((double)N) + 1.0;
+    Moduli md; Garner gr; md.L = 0; double bits = 0.0;
+    for (int c : cand) { if (bits > need_bits || md.L >= MAXL) break; md.p[md.L] = c; md.inv[md.L] = 1.0 / c; bits += log2((double)c); ++md.L; }
+    gr.L = md.L;
+    for (int i = 0; i < md.L; ++i) { gr.p[i] = md.p[i]; for (int j = 0; j < i; ++j) gr.inv[j][i] = modinv(md.p[j], md.p[i]); }
+    printf("N=%lld M=%d B=%d bits: need %.1f bits of modulus, %d moduli give %.1f; %d row splits of %lld rows (int32 exact up to %lld rows)\n",
+           (long long)N, M, B, need_bits, md.L, bits, nsplit, (long long)(N / nsplit), (long long)((1ll << 31) / (128 * 128)));
+    if (bits <= need_bits) { printf("not enough moduli\n"); return 1; }
+    const int64_t rps = N / nsplit;
+    if (nsplit % 8 != 0 || rps % 32 != 0 || rps * 128 * 128 >= (1ll << 31) || M % 256 != 0 || N % 4096 != 0) { printf("bad shape\n"); return 1; }
+    double *dK, *dpart_max, *dphi; int *dsexp, *dpart, *dres; int8_t* dplanes;
+    CK(hipMalloc(&dK, sizeof(double) * N * M));
+    const int nblk = (int)(N / 4096);
+    CK(hipMalloc(&dpart_max, sizeof(double) * nblk * M));
+    CK(hipMalloc(&dsexp, sizeof(int) * M));
+    CK(hipMalloc(&dplanes, (size_t)md.L * N * M));
+    CK(hipMalloc(&dpart, sizeof(int) * (size_t)nsplit * M * M));
+    CK(hipMalloc(&dres, sizeof(int) * (size_t)md.L * M * M));
+    CK(hipMalloc(&dphi, sizeof(double) * (size_t)M * M));
+    CK(hipMemset(dphi, 0, sizeof(double) * (size_t)M * M));
+    make_panel<<<(unsigned)((N * M + 255) / 256), 256>>>(dK, N, M);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    auto timed = [&](const char* what, int reps, auto&& fn) {
+        fn(); CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int r = 0; r < reps; ++r) fn();
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("%-46s %9.3f ms\n", what, ms / reps);
+        return (double)ms / reps;
+    };
+    const double t_scale = timed("column scales (max |K| per column)", 3, [&] {
+        colmax_kernel<<<dim3(M / 256, nblk), 256>>>(dK, N, M, dpart_max);
+        colscale_kernel<<<M / 256, 256>>>(dpart_max, nblk, M, B, dsexp);
+    });
+    const double t_conv = timed("conversion fp64 panel -> int8 residue planes", 3, [&] {
+        convert_kernel<<<dim3((unsigned)(N / 16), M / 256), 256>>>(dK, N, M, dsexp, md, dplanes);
+    });
+    const int nt = M / 128, ntile = nt * (nt + 1) / 2;
+    const double t_syrk = timed("int8 SYRK of ONE plane (all row splits)", 5, [&] {
+        syrk_i8_kernel<<<dim3(ntile * nsplit), 256>>>(dplanes, N, M, nt, rps, dpart);
+    });
+    const double t_red = timed("split reduction mod p of ONE plane", 5, [&] {
+        reduce_mod_kernel<<<(unsigned)(((int64_t)M * M + 255) / 256), 256>>>(dpart, nsplit, M, md.p[0], dres);
+    });
+    for (int i = 0; i < md.L; ++i) {                               // the real thing, every plane
+        syrk_i8_kernel<<<dim3(ntile * nsplit), 256>>>(dplanes + (size_t)i * N * M, N, M, nt, rps, dpart);
+        reduce_mod_kernel<<<(unsigned)(((int64_t)M * M + 255) / 256), 256>>>(dpart, nsplit, M, md.p[i], dres + (size_t)i * M * M);
+    }
+    const double t_crt = timed("Garner reconstruction of all M^2 entries", 3, [&] {
+        crt_kernel<<<(unsigned)(((int64_t)M * M + 255) / 256), 256>>>(dres, M, gr, dsexp, dphi);
+    });
+    const double ops = (double)M * (M + 1) * (double)N;
+    printf("int8 SYRK: %.3e MAC-ops x2 per plane = %.2f POP/s (algorithmic M(M+1)N); executed %d of %d tile pairs\n", ops, ops / (t_syrk * 1e-3) / 1e15,
+           ntile, nt * nt);
+    printf("PROJECTION for %d planes: conversion %.2f + SYRKs %.2f + reductions %.2f + CRT %.2f + scales %.2f = %.2f ms  (fp64 MFMA SYRK: 17.3 ms)\n", md.L,
+           t_conv, md.L * t_syrk, md.L * t_red, t_crt, t_scale, t_conv + md.L * (t_syrk + t_red) + t_crt + t_scale);
+    // accuracy on sampled entries (upper block triangle)
+    const int ne = 256;
+    std::vector<int> ea(ne), eb(ne);
+    for (int e = 0; e < ne; ++e) { int a = (e * 37 + 5) % M, b = (e * 101 + 11) % M; if (a > b) std::swap(a, b); if (e < 32) b = a; ea[e] = a; eb[e] = b; }
+    int *dea, *deb; double *dhi, *dlo, *dpl;
+    CK(hipMalloc(&dea, ne * 4)); CK(hipMalloc(&deb, ne * 4)); CK(hipMalloc(&dhi, ne * 8)); CK(hipMalloc(&dlo, ne * 8)); CK(hipMalloc(&dpl, ne * 8));
+    CK(hipMemcpy(dea, ea.data(), ne * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(deb, eb.data(), ne * 4, hipMemcpyHostToDevice));
+    ref_kernel<<<ne, 256>>>(dK, N, M, dea, deb, ne, dhi, dlo, dpl);
+    std::vector<double> hi(ne), lo(ne), pl(ne), phi((size_t)M * M);
+    CK(hipMemcpy(hi.data(), dhi, ne * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(lo.data(), dlo, ne * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(pl.data(), dpl, ne * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(phi.data(), dphi, sizeof(double) * (size_t)M * M, hipMemcpyDeviceToHost));
+    double diag_scale = 0.0;
+    for (int e = 0; e < 32; ++e) diag_scale = std::max(diag_scale, hi[e]);
+    double worst_oz = 0.0, worst_pl = 0.0, worst_oz_n = 0.0, worst_pl_n = 0.0;
+    for (int e = 0; e < ne; ++e) {
+        const long double truth = (long double)hi[e] + (long double)lo[e];
+        const double eo = (double)fabsl((long double)phi[(size_t)ea[e] * M + eb[e]] - truth), ep = (double)fabsl((long double)pl[e] - truth);
+        worst_oz = std::max(worst_oz, eo / (double)fabsl(truth)); worst_pl = std::max(worst_pl, ep / (double)fabsl(truth));
+        worst_oz_n = std::max(worst_oz_n, eo / diag_scale); worst_pl_n = std::max(worst_pl_n, ep / diag_scale);
+    }
+    printf("ACCURACY over %d sampled entries vs double-double: emulated  max rel %.2e  (max |err| / max diag %.2e);  plain fp64 sum  max rel %.2e  (%.2e)\n",
+           ne, worst_oz, worst_oz_n, worst_pl, worst_pl_n);
+    return 0;
+}
