@@ -171,6 +171,7 @@ struct oak_ctx {
     int64_t n_global_user = 0;       // rows over ALL shards as told by oak_sgpr_set_global_rows (0: not told)
     int64_t n_global_comm = 0;       // ... as summed over the communicator (0: not yet; reset by set_data / comm init / destroy)
     long long* potrf_trace = nullptr; int64_t potrf_trace_steps = 0;   // armed by oak_bench_potrf (OAK_POTRF_TRACE=1) around its own calls only
+    double* h_pin = nullptr;         // pinned host scratch (64 doubles): where the tail's scalars land
     int num_cu = 256;
     int64_t flow_n = 0;              // length of the resident normalising-flow sample "flow_g"
     int syrk_desc_ntile = -1;        // ntile the device descriptor table "syrk_desc" was built for

@@ -751,6 +751,7 @@ int oak_ctx_destroy(oak_ctx* ctx) {
     oak::reset_timings(ctx);
     oak_comm_destroy(ctx);
     for (auto& kv : ctx->bufs) if (kv.second.p) (void)hipFree(kv.second.p);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     {   // the (idle) streams and events go back to the pool: see acquire_streams for why they are never destroyed
         oak::StreamSet ss;
         ss.device = ctx->device; ss.main = ctx->main_full; ss.side = ctx->side_full; ss.main_part = ctx->main_part; ss.side_part = ctx->side_part;

@@ -731,9 +731,16 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
         // L^-1 is lower triangular: each 64 x 64 tile walks only the k range where it is non-zero (half the flops), and k is
         // sliced over gridDim.z (the (M/64)^2 tiles alone leave most CUs idle)
         OAK_CHECK(gemm_tail(ctx, 1, dLinv, st.phi, dT1, M, M, M, M, M, M, 1.0, 0.0, OAK_TRI_A_LOWER));
-        OAK_CHECK(copy_d2d(ctx, dT1 + M * M, st.psi, sizeof(double) * (size_t)M));
-        if (nx > 0) OAK_CHECK(copy_d2d(ctx, dT1 + (M + 1) * M, d_psix_in, sizeof(double) * (size_t)nx * M));     // rows M + 1 ..: psi_p^T
-        OAK_CHECK(gemm_tail(ctx, 1, dT1, dLinv, dT2, M + 1 + nx, M, M, M, M, M, 1.0, 0.0, OAK_TRI_B_LOWER));
+        if (nx == 0) {
+            // one output: the extra row would cost the product a whole ninth row block of tiles (M = 1024: 76 instead of 46 us);
+            // L^-1 psi is one matrix-vector product next to it
+            OAK_CHECK(gemm_tail(ctx, 1, dT1, dLinv, dT2, M, M, M, M, M, M, 1.0, 0.0, OAK_TRI_B_LOWER));
+            OAK_CHECK(gemv_rows(ctx, dLinv, M, M, M, st.psi, dT2 + M * M));
+        } else {
+            OAK_CHECK(copy_d2d(ctx, dT1 + M * M, st.psi, sizeof(double) * (size_t)M));
+            OAK_CHECK(copy_d2d(ctx, dT1 + (M + 1) * M, d_psix_in, sizeof(double) * (size_t)nx * M));     // rows M + 1 ..: psi_p^T
+            OAK_CHECK(gemm_tail(ctx, 1, dT1, dLinv, dT2, M + 1 + nx, M, M, M, M, M, 1.0, 0.0, OAK_TRI_B_LOWER));
+        }
     } else {
         // rows 0..M-1 of T1 = Phi (symmetric), row M = psi: one blocked solve gives (L^-1 Phi)^T and L^-1 psi together
         OAK_CHECK(copy_d2d(ctx, dT1, st.phi, sizeof(double) * (size_t)(M * M + M)));
@@ -782,7 +789,10 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
         OAK_HIP_CHECK(hipMemcpyAsync(hx.data(), d_sq, sizeof(double) * (size_t)2 * nx, hipMemcpyDeviceToHost, ctx->stream));
     }
     ctx->out_sel = 0;
-    double h[11] = {0};
+    // pinned landing buffer: the copy is then a plain asynchronous packet behind the scalars kernel and the host waits once, on the
+    // stream (into pageable memory the runtime stages and blocks inside hipMemcpyAsync)
+    if (ctx->h_pin == nullptr) OAK_HIP_CHECK(hipHostMalloc((void**)&ctx->h_pin, sizeof(double) * 64, hipHostMallocDefault));
+    double* h = ctx->h_pin;
     OAK_HIP_CHECK(hipMemcpyAsync(h, dscal, sizeof(double) * 11, hipMemcpyDeviceToHost, ctx->stream));
     debug_mark(ctx, "tail_wait");
     OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
