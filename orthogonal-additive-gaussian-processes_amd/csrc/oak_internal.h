@@ -137,6 +137,7 @@ struct oak_ctx {
     hipEvent_t ev3 = nullptr;                    // main_part -> main_full hand-over
     int part_cus = 0;                            // compute units of side_part (0: no partition streams)
     int part_cus_req = 0;                        // what OAK_PART_CUS asked for when the streams were made (pool key)
+    bool part_tried = false;                     // the CU-masked pair was asked for once (ensure_partition_streams)
     bool part_active = false;                    // inside a partitioned forward pass
     bool kuu_deferred = false;                   // ... whose side chain is enqueued by local_stats right behind its first Gram launch
     bool part_syrk_full = false;                 // ... whose SYRK runs on the whole chip once the side chain has finished
@@ -220,6 +221,7 @@ constexpr int PK_DEEP = 1;       // effective depth > OAK_MAX_DEPTH (the explici
 constexpr int PK_GROUPED = 2;    // sub-kernels over several columns (gram / gram_diag / gram_bwd / gram_bwd_z / diag_bwd take them; the fp32
                                  // and Sobol kernels do not)
 int prepare_kernel(oak_ctx* ctx, const oak_kernel_desc* desc, PreparedKernel* pk, int allow = 0);
+bool ensure_partition_streams(oak_ctx* ctx);      // runtime.hip: the CU-masked stream pair, created on first use
 // component (single subset) description derived from a full one
 int prepare_component(oak_ctx* ctx, const oak_kernel_desc* desc, const int32_t* subset, int32_t len,
                       int32_t apply_order_var, PreparedKernel* pk);

@@ -668,9 +668,22 @@ static int acquire_streams(int device, int num_cu, StreamSet* out) {
         set_error("hipStreamCreate / hipEventCreate failed");
         return OAK_E_HIP;
     }
-    create_partition_streams(&ss, num_cu);
+    ss.part_cus_req = requested_part_cus();       // the CU-masked pair itself is made on first use (ensure_partition_streams)
+    (void)num_cu;
     *out = ss;
     return OAK_OK;
+}
+// The partition pair of a context, made when its first partitioned pass is about to run: a process that only ever evaluates large
+// problems (the headline bench) never owns CU-masked queues.  false when the driver refuses them (then the pass runs unpartitioned).
+extern "C++" bool ensure_partition_streams(oak_ctx* ctx) {
+    if (ctx->main_part != nullptr) return true;
+    if (ctx->part_tried) return false;
+    ctx->part_tried = true;
+    StreamSet ss;
+    create_partition_streams(&ss, ctx->num_cu);
+    if (ss.main_part == nullptr) return false;
+    ctx->main_part = ss.main_part; ctx->side_part = ss.side_part; ctx->ev3 = ss.ev3; ctx->part_cus = ss.part_cus;
+    return true;
 }
 static void release_streams(const StreamSet& ss) {
     std::lock_guard<std::mutex> lock(g_pool_mu);
@@ -704,7 +717,7 @@ int oak_ctx_create(int device, oak_ctx** out) {
     if (oak::acquire_streams(device, ctx->num_cu, &ss) != OAK_OK) { delete ctx; return OAK_E_HIP; }
     ctx->stream = ctx->main_full = ss.main; ctx->side = ctx->side_full = ss.side;
     ctx->ev0 = ss.ev0; ctx->ev1 = ss.ev1; ctx->ev2 = ss.ev2; ctx->ev3 = ss.ev3;
-    ctx->main_part = ss.main_part; ctx->side_part = ss.side_part; ctx->part_cus = ss.part_cus;
+    ctx->main_part = ss.main_part; ctx->side_part = ss.side_part; ctx->part_cus = ss.part_cus;      // a pooled set may bring its pair along
     ctx->part_cus_req = ss.part_cus_req;
     { std::lock_guard<std::mutex> lock(oak::g_ctx_mu); oak::g_ctxs.insert(ctx); }
     *out = ctx;

@@ -517,24 +517,25 @@ int sgpr_factor_kuu_async(oak_ctx* ctx, const PreparedKernel& pk, double jitter,
 // ---- spatial partition of a small forward pass (oak_ctx::main_part / side_part) ---------------------------------------------------
 // One Kfu panel, and a Gram pass short enough that the chain's enqueue time (a few microseconds per launch, ~0.2 ms at M = 1024)
 // is worth more than the share of the chip the panel gives up (part_cus / 256 of its time).
-static bool partition_wanted(const oak_ctx* ctx, const PreparedKernel& pk) {
-    if (ctx->main_part == nullptr || ctx->stream != ctx->main_full || ctx->side != ctx->side_full) return false;
+static bool partition_wanted(oak_ctx* ctx, const PreparedKernel& pk) {
+    if (ctx->part_cus_req == 0 || ctx->num_cu != 256 || ctx->stream != ctx->main_full || ctx->side != ctx->side_full) return false;
     int mode = -1;
     if (const char* e = getenv("OAK_PARTITION")) mode = atoi(e);       // 0 never, 1 whenever possible, otherwise the size rule
     if (mode == 0) return false;
     const int64_t Mp = pad128(ctx->M);
     const int64_t rows = ctx->panel_rows > 0 ? ctx->panel_rows : (int64_t)(((size_t)16 << 30) / (sizeof(double) * (size_t)Mp));
     if (ctx->N > rows || ctx->M % 32 != 0) return false;
-    if (mode == 1) return true;
+    if (mode == 1) return ensure_partition_streams(ctx);
+    const int part_cus = ctx->part_cus > 0 ? ctx->part_cus : ctx->part_cus_req;
     // Measured (tools/ab_partition.sh, profiles/r05_ab_partition.txt): the row shards N/4, N/8, N/16 of the headline problem gain
     // 0.15-0.3 ms; C2 (Gram 0.2 ms, chain 0.3 ms) gains nothing -- its SYRK would wait for the chain, and without the partition
     // the chain's enqueue time is already spent next to the chain's own execution.  So: the Gram panel must be about as long as
     // the chain (estimates: 1.7e6 pair-dimensions per microsecond on the whole chip; 12 us per 32 columns + Kuu's own Gram on the
     // side's share), and short enough that giving up part_cus / 256 of it costs less than the chain's enqueue time.
-    const double frac = (double)ctx->part_cus / (double)ctx->num_cu;
+    const double frac = (double)part_cus / (double)ctx->num_cu;
     const double gram_us = (double)ctx->N * (double)Mp * (double)pk.dd.D / 1.7e6;
     const double chain_us = 12.0 * (double)ctx->M / 32.0 + 80.0 + (double)Mp * (double)Mp * pk.dd.D / (1.7e6 * frac);
-    return gram_us >= 0.9 * chain_us && gram_us <= 2600.0;
+    return gram_us >= 0.9 * chain_us && gram_us <= 2600.0 && ensure_partition_streams(ctx);
 }
 struct PartitionScope {
     oak_ctx* ctx;
