@@ -143,6 +143,118 @@ __global__ void __launch_bounds__(256) syrk_i8_kernel(const int8_t* __restrict__
                 dst[(int64_t)row * M + col] = acc[x][y][r];
             }
 }
+// ---- 3b. int8 SYRK, second kernel: 256 x 256 per workgroup (10 upper tiles at M = 1024), 128 x 128 per wave = 4 x 4 MFMA tiles (256
+// accumulator registers, one wave per SIMD), operands staged through LDS in 128-row stages (32 KB per side, double-buffered), so that a
+// plane byte enters a CU once per workgroup instead of once per wave; same XCD-aware split mapping.  ALL planes in one launch
+// (blockIdx.y = plane).  With one wave per SIMD nothing overlaps unless the instruction stream interleaves it: the stage's 16 global
+// loads, 16 LDS writes and 32 fragment reads are spread between its 64 MFMAs (sched_group_barrier pattern at the end of the stage).
+// PROBE (deliberately wrong results): 1 no global loads in the loop, 2 also no LDS writes, 3 also no barrier, 4 also fragments read once
+constexpr int T2 = 256, ST = 128;                      // tile edge, rows per stage
+template <int PROBE, int SCHED>
+__global__ void __launch_bounds__(256, 1) syrk_i8_v2_kernel(const int8_t* __restrict__ planes, int64_t N, int M, int nt2, int64_t rows_per_split,
+                                                            int nsplit, int* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) v4i lds[];      // [2 buffers][2 sides][ST / 16 groups][T2 cols]
+    const int ntile = nt2 * (nt2 + 1) / 2;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int split = xcd + 8 * (jx / ntile);
+    int bi = 0, rem = jx % ntile;
+    while (rem >= nt2 - bi) { rem -= nt2 - bi; ++bi; }
+    const int bj = bi + rem;
+    const bool diag = bi == bj;
+    const int8_t* plane = planes + (int64_t)blockIdx.y * N * M;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
+    const int h = lane >> 5, c = lane & 31;
+    const int64_t g0 = (int64_t)split * rows_per_split / 16, g1 = g0 + rows_per_split / 16;
+    const v4i* P = reinterpret_cast<const v4i*>(plane);
+    constexpr int SG = ST / 16;                                  // groups per stage
+    constexpr int SIDE = SG * T2;                                // v4i per side per buffer
+    v4i ra[SG], rb[SG];
+    auto gload = [&](int64_t g) {
+#pragma unroll
+        for (int q = 0; q < SG; ++q) {
+            const int64_t gg = (g + q < g1) ? g + q : g1 - 1;
+            ra[q] = P[gg * M + bi * T2 + tid];
+            if (!diag) rb[q] = P[gg * M + bj * T2 + tid];
+        }
+    };
+    auto lwrite = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < SG; ++q) {
+            lds[(buf * 2 + 0) * SIDE + q * T2 + tid] = ra[q];
+            if (!diag) lds[(buf * 2 + 1) * SIDE + q * T2 + tid] = rb[q];
+        }
+    };
+    v16i acc[4][4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0;
+    gload(g0); lwrite(0);
+    gload(g0 + SG);
+    __syncthreads();
+    int buf = 0;
+    for (int64_t g = g0; g < g1; g += SG) {
+        if (PROBE < 2 && g + SG < g1) lwrite(buf ^ 1);             // next stage into the other buffer (its readers finished before the last barrier)
+        if (PROBE < 1 && g + 2 * SG < g1) gload(g + 2 * SG);
+        const v4i* A = lds + (buf * 2 + 0) * SIDE + wr * 128 + c;
+        const v4i* B = lds + (buf * 2 + (diag ? 0 : 1)) * SIDE + wc * 128 + c;
+        v4i fa[2][4], fb[2][4];                                    // fragments of k-step kk + 1 are read while the MFMAs of k-step kk issue
+        if (PROBE < 4 || g == g0) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) { fa[0][x] = A[h * T2 + 32 * x]; fb[0][x] = B[h * T2 + 32 * x]; }
+        }
+#pragma unroll
+        for (int kk = 0; kk < SG / 2; ++kk) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < SG / 2 && (PROBE < 4 || g == g0)) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) { fa[nxt][x] = A[(2 * (kk + 1) + h) * T2 + 32 * x]; fb[nxt][x] = B[(2 * (kk + 1) + h) * T2 + 32 * x]; }
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 4; ++y) acc[x][y] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[cur][x], fb[cur][y], acc[x][y], 0, 0, 0);
+        }
+        if constexpr (SCHED == 1 && PROBE == 0) {
+            // 16 x { 4 MFMA, 1 LDS write, 1 global load, 2 LDS reads }: memory instructions issue in the shadow of the matrix pipe
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            }
+        }
+        if (PROBE < 3) __syncthreads();
+        buf ^= 1;
+    }
+    int* dst = part + ((int64_t)blockIdx.y * nsplit + split) * M * M;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = bi * T2 + wr * 128 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int col = bj * T2 + wc * 128 + 32 * y + c;
+                dst[(int64_t)row * M + col] = acc[x][y][r];
+            }
+}
+__global__ void reduce_mod_all_kernel(const int* __restrict__ part, int nsplit, int M, Moduli md, int* __restrict__ res) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.y;
+    if (e >= (int64_t)M * M) return;
+    if (((e / M) >> 8) > ((e % M) >> 8)) return;                   // lower block triangle of 256-tiles: not computed
+    long long s = 0;
+    for (int sp = 0; sp < nsplit; ++sp) s += part[((int64_t)i * nsplit + sp) * M * M + e];
+    const int p = md.p[i];
+    long long r = s % p; if (r < 0) r += p;
+    if (2 * r >= p) r -= p;
+    res[(int64_t)i * M * M + e] = (int)r;
+}
+
 // residues[i][a][b] = (sum over splits of part) mod p_i, symmetric range; only the upper block triangle is defined
 __global__ void reduce_mod_kernel(const int* __restrict__ part, int nsplit, int M, int p, int* __restrict__ res) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -160,7 +272,7 @@ __global__ void crt_kernel(const int* __restrict__ res, int M, Garner gr, const 
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= (int64_t)M * M) return;
     const int a = (int)(e / M), b = (int)(e % M);
-    if ((a >> 7) > (b >> 7)) return;                  // lower block triangle: not computed
+    if ((a >> 8) > (b >> 8)) return;                  // lower block triangle (256-tiles): not computed
     int v[MAXL];
     for (int i = 0; i < gr.L; ++i) {
         const int p = gr.p[i];
@@ -262,6 +374,37 @@ int main(int argc, char** argv) {
         syrk_i8_kernel<<<dim3(ntile * nsplit), 256>>>(dplanes + (size_t)i * N * M, N, M, nt, rps, dpart);
         reduce_mod_kernel<<<(unsigned)(((int64_t)M * M + 255) / 256), 256>>>(dpart, nsplit, M, md.p[i], dres + (size_t)i * M * M);
     }
+    // second kernel: all planes in one launch
+    const int ns2 = argc > 5 ? atoi(argv[5]) : 32;
+    const int64_t rps2 = N / ns2;
+    double t_v2 = 0.0, t_red2 = 0.0;
+    if (ns2 % 8 == 0 && rps2 % ST == 0 && rps2 * 128 * 128 < (1ll << 31) && M % T2 == 0) {
+        int* dpart2; CK(hipMalloc(&dpart2, sizeof(int) * (size_t)md.L * ns2 * M * M));
+        const int nt2 = M / T2, ntile2 = nt2 * (nt2 + 1) / 2;
+        const size_t lds2 = sizeof(v4i) * 2 * 2 * (ST / 16) * T2;
+        const dim3 grid2(ntile2 * ns2, md.L);
+#define OZ_ATTR(K) CK(hipFuncSetAttribute((const void*)K, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2))
+        OZ_ATTR((syrk_i8_v2_kernel<0, 0>)); OZ_ATTR((syrk_i8_v2_kernel<0, 1>)); OZ_ATTR((syrk_i8_v2_kernel<1, 0>)); OZ_ATTR((syrk_i8_v2_kernel<2, 0>));
+        OZ_ATTR((syrk_i8_v2_kernel<3, 0>)); OZ_ATTR((syrk_i8_v2_kernel<4, 0>));
+        if (getenv("OZ_PROBE")) {
+            timed("  v2 as the compiler schedules it", 3, [&] { syrk_i8_v2_kernel<0, 0><<<grid2, 256, lds2>>>(dplanes, N, M, nt2, rps2, ns2, dpart2); });
+            timed("  probe 1: no global loads in the loop", 3, [&] { syrk_i8_v2_kernel<1, 0><<<grid2, 256, lds2>>>(dplanes, N, M, nt2, rps2, ns2, dpart2); });
+            timed("  probe 2: + no LDS writes", 3, [&] { syrk_i8_v2_kernel<2, 0><<<grid2, 256, lds2>>>(dplanes, N, M, nt2, rps2, ns2, dpart2); });
+            timed("  probe 3: + no barrier", 3, [&] { syrk_i8_v2_kernel<3, 0><<<grid2, 256, lds2>>>(dplanes, N, M, nt2, rps2, ns2, dpart2); });
+            timed("  probe 4: + fragments read once (MFMA only)", 3, [&] { syrk_i8_v2_kernel<4, 0><<<grid2, 256, lds2>>>(dplanes, N, M, nt2, rps2, ns2, dpart2); });
+        }
+        t_v2 = timed("int8 SYRK v2 of ALL planes (256x256 tiles, LDS, interleaved)", 5, [&] {
+            syrk_i8_v2_kernel<0, 1><<<grid2, 256, lds2>>>(dplanes, N, M, nt2, rps2, ns2, dpart2);
+        });
+        t_red2 = timed("split reduction mod p of ALL planes (v2)", 5, [&] {
+            reduce_mod_all_kernel<<<dim3((unsigned)(((int64_t)M * M + 255) / 256), md.L), 256>>>(dpart2, ns2, M, md, dres);
+        });
+        CK(hipDeviceSynchronize());
+        printf("int8 SYRK v2: %d planes in %.3f ms = %.3f ms per plane = %.2f POP/s algorithmic (%d splits of %lld rows, %d workgroups)\n", md.L, t_v2, t_v2 / md.L,
+               md.L * (double)M * (M + 1) * (double)N / (t_v2 * 1e-3) / 1e15, ns2, (long long)rps2, ntile2 * ns2 * md.L);
+        printf("PROJECTION v2: conversion %.2f + SYRKs %.2f + reductions %.2f + CRT ~0.10 = %.2f ms  (fp64 MFMA SYRK: 17.3 ms)\n", t_conv, t_v2, t_red2,
+               t_conv + t_v2 + t_red2 + 0.1);
+    } else printf("v2 skipped: bad shape\n");
     const double t_crt = timed("Garner reconstruction of all M^2 entries", 3, [&] {
         crt_kernel<<<(unsigned)(((int64_t)M * M + 255) / 256), 256>>>(dres, M, gr, dsexp, dphi);
     });
