@@ -150,18 +150,25 @@ __global__ void __launch_bounds__(256) syrk_i8_kernel(const int8_t* __restrict__
 // loads, 16 LDS writes and 32 fragment reads are spread between its 64 MFMAs (sched_group_barrier pattern at the end of the stage).
 // PROBE (deliberately wrong results): 1 no global loads in the loop, 2 also no LDS writes, 3 also no barrier, 4 also fragments read once
 constexpr int T2 = 256, ST = 128;                      // tile edge, rows per stage
+// SCHED = 2: PERSISTENT -- one workgroup per CU, workgroup w of XCD x walks that XCD's item list (groups of `ntile` tile pairs sharing a
+// plane and a row split) at w, w + 32, ...: all items cost the same, so the 32 workgroups of an XCD advance in step and the ~3 groups
+// they are working on stream their rows through the L2 together.  (With one launch slot per item the members of a group start as
+// slots free up, ~30 % of a workgroup's life apart: 10 MB of rows between the first and the last -- no sharing in a 4 MB L2.)
 template <int PROBE, int SCHED>
 __global__ void __launch_bounds__(256, 1) syrk_i8_v2_kernel(const int8_t* __restrict__ planes, int64_t N, int M, int nt2, int64_t rows_per_split,
-                                                            int nsplit, int* __restrict__ part) {
+                                                            int nsplit, int* __restrict__ part, int nplanes) {
     extern __shared__ __attribute__((aligned(16))) v4i lds[];      // [2 buffers][2 sides][ST / 16 groups][T2 cols]
     const int ntile = nt2 * (nt2 + 1) / 2;
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-    const int split = xcd + 8 * (jx / ntile);
-    int bi = 0, rem = jx % ntile;
+    const int items_per_xcd = (nplanes * nsplit / 8) * ntile;       // groups G = plane * nsplit + split go to XCD G % 8
+    for (int item = (SCHED == 2 ? jx : 0); item < (SCHED == 2 ? items_per_xcd : 1); item += (int)(gridDim.x >> 3)) {
+    int split, pl, trem;
+    if (SCHED == 2) { const int G = (item / ntile) * 8 + xcd; pl = G / nsplit; split = G % nsplit; trem = item % ntile; }
+    else { split = xcd + 8 * (jx / ntile); pl = blockIdx.y; trem = jx % ntile; }
+    int bi = 0, rem = trem;
     while (rem >= nt2 - bi) { rem -= nt2 - bi; ++bi; }
     const int bj = bi + rem;
-    const bool diag = bi == bj;
-    const int8_t* plane = planes + (int64_t)blockIdx.y * N * M;
+    const int8_t* plane = planes + (int64_t)pl * N * M;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 1, wc = wave & 1;
     const int h = lane >> 5, c = lane & 31;
     const int64_t g0 = (int64_t)split * rows_per_split / 16, g1 = g0 + rows_per_split / 16;
@@ -174,14 +181,14 @@ __global__ void __launch_bounds__(256, 1) syrk_i8_v2_kernel(const int8_t* __rest
         for (int q = 0; q < SG; ++q) {
             const int64_t gg = (g + q < g1) ? g + q : g1 - 1;
             ra[q] = P[gg * M + bi * T2 + tid];
-            if (!diag) rb[q] = P[gg * M + bj * T2 + tid];
+            rb[q] = P[gg * M + bj * T2 + tid];                    // (a diagonal tile stages its panel twice: branch-free beats 20 % fewer bytes)
         }
     };
     auto lwrite = [&](int buf) {
 #pragma unroll
         for (int q = 0; q < SG; ++q) {
             lds[(buf * 2 + 0) * SIDE + q * T2 + tid] = ra[q];
-            if (!diag) lds[(buf * 2 + 1) * SIDE + q * T2 + tid] = rb[q];
+            lds[(buf * 2 + 1) * SIDE + q * T2 + tid] = rb[q];
         }
     };
     v16i acc[4][4];
@@ -196,10 +203,8 @@ __global__ void __launch_bounds__(256, 1) syrk_i8_v2_kernel(const int8_t* __rest
     __syncthreads();
     int buf = 0;
     for (int64_t g = g0; g < g1; g += SG) {
-        if (PROBE < 2 && g + SG < g1) lwrite(buf ^ 1);             // next stage into the other buffer (its readers finished before the last barrier)
-        if (PROBE < 1 && g + 2 * SG < g1) gload(g + 2 * SG);
         const v4i* A = lds + (buf * 2 + 0) * SIDE + wr * 128 + c;
-        const v4i* B = lds + (buf * 2 + (diag ? 0 : 1)) * SIDE + wc * 128 + c;
+        const v4i* B = lds + (buf * 2 + 1) * SIDE + wc * 128 + c;
         v4i fa[2][4], fb[2][4];                                    // fragments of k-step kk + 1 are read while the MFMAs of k-step kk issue
         if (PROBE < 4 || g == g0) {
 #pragma unroll
@@ -216,6 +221,23 @@ __global__ void __launch_bounds__(256, 1) syrk_i8_v2_kernel(const int8_t* __rest
             for (int x = 0; x < 4; ++x)
 #pragma unroll
                 for (int y = 0; y < 4; ++y) acc[x][y] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[cur][x], fb[cur][y], acc[x][y], 0, 0, 0);
+            // this k-step's share of the staging, IN PROGRAM ORDER behind its MFMAs (the compiler keeps LDS writes ahead of later LDS
+            // reads it cannot tell apart, so writes at the top of the stage would sit in front of every MFMA): two 16-row groups of the
+            // NEXT stage go registers -> other LDS buffer, then the same registers are reloaded for the stage after that.  Branch-free
+            // (clamped addresses; the last stages' extra copies are never read).
+#pragma unroll
+            for (int q = 2 * kk; q < 2 * kk + 2; ++q) {
+                if (PROBE < 2) {
+                    lds[((buf ^ 1) * 2 + 0) * SIDE + q * T2 + tid] = ra[q];
+                    lds[((buf ^ 1) * 2 + 1) * SIDE + q * T2 + tid] = rb[q];
+                }
+                if (PROBE < 1) {
+                    const int64_t gq = g + 2 * SG + q;
+                    const int64_t gg = gq < g1 ? gq : g1 - 1;
+                    ra[q] = P[gg * M + bi * T2 + tid];
+                    rb[q] = P[gg * M + bj * T2 + tid];
+                }
+            }
         }
         if constexpr (SCHED == 1 && PROBE == 0) {
             // 16 x { 4 MFMA, 1 LDS write, 1 global load, 2 LDS reads }: memory instructions issue in the shadow of the matrix pipe
@@ -230,7 +252,7 @@ __global__ void __launch_bounds__(256, 1) syrk_i8_v2_kernel(const int8_t* __rest
         if (PROBE < 3) __syncthreads();
         buf ^= 1;
     }
-    int* dst = part + ((int64_t)blockIdx.y * nsplit + split) * M * M;
+    int* dst = part + ((int64_t)pl * nsplit + split) * M * M;
 #pragma unroll
     for (int x = 0; x < 4; ++x)
 #pragma unroll
@@ -239,6 +261,90 @@ __global__ void __launch_bounds__(256, 1) syrk_i8_v2_kernel(const int8_t* __rest
             for (int r = 0; r < 16; ++r) {
                 const int row = bi * T2 + wr * 128 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * h;
                 const int col = bj * T2 + wc * 128 + 32 * y + c;
+                dst[(int64_t)row * M + col] = acc[x][y][r];
+            }
+    if (SCHED == 2) __syncthreads();                                // the next item's prologue overwrites LDS buffer 0
+    }
+}
+// ---- 3c. the same 256 x 256 workgroup tile with EIGHT waves (2 x 4, 128 x 64 per wave = 4 x 2 MFMA tiles, 128 accumulator registers): two
+// waves per SIMD, so that one wave's LDS / global-memory waits are covered by the other's MFMAs (a lone wave per SIMD overlaps nothing:
+// the probes of v2 add up -- MFMA 6.1 + fragment reads 0.6 + LDS writes 0.8 + global loads 2.7 = 10.2 ms).
+template <int DUMMY>
+__global__ void __launch_bounds__(512, 1) syrk_i8_v4_kernel(const int8_t* __restrict__ planes, int64_t N, int M, int nt2, int64_t rows_per_split,
+                                                            int nsplit, int* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) v4i lds[];      // [2 buffers][2 sides][ST / 16 groups][T2 cols]
+    const int ntile = nt2 * (nt2 + 1) / 2;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int split = xcd + 8 * (jx / ntile);
+    int bi = 0, rem = jx % ntile;
+    while (rem >= nt2 - bi) { rem -= nt2 - bi; ++bi; }
+    const int bj = bi + rem;
+    const int8_t* plane = planes + (int64_t)blockIdx.y * N * M;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 2, wc = wave & 3;
+    const int h = lane >> 5, c = lane & 31;
+    const int64_t g0 = (int64_t)split * rows_per_split / 16, g1 = g0 + rows_per_split / 16;
+    const v4i* P = reinterpret_cast<const v4i*>(plane);
+    constexpr int SG = ST / 16, SIDE = SG * T2, HQ = SG / 2;       // a thread stages HQ groups per side: threads 0..255 the even groups' ... see item()
+    // item (q, side): thread t moves column t & 255 of group 2 q + (t >> 8)
+    const int tcol = tid & 255, thalf = tid >> 8;
+    v4i ra[HQ], rb[HQ];
+    v16i acc[4][2];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0;
+    auto gaddr = [&](int64_t g, int q) { const int64_t gq = g + 2 * q + thalf; return (gq < g1 ? gq : g1 - 1) * M; };
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) { ra[q] = P[gaddr(g0, q) + bi * T2 + tcol]; rb[q] = P[gaddr(g0, q) + bj * T2 + tcol]; }
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) { lds[(0 * 2 + 0) * SIDE + (2 * q + thalf) * T2 + tcol] = ra[q]; lds[(0 * 2 + 1) * SIDE + (2 * q + thalf) * T2 + tcol] = rb[q]; }
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) { ra[q] = P[gaddr(g0 + SG, q) + bi * T2 + tcol]; rb[q] = P[gaddr(g0 + SG, q) + bj * T2 + tcol]; }
+    __syncthreads();
+    int buf = 0;
+    for (int64_t g = g0; g < g1; g += SG) {
+        const v4i* A = lds + (buf * 2 + 0) * SIDE + wr * 128 + c;
+        const v4i* B = lds + (buf * 2 + 1) * SIDE + wc * 64 + c;
+        v4i fa[2][4], fb[2][2];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) fa[0][x] = A[h * T2 + 32 * x];
+#pragma unroll
+        for (int y = 0; y < 2; ++y) fb[0][y] = B[h * T2 + 32 * y];
+#pragma unroll
+        for (int kk = 0; kk < SG / 2; ++kk) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < SG / 2) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) fa[nxt][x] = A[(2 * (kk + 1) + h) * T2 + 32 * x];
+#pragma unroll
+                for (int y = 0; y < 2; ++y) fb[nxt][y] = B[(2 * (kk + 1) + h) * T2 + 32 * y];
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[cur][x], fb[cur][y], acc[x][y], 0, 0, 0);
+            {   // this k-step's share of the staging (one group pair per k-step), in program order behind its MFMAs
+                const int q = kk;
+                lds[((buf ^ 1) * 2 + 0) * SIDE + (2 * q + thalf) * T2 + tcol] = ra[q];
+                lds[((buf ^ 1) * 2 + 1) * SIDE + (2 * q + thalf) * T2 + tcol] = rb[q];
+                ra[q] = P[gaddr(g + 2 * SG, q) + bi * T2 + tcol];
+                rb[q] = P[gaddr(g + 2 * SG, q) + bj * T2 + tcol];
+            }
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    int* dst = part + ((int64_t)blockIdx.y * nsplit + split) * M * M;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = bi * T2 + wr * 128 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int col = bj * T2 + wc * 64 + 32 * y + c;
                 dst[(int64_t)row * M + col] = acc[x][y][r];
             }
 }
@@ -387,15 +493,33 @@ int main(int argc, char** argv) {
         OZ_ATTR((syrk_i8_v2_kernel<0, 0>)); OZ_ATTR((syrk_i8_v2_kernel<0, 1>)); OZ_ATTR((syrk_i8_v2_kernel<1, 0>)); OZ_ATTR((syrk_i8_v2_kernel<2, 0>));
         OZ_ATTR((syrk_i8_v2_kernel<3, 0>)); OZ_ATTR((syrk_i8_v2_kernel<4, 0>));
         if (getenv("OZ_PROBE")) {
-            timed("  v2 as the compiler schedules it", 3, [&] { syrk_i8_v2_kernel<0, 0><<<grid2, 256, lds2>>>(dplanes, N, M, nt2, rps2, ns2, dpart2); });
-            timed("  probe 1: no global loads in the loop", 3, [&] { syrk_i8_v2_kernel<1, 0><<<grid2, 256, lds2>>>(dplanes, N, M, nt2, rps2, ns2, dpart2); });
-            timed("  probe 2: + no LDS writes", 3, [&] { syrk_i8_v2_kernel<2, 0><<<grid2, 256, lds2>>>(dplanes, N, M, nt2, rps2, ns2, dpart2); });
-            timed("  probe 3: + no barrier", 3, [&] { syrk_i8_v2_kernel<3, 0><<<grid2, 256, lds2>>>(dplanes, N, M, nt2, rps2, ns2, dpart2); });
-            timed("  probe 4: + fragments read once (MFMA only)", 3, [&] { syrk_i8_v2_kernel<4, 0><<<grid2, 256, lds2>>>(dplanes, N, M, nt2, rps2, ns2, dpart2); });
+            timed("  v2 as the compiler schedules it", 3, [&] { syrk_i8_v2_kernel<0, 0><<<grid2, 256, lds2>>>(dplanes, N, M, nt2, rps2, ns2, dpart2, md.L); });
+            timed("  probe 1: no global loads in the loop", 3, [&] { syrk_i8_v2_kernel<1, 0><<<grid2, 256, lds2>>>(dplanes, N, M, nt2, rps2, ns2, dpart2, md.L); });
+            timed("  probe 2: + no LDS writes", 3, [&] { syrk_i8_v2_kernel<2, 0><<<grid2, 256, lds2>>>(dplanes, N, M, nt2, rps2, ns2, dpart2, md.L); });
+            timed("  probe 3: + no barrier", 3, [&] { syrk_i8_v2_kernel<3, 0><<<grid2, 256, lds2>>>(dplanes, N, M, nt2, rps2, ns2, dpart2, md.L); });
+            timed("  probe 4: + fragments read once (MFMA only)", 3, [&] { syrk_i8_v2_kernel<4, 0><<<grid2, 256, lds2>>>(dplanes, N, M, nt2, rps2, ns2, dpart2, md.L); });
         }
         t_v2 = timed("int8 SYRK v2 of ALL planes (256x256 tiles, LDS, interleaved)", 5, [&] {
-            syrk_i8_v2_kernel<0, 1><<<grid2, 256, lds2>>>(dplanes, N, M, nt2, rps2, ns2, dpart2);
+            syrk_i8_v2_kernel<0, 1><<<grid2, 256, lds2>>>(dplanes, N, M, nt2, rps2, ns2, dpart2, md.L);
         });
+        {
+            OZ_ATTR((syrk_i8_v4_kernel<0>));
+            const double t_v4 = timed("int8 SYRK v4 = eight waves, 128 x 64 per wave (two per SIMD)", 5, [&] {
+                syrk_i8_v4_kernel<0><<<grid2, 512, lds2>>>(dplanes, N, M, nt2, rps2, ns2, dpart2);
+            });
+            printf("int8 SYRK v4: %d planes in %.3f ms = %.3f ms per plane = %.2f POP/s algorithmic\n", md.L, t_v4, t_v4 / md.L,
+                   md.L * (double)M * (M + 1) * (double)N / (t_v4 * 1e-3) / 1e15);
+            if (t_v4 < t_v2) t_v2 = t_v4;
+        }
+        if ((md.L * ns2) % 8 == 0) {
+            OZ_ATTR((syrk_i8_v2_kernel<0, 2>));
+            const double t_v3 = timed("int8 SYRK v3 = v2 PERSISTENT (one workgroup per CU)", 5, [&] {
+                syrk_i8_v2_kernel<0, 2><<<dim3(256), 256, lds2>>>(dplanes, N, M, nt2, rps2, ns2, dpart2, md.L);
+            });
+            printf("int8 SYRK v3: %d planes in %.3f ms = %.3f ms per plane = %.2f POP/s algorithmic\n", md.L, t_v3, t_v3 / md.L,
+                   md.L * (double)M * (M + 1) * (double)N / (t_v3 * 1e-3) / 1e15);
+            if (t_v3 < t_v2) t_v2 = t_v3;
+        }
         t_red2 = timed("split reduction mod p of ALL planes (v2)", 5, [&] {
             reduce_mod_all_kernel<<<dim3((unsigned)(((int64_t)M * M + 255) / 256), md.L), 256>>>(dpart2, ns2, M, md, dres);
         });
