@@ -367,9 +367,11 @@ static int launch_gram_t(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, 
     if (lds > 160 * 1024) { set_error("gram: LDS request %zu exceeds 160 KiB (D=%d)", lds, D); return OAK_E_ARG; }
     const int64_t nb = B.n;
     const int64_t ncb = (nb + TJ - 1) / TJ;
-    // rows per workgroup: enough row-blocks to fill the chip several times over (16 WGs per CU measured best at 2^20 rows:
-    // shorter workgroups leave smaller tails and let the side stream's small kernels in sooner), at least one row-step
-    int64_t target_wg = (int64_t)ctx->num_cu * 16;
+    // rows per workgroup: enough row-blocks to fill the chip several times over (r05, inside the step at 2^20 rows: 9.51-9.54 ms at 16
+    // workgroups per CU, 9.25-9.36 at 24 -- twelve rounds instead of eight leave a shorter ragged end, PMC: 1.64 resident waves per SIMD
+    // on average where two fit; resident back-to-back launches measure the same with either), at least one row-step
+    // (row shards of 131 072 rows measure 1.32 ms at 16 and 1.33-1.345 at 24: the finer split only pays on long panels)
+    int64_t target_wg = (int64_t)ctx->num_cu * (na >= (1 << 19) ? 24 : 16);
     if (const char* e = getenv("OAK_GRAM_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 64) target_wg = (int64_t)ctx->num_cu * v; }   // tuning knob
     int64_t nrb = (target_wg + ncb - 1) / ncb;
     if (nrb < 1) nrb = 1;
