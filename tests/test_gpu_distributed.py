@@ -564,3 +564,29 @@ def test_three_call_sequence_with_extra_outputs_under_a_loopback_communicator(ro
         assert abs(e_seq - e_fused) <= 1e-13 * abs(e_ref)
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("route", ["phi", "auto", "whitened"])
+def test_partitioned_forward_pass_under_a_loopback_communicator(route, monkeypatch):
+    """The spatially partitioned forward pass (CU-masked streams, sgpr.hip) with a communicator attached: the packed statistics are
+    all-reduced after the partition has been left, the auto route's conditioning decision is a scalar collective on the (masked)
+    side stream.  Two loopback ranks holding the same rows must equal one rank on the stacked rows, with the partition forced on."""
+    monkeypatch.setenv("OAK_PARTITION", "1")
+    X, y, Z = o.synthetic_problem(24000, 6, 256, seed=17)
+    spec = o.make_spec(6, 2, lengthscales=[1.1, 0.8, 1.5, 1.0, 0.9, 1.2], order_variances=[0.7, 1.2, 0.9])
+    d = _capi.KernelDesc(spec)
+    world = 2
+    ref_ctx = _capi.HipContext(0)
+    ctx = _capi.HipContext(0)
+    try:
+        ref_ctx.sgpr_set_data(np.tile(X, (world, 1)), np.tile(y, (world, 1))); ref_ctx.sgpr_set_inducing(Z); ref_ctx.sgpr_set_route(route)
+        e_ref, g_ref = ref_ctx.sgpr_elbo_grad(d, 0.05)
+        ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route(route)
+        ctx.comm_init_loopback(world)
+        e = ctx.sgpr_elbo(d, 0.05)
+        e2, g = ctx.sgpr_elbo_grad(d, 0.05)
+        assert abs(e - e_ref) <= 1e-11 * abs(e_ref) and e2 == e
+        np.testing.assert_allclose(g, g_ref, rtol=1e-9, atol=1e-9 * np.abs(g_ref).max())
+        assert ref_ctx.sgpr_stats_whitened() == ctx.sgpr_stats_whitened()
+    finally:
+        ctx.close(); ref_ctx.close()
