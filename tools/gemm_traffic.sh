@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/gemm_traffic
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-for V in 0 2; do
+for V in ${VS:-0 2}; do
   export OAK_GEMM_XCD_COLS=$V
   timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_$V -- python3 $ROOT/tools/dev_bwd_time.py > /dev/null 2> $OUT/pmc_$V.err
   for r in 1 2; do timeout 200 python3 $ROOT/tools/dev_bwd_time.py 2>&1 | head -1 >> $OUT/time_$V.txt; done
