@@ -165,9 +165,21 @@ def load_library():
 _live_contexts = weakref.WeakSet()
 
 
+def _profiler_attached() -> bool:
+    """rocprofv3 (or another rocprofiler-sdk tool) is loaded into this process."""
+    env = os.environ
+    return any("rocprofiler" in env.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")) or "ROCPROFILER_LIBRARY_CTOR" in env
+
+
 def _shutdown_runtime():
-    """Interpreter exit: close the contexts still alive, then let the library destroy its pooled streams (oak_runtime_shutdown) --
-    while the process is still whole (a C-level exit handler would run after a profiler's per-thread state is gone)."""
+    """Interpreter exit.  Only when a profiler is attached (its finaliser crashes on CU-masked queues left alive) or OAK_SHUTDOWN_AT_EXIT=1
+    asks for it: close the contexts still alive, then let the library destroy its pooled streams (oak_runtime_shutdown) -- while the process
+    is still whole (a C-level exit handler would run after the profiler's per-thread state is gone).  Otherwise nothing is torn down at
+    exit, as before r05: an ordinary process makes no HIP call on its way out (hipStreamDestroy is the call that can deadlock against the
+    runtime's event thread), the driver reclaims streams and memory."""
+    want = os.environ.get("OAK_SHUTDOWN_AT_EXIT")
+    if want == "0" or (want is None and not _profiler_attached()):
+        return
     for ctx in list(_live_contexts):
         try:
             ctx.close()
