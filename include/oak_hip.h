@@ -202,7 +202,14 @@ int oak_sgpr_set_global_rows(oak_ctx* ctx, int64_t n_total);
    under-reads cond(Kuu) by 20-600x);
    otherwise that evaluation runs in fp64 -- oak_sgpr_stats_precision reports what the last statistics used.  Not the
    reference's arithmetic: ELBO within 1e-5 relative of the fp64 path on the benchmark problems (7e-6 at the headline size, terms <= 2e-6) (tests/test_gpu_fp32.py),
-   never used for `value`. */
+   never used for `value`.
+   2: "int8 CRT" -- Phi = Kuf Kuf^T is accumulated EXACTLY on the int8 matrix pipe (csrc/crt.hip): every panel entry is scaled by
+   an a-priori power of two per column and rounded to a 48-bit integer, split into residues modulo 15-16 coprime moduli <= 254,
+   the residue planes are multiplied by v_mfma_i32_32x32x32_i8 with exact int32 / int64 sums, and the integer Gram matrix is
+   reconstructed by the Chinese remainder theorem.  The one rounding per entry (2^-48 of the column bound) replaces the N
+   roundings of an fp64 accumulation: this is not a lower precision (Phi is closer to the exact sum than the fp64 SYRK's).  phi
+   route only (a whitened panel has no a-priori bound); M <= 4096, N >= 4096; otherwise the evaluation runs the fp64 kernels --
+   oak_sgpr_stats_precision tells. */
 int oak_sgpr_set_precision(oak_ctx* ctx, int32_t mode);
 int oak_sgpr_stats_precision(oak_ctx* ctx, int32_t* mode);
 int oak_sgpr_stats_whitened(oak_ctx* ctx, int32_t* flag);

@@ -1,0 +1,299 @@
+// Phi = Kuf Kuf^T (oak/utils.py:189-190; GPflow's AAT before whitening) on the INT8 matrix pipe, exactly: the "Ozaki scheme II" /
+// Chinese-remainder construction.  Opt-in (oak_sgpr_set_precision(ctx, 2)), phi route only.
+//
+//   1. every column m of the Kfu panel gets a power-of-two scale 2^s_m from an A-PRIORI bound (no pass over the panel):
+//          |K(x, z_m)| <= sqrt(K(x, x) K(z_m, z_m)) <= sqrt(Kmax * K_diag(z_m))          (K is positive semi-definite)
+//      with Kmax = sum_r w_r e_r(max_x k_1(x, x), .., max_x k_D(x, x)) from the kernel description alone;
+//      A[n, m] = rint(K[n, m] 2^s_m) is an integer of at most B = 48 bits;
+//   2. L pairwise coprime moduli p_i <= 254 with prod p_i > 2 N 2^(2B-2); residue planes R_i = A mod p_i (int8, |r| <= 127),
+//      laid out [plane][n / 16][m][n % 16] so that an MFMA operand fragment is one 16-byte unit;
+//   3. C_i = R_i^T R_i by v_mfma_i32_32x32x32_i8, int32 accumulation over row splits short enough to be exact, summed (int64) and
+//      reduced mod p_i;
+//   4. Garner / mixed-radix reconstruction of the exact integer X = A^T A from (C_1 .. C_L), Phi[a, b] = X[a, b] 2^(-s_a - s_b).
+// The only error is the rounding of step 1 (|delta| <= 1/2 in the last of 48 bits, independent from entry to entry): the sum over
+// N rows is exact, where the fp64 MFMA SYRK rounds N times (measured r05, tools/ubench/ozaki2_syrk.hip: 3.8e-16 against 1.7e-15).
+#include "oak_internal.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+
+namespace oak {
+
+typedef int crt_v4i __attribute__((ext_vector_type(4)));
+typedef int crt_v16i __attribute__((ext_vector_type(16)));
+
+constexpr int CRT_MAXL = 20;
+// pairwise coprime, largest first; <= 254 so that a residue formed with one sloppy fp32 rounding of the quotient (fused epilogue of
+// the Gram kernel) still fits a signed byte
+static const int kCrtModuli[CRT_MAXL] = {254, 253, 251, 249, 247, 245, 241, 239, 233, 229, 227, 223, 211, 199, 197, 193, 191, 181, 179, 173};
+struct CrtMod { int L; int p[CRT_MAXL]; double inv[CRT_MAXL]; };
+struct CrtGarner {
+    int L, ngroups;
+    int p[CRT_MAXL];
+    short inv[CRT_MAXL][CRT_MAXL];      // inv[j][i] = p_j^-1 mod p_i  (j < i)
+    double pg[CRT_MAXL / 5];            // product of the moduli of digit group k (five digits per group: < 2^40, exact)
+};
+
+static int modinv(int a, int p) {
+    a %= p; if (a < 0) a += p;
+    for (int x = 1; x < p; ++x) if ((a * x) % p == 1) return x;
+    return 0;
+}
+
+// ---- 1. column scales -------------------------------------------------------------------------------------------------------------
+// sexp[m] = B - 1 - e with bound_m < 2^e; columns beyond M (zero padding) get the scale of column 0 (their entries are exact zeros)
+__global__ void __launch_bounds__(256) crt_scales_kernel(const double* __restrict__ kdiagZ, int64_t M, int64_t Mp2, double kmax, int B,
+                                                         int* __restrict__ sexp) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= Mp2) return;
+    const double kd = kdiagZ[m < M ? m : 0];
+    const double bound = sqrt(kmax * (kd > 0.0 ? kd : 0.0)) * (1.0 + 0x1p-20) + 0x1p-300;
+    int e = 0;
+    frexp(bound, &e);                                  // bound < 2^e
+    sexp[m] = B - 1 - e;
+}
+
+// ---- 2. conversion (stand-alone form): fp64 panel -> L residue planes ----------------------------------------------------------------
+// thread = (16-row group, column): reads 16 doubles of its column (coalesced across the columns of a wave), writes 16 bytes per plane.
+// a mod p through fp64: q = rint(a / p), r = a - q p (exact: |a| < 2^52), folded into [-p/2, p/2).  Rows >= na and columns >= ncols
+// of the panel are zeros.
+__global__ void __launch_bounds__(256) crt_convert_kernel(const double* __restrict__ K, int64_t ldk, int64_t na, int64_t ncols, int64_t Mp2,
+                                                          const int* __restrict__ sexp, CrtMod md, int8_t* __restrict__ planes, int64_t rows_pad) {
+    const int64_t m = (int64_t)blockIdx.y * 256 + threadIdx.x;
+    const int64_t g = blockIdx.x;
+    const double sc = ldexp(1.0, sexp[m]);
+    double a[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int64_t n = g * 16 + j;
+        a[j] = (n < na && m < ncols) ? rint(K[n * ldk + m] * sc) : 0.0;
+    }
+    const int64_t plane_bytes = rows_pad * Mp2;
+    for (int i = 0; i < md.L; ++i) {
+        const double p = (double)md.p[i], ip = md.inv[i], hp = 0.5 * p;
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            double r = __builtin_fma(-rint(a[j] * ip), p, a[j]);
+            r = r >= hp ? r - p : (r < -hp ? r + p : r);
+            w[j >> 2] |= ((uint32_t)(int)r & 0xffu) << (8 * (j & 3));
+        }
+        *reinterpret_cast<uint4*>(planes + i * plane_bytes + (g * Mp2 + m) * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// ---- 3. int8 SYRK of all planes --------------------------------------------------------------------------------------------------------
+// workgroup = one 256 x 256 tile (bi <= bj) of one row split of one plane, eight waves (2 x 4), 128 x 64 per wave = 4 x 2
+// v_mfma_i32_32x32x32_i8 tiles (128 accumulator registers, two waves per SIMD: one wave's LDS / memory waits are covered by the
+// other's MFMAs).  Operands staged through LDS in 128-row stages (32 KiB per side, double-buffered): a plane byte enters a CU once per
+// workgroup.  Lane (h = l >> 5, c = l & 31) takes rows 16 h .. 16 h + 15 of a 32-row k-step of column c -- the same k order for both
+// operands, so the contraction is right whatever order the instruction gives the bytes.  XCD-aware decode (workgroup b runs on XCD
+// b % 8): all tile pairs of a row split on ONE XCD, so that the split's rows stream through that XCD's L2 once.
+constexpr int CT2 = 256, CST = 128;
+__global__ void __launch_bounds__(512, 1) crt_syrk_i8_kernel(const int8_t* __restrict__ planes, int64_t rows_pad, int Mp2, int nt2, int64_t rows_per_split,
+                                                             int nsplit, int* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) crt_v4i crt_lds[];      // [2 buffers][2 sides][CST / 16 groups][CT2 cols]
+    const int ntile = nt2 * (nt2 + 1) / 2;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int split = xcd + 8 * (jx / ntile);
+    int bi = 0, rem = jx % ntile;
+    while (rem >= nt2 - bi) { rem -= nt2 - bi; ++bi; }
+    const int bj = bi + rem;
+    const int8_t* plane = planes + (int64_t)blockIdx.y * rows_pad * Mp2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 2, wc = wave & 3;
+    const int h = lane >> 5, c = lane & 31;
+    const int64_t g0 = (int64_t)split * rows_per_split / 16, g1 = g0 + rows_per_split / 16;
+    const crt_v4i* P = reinterpret_cast<const crt_v4i*>(plane);
+    constexpr int SG = CST / 16, SIDE = SG * CT2, HQ = SG / 2;
+    // staging item (q, side): thread t moves column t & 255 of group 2 q + (t >> 8)
+    const int tcol = tid & 255, thalf = tid >> 8;
+    crt_v4i ra[HQ], rb[HQ];
+    crt_v16i acc[4][2];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0;
+    auto gaddr = [&](int64_t g, int q) { const int64_t gq = g + 2 * q + thalf; return (gq < g1 ? gq : g1 - 1) * Mp2; };
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) { ra[q] = P[gaddr(g0, q) + bi * CT2 + tcol]; rb[q] = P[gaddr(g0, q) + bj * CT2 + tcol]; }
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) { crt_lds[(0 * 2 + 0) * SIDE + (2 * q + thalf) * CT2 + tcol] = ra[q]; crt_lds[(0 * 2 + 1) * SIDE + (2 * q + thalf) * CT2 + tcol] = rb[q]; }
+#pragma unroll
+    for (int q = 0; q < HQ; ++q) { ra[q] = P[gaddr(g0 + SG, q) + bi * CT2 + tcol]; rb[q] = P[gaddr(g0 + SG, q) + bj * CT2 + tcol]; }
+    __syncthreads();
+    int buf = 0;
+    for (int64_t g = g0; g < g1; g += SG) {
+        const crt_v4i* A = crt_lds + (buf * 2 + 0) * SIDE + wr * 128 + c;
+        const crt_v4i* Bf = crt_lds + (buf * 2 + 1) * SIDE + wc * 64 + c;
+        crt_v4i fa[2][4], fb[2][2];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) fa[0][x] = A[h * CT2 + 32 * x];
+#pragma unroll
+        for (int y = 0; y < 2; ++y) fb[0][y] = Bf[h * CT2 + 32 * y];
+#pragma unroll
+        for (int kk = 0; kk < SG / 2; ++kk) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < SG / 2) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) fa[nxt][x] = A[(2 * (kk + 1) + h) * CT2 + 32 * x];
+#pragma unroll
+                for (int y = 0; y < 2; ++y) fb[nxt][y] = Bf[(2 * (kk + 1) + h) * CT2 + 32 * y];
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[cur][x], fb[cur][y], acc[x][y], 0, 0, 0);
+            {   // this k-step's share of the staging (one group pair per k-step), in program order behind its MFMAs
+                const int q = kk;
+                crt_lds[((buf ^ 1) * 2 + 0) * SIDE + (2 * q + thalf) * CT2 + tcol] = ra[q];
+                crt_lds[((buf ^ 1) * 2 + 1) * SIDE + (2 * q + thalf) * CT2 + tcol] = rb[q];
+                ra[q] = P[gaddr(g + 2 * SG, q) + bi * CT2 + tcol];
+                rb[q] = P[gaddr(g + 2 * SG, q) + bj * CT2 + tcol];
+            }
+        }
+        __syncthreads();
+        buf ^= 1;
+    }
+    int* dst = part + ((int64_t)blockIdx.y * nsplit + split) * Mp2 * Mp2;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = bi * CT2 + wr * 128 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int col = bj * CT2 + wc * 64 + 32 * y + c;
+                dst[(int64_t)row * Mp2 + col] = acc[x][y][r];
+            }
+}
+
+// ---- 3b + 4. split sums mod p_i, then (last chunk) Garner digits and Phi ---------------------------------------------------------------
+// thread = entry (a, b), a <= b < M.  res[i][a * Mp2 + b] carries the residues between the chunks of a panel that does not fit one pass.
+// The mixed-radix digits v_i (symmetric) give X = v_0 + v_1 p_0 + v_2 p_0 p_1 + ...: Horner in exact int64 inside groups of five digits
+// (< 2^40), the two or three groups joined by fp64 FMAs (one rounding each).
+__global__ void __launch_bounds__(256) crt_reduce_kernel(const int* __restrict__ part, int nsplit, int64_t M, int64_t Mp2, CrtGarner gr,
+                                                         int* __restrict__ res, int first, int last, const int* __restrict__ sexp,
+                                                         double* __restrict__ phi) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x, a = blockIdx.y;
+    if (b >= M || a > b) return;
+    const int64_t e = a * Mp2 + b, MM = Mp2 * Mp2;
+    int v[CRT_MAXL];
+    for (int i = 0; i < gr.L; ++i) {
+        long long s = first ? 0 : (long long)res[(int64_t)i * MM + e];
+        const int* pp = part + (int64_t)i * nsplit * MM + e;
+        for (int sp = 0; sp < nsplit; ++sp) s += pp[(int64_t)sp * MM];
+        const int p = gr.p[i];
+        int r = (int)(s % p);
+        if (r < 0) r += p;
+        if (2 * r >= p) r -= p;
+        v[i] = r;
+    }
+    if (!last) {
+        for (int i = 0; i < gr.L; ++i) res[(int64_t)i * MM + e] = v[i];
+        return;
+    }
+    for (int i = 1; i < gr.L; ++i) {                      // Garner: v_i <- ((..((r_i - v_0) / p_0 - v_1) / p_1 ..) mod p_i
+        const int p = gr.p[i];
+        int t = v[i];
+        for (int j = 0; j < i; ++j) t = ((t - v[j]) % p) * (int)gr.inv[j][i] % p;
+        if (t < 0) t += p;
+        if (2 * t >= p) t -= p;
+        v[i] = t;
+    }
+    double x = 0.0;
+    for (int k = gr.ngroups - 1; k >= 0; --k) {
+        const int lo = 5 * k, hi = (lo + 5 < gr.L) ? lo + 5 : gr.L;
+        long long G = 0;
+        for (int i = hi - 1; i >= lo; --i) G = G * gr.p[i] + v[i];
+        x = __builtin_fma(x, gr.pg[k], (double)G);
+    }
+    const double out = ldexp(x, -(sexp[a] + sexp[b]));
+    phi[a * M + b] = out;
+    phi[b * M + a] = out;
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------------------
+static inline int64_t pad_to(int64_t v, int64_t q) { return ((v + q - 1) / q) * q; }
+
+// Kmax = sum_r w_r e_r(kmax_1 .. kmax_D), kmax_d = sup_x k_d(x, x): the base variance of a continuous sub-kernel (k = bv - cn^2), the
+// largest diagonal entry of a discrete one's table
+static double crt_kmax(const PreparedKernel& pk) {
+    const int D = pk.dd.D, R = (int)pk.w_full.size() - 1;
+    std::vector<double> e((size_t)R + 1, 0.0);
+    e[0] = 1.0;
+    for (int d = 0; d < D; ++d) {
+        double km = pk.dd.bv[d];
+        if (pk.dd.type[d] != OAK_DIM_RBF) {
+            const int C = pk.dd.ncat[d];
+            km = 0.0;
+            for (int c = 0; c < C; ++c) km = std::max(km, pk.tables[(size_t)pk.dd.tab_off[d] + (size_t)C * C + c]);
+        }
+        for (int q = R; q >= 1; --q) e[q] += km * e[q - 1];
+    }
+    double K = 0.0;
+    for (int r = 0; r <= R; ++r) K += std::fabs(pk.w_full[r]) * e[r];
+    return K;
+}
+
+bool crt_supported(const oak_ctx* ctx, int64_t M) {
+    return pad_to(M, 256) <= 4096 && ctx->N >= 4096;
+}
+
+// all of it for one panel chunk (stand-alone conversion from the fp64 panel): planes, int8 SYRK, split sums; on the last chunk Phi
+int crt_phi_from_panel(oak_ctx* ctx, const PreparedKernel& pk, const Feat& FZ, const double* d_panel, int64_t ldp, int64_t na, int64_t M,
+                       int64_t n_total, bool first_chunk, bool last_chunk, double* d_phi) {
+    const int B = 48;
+    const int64_t Mp2 = pad_to(M, 256);
+    const double need = 2.0 * B - 1.0 + std::log2((double)n_total) + 0.25;
+    CrtMod md; CrtGarner gr;
+    md.L = 0;
+    double bits = 0.0;
+    while (bits <= need && md.L < CRT_MAXL) { md.p[md.L] = kCrtModuli[md.L]; md.inv[md.L] = 1.0 / kCrtModuli[md.L]; bits += std::log2((double)kCrtModuli[md.L]); ++md.L; }
+    OAK_REQUIRE(bits > need, "int8 CRT statistics: %lld rows need more than %d moduli", (long long)n_total, CRT_MAXL);
+    gr.L = md.L; gr.ngroups = (md.L + 4) / 5;
+    for (int i = 0; i < md.L; ++i) { gr.p[i] = md.p[i]; for (int j = 0; j < i; ++j) gr.inv[j][i] = (short)modinv(md.p[j], md.p[i]); }
+    for (int k = 0; k < gr.ngroups; ++k) { double pgk = 1.0; for (int i = 5 * k; i < std::min(5 * k + 5, md.L); ++i) pgk *= md.p[i]; gr.pg[k] = pgk; }
+    // row splits: a multiple of 8 (one XCD each), <= 32768 rows (int32 exact to 2^31 / 127^2 = 133 152), whole 128-row stages
+    int nsplit = (int)pad_to((na + 32767) / 32768, 8);
+    const int64_t rps = pad_to((na + nsplit - 1) / nsplit, CST);
+    const int64_t rows_pad = rps * nsplit;
+    int* d_sexp = nullptr; double* d_kdz = nullptr; int8_t* d_planes = nullptr; int* d_part = nullptr; int* d_res = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "crt_sexp", (size_t)Mp2, &d_sexp));
+    OAK_CHECK(get_buf_t(ctx, "crt_kdiagZ", (size_t)M, &d_kdz));
+    OAK_CHECK(get_buf_t(ctx, "crt_planes", (size_t)md.L * rows_pad * Mp2, &d_planes));
+    OAK_CHECK(get_buf_t(ctx, "crt_part", (size_t)md.L * nsplit * Mp2 * Mp2, &d_part));
+    OAK_CHECK(get_buf_t(ctx, "crt_res", (size_t)md.L * Mp2 * Mp2, &d_res));
+    if (first_chunk) {
+        OAK_CHECK(gram_diag(ctx, pk, FZ, d_kdz, nullptr));
+        crt_scales_kernel<<<(unsigned)((Mp2 + 255) / 256), 256, 0, ctx->stream>>>(d_kdz, M, Mp2, crt_kmax(pk), B, d_sexp);
+        OAK_HIP_CHECK(hipGetLastError());
+    }
+    {
+        PhaseTimer t(ctx, "crt_convert");
+        crt_convert_kernel<<<dim3((unsigned)(rows_pad / 16), (unsigned)(Mp2 / 256)), 256, 0, ctx->stream>>>(d_panel, ldp, na, std::min<int64_t>(ldp, Mp2), Mp2, d_sexp, md,
+                                                                                                           d_planes, rows_pad);
+        OAK_HIP_CHECK(hipGetLastError());
+        t.stop();
+    }
+    {
+        PhaseTimer t(ctx, "crt_syrk");
+        const int nt2 = (int)(Mp2 / CT2), ntile2 = nt2 * (nt2 + 1) / 2;
+        const size_t lds = sizeof(crt_v4i) * 2 * 2 * (CST / 16) * CT2;
+        OAK_CHECK(ensure_max_dynamic_lds((const void*)crt_syrk_i8_kernel));
+        crt_syrk_i8_kernel<<<dim3((unsigned)(ntile2 * nsplit), (unsigned)md.L), 512, lds, ctx->stream>>>(d_planes, rows_pad, (int)Mp2, nt2, rps, nsplit, d_part);
+        OAK_HIP_CHECK(hipGetLastError());
+        t.stop();
+    }
+    {
+        PhaseTimer t(ctx, "crt_reduce");
+        crt_reduce_kernel<<<dim3((unsigned)((M + 255) / 256), (unsigned)M), 256, 0, ctx->stream>>>(d_part, nsplit, M, Mp2, gr, d_res, first_chunk ? 1 : 0,
+                                                                                                   last_chunk ? 1 : 0, d_sexp, d_phi);
+        OAK_HIP_CHECK(hipGetLastError());
+        t.stop();
+    }
+    return OAK_OK;
+}
+
+}  // namespace oak

@@ -153,13 +153,15 @@ struct oak_ctx {
     bool have_linv = false;          // buffers "Linv" / "LinvT" hold L^-1 and its transpose for the current L
     int route = 0;   // 0 auto, 1 phi, 2 whitened
     int gram_form = 0;               // explicit Gram entry points: 0 native arithmetic, 1 the reference's (oak_set_gram_form)
-    int precision = 0;               // 0: fp64 throughout; 1: fp32 Kfu panel + fp32-MFMA Phi partials on the phi route (forward only)
+    int precision = 0;               // 0: fp64 throughout; 1: fp32 Kfu panel + fp32-MFMA Phi partials on the phi route (forward only);
+                                     // 2: Phi accumulated exactly on the int8 matrix pipe (scaled 48-bit integers, CRT; phi route)
     int auto_whiten = -1;            // decision of the conditioning check for this evaluation (-1: none, use the size rule)
     bool auto_pending = false;       // the check's result (cond_mm) is still in flight on the side stream
     bool kuu_async = false;          // sgpr_forward started chol(Kuu + jitter I) and L^-1 on the side stream (join on ev1)
     bool cond_requested = false;     // this evaluation's side-stream factorisation also reports cond_mm (auto route / fp32 mode)
     bool cond_seen = false;          // ... and cond_mm holds it for the tail's report (oak_sgpr_last_terms slot 7)
     bool stats_fp32 = false;         // the statistics in "stats" came from the fp32 panel path
+    bool stats_crt = false;          // ... Phi of the statistics in "stats" was accumulated exactly on the int8 pipe (crt.hip)
     double cond_mm[2] = {1.0, 1.0};  // min / max of diag chol(Kuu), written by the side stream
     hipEvent_t ev2 = nullptr;        // side stream: conditioning estimate ready
     double noise_var = 0, jitter = 0;
@@ -257,6 +259,10 @@ int gram_f32(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
              const double* d_yA, double* d_psi, int64_t zero_pad_to);
 int syrk_panel_f32(oak_ctx* ctx, const float* d_panel, int64_t ldp, int64_t nrows, int64_t M, double* d_part, int nsplit, bool accumulate);
 int syrk_reduce(oak_ctx* ctx, const double* d_part, int nsplit, int64_t M, double* d_phi /*[M*M]*/, bool accumulate);
+// exact int8 / CRT accumulation of Phi (crt.hip): one panel chunk; Phi (full, symmetric) is written on the last chunk
+bool crt_supported(const oak_ctx* ctx, int64_t M);
+int crt_phi_from_panel(oak_ctx* ctx, const PreparedKernel& pk, const Feat& FZ, const double* d_panel, int64_t ldp, int64_t na, int64_t M,
+                       int64_t n_total, bool first_chunk, bool last_chunk, double* d_phi);
 // in place; strict upper zeroed.  nrows > n carries nrows - n extra rows through the panel solves and trailing updates
 // (row r >= n ends up as  A[r, :n] L^-T,  i.e. the solution of L x = A[r, :n]^T: a right-hand side rides for free).
 int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, bool check = true, int64_t nrows = -1, bool identity_below = false);

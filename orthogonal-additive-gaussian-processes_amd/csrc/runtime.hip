@@ -719,6 +719,8 @@ int oak_ctx_create(int device, oak_ctx** out) {
     ctx->ev0 = ss.ev0; ctx->ev1 = ss.ev1; ctx->ev2 = ss.ev2; ctx->ev3 = ss.ev3;
     ctx->main_part = ss.main_part; ctx->side_part = ss.side_part; ctx->part_cus = ss.part_cus;      // a pooled set may bring its pair along
     ctx->part_cus_req = ss.part_cus_req;
+    // development / A-B knob: the statistics precision every new context starts with (oak_sgpr_set_precision overrides it)
+    if (const char* e = getenv("OAK_PRECISION")) { const int v = atoi(e); if (v >= 0 && v <= 2) ctx->precision = v; }
     { std::lock_guard<std::mutex> lock(oak::g_ctx_mu); oak::g_ctxs.insert(ctx); }
     *out = ctx;
     return OAK_OK;

@@ -293,6 +293,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
         l_joined = true;
     }
     int chunk_idx = 0;
+    bool use_crt = false;
     for (int64_t a0 = 0; a0 < N; a0 += rows, ++chunk_idx) {
         const int64_t na = (a0 + rows <= N) ? rows : N - a0;
         {
@@ -359,7 +360,11 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
             }
             t.stop();
         }
-        {
+        // exact int8 / CRT accumulation of Phi (crt.hip): phi route only -- a whitened panel has no a-priori bound to scale by
+        use_crt = ctx->precision == 2 && !whiten && !use32 && crt_supported(ctx, M);
+        if (use_crt) {
+            OAK_CHECK(crt_phi_from_panel(ctx, pk, FZ, dSy, Mp, na, M, N, chunk_idx == 0, a0 + rows >= N, st.phi));
+        } else {
             PhaseTimer t(ctx, "syrk");
             if (use32) OAK_CHECK(syrk_panel_f32(ctx, dPanel32, Mp, na, M, dPart, nsplit, chunk_idx > 0));
             else OAK_CHECK(syrk_panel(ctx, dSy, Mp, na, M, dPart, nsplit, chunk_idx > 0));
@@ -373,7 +378,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     }
     {
         PhaseTimer t(ctx, "reduce");
-        OAK_CHECK(syrk_reduce(ctx, dPart, nsplit, M, st.phi, false));
+        if (!use_crt) OAK_CHECK(syrk_reduce(ctx, dPart, nsplit, M, st.phi, false));
         if (!kappa_done) {
             double* dDiag = nullptr;
             OAK_CHECK(get_buf_t(ctx, "kdiag", (size_t)N, &dDiag));
@@ -390,6 +395,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     ctx->have_stats = true;
     ctx->stats_whitened = whiten;
     ctx->stats_fp32 = use32;
+    ctx->stats_crt = use_crt;
     ctx->have_post = false;
     return OAK_OK;
 }
@@ -1029,7 +1035,7 @@ int oak_sgpr_set_route(oak_ctx* ctx, int32_t route) {
 
 int oak_sgpr_set_precision(oak_ctx* ctx, int32_t mode) {
     OAK_CHECK(guard(ctx));
-    OAK_REQUIRE(mode == 0 || mode == 1, "precision must be 0 (fp64) or 1 (fp32 statistics)");
+    OAK_REQUIRE(mode >= 0 && mode <= 2, "precision must be 0 (fp64), 1 (fp32 statistics) or 2 (exact int8 CRT accumulation of Phi)");
     ctx->precision = mode;
     return OAK_OK;
 }
@@ -1037,7 +1043,7 @@ int oak_sgpr_set_precision(oak_ctx* ctx, int32_t mode) {
 int oak_sgpr_stats_precision(oak_ctx* ctx, int32_t* mode) {
     OAK_CHECK(guard(ctx));
     OAK_REQUIRE(ctx->have_stats && mode, "no statistics available");
-    *mode = ctx->stats_fp32 ? 1 : 0;
+    *mode = ctx->stats_fp32 ? 1 : (ctx->stats_crt ? 2 : 0);
     return OAK_OK;
 }
 

@@ -505,10 +505,12 @@ class HipContext:
     def sgpr_set_route(self, route):
         _check(self._lib.oak_sgpr_set_route(self._h, self.ROUTES.get(route, route)))
 
-    PRECISIONS = {"fp64": 0, "fp32": 1}
+    PRECISIONS = {"fp64": 0, "fp32": 1, "int8crt": 2}
 
     def sgpr_set_precision(self, mode):
-        """'fp64' (default, the reference's arithmetic) or 'fp32' = fp32 Kfu panel + fp32-MFMA Phi partials (forward, phi route)."""
+        """'fp64' (default, the reference's arithmetic), 'fp32' = fp32 Kfu panel + fp32-MFMA Phi partials (forward, phi route), or
+        'int8crt' = Phi accumulated EXACTLY on the int8 matrix pipe from 48-bit scaled integers (residue planes + Chinese
+        remainder reconstruction, csrc/crt.hip; phi route): at least as accurate as the fp64 accumulation, not a lower precision."""
         _check(self._lib.oak_sgpr_set_precision(self._h, self.PRECISIONS.get(mode, mode)))
 
     def sgpr_stats_precision(self) -> str:
@@ -516,7 +518,7 @@ class HipContext:
         ill-conditioned Kuu, on the whitened route and for gradient calls)."""
         f = C.c_int32()
         _check(self._lib.oak_sgpr_stats_precision(self._h, C.byref(f)))
-        return "fp32" if f.value else "fp64"
+        return {0: "fp64", 1: "fp32", 2: "int8crt"}[f.value]
 
     def sgpr_set_global_rows(self, n_total: int):
         """Rows over all shards (0 = unknown): what the auto route's size rule looks at when this context holds one shard."""
