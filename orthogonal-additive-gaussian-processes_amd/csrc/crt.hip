@@ -22,11 +22,9 @@ namespace oak {
 typedef int crt_v4i __attribute__((ext_vector_type(4)));
 typedef int crt_v16i __attribute__((ext_vector_type(16)));
 
-constexpr int CRT_MAXL = 20;
 // pairwise coprime, largest first; <= 254 so that a residue formed with one sloppy fp32 rounding of the quotient (fused epilogue of
 // the Gram kernel) still fits a signed byte
 static const int kCrtModuli[CRT_MAXL] = {254, 253, 251, 249, 247, 245, 241, 239, 233, 229, 227, 223, 211, 199, 197, 193, 191, 181, 179, 173};
-struct CrtMod { int L; int p[CRT_MAXL]; double inv[CRT_MAXL]; };
 struct CrtGarner {
     int L, ngroups;
     int p[CRT_MAXL];
@@ -241,55 +239,71 @@ bool crt_supported(const oak_ctx* ctx, int64_t M) {
     return pad_to(M, 256) <= 4096 && ctx->N >= 4096;
 }
 
-// all of it for one panel chunk (stand-alone conversion from the fp64 panel): planes, int8 SYRK, split sums; on the last chunk Phi
-int crt_phi_from_panel(oak_ctx* ctx, const PreparedKernel& pk, const Feat& FZ, const double* d_panel, int64_t ldp, int64_t na, int64_t M,
-                       int64_t n_total, bool first_chunk, bool last_chunk, double* d_phi) {
-    const int B = 48;
-    const int64_t Mp2 = pad_to(M, 256);
-    const double need = 2.0 * B - 1.0 + std::log2((double)n_total) + 0.25;
-    CrtMod md; CrtGarner gr;
-    md.L = 0;
+// Plan of one panel chunk of `na` rows: moduli for n_total rows in all (residues are carried from chunk to chunk), row splits (a
+// multiple of 8 -- one XCD each --, <= 32768 rows: int32 sums are exact to 2^31 / 128^2 = 131 072 rows, whole 128-row stages) and the
+// buffers (grow-only, so a later, shorter chunk fits).
+int crt_plan(oak_ctx* ctx, int64_t na, int64_t M, int64_t n_total, CrtPlan* pl) {
+    pl->B = 48;
+    pl->Mp2 = pad_to(M, 256);
+    const double need = 2.0 * pl->B - 1.0 + std::log2((double)n_total) + 0.25;
+    pl->md.L = 0;
     double bits = 0.0;
-    while (bits <= need && md.L < CRT_MAXL) { md.p[md.L] = kCrtModuli[md.L]; md.inv[md.L] = 1.0 / kCrtModuli[md.L]; bits += std::log2((double)kCrtModuli[md.L]); ++md.L; }
+    while (bits <= need && pl->md.L < CRT_MAXL) {
+        pl->md.p[pl->md.L] = kCrtModuli[pl->md.L]; pl->md.inv[pl->md.L] = 1.0 / kCrtModuli[pl->md.L];
+        bits += std::log2((double)kCrtModuli[pl->md.L]); ++pl->md.L;
+    }
     OAK_REQUIRE(bits > need, "int8 CRT statistics: %lld rows need more than %d moduli", (long long)n_total, CRT_MAXL);
+    pl->nsplit = (int)pad_to((na + 32767) / 32768, 8);
+    pl->rps = pad_to((na + pl->nsplit - 1) / pl->nsplit, CST);
+    pl->rows_pad = pl->rps * pl->nsplit;
+    OAK_CHECK(get_buf_t(ctx, "crt_sexp", (size_t)pl->Mp2, &pl->d_sexp));
+    OAK_CHECK(get_buf_t(ctx, "crt_planes", (size_t)pl->md.L * pl->rows_pad * pl->Mp2, &pl->d_planes));
+    OAK_CHECK(get_buf_t(ctx, "crt_part", (size_t)pl->md.L * pl->nsplit * pl->Mp2 * pl->Mp2, &pl->d_part));
+    OAK_CHECK(get_buf_t(ctx, "crt_res", (size_t)pl->md.L * pl->Mp2 * pl->Mp2, &pl->d_res));
+    return OAK_OK;
+}
+
+// column scales from K_diag(Z) and the a-priori bound on K_diag(x): once per evaluation, before the first chunk
+int crt_scales(oak_ctx* ctx, const PreparedKernel& pk, const Feat& FZ, int64_t M, const CrtPlan& pl) {
+    double* d_kdz = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "crt_kdiagZ", (size_t)M, &d_kdz));
+    OAK_CHECK(gram_diag(ctx, pk, FZ, d_kdz, nullptr));
+    crt_scales_kernel<<<(unsigned)((pl.Mp2 + 255) / 256), 256, 0, ctx->stream>>>(d_kdz, M, pl.Mp2, crt_kmax(pk), pl.B, pl.d_sexp);
+    OAK_HIP_CHECK(hipGetLastError());
+    return OAK_OK;
+}
+
+// stand-alone conversion of an fp64 panel chunk (the fallback of the fused Gram epilogue, gram.hip::gram_crt_kernel)
+int crt_convert_panel(oak_ctx* ctx, const CrtPlan& pl, const double* d_panel, int64_t ldp, int64_t na) {
+    PhaseTimer t(ctx, "crt_convert");
+    crt_convert_kernel<<<dim3((unsigned)(pl.rows_pad / 16), (unsigned)(pl.Mp2 / 256)), 256, 0, ctx->stream>>>(d_panel, ldp, na, std::min<int64_t>(ldp, pl.Mp2), pl.Mp2,
+                                                                                                             pl.d_sexp, pl.md, pl.d_planes, pl.rows_pad);
+    OAK_HIP_CHECK(hipGetLastError());
+    t.stop();
+    return OAK_OK;
+}
+
+// int8 SYRK of the chunk's planes, split sums joined to the residues carried so far; on the last chunk Phi (full, symmetric)
+int crt_accumulate(oak_ctx* ctx, const CrtPlan& pl, int64_t M, bool first_chunk, bool last_chunk, double* d_phi) {
+    CrtGarner gr;
+    const CrtMod& md = pl.md;
     gr.L = md.L; gr.ngroups = (md.L + 4) / 5;
     for (int i = 0; i < md.L; ++i) { gr.p[i] = md.p[i]; for (int j = 0; j < i; ++j) gr.inv[j][i] = (short)modinv(md.p[j], md.p[i]); }
     for (int k = 0; k < gr.ngroups; ++k) { double pgk = 1.0; for (int i = 5 * k; i < std::min(5 * k + 5, md.L); ++i) pgk *= md.p[i]; gr.pg[k] = pgk; }
-    // row splits: a multiple of 8 (one XCD each), <= 32768 rows (int32 exact to 2^31 / 127^2 = 133 152), whole 128-row stages
-    int nsplit = (int)pad_to((na + 32767) / 32768, 8);
-    const int64_t rps = pad_to((na + nsplit - 1) / nsplit, CST);
-    const int64_t rows_pad = rps * nsplit;
-    int* d_sexp = nullptr; double* d_kdz = nullptr; int8_t* d_planes = nullptr; int* d_part = nullptr; int* d_res = nullptr;
-    OAK_CHECK(get_buf_t(ctx, "crt_sexp", (size_t)Mp2, &d_sexp));
-    OAK_CHECK(get_buf_t(ctx, "crt_kdiagZ", (size_t)M, &d_kdz));
-    OAK_CHECK(get_buf_t(ctx, "crt_planes", (size_t)md.L * rows_pad * Mp2, &d_planes));
-    OAK_CHECK(get_buf_t(ctx, "crt_part", (size_t)md.L * nsplit * Mp2 * Mp2, &d_part));
-    OAK_CHECK(get_buf_t(ctx, "crt_res", (size_t)md.L * Mp2 * Mp2, &d_res));
-    if (first_chunk) {
-        OAK_CHECK(gram_diag(ctx, pk, FZ, d_kdz, nullptr));
-        crt_scales_kernel<<<(unsigned)((Mp2 + 255) / 256), 256, 0, ctx->stream>>>(d_kdz, M, Mp2, crt_kmax(pk), B, d_sexp);
-        OAK_HIP_CHECK(hipGetLastError());
-    }
-    {
-        PhaseTimer t(ctx, "crt_convert");
-        crt_convert_kernel<<<dim3((unsigned)(rows_pad / 16), (unsigned)(Mp2 / 256)), 256, 0, ctx->stream>>>(d_panel, ldp, na, std::min<int64_t>(ldp, Mp2), Mp2, d_sexp, md,
-                                                                                                           d_planes, rows_pad);
-        OAK_HIP_CHECK(hipGetLastError());
-        t.stop();
-    }
     {
         PhaseTimer t(ctx, "crt_syrk");
-        const int nt2 = (int)(Mp2 / CT2), ntile2 = nt2 * (nt2 + 1) / 2;
+        const int nt2 = (int)(pl.Mp2 / CT2), ntile2 = nt2 * (nt2 + 1) / 2;
         const size_t lds = sizeof(crt_v4i) * 2 * 2 * (CST / 16) * CT2;
         OAK_CHECK(ensure_max_dynamic_lds((const void*)crt_syrk_i8_kernel));
-        crt_syrk_i8_kernel<<<dim3((unsigned)(ntile2 * nsplit), (unsigned)md.L), 512, lds, ctx->stream>>>(d_planes, rows_pad, (int)Mp2, nt2, rps, nsplit, d_part);
+        crt_syrk_i8_kernel<<<dim3((unsigned)(ntile2 * pl.nsplit), (unsigned)md.L), 512, lds, ctx->stream>>>(pl.d_planes, pl.rows_pad, (int)pl.Mp2, nt2, pl.rps, pl.nsplit,
+                                                                                                             pl.d_part);
         OAK_HIP_CHECK(hipGetLastError());
         t.stop();
     }
     {
         PhaseTimer t(ctx, "crt_reduce");
-        crt_reduce_kernel<<<dim3((unsigned)((M + 255) / 256), (unsigned)M), 256, 0, ctx->stream>>>(d_part, nsplit, M, Mp2, gr, d_res, first_chunk ? 1 : 0,
-                                                                                                   last_chunk ? 1 : 0, d_sexp, d_phi);
+        crt_reduce_kernel<<<dim3((unsigned)((M + 255) / 256), (unsigned)M), 256, 0, ctx->stream>>>(pl.d_part, pl.nsplit, M, pl.Mp2, gr, pl.d_res, first_chunk ? 1 : 0,
+                                                                                                   last_chunk ? 1 : 0, pl.d_sexp, d_phi);
         OAK_HIP_CHECK(hipGetLastError());
         t.stop();
     }

@@ -454,6 +454,284 @@ int gram(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int6
 }
 
 // ---------------------------------------------------------------------------------------------
+// Gram kernel with the int8 CRT epilogue (crt.hip, oak_sgpr_set_precision 2): the same pair arithmetic, and every finished entry
+// K[n, m] leaves the kernel as its L residues  rint(K 2^s_m) mod p_i  (one signed byte each) in the plane layout
+// [plane][n / 16][m][n % 16] the int8 SYRK reads -- the fp64 panel is written only when a gradient or a further output needs it
+// (PANEL).  Geometry: a WAVE owns all 16 rows of a row step for 16 CPT columns (lane = (tr, tc): rows 4 tr .. 4 tr + 3, columns
+// tc + 16 c), so that the four rows of a lane are one dword of a 16-byte plane unit and the four tr lanes of a column fill it.
+// Conversion per entry and modulus, all on the DP pipe with exact results: xm = K 2^s + 1.5 2^52 (the integer x in the low mantissa
+// bits), q = rint(x / p) by the same magic constant, xm - q p = r + 1.5 2^52: the low byte of the low word is r in two's complement.
+// ---------------------------------------------------------------------------------------------
+template <int R, int CPT, bool ALLRBF, int TB, bool PANEL>
+__global__ void __launch_bounds__(256, 2)
+gram_crt_kernel(const DevDesc dd, const double* __restrict__ tables, const double* __restrict__ Axs, const double* __restrict__ Acn,
+                int64_t a_ld, int64_t a0, int64_t na, const double* __restrict__ Bxs, const double* __restrict__ Bcn, int64_t b_ld,
+                int64_t nb, double* __restrict__ out, int64_t ldo, int rows_per_wg, const double* __restrict__ yA,
+                double* __restrict__ psi_part, int64_t zero_pad_to, const CrtMod md, const int* __restrict__ sexp,
+                int8_t* __restrict__ planes, int64_t plane_stride, int64_t Mp2, int tablen) {
+    constexpr int RT = 4, RS = 16, WC = 16 * CPT, TJ = 4 * WC;
+    constexpr double M52 = 6755399441055744.0;      // 1.5 * 2^52
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int D = dd.D;
+    constexpr int TABN = 1 << TB;
+    double* Tab = smem;
+    double* Bx = Tab + TABN;           // [D][TJ], columns permuted so that a lane's CPT columns are 16-byte pairs (see pos below)
+    double* Bc = Bx + D * TJ;
+    double* Ax = Bc + D * TJ;          // [D][RS]
+    double* Ac = Ax + D * RS;
+    double* Ay = Ac + D * RS;          // [RS]
+    double* Tl = Ay + RS;              // [tablen]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tr = lane >> 4, tc = lane & 15;
+    const int64_t jb = (int64_t)blockIdx.x * TJ;
+    const int64_t ib = (int64_t)blockIdx.y * rows_per_wg;
+    const int64_t iend = (ib + rows_per_wg < na) ? ib + rows_per_wg : na;
+
+    for (int idx = tid; idx < D * TJ; idx += 256) {
+        const int d = idx / TJ, j = idx - d * TJ;
+        const int ww = j / WC, jj = j - ww * WC, c = jj >> 4, t = jj & 15;
+        const int pos = ww * WC + (c >> 1) * 32 + t * 2 + (c & 1);
+        const int64_t gj = jb + j;
+        const bool ok = gj < nb;
+        const double pre = (ALLRBF || dd.type[d] == OAK_DIM_RBF) ? 0.03125 : 1.0;
+        Bx[d * TJ + pos] = ok ? Bxs[(int64_t)d * b_ld + gj] * pre : 0.0;
+        Bc[d * TJ + pos] = ok ? Bcn[(int64_t)d * b_ld + gj] : 0.0;
+    }
+    for (int j = tid; j < TABN; j += 256) Tab[j] = biased_table_entry<TB>(j);
+    if constexpr (!ALLRBF) {
+        for (int j = tid; j < tablen; j += 256) Tl[j] = tables[j];
+    }
+    double psi[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) psi[c] = 0.0;
+    const int colbase = (int)jb + w * WC + tc;             // this lane's columns: colbase + 16 c  (the planes and sexp have Mp2 >= gridDim.x * TJ columns)
+    const int nbi = (int)nb;
+
+    constexpr int NS = (CPT == 4) ? 1 : RS / 4;
+    double rx[NS], rc[NS], ry = 0.0;
+    auto fetch_rows = [&](int64_t i0n) {
+#pragma unroll
+        for (int s4 = 0; s4 < NS; ++s4) {
+            const int idx = tid + 256 * s4;
+            const int d = idx / RS, r = idx - d * RS;
+            int64_t gi = i0n + r;
+            gi = gi < iend ? gi : iend - 1;
+            const bool in = idx < D * RS;
+            rx[s4] = in ? Axs[(int64_t)d * a_ld + a0 + gi] : 0.0;
+            rc[s4] = in ? Acn[(int64_t)d * a_ld + a0 + gi] : 0.0;
+        }
+        if (yA != nullptr && tid < RS) { const int64_t gi = i0n + tid; ry = yA[a0 + (gi < iend ? gi : iend - 1)]; }
+    };
+    if (ib < iend) fetch_rows(ib);
+    for (int64_t i0 = ib; i0 < iend; i0 += RS) {
+        __syncthreads();
+#pragma unroll
+        for (int s4 = 0; s4 < NS; ++s4) {
+            const int idx = tid + 256 * s4;
+            if (idx < D * RS) {
+                const int d = idx / RS, r = idx - d * RS;
+                const bool ok = i0 + r < iend;
+                const double pre = (ALLRBF || dd.type[d] == OAK_DIM_RBF) ? 0.03125 : 1.0;
+                Ax[idx] = ok ? rx[s4] * pre : 0.0;
+                Ac[idx] = ok ? rc[s4] : 0.0;
+            }
+        }
+        if (yA != nullptr && tid < RS) Ay[tid] = (i0 + tid < iend) ? ry : 0.0;
+        __syncthreads();
+        if (i0 + RS < iend) fetch_rows(i0 + RS);
+
+        double e[RT][CPT][R > 0 ? R : 1];
+#pragma unroll
+        for (int r = 0; r < RT; ++r)
+#pragma unroll
+            for (int c = 0; c < CPT; ++c)
+#pragma unroll
+                for (int q = 0; q < (R > 0 ? R : 1); ++q) e[r][c][q] = 0.0;
+        if constexpr (R > 0) {
+            for (int d = 0; d < D; ++d) {
+                double xb[CPT], cb[CPT], xa[RT], ca[RT];
+#pragma unroll
+                for (int c2 = 0; c2 < CPT / 2; ++c2) {
+                    const double2 vx = *reinterpret_cast<const double2*>(&Bx[d * TJ + w * WC + c2 * 32 + 2 * tc]);
+                    const double2 vc = *reinterpret_cast<const double2*>(&Bc[d * TJ + w * WC + c2 * 32 + 2 * tc]);
+                    xb[2 * c2] = vx.x; xb[2 * c2 + 1] = vx.y;
+                    cb[2 * c2] = vc.x; cb[2 * c2 + 1] = vc.y;
+                }
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    xa[r] = Ax[d * RS + tr * RT + r];
+                    ca[r] = Ac[d * RS + tr * RT + r];
+                }
+                double kk[RT][CPT];
+                if (ALLRBF || dd.type[d] == OAK_DIM_RBF) {
+                    const double woff = dd.woff[d], magic = (dd.magic[d] - EW_MAGIC) + ew_magic<TB>();
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) {
+                        double wv[CPT], E[CPT], mg[CPT];
+#pragma unroll
+                        for (int c = 0; c < CPT; ++c) {
+                            const double u = xa[r] - xb[c];
+                            wv[c] = fma_clamp01(u, u, woff);
+                            mg[c] = magic;
+                        }
+                        exp2_w_vec<CPT, TB>(wv, mg, E, Tab);
+#pragma unroll
+                        for (int c = 0; c < CPT; ++c) kk[r][c] = __builtin_fma(-ca[r], cb[c], E[c]);
+                    }
+                } else if (dd.type[d] == OAK_DIM_BINARY) {
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+#pragma unroll
+                        for (int c = 0; c < CPT; ++c) kk[r][c] = ca[r] * cb[c];
+                } else {
+                    const int C = dd.ncat[d];
+                    int ia[RT], ibb[CPT];
+#pragma unroll
+                    for (int r = 0; r < RT; ++r) ia[r] = dd.tab_off[d] + (int)xa[r] * C;
+#pragma unroll
+                    for (int c = 0; c < CPT; ++c) ibb[c] = (int)xb[c];
+#pragma unroll
+                    for (int r = 0; r < RT; ++r)
+#pragma unroll
+                        for (int c = 0; c < CPT; ++c) kk[r][c] = tablen > 0 ? Tl[ia[r] + ibb[c]] : tables[ia[r] + ibb[c]];
+                }
+#pragma unroll
+                for (int r = 0; r < RT; ++r)
+#pragma unroll
+                    for (int c = 0; c < CPT; ++c) esp_update<R>(e[r][c], kk[r][c]);
+            }
+        }
+        // epilogue: combine orders, psi, optional fp64 panel, scaled integers
+        double xm[RT][CPT], xi[RT][CPT];
+#pragma unroll
+        for (int r = 0; r < RT; ++r) {
+            const int64_t gi = i0 + tr * RT + r;
+            const double yv = (yA != nullptr) ? Ay[tr * RT + r] : 0.0;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                const double kv = esp_combine<R>(e[r][c], dd);
+                if (yA != nullptr) psi[c] = __builtin_fma(kv, yv, psi[c]);
+                const int cc = colbase + 16 * c;
+                const bool live = gi < iend && cc < nbi;
+                if constexpr (PANEL) {
+                    if (gi < iend) {
+                        if (cc < nbi) out[gi * ldo + cc] = kv;
+                        else if (cc < zero_pad_to) out[gi * ldo + cc] = 0.0;
+                    }
+                }
+                const double sc = __builtin_ldexp(1.0, sexp[cc]);      // (an L1 hit per step: cheaper than four live doubles in the pair loop)
+                xm[r][c] = live ? __builtin_fma(kv, sc, M52) : M52;
+                xi[r][c] = xm[r][c] - M52;
+            }
+        }
+        const int64_t unit = ((i0 >> 4) * Mp2) * 16 + tr * 4;          // byte offset of this lane's dword inside a plane, column 0
+        for (int i = 0; i < md.L; ++i) {
+            const double p = (double)md.p[i], ip = md.inv[i];
+            int8_t* pl = planes + (int64_t)i * plane_stride + unit;
+#pragma unroll
+            for (int c = 0; c < CPT; ++c) {
+                unsigned b[RT];
+#pragma unroll
+                for (int r = 0; r < RT; ++r) {
+                    const double q = __builtin_fma(xi[r][c], ip, M52) - M52;
+                    b[r] = (unsigned)__double2loint(__builtin_fma(q, -p, xm[r][c]));
+                }
+                const unsigned w01 = __builtin_amdgcn_perm(b[1], b[0], 0x0c0c0400u);      // bytes: b0.0, b1.0, 0, 0
+                const unsigned w23 = __builtin_amdgcn_perm(b[3], b[2], 0x04000c0cu);      // bytes: 0, 0, b2.0, b3.0
+                *reinterpret_cast<unsigned*>(pl + (colbase + 16 * c) * 16) = w01 | w23;
+            }
+        }
+    }
+    if (yA != nullptr) {
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+            double v = psi[c];
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            if (tr == 0 && colbase + 16 * c < nbi) psi_part[(int64_t)blockIdx.y * nb + colbase + 16 * c] = v;
+        }
+    }
+}
+
+// row groups [g_lo, g_hi) of every plane <- 0 (the rows between the end of the data and the end of the last row split)
+__global__ void __launch_bounds__(256) crt_zero_groups_kernel(int8_t* __restrict__ planes, int64_t plane_stride, int64_t Mp2, int64_t g_lo, int64_t g_hi) {
+    const int64_t n16 = (g_hi - g_lo) * Mp2;            // 16-byte units per plane
+    uint4* base = reinterpret_cast<uint4*>(planes + (int64_t)blockIdx.y * plane_stride + g_lo * Mp2 * 16);
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < n16; u += (int64_t)gridDim.x * 256) base[u] = make_uint4(0, 0, 0, 0);
+}
+
+bool gram_crt_supported(const PreparedKernel& pk) { return !pk.deep && !pk.grouped && pk.dd.R <= 4 && pk.dd.D <= 64; }
+
+template <int R, int CPT>
+static int launch_gram_crt_t(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int64_t na, const Feat& B, double* d_out, int64_t ldo,
+                             const double* d_yA, double* d_psi, int64_t zero_pad_to, const CrtMod& md, const int* d_sexp, int8_t* d_planes,
+                             int64_t plane_stride, int64_t Mp2) {
+    constexpr int TJ = 64 * CPT, RS = 16;
+    const int D = pk.dd.D;
+    OAK_REQUIRE(D * RS <= 256 * ((CPT == 4) ? 1 : RS / 4), "gram (CRT): %d sub-kernels do not fit this tile shape's row staging", D);
+    OAK_REQUIRE(Mp2 % TJ == 0, "gram (CRT): the plane width %lld is not a multiple of the column tile", (long long)Mp2);
+    bool all_rbf = true;
+    for (int d = 0; d < D; ++d) all_rbf = all_rbf && pk.dd.type[d] == OAK_DIM_RBF;
+    const int tablen = (!all_rbf && pk.tables.size() <= 1024) ? (int)pk.tables.size() : 0;
+    const size_t lds_body = sizeof(double) * ((size_t)D * TJ * 2 + (size_t)D * RS * 2 + RS + (size_t)tablen);
+    const size_t cu_lds = 160 * 1024;
+    const bool big_table = cu_lds / (lds_body + sizeof(double) * 1024) == cu_lds / (lds_body + sizeof(double) * 512);
+    const size_t lds = lds_body + sizeof(double) * (big_table ? 1024 : 512);
+    if (lds > 160 * 1024) { set_error("gram (CRT): LDS request %zu exceeds 160 KiB (D=%d)", lds, D); return OAK_E_ARG; }
+    const int64_t nb = B.n;
+    const int64_t ncb = Mp2 / TJ;                       // every plane column is written (zeros beyond nb)
+    int64_t target_wg = (int64_t)ctx->num_cu * (na >= (1 << 19) ? 24 : 16);
+    if (const char* e = getenv("OAK_GRAM_WG_PER_CU")) { int v = atoi(e); if (v >= 1 && v <= 64) target_wg = (int64_t)ctx->num_cu * v; }
+    int64_t nrb = (target_wg + ncb - 1) / ncb;
+    if (nrb < 1) nrb = 1;
+    int64_t rows = (na + nrb - 1) / nrb;
+    rows = ((rows + RS - 1) / RS) * RS;
+    if (rows < RS) rows = RS;
+    if (rows > 4096) rows = 4096;
+    nrb = (na + rows - 1) / rows;
+    if (nrb > 65535) { rows = ((na + 65534) / 65535 + RS - 1) / RS * RS; nrb = (na + rows - 1) / rows; }
+    double* d_part = nullptr;
+    if (d_yA != nullptr) OAK_CHECK(get_buf_t(ctx, "psi_part", (size_t)(nrb * nb), &d_part));
+    const bool panel = d_out != nullptr;
+#define OAK_GC(AR, TBV, PN) gram_crt_kernel<R, CPT, AR, TBV, PN>
+    auto kern = big_table ? (all_rbf ? (panel ? OAK_GC(true, 10, true) : OAK_GC(true, 10, false)) : (panel ? OAK_GC(false, 10, true) : OAK_GC(false, 10, false)))
+                          : (all_rbf ? (panel ? OAK_GC(true, 9, true) : OAK_GC(true, 9, false)) : (panel ? OAK_GC(false, 9, true) : OAK_GC(false, 9, false)));
+#undef OAK_GC
+    if (lds > 64 * 1024) OAK_CHECK(ensure_max_dynamic_lds((const void*)kern));
+    dim3 grid((unsigned)ncb, (unsigned)nrb);
+    kern<<<grid, 256, lds, ctx->stream>>>(pk.dd, pk.d_tables, A.xs, A.cn, A.ld, a0, na, B.xs, B.cn, B.ld, nb, d_out, ldo, (int)rows, d_yA, d_part,
+                                          zero_pad_to, md, d_sexp, d_planes, plane_stride, Mp2, tablen);
+    OAK_HIP_CHECK(hipGetLastError());
+    if (d_yA != nullptr) {
+        colsum_accum_kernel<<<(unsigned)((nb + 31) / 32), 256, 0, ctx->stream>>>(d_part, nrb, nb, d_psi);
+        OAK_HIP_CHECK(hipGetLastError());
+    }
+    return OAK_OK;
+}
+
+// Gram panel chunk + its residue planes (rows [0, rows_pad) of the chunk: zeros beyond na).  d_out == NULL: no fp64 panel.
+int gram_crt(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int64_t na, const Feat& B, double* d_out, int64_t ldo,
+             const double* d_yA, double* d_psi, int64_t zero_pad_to, const CrtMod& md, const int* d_sexp, int8_t* d_planes, int64_t rows_pad,
+             int64_t Mp2) {
+    OAK_REQUIRE(gram_crt_supported(pk), "gram (CRT): kernel description outside the fused residue kernel's shapes");
+    if (na <= 0 || B.n <= 0) return OAK_OK;
+    const int64_t plane_stride = rows_pad * Mp2;
+    const int64_t g_lo = (na + 15) / 16, g_hi = rows_pad / 16;
+    if (g_hi > g_lo) {
+        crt_zero_groups_kernel<<<dim3(64, (unsigned)md.L), 256, 0, ctx->stream>>>(d_planes, plane_stride, Mp2, g_lo, g_hi);
+        OAK_HIP_CHECK(hipGetLastError());
+    }
+    const bool wide = pk.dd.D <= 16;
+#define OAK_GCL(RR) case RR: return wide ? launch_gram_crt_t<RR, 4>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to, md, d_sexp, d_planes, plane_stride, Mp2) \
+                                         : launch_gram_crt_t<RR, 2>(ctx, pk, A, a0, na, B, d_out, ldo, d_yA, d_psi, zero_pad_to, md, d_sexp, d_planes, plane_stride, Mp2);
+    switch (pk.dd.R) { OAK_GCL(0) OAK_GCL(1) OAK_GCL(2) OAK_GCL(3) OAK_GCL(4) }
+#undef OAK_GCL
+    set_error("gram (CRT): unsupported depth %d", pk.dd.R);
+    return OAK_E_ARG;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Generic Gram: one thread per entry, runtime depth (<= OAK_MAX_DIMS), two arithmetic forms (oak_internal.h: gram_generic).
 // FORM 1 follows oracle/oak_oracle.py -- i.e. the reference -- operation by operation: u = x / l (IEEE division, as NumPy),
 // r2 = ((-2 u_x) u_z + u_x^2) + u_z^2, k = variance * exp(-r2 / 2) - c(x) c(z) / var_s, s_p = sum_d k^p by repeated products,

@@ -259,10 +259,22 @@ int gram_f32(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
              const double* d_yA, double* d_psi, int64_t zero_pad_to);
 int syrk_panel_f32(oak_ctx* ctx, const float* d_panel, int64_t ldp, int64_t nrows, int64_t M, double* d_part, int nsplit, bool accumulate);
 int syrk_reduce(oak_ctx* ctx, const double* d_part, int nsplit, int64_t M, double* d_phi /*[M*M]*/, bool accumulate);
-// exact int8 / CRT accumulation of Phi (crt.hip): one panel chunk; Phi (full, symmetric) is written on the last chunk
+// exact int8 / CRT accumulation of Phi (crt.hip; the fused Gram epilogue is gram.hip::gram_crt_kernel)
+constexpr int CRT_MAXL = 20;
+struct CrtMod { int L; int p[CRT_MAXL]; double inv[CRT_MAXL]; };
+struct CrtPlan {
+    CrtMod md; int B = 48, nsplit = 0; int64_t Mp2 = 0, rows_pad = 0, rps = 0;
+    int* d_sexp = nullptr; int8_t* d_planes = nullptr; int* d_part = nullptr; int* d_res = nullptr;
+};
 bool crt_supported(const oak_ctx* ctx, int64_t M);
-int crt_phi_from_panel(oak_ctx* ctx, const PreparedKernel& pk, const Feat& FZ, const double* d_panel, int64_t ldp, int64_t na, int64_t M,
-                       int64_t n_total, bool first_chunk, bool last_chunk, double* d_phi);
+int crt_plan(oak_ctx* ctx, int64_t na, int64_t M, int64_t n_total, CrtPlan* pl);
+int crt_scales(oak_ctx* ctx, const PreparedKernel& pk, const Feat& FZ, int64_t M, const CrtPlan& pl);
+int crt_convert_panel(oak_ctx* ctx, const CrtPlan& pl, const double* d_panel, int64_t ldp, int64_t na);
+int crt_accumulate(oak_ctx* ctx, const CrtPlan& pl, int64_t M, bool first_chunk, bool last_chunk, double* d_phi);
+bool gram_crt_supported(const PreparedKernel& pk);
+int gram_crt(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int64_t na, const Feat& B, double* d_out, int64_t ldo,
+             const double* d_yA, double* d_psi, int64_t zero_pad_to, const CrtMod& md, const int* d_sexp, int8_t* d_planes, int64_t rows_pad,
+             int64_t Mp2);
 // in place; strict upper zeroed.  nrows > n carries nrows - n extra rows through the panel solves and trailing updates
 // (row r >= n ends up as  A[r, :n] L^-T,  i.e. the solution of L x = A[r, :n]^T: a right-hand side rides for free).
 int potrf_lower(oak_ctx* ctx, double* dA, int64_t n, int64_t lda, bool check = true, int64_t nrows = -1, bool identity_below = false);

@@ -293,12 +293,26 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
         l_joined = true;
     }
     int chunk_idx = 0;
+    // exact int8 / CRT accumulation of Phi (oak_sgpr_set_precision 2, crt.hip): phi route only -- a whitened panel has no a-priori
+    // bound to scale by.  Route known before the Gram launch: the residue planes come out of the Gram kernel's epilogue (and the fp64
+    // panel is written only when a gradient or a further output column reads it); route still pending (auto, large problem) or a
+    // kernel shape the fused epilogue is not instantiated for: the fp64 panel is converted by a pass of its own once the route is settled.
+    const bool crt_wanted = ctx->precision == 2 && !use32 && crt_supported(ctx, M);
+    const bool crt_fused = crt_wanted && !lazy && !whiten && gram_crt_supported(pk) && getenv("OAK_CRT_UNFUSED") == nullptr;
+    const bool crt_panel = ctx->keep_kfu || ctx->n_extra > 0;      // fused pass: somebody reads the fp64 panel afterwards
     bool use_crt = false;
+    CrtPlan cp;
     for (int64_t a0 = 0; a0 < N; a0 += rows, ++chunk_idx) {
         const int64_t na = (a0 + rows <= N) ? rows : N - a0;
+        if (crt_fused) {
+            OAK_CHECK(crt_plan(ctx, na, M, N, &cp));
+            if (chunk_idx == 0) OAK_CHECK(crt_scales(ctx, pk, FZ, M, cp));
+        }
         {
             PhaseTimer t(ctx, "gram");
             if (use32) OAK_CHECK(gram_f32(ctx, pk, FX, a0, na, FZ, dPanel32, Mp, dY, st.psi, Mp));
+            else if (crt_fused) OAK_CHECK(gram_crt(ctx, pk, FX, a0, na, FZ, crt_panel ? dPanel : nullptr, Mp, dY, st.psi, Mp, cp.md, cp.d_sexp, cp.d_planes,
+                                                   cp.rows_pad, cp.Mp2));
             else OAK_CHECK(gram(ctx, pk, FX, a0, na, FZ, dPanel, Mp, dY, st.psi, Mp));
             t.stop();
         }
@@ -360,10 +374,14 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
             }
             t.stop();
         }
-        // exact int8 / CRT accumulation of Phi (crt.hip): phi route only -- a whitened panel has no a-priori bound to scale by
-        use_crt = ctx->precision == 2 && !whiten && !use32 && crt_supported(ctx, M);
+        use_crt = crt_wanted && !whiten;
         if (use_crt) {
-            OAK_CHECK(crt_phi_from_panel(ctx, pk, FZ, dSy, Mp, na, M, N, chunk_idx == 0, a0 + rows >= N, st.phi));
+            if (!crt_fused) {
+                OAK_CHECK(crt_plan(ctx, na, M, N, &cp));
+                if (chunk_idx == 0) OAK_CHECK(crt_scales(ctx, pk, FZ, M, cp));
+                OAK_CHECK(crt_convert_panel(ctx, cp, dSy, Mp, na));
+            }
+            OAK_CHECK(crt_accumulate(ctx, cp, M, chunk_idx == 0, a0 + rows >= N, st.phi));
         } else {
             PhaseTimer t(ctx, "syrk");
             if (use32) OAK_CHECK(syrk_panel_f32(ctx, dPanel32, Mp, na, M, dPart, nsplit, chunk_idx > 0));

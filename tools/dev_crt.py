@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--oracle", action="store_true")
 ap.add_argument("--configs", default="c2,headline,c3,c5")
 ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--check-fused", action="store_true", help="the fused Gram epilogue against the stand-alone conversion pass: Phi must be bit-identical")
 args = ap.parse_args()
 ctx = _capi.default_context()
 TERMS = ("sum_log_diag_LB", "cTc", "tr_AAT", "kappa", "logdet_Kuu")
@@ -42,6 +43,19 @@ for name in args.configs.split(","):
             except Exception:
                 pass
         out[mode] = dict(e=e, terms=ctx.sgpr_last_terms(), dt=dt, used=ctx.sgpr_stats_precision(), stats=ctx.sgpr_get_stats(), phases=ph)
+    if args.check_fused:
+        import os
+        ctx.sgpr_set_precision("int8crt")
+        os.environ["OAK_CRT_UNFUSED"] = "1"
+        eu = ctx.sgpr_elbo(d, 0.01); su = ctx.sgpr_get_stats()
+        del os.environ["OAK_CRT_UNFUSED"]
+        ef = ctx.sgpr_elbo(d, 0.01); sf = ctx.sgpr_get_stats()
+        print(f"   fused vs stand-alone conversion: Phi identical={np.array_equal(su[:M * M], sf[:M * M])} (max |d| {np.abs(su[:M * M] - sf[:M * M]).max():.3e}), "
+              f"psi max rel d {np.abs(su[M * M:M * M + M] - sf[M * M:M * M + M]).max() / np.abs(su[M * M:M * M + M]).max():.2e}, ELBO {eu!r} {ef!r}", flush=True)
+        eg, g = ctx.sgpr_elbo_grad(d, 0.01)           # fused pass that also writes the fp64 panel for the backward
+        ctx.sgpr_set_precision("fp64")
+        eg64, g64 = ctx.sgpr_elbo_grad(d, 0.01)
+        print(f"   gradient call: ELBO rel d {abs(eg - eg64) / abs(eg64):.2e}, grad max rel d {np.abs(g - g64).max() / np.abs(g64).max():.2e}", flush=True)
     ctx.sgpr_set_precision("fp64")
     a, b = out["fp64"], out["int8crt"]
     P64, Pc = a["stats"][:M * M].reshape(M, M), b["stats"][:M * M].reshape(M, M)
