@@ -25,12 +25,6 @@ typedef int crt_v16i __attribute__((ext_vector_type(16)));
 // pairwise coprime, largest first; <= 254 so that a residue formed with one sloppy fp32 rounding of the quotient (fused epilogue of
 // the Gram kernel) still fits a signed byte
 static const int kCrtModuli[CRT_MAXL] = {254, 253, 251, 249, 247, 245, 241, 239, 233, 229, 227, 223, 211, 199, 197, 193, 191, 181, 179, 173};
-struct CrtGarner {
-    int L, ngroups;
-    int p[CRT_MAXL];
-    short inv[CRT_MAXL][CRT_MAXL];      // inv[j][i] = p_j^-1 mod p_i  (j < i)
-    double pg[CRT_MAXL / 5];            // product of the moduli of digit group k (five digits per group: < 2^40, exact)
-};
 
 static int modinv(int a, int p) {
     a %= p; if (a < 0) a += p;
@@ -167,49 +161,181 @@ __global__ void __launch_bounds__(512, 1) crt_syrk_i8_kernel(const int8_t* __res
             }
 }
 
+// ---- 3 (default). the same tile and wave layout with the operands brought global -> LDS by the DMA path (global_load_lds_dwordx4:
+// no staging registers, no ds_write pass, one instruction per KiB): at the top of a stage every wave issues its eight 1 KiB pieces of
+// the NEXT stage (wave w: row group w of both sides) into the other buffer, computes the stage's four k-steps, and the stage ends with
+// s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier (trsm_fused.hip: counted waits are wrong for LDS-DMA, which does not retire in order).
+__global__ void __launch_bounds__(512, 1) crt_syrk_i8_dma_kernel(const int8_t* __restrict__ planes, int64_t rows_pad, int Mp2, int nt2, int64_t rows_per_split,
+                                                                 int nsplit, int* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) crt_v4i crt_lds[];      // [2 buffers][2 sides][CST / 16 groups][CT2 cols]
+    const int ntile = nt2 * (nt2 + 1) / 2;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int split = xcd + 8 * (jx / ntile);
+    int bi = 0, rem = jx % ntile;
+    while (rem >= nt2 - bi) { rem -= nt2 - bi; ++bi; }
+    const int bj = bi + rem;
+    const int8_t* plane = planes + (int64_t)blockIdx.y * rows_pad * Mp2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int h = lane >> 5, c = lane & 31;
+    const int64_t g0 = (int64_t)split * rows_per_split / 16, g1 = g0 + rows_per_split / 16;
+    const crt_v4i* P = reinterpret_cast<const crt_v4i*>(plane);
+    constexpr int SG = CST / 16, SIDE = SG * CT2;
+    crt_v16i acc[4][2];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0;
+    // stage starting at group g -> buffer b: this wave brings row group g + wave (clamped: the copies past the end are never read)
+    auto fill = [&](int64_t g, int b) {
+        const int64_t gq = (g + wave < g1) ? g + wave : g1 - 1;
+        const crt_v4i* sa = P + gq * Mp2 + bi * CT2 + lane;
+        const crt_v4i* sb = P + gq * Mp2 + bj * CT2 + lane;
+        crt_v4i* da = crt_lds + (b * 2 + 0) * SIDE + wave * CT2;
+        crt_v4i* db = crt_lds + (b * 2 + 1) * SIDE + wave * CT2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sa + 64 * j), (__attribute__((address_space(3))) void*)(da + 64 * j), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + 64 * j), (__attribute__((address_space(3))) void*)(db + 64 * j), 16, 0, 0);
+        }
+    };
+    fill(g0, 0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int buf = 0;
+    for (int64_t g = g0; g < g1; g += SG) {
+        fill(g + SG, buf ^ 1);
+        const crt_v4i* A = crt_lds + (buf * 2 + 0) * SIDE + wr * 128 + c;
+        const crt_v4i* Bf = crt_lds + (buf * 2 + 1) * SIDE + wc * 64 + c;
+        crt_v4i fa[2][4], fb[2][2];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) fa[0][x] = A[h * CT2 + 32 * x];
+#pragma unroll
+        for (int y = 0; y < 2; ++y) fb[0][y] = Bf[h * CT2 + 32 * y];
+#pragma unroll
+        for (int kk = 0; kk < SG / 2; ++kk) {
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < SG / 2) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) fa[nxt][x] = A[(2 * (kk + 1) + h) * CT2 + 32 * x];
+#pragma unroll
+                for (int y = 0; y < 2; ++y) fb[nxt][y] = Bf[(2 * (kk + 1) + h) * CT2 + 32 * y];
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[cur][x], fb[cur][y], acc[x][y], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        buf ^= 1;
+    }
+    int* dst = part + ((int64_t)blockIdx.y * nsplit + split) * Mp2 * Mp2;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = bi * CT2 + wr * 128 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int col = bj * CT2 + wc * 64 + 32 * y + c;
+                dst[(int64_t)row * Mp2 + col] = acc[x][y][r];
+            }
+}
+
 // ---- 3b + 4. split sums mod p_i, then (last chunk) Garner digits and Phi ---------------------------------------------------------------
-// thread = entry (a, b), a <= b < M.  res[i][a * Mp2 + b] carries the residues between the chunks of a panel that does not fit one pass.
-// The mixed-radix digits v_i (symmetric) give X = v_0 + v_1 p_0 + v_2 p_0 p_1 + ...: Horner in exact int64 inside groups of five digits
-// (< 2^40), the two or three groups joined by fp64 FMAs (one rounding each).
-__global__ void __launch_bounds__(256) crt_reduce_kernel(const int* __restrict__ part, int nsplit, int64_t M, int64_t Mp2, CrtGarner gr,
+// thread = four consecutive entries (a, b .. b + 3) of the upper triangle (16-byte loads of the int32 partials, eight splits in flight).
+// res[i][a * Mp2 + b] carries the residues between the chunks of a panel that does not fit one pass.  The mixed-radix digits v_i give
+// X = v_0 + v_1 p_0 + v_2 p_0 p_1 + ...: Horner in exact int64 inside groups of five digits (< 2^40), the two or three groups joined
+// by fp64 FMAs (one rounding each).  All modular steps in floating point, exact: x - p rint(x / p) with |x| < 2^24 (fp32) or 2^53
+// (fp64); a quotient off by one near a tie leaves a digit of magnitude <= p / 2 + 1, which the congruences and the head room of
+// prod p_i (> 2 bits) do not mind.  LT = number of moduli (compile time: the digit arrays stay in registers).
+struct CrtGarnerF {
+    int L, ngroups;
+    float p[CRT_MAXL], ip[CRT_MAXL];
+    float inv[CRT_MAXL][CRT_MAXL];      // inv[j][i] = p_j^-1 mod p_i  (j < i), symmetric representative
+    double pg[CRT_MAXL / 5];            // product of the moduli of digit group k (five digits per group: < 2^40, exact)
+};
+template <int LT>
+__global__ void __launch_bounds__(256) crt_reduce_kernel(const int* __restrict__ part, int nsplit, int64_t M, int64_t Mp2, const CrtGarnerF gr,
                                                          int* __restrict__ res, int first, int last, const int* __restrict__ sexp,
                                                          double* __restrict__ phi) {
-    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x, a = blockIdx.y;
-    if (b >= M || a > b) return;
-    const int64_t e = a * Mp2 + b, MM = Mp2 * Mp2;
-    int v[CRT_MAXL];
-    for (int i = 0; i < gr.L; ++i) {
-        long long s = first ? 0 : (long long)res[(int64_t)i * MM + e];
+    const int64_t a = blockIdx.y;
+    const int64_t b0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4 + (a & ~(int64_t)3);      // first column group that touches the diagonal
+    if (b0 >= M) return;
+    const int64_t e = a * Mp2 + b0, MM = Mp2 * Mp2;
+    float v[LT][4];
+#pragma unroll
+    for (int i = 0; i < LT; ++i) {
+        long long s[4] = {0, 0, 0, 0};
+        if (!first) {
+            const crt_v4i r0 = *reinterpret_cast<const crt_v4i*>(res + (int64_t)i * MM + e);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s[k] = r0[k];
+        }
         const int* pp = part + (int64_t)i * nsplit * MM + e;
-        for (int sp = 0; sp < nsplit; ++sp) s += pp[(int64_t)sp * MM];
-        const int p = gr.p[i];
-        int r = (int)(s % p);
-        if (r < 0) r += p;
-        if (2 * r >= p) r -= p;
-        v[i] = r;
+        for (int sp = 0; sp < nsplit; sp += 8) {              // nsplit is a multiple of 8
+            crt_v4i t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const crt_v4i*>(pp + (int64_t)(sp + u) * MM);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s[k] += t[u][k];
+        }
+        const double pd = (double)gr.p[i], ipd = 1.0 / pd;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const double sd = (double)s[k];
+            v[i][k] = (float)__builtin_fma(-__builtin_rint(sd * ipd), pd, sd);
+        }
     }
     if (!last) {
-        for (int i = 0; i < gr.L; ++i) res[(int64_t)i * MM + e] = v[i];
+#pragma unroll
+        for (int i = 0; i < LT; ++i) {
+            crt_v4i o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (int)v[i][k];
+            *reinterpret_cast<crt_v4i*>(res + (int64_t)i * MM + e) = o;
+        }
         return;
     }
-    for (int i = 1; i < gr.L; ++i) {                      // Garner: v_i <- ((..((r_i - v_0) / p_0 - v_1) / p_1 ..) mod p_i
-        const int p = gr.p[i];
-        int t = v[i];
-        for (int j = 0; j < i; ++j) t = ((t - v[j]) % p) * (int)gr.inv[j][i] % p;
-        if (t < 0) t += p;
-        if (2 * t >= p) t -= p;
-        v[i] = t;
+#pragma unroll
+    for (int i = 1; i < LT; ++i) {                            // Garner: v_i <- ((..((r_i - v_0) / p_0 - v_1) / p_1 ..) mod p_i
+        const float p = gr.p[i], ip = gr.ip[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j) {
+            const float inv = gr.inv[j][i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float u = (v[i][k] - v[j][k]) * inv;
+                v[i][k] = __builtin_fmaf(-__builtin_rintf(u * ip), p, u);
+            }
+        }
     }
-    double x = 0.0;
-    for (int k = gr.ngroups - 1; k >= 0; --k) {
-        const int lo = 5 * k, hi = (lo + 5 < gr.L) ? lo + 5 : gr.L;
-        long long G = 0;
-        for (int i = hi - 1; i >= lo; --i) G = G * gr.p[i] + v[i];
-        x = __builtin_fma(x, gr.pg[k], (double)G);
+    const int sa = sexp[a];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t b = b0 + k;
+        double x = 0.0;
+#pragma unroll
+        for (int g = (LT + 4) / 5 - 1; g >= 0; --g) {
+            constexpr int dummy = 0; (void)dummy;
+            const int lo = 5 * g, hi = (lo + 5 < LT) ? lo + 5 : LT;
+            long long G = 0;
+#pragma unroll
+            for (int i = hi - 1; i >= lo; --i) G = G * (long long)gr.p[i] + (long long)v[i][k];
+            x = __builtin_fma(x, gr.pg[g], (double)G);
+        }
+        if (b >= a && b < M) {
+            const double out = ldexp(x, -(sa + sexp[b]));
+            phi[a * M + b] = out;
+            phi[b * M + a] = out;
+        }
     }
-    const double out = ldexp(x, -(sexp[a] + sexp[b]));
-    phi[a * M + b] = out;
-    phi[b * M + a] = out;
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------------
@@ -285,25 +411,35 @@ int crt_convert_panel(oak_ctx* ctx, const CrtPlan& pl, const double* d_panel, in
 
 // int8 SYRK of the chunk's planes, split sums joined to the residues carried so far; on the last chunk Phi (full, symmetric)
 int crt_accumulate(oak_ctx* ctx, const CrtPlan& pl, int64_t M, bool first_chunk, bool last_chunk, double* d_phi) {
-    CrtGarner gr;
+    CrtGarnerF gr;
     const CrtMod& md = pl.md;
     gr.L = md.L; gr.ngroups = (md.L + 4) / 5;
-    for (int i = 0; i < md.L; ++i) { gr.p[i] = md.p[i]; for (int j = 0; j < i; ++j) gr.inv[j][i] = (short)modinv(md.p[j], md.p[i]); }
+    for (int i = 0; i < md.L; ++i) {
+        gr.p[i] = (float)md.p[i]; gr.ip[i] = 1.0f / (float)md.p[i];
+        for (int j = 0; j < i; ++j) { int v = modinv(md.p[j], md.p[i]); if (2 * v >= md.p[i]) v -= md.p[i]; gr.inv[j][i] = (float)v; }
+    }
     for (int k = 0; k < gr.ngroups; ++k) { double pgk = 1.0; for (int i = 5 * k; i < std::min(5 * k + 5, md.L); ++i) pgk *= md.p[i]; gr.pg[k] = pgk; }
     {
         PhaseTimer t(ctx, "crt_syrk");
         const int nt2 = (int)(pl.Mp2 / CT2), ntile2 = nt2 * (nt2 + 1) / 2;
         const size_t lds = sizeof(crt_v4i) * 2 * 2 * (CST / 16) * CT2;
-        OAK_CHECK(ensure_max_dynamic_lds((const void*)crt_syrk_i8_kernel));
-        crt_syrk_i8_kernel<<<dim3((unsigned)(ntile2 * pl.nsplit), (unsigned)md.L), 512, lds, ctx->stream>>>(pl.d_planes, pl.rows_pad, (int)pl.Mp2, nt2, pl.rps, pl.nsplit,
-                                                                                                             pl.d_part);
+        static const int variant = getenv("OAK_CRT_SYRK") ? atoi(getenv("OAK_CRT_SYRK")) : 5;      // 4: register-staged operands (A/B knob)
+        auto kern = variant == 4 ? crt_syrk_i8_kernel : crt_syrk_i8_dma_kernel;
+        OAK_CHECK(ensure_max_dynamic_lds((const void*)kern));
+        kern<<<dim3((unsigned)(ntile2 * pl.nsplit), (unsigned)md.L), 512, lds, ctx->stream>>>(pl.d_planes, pl.rows_pad, (int)pl.Mp2, nt2, pl.rps, pl.nsplit, pl.d_part);
         OAK_HIP_CHECK(hipGetLastError());
         t.stop();
     }
     {
         PhaseTimer t(ctx, "crt_reduce");
-        crt_reduce_kernel<<<dim3((unsigned)((M + 255) / 256), (unsigned)M), 256, 0, ctx->stream>>>(pl.d_part, pl.nsplit, M, pl.Mp2, gr, pl.d_res, first_chunk ? 1 : 0,
-                                                                                                   last_chunk ? 1 : 0, pl.d_sexp, d_phi);
+        const dim3 grid((unsigned)((M + 1023) / 1024), (unsigned)M);
+#define OAK_CRT_RED(LL) case LL: crt_reduce_kernel<LL><<<grid, 256, 0, ctx->stream>>>(pl.d_part, pl.nsplit, M, pl.Mp2, gr, pl.d_res, first_chunk ? 1 : 0, \
+                                                                                      last_chunk ? 1 : 0, pl.d_sexp, d_phi); break;
+        switch (md.L) {
+            OAK_CRT_RED(13) OAK_CRT_RED(14) OAK_CRT_RED(15) OAK_CRT_RED(16) OAK_CRT_RED(17) OAK_CRT_RED(18)
+            default: set_error("int8 CRT statistics: %d moduli outside the instantiated range 13..18", md.L); return OAK_E_ARG;
+        }
+#undef OAK_CRT_RED
         OAK_HIP_CHECK(hipGetLastError());
         t.stop();
     }
