@@ -246,6 +246,201 @@ __global__ void __launch_bounds__(512, 1) crt_syrk_i8_dma_kernel(const int8_t* _
             }
 }
 
+// ---- 3 (deep pipeline). PMC of the two kernels above (profiles/r06_pmc_crt_first.json): MFMA pipe 43 % busy, 37 % of the wave time
+// parked in s_waitcnt / s_barrier -- a stage's operands are requested ONE stage (~2000 cycles) before they are needed and a quarter
+// of them come from beyond the L2.  Here: 64-row stages (32 KiB) in NBUF slots, requested NBUF - 1 stages ahead; the stage ends with
+// a COUNTED wait (the loop's only memory operations are LDS-DMA loads, which retire in order among themselves -- the unordered mix
+// of trsm_fused.hip had register loads and stores in the same queue): vmcnt(4 (NBUF - 2)) = everything but the youngest NBUF - 2
+// stages has landed.  Wave w brings row group w & 3 of side w >> 2.  Integer results: any mistake in the hand-written waits shows as
+// a Phi that differs from the register-staged kernel's bit for bit (tests/test_gpu_crt.py).
+// PROBE (timing experiments, wrong results): 1 no fills inside the loop, 2 also no waits / barriers, 3 fills and barriers but no MFMA
+template <int NBUF, int PROBE = 0>
+__global__ void __launch_bounds__(512, 1) crt_syrk_i8_deep_kernel(const int8_t* __restrict__ planes, int64_t rows_pad, int Mp2, int nt2, int64_t rows_per_split,
+                                                                  int nsplit, int* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) crt_v4i crt_lds[];      // [NBUF][2 sides][4 groups][CT2 cols]
+    constexpr int SGR = 4, SIDE = SGR * CT2, SLOT = 2 * SIDE, D = NBUF - 1;
+    const int ntile = nt2 * (nt2 + 1) / 2;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int split = xcd + 8 * (jx / ntile);
+    int bi = 0, rem = jx % ntile;
+    while (rem >= nt2 - bi) { rem -= nt2 - bi; ++bi; }
+    const int bj = bi + rem;
+    const int8_t* plane = planes + (int64_t)blockIdx.y * rows_pad * Mp2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int h = lane >> 5, c = lane & 31;
+    const int64_t g0 = (int64_t)split * rows_per_split / 16, g1 = g0 + rows_per_split / 16;
+    const crt_v4i* P = reinterpret_cast<const crt_v4i*>(plane);
+    crt_v16i acc[4][2];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0;
+    // A diagonal tile (bi == bj) brings ONE side (both operands are the same columns) and issues only the MFMA tiles that touch the
+    // upper triangle: 36 of its 64 per k-step; waves (wr 1, wc 0 / 1) lie below the diagonal and only keep the barriers company.  The
+    // kernel runs against the power limit (1.7 GHz with every MFMA issued, profiles/r06_crt_syrk_clocks.txt): work not done is time.
+    const bool diag = bi == bj;
+    const bool idle = diag && wr == 1 && wc < 2;
+    const int fq = wave & 3, fside = wave >> 2;
+    const int64_t fcol = (fside ? bj : bi) * CT2 + lane;
+    auto fill = [&](int64_t g, int slot) {            // the stage starting at row group g (clamped: copies past the end are never read)
+        if (diag && fside) return;
+        const int64_t gq = (g + fq < g1) ? g + fq : g1 - 1;
+        const crt_v4i* src = P + gq * Mp2 + fcol;
+        crt_v4i* dst = crt_lds + slot * SLOT + fside * SIDE + fq * CT2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64 * j), (__attribute__((address_space(3))) void*)(dst + 64 * j), 16, 0, 0);
+    };
+#pragma unroll
+    for (int d = 0; d < D; ++d) fill(g0 + SGR * d, d);
+    if constexpr (NBUF == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    int slot = 0, fslot = D;
+    for (int64_t g = g0; g < g1; g += SGR) {
+        if (PROBE != 1 && PROBE != 2) fill(g + SGR * D, fslot);                      // into the slot whose readers all passed the barrier that ended the previous stage
+        const crt_v4i* A = crt_lds + slot * SLOT + wr * 128 + c;
+        const crt_v4i* Bf = crt_lds + slot * SLOT + (diag ? 0 : SIDE) + wc * 64 + c;
+        crt_v4i fa[2][4], fb[2][2];
+        if (!idle) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) fa[kk][x] = A[(2 * kk + h) * CT2 + 32 * x];
+#pragma unroll
+            for (int y = 0; y < 2; ++y) fb[kk][y] = Bf[(2 * kk + h) * CT2 + 32 * y];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) {
+                    if (diag && 2 * wc + y < 4 * wr + x) continue;             // (wave-uniform) this 32 x 32 tile lies below the diagonal
+                    if (PROBE != 3) acc[x][y] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[kk][x], fb[kk][y], acc[x][y], 0, 0, 0);
+                    else acc[x][y][0] += fa[kk][x][0] ^ fb[kk][y][1];
+                }
+        }
+        if (PROBE != 2) {
+            if constexpr (NBUF == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        slot = (slot + 1 == NBUF) ? 0 : slot + 1;
+        fslot = (fslot + 1 == NBUF) ? 0 : fslot + 1;
+    }
+    int* dst = part + ((int64_t)blockIdx.y * nsplit + split) * Mp2 * Mp2;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (diag && 2 * wc + y < 4 * wr + x) continue;
+                const int row = bi * CT2 + wr * 128 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int col = bj * CT2 + wc * 64 + 32 * y + c;
+                dst[(int64_t)row * Mp2 + col] = acc[x][y][r];
+            }
+}
+
+// ---- 3 (loader waves). Timing probes of the deep kernel (profiles/r06_crt_syrk_probes.txt, 15 planes): everything 9.3 ms; without the
+// fills 7.2; without fills and barriers 7.2; fills + barriers + fragment reads WITHOUT the MFMAs 5.5 -- the two halves do not overlap
+// because the waves that issue the LDS-DMA requests are the waves that issue the MFMAs: a request costs its wave 60-180 issue cycles
+// (MI355X_MICROARCH.md), all eight waves pay them right behind the barrier, and the matrix pipe idles meanwhile.  Here the workgroup
+// has TWELVE waves: eight compute waves (as above, no memory instruction but their fragment reads) and four loader waves, one per
+// SIMD, that do nothing but request row group l of both sides of the stage NBUF - 1 ahead, wait for the next stage's data with a
+// counted vmcnt, and meet the compute waves at the stage barrier.
+template <int NBUF>
+__global__ void __launch_bounds__(768) crt_syrk_i8_ldr_kernel(const int8_t* __restrict__ planes, int64_t rows_pad, int Mp2, int nt2, int64_t rows_per_split,
+                                                              int nsplit, int* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) crt_v4i crt_lds[];      // [NBUF][2 sides][4 groups][CT2 cols]
+    constexpr int SGR = 4, SIDE = SGR * CT2, SLOT = 2 * SIDE, D = NBUF - 1;
+    const int ntile = nt2 * (nt2 + 1) / 2;
+    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
+    const int split = xcd + 8 * (jx / ntile);
+    int bi = 0, rem = jx % ntile;
+    while (rem >= nt2 - bi) { rem -= nt2 - bi; ++bi; }
+    const int bj = bi + rem;
+    const int8_t* plane = planes + (int64_t)blockIdx.y * rows_pad * Mp2;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t g0 = (int64_t)split * rows_per_split / 16, g1 = g0 + rows_per_split / 16;
+    const crt_v4i* P = reinterpret_cast<const crt_v4i*>(plane);
+    if (wave >= 8) {
+        // ---- loader wave l: row group l of both sides of every stage ----
+        const int l = wave - 8;
+        auto fill = [&](int64_t g, int slot) {        // (clamped: copies past the end of the split are never read)
+            const int64_t gq = (g + l < g1) ? g + l : g1 - 1;
+            const crt_v4i* sa = P + gq * Mp2 + bi * CT2 + lane;
+            const crt_v4i* sb = P + gq * Mp2 + bj * CT2 + lane;
+            crt_v4i* da = crt_lds + slot * SLOT + l * CT2;
+            crt_v4i* db = da + SIDE;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sa + 64 * j), (__attribute__((address_space(3))) void*)(da + 64 * j), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + 64 * j), (__attribute__((address_space(3))) void*)(db + 64 * j), 16, 0, 0);
+            }
+        };
+#pragma unroll
+        for (int d = 0; d < D; ++d) fill(g0 + SGR * d, d);
+        if constexpr (NBUF == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        int fslot = D;
+        for (int64_t g = g0; g < g1; g += SGR) {
+            fill(g + SGR * D, fslot);
+            if constexpr (NBUF == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            fslot = (fslot + 1 == NBUF) ? 0 : fslot + 1;
+        }
+        return;
+    }
+    const int wr = wave >> 2, wc = wave & 3;
+    const int h = lane >> 5, c = lane & 31;
+    crt_v16i acc[4][2];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0;
+    __builtin_amdgcn_s_barrier();
+    int slot = 0;
+    for (int64_t g = g0; g < g1; g += SGR) {
+        const crt_v4i* A = crt_lds + slot * SLOT + wr * 128 + c;
+        const crt_v4i* Bf = crt_lds + slot * SLOT + SIDE + wc * 64 + c;
+        crt_v4i fa[2][4], fb[2][2];
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) fa[kk][x] = A[(2 * kk + h) * CT2 + 32 * x];
+#pragma unroll
+            for (int y = 0; y < 2; ++y) fb[kk][y] = Bf[(2 * kk + h) * CT2 + 32 * y];
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+#pragma unroll
+                for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[kk][x], fb[kk][y], acc[x][y], 0, 0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        slot = (slot + 1 == NBUF) ? 0 : slot + 1;
+    }
+    int* dst = part + ((int64_t)blockIdx.y * nsplit + split) * Mp2 * Mp2;
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = bi * CT2 + wr * 128 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int col = bj * CT2 + wc * 64 + 32 * y + c;
+                dst[(int64_t)row * Mp2 + col] = acc[x][y][r];
+            }
+}
+
 // ---- 3b + 4. split sums mod p_i, then (last chunk) Garner digits and Phi ---------------------------------------------------------------
 // thread = four consecutive entries (a, b .. b + 3) of the upper triangle (16-byte loads of the int32 partials, eight splits in flight).
 // res[i][a * Mp2 + b] carries the residues between the chunks of a panel that does not fit one pass.  The mixed-radix digits v_i give
@@ -422,11 +617,19 @@ int crt_accumulate(oak_ctx* ctx, const CrtPlan& pl, int64_t M, bool first_chunk,
     {
         PhaseTimer t(ctx, "crt_syrk");
         const int nt2 = (int)(pl.Mp2 / CT2), ntile2 = nt2 * (nt2 + 1) / 2;
-        const size_t lds = sizeof(crt_v4i) * 2 * 2 * (CST / 16) * CT2;
-        static const int variant = getenv("OAK_CRT_SYRK") ? atoi(getenv("OAK_CRT_SYRK")) : 5;      // 4: register-staged operands (A/B knob)
-        auto kern = variant == 4 ? crt_syrk_i8_kernel : crt_syrk_i8_dma_kernel;
+        size_t lds = sizeof(crt_v4i) * 2 * 2 * (CST / 16) * CT2;
+        // A/B knob: 4 register-staged operands, 5 LDS-DMA with two 128-row slots, 64 / 65 LDS-DMA with four / five 64-row slots
+        static const int variant = getenv("OAK_CRT_SYRK") ? atoi(getenv("OAK_CRT_SYRK")) : 64;
+        auto kern = variant == 4 ? crt_syrk_i8_kernel : (variant == 5 ? crt_syrk_i8_dma_kernel : (variant == 65 ? crt_syrk_i8_deep_kernel<5> : crt_syrk_i8_deep_kernel<4>));
+        int threads = 512;
+        if (variant == 66) { kern = crt_syrk_i8_ldr_kernel<4>; threads = 768; }
+        if (variant == 67) { kern = crt_syrk_i8_ldr_kernel<5>; threads = 768; lds = sizeof(crt_v4i) * 5 * 2 * 4 * CT2; }
+        if (variant == 641) kern = crt_syrk_i8_deep_kernel<4, 1>;
+        if (variant == 642) kern = crt_syrk_i8_deep_kernel<4, 2>;
+        if (variant == 643) kern = crt_syrk_i8_deep_kernel<4, 3>;
+        if (variant == 65) lds = sizeof(crt_v4i) * 5 * 2 * 4 * CT2;
         OAK_CHECK(ensure_max_dynamic_lds((const void*)kern));
-        kern<<<dim3((unsigned)(ntile2 * pl.nsplit), (unsigned)md.L), 512, lds, ctx->stream>>>(pl.d_planes, pl.rows_pad, (int)pl.Mp2, nt2, pl.rps, pl.nsplit, pl.d_part);
+        kern<<<dim3((unsigned)(ntile2 * pl.nsplit), (unsigned)md.L), threads, lds, ctx->stream>>>(pl.d_planes, pl.rows_pad, (int)pl.Mp2, nt2, pl.rps, pl.nsplit, pl.d_part);
         OAK_HIP_CHECK(hipGetLastError());
         t.stop();
     }
