@@ -161,104 +161,25 @@ __global__ void __launch_bounds__(512, 1) crt_syrk_i8_kernel(const int8_t* __res
             }
 }
 
-// ---- 3 (default). the same tile and wave layout with the operands brought global -> LDS by the DMA path (global_load_lds_dwordx4:
-// no staging registers, no ds_write pass, one instruction per KiB): at the top of a stage every wave issues its eight 1 KiB pieces of
-// the NEXT stage (wave w: row group w of both sides) into the other buffer, computes the stage's four k-steps, and the stage ends with
-// s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier (trsm_fused.hip: counted waits are wrong for LDS-DMA, which does not retire in order).
-__global__ void __launch_bounds__(512, 1) crt_syrk_i8_dma_kernel(const int8_t* __restrict__ planes, int64_t rows_pad, int Mp2, int nt2, int64_t rows_per_split,
-                                                                 int nsplit, int* __restrict__ part) {
-    extern __shared__ __attribute__((aligned(16))) crt_v4i crt_lds[];      // [2 buffers][2 sides][CST / 16 groups][CT2 cols]
-    const int ntile = nt2 * (nt2 + 1) / 2;
-    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-    const int split = xcd + 8 * (jx / ntile);
-    int bi = 0, rem = jx % ntile;
-    while (rem >= nt2 - bi) { rem -= nt2 - bi; ++bi; }
-    const int bj = bi + rem;
-    const int8_t* plane = planes + (int64_t)blockIdx.y * rows_pad * Mp2;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 2, wc = wave & 3;
-    const int h = lane >> 5, c = lane & 31;
-    const int64_t g0 = (int64_t)split * rows_per_split / 16, g1 = g0 + rows_per_split / 16;
-    const crt_v4i* P = reinterpret_cast<const crt_v4i*>(plane);
-    constexpr int SG = CST / 16, SIDE = SG * CT2;
-    crt_v16i acc[4][2];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0;
-    // stage starting at group g -> buffer b: this wave brings row group g + wave (clamped: the copies past the end are never read)
-    auto fill = [&](int64_t g, int b) {
-        const int64_t gq = (g + wave < g1) ? g + wave : g1 - 1;
-        const crt_v4i* sa = P + gq * Mp2 + bi * CT2 + lane;
-        const crt_v4i* sb = P + gq * Mp2 + bj * CT2 + lane;
-        crt_v4i* da = crt_lds + (b * 2 + 0) * SIDE + wave * CT2;
-        crt_v4i* db = crt_lds + (b * 2 + 1) * SIDE + wave * CT2;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sa + 64 * j), (__attribute__((address_space(3))) void*)(da + 64 * j), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + 64 * j), (__attribute__((address_space(3))) void*)(db + 64 * j), 16, 0, 0);
-        }
-    };
-    fill(g0, 0);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    int buf = 0;
-    for (int64_t g = g0; g < g1; g += SG) {
-        fill(g + SG, buf ^ 1);
-        const crt_v4i* A = crt_lds + (buf * 2 + 0) * SIDE + wr * 128 + c;
-        const crt_v4i* Bf = crt_lds + (buf * 2 + 1) * SIDE + wc * 64 + c;
-        crt_v4i fa[2][4], fb[2][2];
-#pragma unroll
-        for (int x = 0; x < 4; ++x) fa[0][x] = A[h * CT2 + 32 * x];
-#pragma unroll
-        for (int y = 0; y < 2; ++y) fb[0][y] = Bf[h * CT2 + 32 * y];
-#pragma unroll
-        for (int kk = 0; kk < SG / 2; ++kk) {
-            const int cur = kk & 1, nxt = cur ^ 1;
-            if (kk + 1 < SG / 2) {
-#pragma unroll
-                for (int x = 0; x < 4; ++x) fa[nxt][x] = A[(2 * (kk + 1) + h) * CT2 + 32 * x];
-#pragma unroll
-                for (int y = 0; y < 2; ++y) fb[nxt][y] = Bf[(2 * (kk + 1) + h) * CT2 + 32 * y];
-            }
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[cur][x], fb[cur][y], acc[x][y], 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        buf ^= 1;
-    }
-    int* dst = part + ((int64_t)blockIdx.y * nsplit + split) * Mp2 * Mp2;
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = bi * CT2 + wr * 128 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int col = bj * CT2 + wc * 64 + 32 * y + c;
-                dst[(int64_t)row * Mp2 + col] = acc[x][y][r];
-            }
-}
-
-// ---- 3 (deep pipeline). PMC of the two kernels above (profiles/r06_pmc_crt_first.json): MFMA pipe 43 % busy, 37 % of the wave time
-// parked in s_waitcnt / s_barrier -- a stage's operands are requested ONE stage (~2000 cycles) before they are needed and a quarter
-// of them come from beyond the L2.  Here: 64-row stages (32 KiB) in NBUF slots, requested NBUF - 1 stages ahead; the stage ends with
-// a COUNTED wait (the loop's only memory operations are LDS-DMA loads, which retire in order among themselves -- the unordered mix
-// of trsm_fused.hip had register loads and stores in the same queue): vmcnt(4 (NBUF - 2)) = everything but the youngest NBUF - 2
-// stages has landed.  Wave w brings row group w & 3 of side w >> 2.  Integer results: any mistake in the hand-written waits shows as
-// a Phi that differs from the register-staged kernel's bit for bit (tests/test_gpu_crt.py).
-// PROBE (timing experiments, wrong results): 1 no fills inside the loop, 2 also no waits / barriers, 3 fills and barriers but no MFMA
-template <int NBUF, int PROBE = 0>
+// ---- 3 (default). LDS-DMA operands, deep pipeline, diagonal-aware --------------------------------------------------------------------
+// Same tile and wave layout; the operands go global -> LDS by the DMA path (global_load_lds_dwordx4: no staging registers, no ds_write
+// pass) in 64-row stages (32 KiB) through NBUF = 4 slots, requested three stages ahead; a stage ends with a COUNTED wait -- the loop's
+// only memory operations are LDS-DMA loads, which retire in order among themselves (the unordered mix of trsm_fused.hip had register
+// loads and stores in the same queue) -- vmcnt(8) = everything but the two youngest stages has landed -- and s_barrier.  Wave w
+// brings row group w & 3 of side w >> 2.
+// What was measured on the way (r06, profiles/r06_crt_syrk_{probes,clocks,loader_waves}.txt, 15 planes at N = 2^20, M = 1024): two
+// 128-row slots with vmcnt(0) 9.6 ms, four or five 64-row slots 9.3-9.5, four extra LOADER waves (twelve per workgroup, the compute
+// waves issue no memory instruction) 9.2 -- with 10 % fewer active cycles at a 10 % lower clock: the kernel runs against the POWER
+// limit (1.55-1.75 GHz; the MFMAs alone take 9.8e6 of 1.27e7 cycles), so only work NOT done is time.  Hence the diagonal tiles
+// (bi == bj): one side is fetched (both operands are the same columns) and only the 36 of 64 MFMA tiles per k-step that touch the
+// upper triangle are issued -- by straight-line code per wave role (MASK, bit 2 x + y), not by predicates in one loop (those cost
+// the schedule of EVERY tile: 9.8 ms).  Integer results: any mistake in the hand-written waits shows as a Phi that differs from the
+// register-staged kernel's bit for bit (tests/test_gpu_crt.py).
+template <unsigned MASK> struct CrtMask { static constexpr unsigned value = MASK; };
 __global__ void __launch_bounds__(512, 1) crt_syrk_i8_deep_kernel(const int8_t* __restrict__ planes, int64_t rows_pad, int Mp2, int nt2, int64_t rows_per_split,
                                                                   int nsplit, int* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) crt_v4i crt_lds[];      // [NBUF][2 sides][4 groups][CT2 cols]
-    constexpr int SGR = 4, SIDE = SGR * CT2, SLOT = 2 * SIDE, D = NBUF - 1;
+    constexpr int NBUF = 4, SGR = 4, SIDE = SGR * CT2, SLOT = 2 * SIDE, D = NBUF - 1;
     const int ntile = nt2 * (nt2 + 1) / 2;
     const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
     const int split = xcd + 8 * (jx / ntile);
@@ -272,6 +193,7 @@ __global__ void __launch_bounds__(512, 1) crt_syrk_i8_deep_kernel(const int8_t* 
     const int h = lane >> 5, c = lane & 31;
     const int64_t g0 = (int64_t)split * rows_per_split / 16, g1 = g0 + rows_per_split / 16;
     const crt_v4i* P = reinterpret_cast<const crt_v4i*>(plane);
+    const bool diag = bi == bj;
     crt_v16i acc[4][2];
 #pragma unroll
     for (int x = 0; x < 4; ++x)
@@ -279,15 +201,10 @@ __global__ void __launch_bounds__(512, 1) crt_syrk_i8_deep_kernel(const int8_t* 
         for (int y = 0; y < 2; ++y)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[x][y][r] = 0;
-    // A diagonal tile (bi == bj) brings ONE side (both operands are the same columns) and issues only the MFMA tiles that touch the
-    // upper triangle: 36 of its 64 per k-step; waves (wr 1, wc 0 / 1) lie below the diagonal and only keep the barriers company.  The
-    // kernel runs against the power limit (1.7 GHz with every MFMA issued, profiles/r06_crt_syrk_clocks.txt): work not done is time.
-    const bool diag = bi == bj;
-    const bool idle = diag && wr == 1 && wc < 2;
     const int fq = wave & 3, fside = wave >> 2;
+    const bool filler = !(diag && fside);             // a diagonal tile has one side
     const int64_t fcol = (fside ? bj : bi) * CT2 + lane;
     auto fill = [&](int64_t g, int slot) {            // the stage starting at row group g (clamped: copies past the end are never read)
-        if (diag && fside) return;
         const int64_t gq = (g + fq < g1) ? g + fq : g1 - 1;
         const crt_v4i* src = P + gq * Mp2 + fcol;
         crt_v4i* dst = crt_lds + slot * SLOT + fside * SIDE + fq * CT2;
@@ -295,150 +212,63 @@ __global__ void __launch_bounds__(512, 1) crt_syrk_i8_deep_kernel(const int8_t* 
         for (int j = 0; j < 4; ++j)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 64 * j), (__attribute__((address_space(3))) void*)(dst + 64 * j), 16, 0, 0);
     };
-#pragma unroll
-    for (int d = 0; d < D; ++d) fill(g0 + SGR * d, d);
-    if constexpr (NBUF == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    int slot = 0, fslot = D;
-    for (int64_t g = g0; g < g1; g += SGR) {
-        if (PROBE != 1 && PROBE != 2) fill(g + SGR * D, fslot);                      // into the slot whose readers all passed the barrier that ended the previous stage
-        const crt_v4i* A = crt_lds + slot * SLOT + wr * 128 + c;
-        const crt_v4i* Bf = crt_lds + slot * SLOT + (diag ? 0 : SIDE) + wc * 64 + c;
-        crt_v4i fa[2][4], fb[2][2];
-        if (!idle) {
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-            for (int x = 0; x < 4; ++x) fa[kk][x] = A[(2 * kk + h) * CT2 + 32 * x];
-#pragma unroll
-            for (int y = 0; y < 2; ++y) fb[kk][y] = Bf[(2 * kk + h) * CT2 + 32 * y];
-        }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int y = 0; y < 2; ++y) {
-                    if (diag && 2 * wc + y < 4 * wr + x) continue;             // (wave-uniform) this 32 x 32 tile lies below the diagonal
-                    if (PROBE != 3) acc[x][y] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[kk][x], fb[kk][y], acc[x][y], 0, 0, 0);
-                    else acc[x][y][0] += fa[kk][x][0] ^ fb[kk][y][1];
-                }
-        }
-        if (PROBE != 2) {
-            if constexpr (NBUF == 4) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(12) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-        }
-        slot = (slot + 1 == NBUF) ? 0 : slot + 1;
-        fslot = (fslot + 1 == NBUF) ? 0 : fslot + 1;
-    }
-    int* dst = part + ((int64_t)blockIdx.y * nsplit + split) * Mp2 * Mp2;
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                if (diag && 2 * wc + y < 4 * wr + x) continue;
-                const int row = bi * CT2 + wr * 128 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int col = bj * CT2 + wc * 64 + 32 * y + c;
-                dst[(int64_t)row * Mp2 + col] = acc[x][y][r];
-            }
-}
-
-// ---- 3 (loader waves). Timing probes of the deep kernel (profiles/r06_crt_syrk_probes.txt, 15 planes): everything 9.3 ms; without the
-// fills 7.2; without fills and barriers 7.2; fills + barriers + fragment reads WITHOUT the MFMAs 5.5 -- the two halves do not overlap
-// because the waves that issue the LDS-DMA requests are the waves that issue the MFMAs: a request costs its wave 60-180 issue cycles
-// (MI355X_MICROARCH.md), all eight waves pay them right behind the barrier, and the matrix pipe idles meanwhile.  Here the workgroup
-// has TWELVE waves: eight compute waves (as above, no memory instruction but their fragment reads) and four loader waves, one per
-// SIMD, that do nothing but request row group l of both sides of the stage NBUF - 1 ahead, wait for the next stage's data with a
-// counted vmcnt, and meet the compute waves at the stage barrier.
-template <int NBUF>
-__global__ void __launch_bounds__(768) crt_syrk_i8_ldr_kernel(const int8_t* __restrict__ planes, int64_t rows_pad, int Mp2, int nt2, int64_t rows_per_split,
-                                                              int nsplit, int* __restrict__ part) {
-    extern __shared__ __attribute__((aligned(16))) crt_v4i crt_lds[];      // [NBUF][2 sides][4 groups][CT2 cols]
-    constexpr int SGR = 4, SIDE = SGR * CT2, SLOT = 2 * SIDE, D = NBUF - 1;
-    const int ntile = nt2 * (nt2 + 1) / 2;
-    const int xcd = blockIdx.x & 7, jx = blockIdx.x >> 3;
-    const int split = xcd + 8 * (jx / ntile);
-    int bi = 0, rem = jx % ntile;
-    while (rem >= nt2 - bi) { rem -= nt2 - bi; ++bi; }
-    const int bj = bi + rem;
-    const int8_t* plane = planes + (int64_t)blockIdx.y * rows_pad * Mp2;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t g0 = (int64_t)split * rows_per_split / 16, g1 = g0 + rows_per_split / 16;
-    const crt_v4i* P = reinterpret_cast<const crt_v4i*>(plane);
-    if (wave >= 8) {
-        // ---- loader wave l: row group l of both sides of every stage ----
-        const int l = wave - 8;
-        auto fill = [&](int64_t g, int slot) {        // (clamped: copies past the end of the split are never read)
-            const int64_t gq = (g + l < g1) ? g + l : g1 - 1;
-            const crt_v4i* sa = P + gq * Mp2 + bi * CT2 + lane;
-            const crt_v4i* sb = P + gq * Mp2 + bj * CT2 + lane;
-            crt_v4i* da = crt_lds + slot * SLOT + l * CT2;
-            crt_v4i* db = da + SIDE;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sa + 64 * j), (__attribute__((address_space(3))) void*)(da + 64 * j), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + 64 * j), (__attribute__((address_space(3))) void*)(db + 64 * j), 16, 0, 0);
-            }
-        };
+    if (filler) {
 #pragma unroll
         for (int d = 0; d < D; ++d) fill(g0 + SGR * d, d);
-        if constexpr (NBUF == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        int fslot = D;
+    }
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int a_off = wr * 128 + c, b_off = (diag ? 0 : SIDE) + wc * 64 + c;
+    auto run = [&](auto mask_c) {
+        constexpr unsigned MASK = decltype(mask_c)::value;
+        int slot = 0, fslot = D;
         for (int64_t g = g0; g < g1; g += SGR) {
-            fill(g + SGR * D, fslot);
-            if constexpr (NBUF == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            if (filler) fill(g + SGR * D, fslot);      // into the slot whose readers all passed the barrier that ended the previous stage
+            const crt_v4i* A = crt_lds + slot * SLOT + a_off;
+            const crt_v4i* Bf = crt_lds + slot * SLOT + b_off;
+            crt_v4i fa[2][4], fb[2][2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+                    if ((MASK >> (2 * x)) & 3u) fa[kk][x] = A[(2 * kk + h) * CT2 + 32 * x];
+#pragma unroll
+                for (int y = 0; y < 2; ++y)
+                    if (MASK & (0x55u << y)) fb[kk][y] = Bf[(2 * kk + h) * CT2 + 32 * y];
+            }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+#pragma unroll
+                    for (int y = 0; y < 2; ++y)
+                        if ((MASK >> (2 * x + y)) & 1u) acc[x][y] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[kk][x], fb[kk][y], acc[x][y], 0, 0, 0);
+            asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+            slot = (slot + 1 == NBUF) ? 0 : slot + 1;
             fslot = (fslot + 1 == NBUF) ? 0 : fslot + 1;
         }
-        return;
-    }
-    const int wr = wave >> 2, wc = wave & 3;
-    const int h = lane >> 5, c = lane & 31;
-    crt_v16i acc[4][2];
+        int* dst = part + ((int64_t)blockIdx.y * nsplit + split) * Mp2 * Mp2;
 #pragma unroll
-    for (int x = 0; x < 4; ++x)
+        for (int x = 0; x < 4; ++x)
 #pragma unroll
-        for (int y = 0; y < 2; ++y)
+            for (int y = 0; y < 2; ++y)
+                if ((MASK >> (2 * x + y)) & 1u) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[x][y][r] = 0;
-    __builtin_amdgcn_s_barrier();
-    int slot = 0;
-    for (int64_t g = g0; g < g1; g += SGR) {
-        const crt_v4i* A = crt_lds + slot * SLOT + wr * 128 + c;
-        const crt_v4i* Bf = crt_lds + slot * SLOT + SIDE + wc * 64 + c;
-        crt_v4i fa[2][4], fb[2][2];
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-            for (int x = 0; x < 4; ++x) fa[kk][x] = A[(2 * kk + h) * CT2 + 32 * x];
-#pragma unroll
-            for (int y = 0; y < 2; ++y) fb[kk][y] = Bf[(2 * kk + h) * CT2 + 32 * y];
-        }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[kk][x], fb[kk][y], acc[x][y], 0, 0, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        slot = (slot + 1 == NBUF) ? 0 : slot + 1;
-    }
-    int* dst = part + ((int64_t)blockIdx.y * nsplit + split) * Mp2 * Mp2;
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 2; ++y)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = bi * CT2 + wr * 128 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * h;
-                const int col = bj * CT2 + wc * 64 + 32 * y + c;
-                dst[(int64_t)row * Mp2 + col] = acc[x][y][r];
-            }
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = bi * CT2 + wr * 128 + 32 * x + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const int col = bj * CT2 + wc * 64 + 32 * y + c;
+                        dst[(int64_t)row * Mp2 + col] = acc[x][y][r];
+                    }
+                }
+    };
+    // tile (x, y) of this wave covers 32-row block 4 wr + x and 32-column block 2 wc + y: on a diagonal tile it is needed when
+    // 2 wc + y >= 4 wr + x, i.e. with dg = 2 wc - 4 wr: all eight for dg >= 4, seven (not (3, 0)) for dg = 2, three for dg = 0, none below
+    const int dg = diag ? 2 * wc - 4 * wr : 4;
+    if (dg >= 4) run(CrtMask<0xFFu>{});
+    else if (dg == 2) run(CrtMask<0xBFu>{});
+    else if (dg == 0) run(CrtMask<0x0Bu>{});
+    else run(CrtMask<0u>{});
 }
 
 // ---- 3b + 4. split sums mod p_i, then (last chunk) Garner digits and Phi ---------------------------------------------------------------
@@ -617,17 +447,12 @@ int crt_accumulate(oak_ctx* ctx, const CrtPlan& pl, int64_t M, bool first_chunk,
     {
         PhaseTimer t(ctx, "crt_syrk");
         const int nt2 = (int)(pl.Mp2 / CT2), ntile2 = nt2 * (nt2 + 1) / 2;
-        size_t lds = sizeof(crt_v4i) * 2 * 2 * (CST / 16) * CT2;
-        // A/B knob: 4 register-staged operands, 5 LDS-DMA with two 128-row slots, 64 / 65 LDS-DMA with four / five 64-row slots
-        static const int variant = getenv("OAK_CRT_SYRK") ? atoi(getenv("OAK_CRT_SYRK")) : 64;
-        auto kern = variant == 4 ? crt_syrk_i8_kernel : (variant == 5 ? crt_syrk_i8_dma_kernel : (variant == 65 ? crt_syrk_i8_deep_kernel<5> : crt_syrk_i8_deep_kernel<4>));
-        int threads = 512;
-        if (variant == 66) { kern = crt_syrk_i8_ldr_kernel<4>; threads = 768; }
-        if (variant == 67) { kern = crt_syrk_i8_ldr_kernel<5>; threads = 768; lds = sizeof(crt_v4i) * 5 * 2 * 4 * CT2; }
-        if (variant == 641) kern = crt_syrk_i8_deep_kernel<4, 1>;
-        if (variant == 642) kern = crt_syrk_i8_deep_kernel<4, 2>;
-        if (variant == 643) kern = crt_syrk_i8_deep_kernel<4, 3>;
-        if (variant == 65) lds = sizeof(crt_v4i) * 5 * 2 * 4 * CT2;
+        const size_t lds = sizeof(crt_v4i) * 2 * 2 * (CST / 16) * CT2;          // 128 KiB in both kernels (2 x 128 or 4 x 64 rows)
+        // A/B knob (and the reference of tests/test_gpu_crt.py): OAK_CRT_SYRK=4 runs the register-staged kernel
+        const char* ev = getenv("OAK_CRT_SYRK");
+        const int variant = ev ? atoi(ev) : 64;
+        auto kern = variant == 4 ? crt_syrk_i8_kernel : crt_syrk_i8_deep_kernel;
+        const int threads = 512;
         OAK_CHECK(ensure_max_dynamic_lds((const void*)kern));
         kern<<<dim3((unsigned)(ntile2 * pl.nsplit), (unsigned)md.L), threads, lds, ctx->stream>>>(pl.d_planes, pl.rows_pad, (int)pl.Mp2, nt2, pl.rps, pl.nsplit, pl.d_part);
         OAK_HIP_CHECK(hipGetLastError());

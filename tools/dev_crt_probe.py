@@ -16,8 +16,9 @@ ctx = _capi.default_context()
 ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("phi"); ctx.sgpr_set_precision("int8crt")
 for _ in range(2): ctx.sgpr_local_stats(d)
 ctx.sync(); ctx.reset_timings(); t0 = time.perf_counter()
-for _ in range(5): ctx.sgpr_local_stats(d)
-ctx.sync(); dt = (time.perf_counter() - t0) / 5
+REPS = int(__import__("os").environ.get("OAK_PROBE_REPS", "5"))
+for _ in range(REPS): ctx.sgpr_local_stats(d)
+ctx.sync(); dt = (time.perf_counter() - t0) / REPS
 ph = {}
 for p in ("featurize", "gram", "crt_convert", "crt_syrk", "crt_reduce", "reduce"):
     ms, cnt = ctx.timing(p)
