@@ -38,6 +38,7 @@ CONFIGS = {
     # BASELINE.json configs[4] in fp64 (the reference is fp64-only): 20 continuous + 8 binary + 4 categorical (C=5) inputs
     "c5": dict(N=262144, D=32, M=2048, R=4, mixed=True),
 }
+INT8_PEAK_TOPS = 5000.0       # int8 MFMA, dense: 2x the 2.5 PFLOP/s bf16 rate (MI355X_MICROARCH.md: >= 3944 measured; tools/ubench: 4956 with constant operands)
 FP64_PEAK_TFLOPS = 78.6       # MI355X fp64 vector == matrix peak; measured ceiling 61-68 TF/s (tools/ubench)
 HBM_PEAK_GBPS = 8000.0
 # fp64 VALU issue roofline: 16 DP lanes per clock per SIMD = 4 clocks per wave64 instruction, 1024 SIMDs, 2.4 GHz
@@ -155,6 +156,10 @@ def sobol_record(ctx, desc, spec, Z, M, D, R):
                     "executed_TFLOPs": flop_exec / (ph["sobol_syrk"] * 1e-3) / 1e12 if ph["sobol_syrk"] else None,
                     "peak_TFLOPs": FP64_PEAK_TFLOPS,
                     "frac": flop_alg / (ph["sobol_syrk"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if ph["sobol_syrk"] else None,
+                    "executed_frac": flop_exec / (ph["sobol_syrk"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if ph["sobol_syrk"] else None,
+                    "padding_ratio_executed_over_algorithmic": flop_exec / flop_alg,
+                    "frac_note": "`frac` prices the ALGORITHMIC flops: with few Gram columns (headline: 17 padded to 128) it is a statement "
+                                 "about padding, not about the kernel -- `executed_frac` is the kernel's rate on what it ran",
                     "order4_pairing_disagreement": info["pairing_disagreement"]})
     # the independent per-term kernel (a fused product-reduction over the stacked L_d) on a sample of the terms
     pick = np.random.default_rng(0).choice(len(subsets), min(512, len(subsets)), replace=False)
@@ -223,8 +228,11 @@ def main():
     ap.add_argument("--config", default="headline", choices=sorted(CONFIGS))
     ap.add_argument("--grad", action="store_true", help="time forward + analytic gradient instead of forward only")
     ap.add_argument("--route", default="phi", choices=["phi", "whitened", "auto"])
-    ap.add_argument("--precision", default="fp64", choices=["fp64", "fp32"],
-                    help="fp32 = the opt-in fp32-statistics mode (fp32 Kfu panel + fp32-MFMA Phi partials, fp64 everywhere else): "
+    ap.add_argument("--precision", default="auto", choices=["auto", "fp64", "int8crt", "fp32"],
+                    help="auto (the library's default) = Phi accumulated exactly on the int8 matrix pipe (48-bit scaled integers, residue "
+                         "planes, Chinese remainder reconstruction; csrc/crt.hip) on large phi-route problems, the fp64 kernels otherwise; "
+                         "fp64 = the fp64 kernels throughout; int8crt = the int8 route wherever it is supported; "
+                         "fp32 = the opt-in fp32-statistics mode (fp32 Kfu panel + fp32-MFMA Phi partials, fp64 everywhere else): "
                          "NOT the reference's arithmetic, reported as its own labelled line, never the headline")
     ap.add_argument("--exchange", default="rccl", choices=["rccl", "host"],
                     help="N>1: 'rccl' = reduce-scatter + all-gather over xGMI inside liboak_hip (default); 'host' = debug path that "
@@ -367,13 +375,39 @@ def main():
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
 
-    PHASES = ["featurize", "gram", "trsm", "syrk", "reduce", "allreduce", "tail", "total", "bwd_gemm", "bwd_gram", "bwd_tail",
-              "bwd_small"]
+    PHASES = ["featurize", "gram", "trsm", "syrk", "crt_convert", "crt_syrk", "crt_reduce", "reduce", "allreduce", "tail", "total", "bwd_gemm",
+              "bwd_gram", "bwd_tail", "bwd_small"]
     timings = {k: ctx.timing(k) for k in PHASES}
     try:
         precision_used = ctx.sgpr_stats_precision()        # of the timed loop's last evaluation
+        crt_info = ctx.bench_crt_info()
     except Exception:
-        precision_used = args.precision
+        precision_used, crt_info = args.precision, {}
+
+    # ---- the same step on the fp64 kernels alone (v_mfma_f64 SYRK): what the int8 route is measured against ----------------
+    fp64_info = None
+    if precision_used == "int8crt":
+        ctx.sgpr_set_precision("fp64")
+        fsteps = max(2, min(args.steps, 10))
+        step()
+        ctx.reset_timings()
+        barrier()
+        tf_ = time.perf_counter()
+        for _ in range(fsteps):
+            loss64 = step()
+        barrier()
+        dtf = max_over_ranks(time.perf_counter() - tf_)
+        ft = {k: ctx.timing(k) for k in PHASES}
+        f_syrk_ms = ft["syrk"][0] / max(ft["syrk"][1], 1)
+        f_flops = float(M) * (M + 1) * (hi - lo)
+        fp64_info = {"ms_per_step": dtf / fsteps * 1e3, "steps_per_sec": fsteps / dtf, "steps": fsteps, "loss": loss64,
+                     "loss_rel_diff_vs_timed_mode": abs(loss64 - loss) / abs(loss),
+                     "phase_ms_per_step": {k: v[0] / fsteps for k, v in ft.items() if v[1]},
+                     "syrk_roofline": {"bound": "mfma", "kernel": "syrk_kernel (v_mfma_f64_16x16x4_f64)", "avg_launch_ms": f_syrk_ms,
+                                       "achieved": f_flops / (f_syrk_ms * 1e-3) / 1e12 if f_syrk_ms else None, "peak": FP64_PEAK_TFLOPS,
+                                       "unit": "TFLOP/s", "frac": f_flops / (f_syrk_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if f_syrk_ms else None},
+                     "note": "precision=fp64: the fp64 kernels throughout (r01-r05's headline path), same inputs, same run"}
+        ctx.sgpr_set_precision(args.precision)
 
     # ---- secondary measurement: forward + analytic gradient (what one BFGS iteration of the reference computes) ----
     grad_info = None
@@ -398,7 +432,7 @@ def main():
     # ---- the route real fits take: GPflow's literal A = L^-1 Kuf (whitened), forward and forward + gradient ----------
     # (with k-means inducing points the conditioning estimate sends most BFGS evaluations of the auto route here)
     whitened_info = None
-    if args.route == "phi" and args.precision == "fp64":
+    if args.route == "phi" and args.precision != "fp32":
         ctx.sgpr_set_route("whitened")
         wsteps = max(2, min(args.steps, 5))
 
@@ -455,7 +489,8 @@ def main():
         ms, cnt = timings[name]
         return (ms / cnt) if cnt else 0.0
 
-    syrk_ms, gram_step_ms = per_launch("syrk"), per_launch("gram")
+    crt = precision_used == "int8crt"
+    syrk_ms, gram_step_ms = per_launch("crt_syrk" if crt else "syrk"), per_launch("gram")
     syrk_flops = float(M) * (M + 1) * n_local                     # M(M+1)N flops (FMA = 2) per SYRK launch
     E = 22.0
     gram_flops = float(n_local) * M * (D * (2 * E + 2 * (4 + R)) + 2 * (R + 1))   # BASELINE.md section 4 F_gram (E = 22 per exp)
@@ -464,28 +499,42 @@ def main():
     traffic_src = traffic.get("_source", "profiles/traffic.json") + " -- collected in separate rocprofv3 --pmc passes, NOT measured in this run"
     pmc = committed_profile("pmc_counts.json")
     # what the library actually ran (the fp32 statistics mode is refused on an ill-conditioned Kuu, on the whitened route
-    # and for gradient calls): labels, kernel names and peaks follow THAT, not the request
-    precision_honoured = precision_used == args.precision
-    dominant = "syrk" if syrk_ms >= gram_step_ms else "gram"
-    if dominant == "syrk":
+    # and for gradient calls; "auto" resolves to int8crt or fp64): labels, kernel names and peaks follow THAT, not the request
+    precision_honoured = precision_used == args.precision or args.precision == "auto"
+    if crt:
+        # the MFMA kernel of the step: L residue planes of int8 SYRK.  Algorithmic operations: M(M+1)N multiply-adds (x2) per plane.
+        planes = crt_info.get("planes", 0)
+        ops = planes * syrk_flops
+        ach = ops / (syrk_ms * 1e-3) / 1e12 if syrk_ms else 0.0
+        conv_ms = (gram_step_ms - fp64_info["phase_ms_per_step"].get("gram", gram_step_ms)) if fp64_info else None
+        red_ms = per_launch("crt_reduce")
+        emu_ms = (syrk_ms + red_ms + conv_ms) if conv_ms is not None else None
+        roofline = dict(bound="mfma", kernel=f"crt_syrk_i8_deep_kernel (v_mfma_i32_32x32x32_i8 over {planes} residue planes)", achieved=ach,
+                        peak=INT8_PEAK_TOPS, unit="TOP/s", frac=ach / INT8_PEAK_TOPS, traffic=traffic.get(args.config, {}).get("crt_syrk"),
+                        traffic_source=traffic_src, avg_launch_ms=syrk_ms, algorithmic_ops_per_launch=ops, planes=planes, crt=crt_info,
+                        note="int8 operations (multiply-add = 2), algorithmic = upper triangle; the kernel runs against the 1400 W power "
+                             "limit at 1.55-1.75 GHz (profiles/r06_crt_syrk_clocks.txt, r06_power_crt_step.txt), not at the 2.4 GHz the peak assumes",
+                        fp64_equivalent={"what": "M(M+1)N fp64 flops of Phi / (residue conversion in the Gram epilogue + int8 SYRK + split sums and "
+                                                 "reconstruction)", "ms": emu_ms,
+                                         "conversion_ms (Gram kernel with epilogue minus without, same run)": conv_ms, "reduce_ms": red_ms,
+                                         "TFLOPs": syrk_flops / (emu_ms * 1e-3) / 1e12 if emu_ms else None, "fp64_mfma_peak_TFLOPs": FP64_PEAK_TFLOPS,
+                                         "frac_of_fp64_mfma_peak": syrk_flops / (emu_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if emu_ms else None})
+    else:
         ach = syrk_flops / (syrk_ms * 1e-3) / 1e12 if syrk_ms else 0.0
         mfma_peak = FP64_PEAK_TFLOPS if precision_used == "fp64" else 157.3       # fp32 matrix peak (dense)
         roofline = dict(bound="mfma", kernel="syrk_kernel (v_mfma_f64_16x16x4_f64)" if precision_used == "fp64"
                         else "syrk32_kernel (v_mfma_f32_16x16x4_f32)", achieved=ach, peak=mfma_peak,
                         unit="TFLOP/s", frac=ach / mfma_peak, traffic=traffic.get(args.config, {}).get("syrk"),
                         traffic_source=traffic_src, avg_launch_ms=syrk_ms, algorithmic_flops_per_launch=syrk_flops)
-    else:
-        ach = gram_flops / (gram_step_ms * 1e-3) / 1e12 if gram_step_ms else 0.0
-        roofline = dict(bound="mfma", kernel="gram_kernel (fp64 VALU, shares the DP pipe with MFMA)", achieved=ach,
-                        peak=FP64_PEAK_TFLOPS, unit="TFLOP/s", frac=ach / FP64_PEAK_TFLOPS,
-                        traffic=traffic.get(args.config, {}).get("gram"), traffic_source=traffic_src,
-                        avg_launch_ms=gram_step_ms, algorithmic_flops_per_launch=gram_flops)
+    roofline["share_of_step"] = syrk_ms / ms_per_step if ms_per_step else None
+    roofline["largest_kernel_of_the_step"] = "gram (see gram_roofline: fp64 VALU issue-bound)" if gram_step_ms > syrk_ms else "this one"
 
     # Gram generation is bound by fp64 VALU ISSUE (one software exp2 per pair-dimension), not by HBM and not by a flop count:
     # its roofline is wave-instructions per second against 4 clocks per DP instruction per SIMD.  The instruction count per
     # pair-dimension is a property of the compiled kernel (SQ_INSTS_VALU of a committed rocprofv3 --pmc pass).
     gram_GBps = gram_bytes / (gram_ms * 1e-3) / 1e9 if gram_ms else None
-    ipd = pmc.get(args.config, {}).get("gram_valu_wave_instr_per_pair_dim")
+    ipd = pmc.get(args.config, {}).get("gram_valu_wave_instr_per_pair_dim")            # resident explicit-Gram launches: gram_kernel
+    ipd_step = pmc.get(args.config, {}).get("gram_crt_valu_wave_instr_per_pair_dim") if crt else ipd      # the step's Gram kernel
     pair_dims = float(n_local) * M * D
     gram_roofline = {"bound": "dp-issue", "unit": "wave-instr/s", "peak": DP_ISSUE_PEAK,
                      "peak_note": "1024 SIMDs x 2.4 GHz / 4 clocks per fp64 wave instruction",
@@ -500,7 +549,9 @@ def main():
         gram_roofline["achieved"] = gram_roofline["frac"] = None
     # the same kernel inside the step (it follows 17 ms of MFMA work there and shares the chip with the factorisation chain)
     gram_roofline["in_step_avg_launch_ms"] = gram_step_ms
-    gram_roofline["in_step_frac"] = (ipd * pair_dims / 64.0 / (gram_step_ms * 1e-3) / DP_ISSUE_PEAK) if (ipd and gram_step_ms) else None
+    gram_roofline["in_step_kernel"] = "gram_crt_kernel (pair arithmetic + residue conversion of every entry in the epilogue)" if crt else "gram_kernel"
+    gram_roofline["in_step_valu_wave_instr_per_pair_dim"] = ipd_step
+    gram_roofline["in_step_frac"] = (ipd_step * pair_dims / 64.0 / (gram_step_ms * 1e-3) / DP_ISSUE_PEAK) if (ipd_step and gram_step_ms) else None
     # ... and against an ALGORITHMIC floor that does not move when the kernel's own instruction count does: per pair-dimension
     # exp2 (10: range reduction 2, table 2, degree-3 polynomial 3, exponent patch 1, clamp/offset 2), distance 2 (subtract,
     # square-with-offset), constraint FMA 1, ESP recurrence R  =>  13 + R fp64 wave-instructions per 64 pair-dimensions
@@ -517,7 +568,9 @@ def main():
                   + ("" if precision_honoured else " [fp32 REQUESTED BUT NOT HONOURED: fp64 kernels ran]"),
         "value": value, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64" if precision_used == "fp64" else "f32 panel + f32-MFMA partials, f64 sums / tail",
+        "dtype": {"fp64": "f64", "int8crt": "f64 (Gram entries, psi, kappa, O(M^3) tail) + exact integer accumulation of Phi (48-bit scaled "
+                                            "entries as int8 residue planes, int32 / int64 sums, Chinese remainder reconstruction)"}.get(
+                      precision_used, "f32 panel + f32-MFMA partials, f64 sums / tail"),
         "precision_requested": args.precision, "precision_used": precision_used,
         "data": "synthetic", "degraded": degraded,
         "config": {"workload": f"{args.config}: SGPR ELBO, N={N} D={D} M={M} order={R}, {kernel_note}, "
@@ -533,14 +586,20 @@ def main():
         "step_roofline": {"F_elbo_flops": f_elbo * world, "achieved_TFLOPs": f_elbo * world / (ms_per_step * 1e-3) / 1e12,
                           "peak_TFLOPs": FP64_PEAK_TFLOPS * world,
                           "frac": f_elbo / (ms_per_step * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                          "formula": "BASELINE.md section 4: F_gram(E=22) + M(M+1)N + 2MN + (2/3)M^3 + 2M^3, rows of all ranks"},
+                          "formula": "BASELINE.md section 4: F_gram(E=22) + M(M+1)N + 2MN + (2/3)M^3 + 2M^3, rows of all ranks",
+                          # the DP pipe's own view: fp64 VALU wave-instructions actually issued by the Gram kernel (4 clocks each) plus, on
+                          # the fp64 kernels, the SYRK's flops at the fp64 MFMA peak -- as a share of the step (with the int8 route the
+                          # SYRK is not on the DP pipe and BASELINE's formula can exceed 1: Phi's flops run as int8 operations)
+                          "dp_pipe_frac": ((ipd_step * pair_dims / 64.0 / DP_ISSUE_PEAK if ipd_step else 0.0)
+                                           + (0.0 if crt else syrk_flops / (FP64_PEAK_TFLOPS * 1e12))) / (ms_per_step * 1e-3) if ipd_step else None},
         "phase_ms_per_step": {k: (v[0] / args.steps) for k, v in timings.items() if v[1]},
         "forward_plus_gradient": grad_info,
         "whitened": whitened_info,
+        "fp64_kernels": fp64_info,
     }
 
     # ---- Sobol indices of every term of the model (BASELINE configs[4] names the Sobol path) ----------------
-    if world == 1 and args.precision == "fp64":
+    if world == 1 and args.precision != "fp32":
         try:
             ctx.sgpr_elbo(_capi.KernelDesc(spec), noise, jitter)
             out["sobol"] = sobol_record(ctx, _capi.KernelDesc(spec), spec, Z, M, D, R)
@@ -548,7 +607,7 @@ def main():
             out["sobol"] = {"error": repr(ex)}
 
     # ---- a bounded real fit through the model API: what a user of oak_model.fit gets (auto route, k-means inducing points) ----
-    if not args.no_fit and world == 1 and args.precision == "fp64":
+    if not args.no_fit and world == 1 and args.precision != "fp32":
         try:
             with _stdout_to_stderr():
                 out["fit"] = bounded_fit(X, y, M, R, args.fit_maxiter)

@@ -34,12 +34,32 @@ static int modinv(int a, int p) {
 
 // ---- 1. column scales -------------------------------------------------------------------------------------------------------------
 // sexp[m] = B - 1 - e with bound_m < 2^e; columns beyond M (zero padding) get the scale of column 0 (their entries are exact zeros)
-__global__ void __launch_bounds__(256) crt_scales_kernel(const double* __restrict__ kdiagZ, int64_t M, int64_t Mp2, double kmax, int B,
-                                                         int* __restrict__ sexp) {
+// kmax_x[0] <- max of x[0 .. n) (one workgroup; n = the featurize pass's per-workgroup maxima of K_diag, or all K_diag values)
+__global__ void __launch_bounds__(256) crt_max_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ out) {
+    __shared__ double sh[256];
+    double m = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += 256) m = fmax(m, x[i]);
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int off = 128; off >= 1; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+// psd = 0 (a negative order variance in the description: K need not be positive semi-definite): the entry-wise bound
+// |K| <= sum_r |w_r| e_r(kmax_1 .. kmax_D) = kmax for every column instead of the Cauchy-Schwarz one
+// psd = 1: |K(x, z_m)| <= sqrt(max_n K_diag(x_n) K_diag(z_m)) with the largest K_diag of THIS rank's rows from the device (kmax_x; never
+// above the a-priori kmax, which caps it against a stray value)
+__global__ void __launch_bounds__(256) crt_scales_kernel(const double* __restrict__ kdiagZ, int64_t M, int64_t Mp2, double kmax, const double* __restrict__ kmax_x,
+                                                         int B, int psd, int* __restrict__ sexp) {
     const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (m >= Mp2) return;
     const double kd = kdiagZ[m < M ? m : 0];
-    const double bound = sqrt(kmax * (kd > 0.0 ? kd : 0.0)) * (1.0 + 0x1p-20) + 0x1p-300;
+    double kx = kmax_x != nullptr ? kmax_x[0] : kmax;
+    kx = (kx > 0.0 && kx < kmax) ? kx : kmax;
+    const double bound = (psd ? sqrt(kx * (kd > 0.0 ? kd : 0.0)) : kmax) * (1.0 + 0x1p-20) + 0x1p-300;
     int e = 0;
     frexp(bound, &e);                                  // bound < 2^e
     sexp[m] = B - 1 - e;
@@ -377,8 +397,9 @@ static double crt_kmax(const PreparedKernel& pk) {
         if (pk.dd.type[d] != OAK_DIM_RBF) {
             const int C = pk.dd.ncat[d];
             km = 0.0;
-            for (int c = 0; c < C; ++c) km = std::max(km, pk.tables[(size_t)pk.dd.tab_off[d] + (size_t)C * C + c]);
+            for (int c = 0; c < C; ++c) km = std::max(km, std::fabs(pk.tables[(size_t)pk.dd.tab_off[d] + (size_t)C * C + c]));
         }
+        km = std::fabs(km);
         for (int q = R; q >= 1; --q) e[q] += km * e[q - 1];
     }
     double K = 0.0;
@@ -387,7 +408,7 @@ static double crt_kmax(const PreparedKernel& pk) {
 }
 
 bool crt_supported(const oak_ctx* ctx, int64_t M) {
-    return pad_to(M, 256) <= 4096 && ctx->N >= 4096;
+    return pad_to(M, 256) <= 4096 && ctx->N >= 4096;      // (partials: L x nsplit x Mp2^2 x 4 bytes; 13-18 moduli cover 2^12 .. 2^45 rows)
 }
 
 // Plan of one panel chunk of `na` rows: moduli for n_total rows in all (residues are carried from chunk to chunk), row splits (a
@@ -395,6 +416,7 @@ bool crt_supported(const oak_ctx* ctx, int64_t M) {
 // buffers (grow-only, so a later, shorter chunk fits).
 int crt_plan(oak_ctx* ctx, int64_t na, int64_t M, int64_t n_total, CrtPlan* pl) {
     pl->B = 48;
+    if (const char* e = getenv("OAK_CRT_BITS")) { const int v = atoi(e); if (v >= 40 && v <= 50) pl->B = v; }      // experiment knob
     pl->Mp2 = pad_to(M, 256);
     const double need = 2.0 * pl->B - 1.0 + std::log2((double)n_total) + 0.25;
     pl->md.L = 0;
@@ -415,11 +437,26 @@ int crt_plan(oak_ctx* ctx, int64_t na, int64_t M, int64_t n_total, CrtPlan* pl) 
 }
 
 // column scales from K_diag(Z) and the a-priori bound on K_diag(x): once per evaluation, before the first chunk
-int crt_scales(oak_ctx* ctx, const PreparedKernel& pk, const Feat& FZ, int64_t M, const CrtPlan& pl) {
-    double* d_kdz = nullptr;
+int crt_scales(oak_ctx* ctx, const PreparedKernel& pk, const Feat& FX, const Feat& FZ, int64_t M, const CrtPlan& pl, bool kdiag_parts) {
+    double *d_kdz = nullptr, *d_kmx = nullptr;
     OAK_CHECK(get_buf_t(ctx, "crt_kdiagZ", (size_t)M, &d_kdz));
+    OAK_CHECK(get_buf_t(ctx, "crt_kmax_x", 1, &d_kmx));
     OAK_CHECK(gram_diag(ctx, pk, FZ, d_kdz, nullptr));
-    crt_scales_kernel<<<(unsigned)((pl.Mp2 + 255) / 256), 256, 0, ctx->stream>>>(d_kdz, M, pl.Mp2, crt_kmax(pk), pl.B, pl.d_sexp);
+    if (kdiag_parts) {
+        // the featurize pass of X left one maximum of K_diag per 256-row workgroup behind its per-workgroup sums ("feat_kpart")
+        const int64_t nblk = (FX.ld + 255) / 256;
+        crt_max_kernel<<<1, 256, 0, ctx->stream>>>((const double*)peek_buf(ctx, "feat_kpart") + nblk, nblk, d_kmx);
+    } else {
+        double* d_kd = nullptr;
+        OAK_CHECK(get_buf_t(ctx, "kdiag", (size_t)FX.n, &d_kd));
+        OAK_CHECK(gram_diag(ctx, pk, FX, d_kd, nullptr));
+        crt_max_kernel<<<1, 256, 0, ctx->stream>>>(d_kd, FX.n, d_kmx);
+    }
+    OAK_HIP_CHECK(hipGetLastError());
+    bool psd = true;
+    for (double w : pk.w_full) psd = psd && w >= 0.0;
+    for (int d = 0; d < pk.dd.D; ++d) psd = psd && pk.dd.bv[d] >= 0.0;
+    crt_scales_kernel<<<(unsigned)((pl.Mp2 + 255) / 256), 256, 0, ctx->stream>>>(d_kdz, M, pl.Mp2, crt_kmax(pk), d_kmx, pl.B, psd ? 1 : 0, pl.d_sexp);
     OAK_HIP_CHECK(hipGetLastError());
     return OAK_OK;
 }

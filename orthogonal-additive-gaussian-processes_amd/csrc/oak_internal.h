@@ -153,7 +153,7 @@ struct oak_ctx {
     bool have_linv = false;          // buffers "Linv" / "LinvT" hold L^-1 and its transpose for the current L
     int route = 0;   // 0 auto, 1 phi, 2 whitened
     int gram_form = 0;               // explicit Gram entry points: 0 native arithmetic, 1 the reference's (oak_set_gram_form)
-    int precision = 0;               // 0: fp64 throughout; 1: fp32 Kfu panel + fp32-MFMA Phi partials on the phi route (forward only);
+    int precision = -1;              // -1 (default): 2 where it pays (sgpr_local_stats), 0 elsewhere; 0: fp64 kernels throughout; 1: fp32 Kfu panel + fp32-MFMA Phi partials on the phi route (forward only);
                                      // 2: Phi accumulated exactly on the int8 matrix pipe (scaled 48-bit integers, CRT; phi route)
     int auto_whiten = -1;            // decision of the conditioning check for this evaluation (-1: none, use the size rule)
     bool auto_pending = false;       // the check's result (cond_mm) is still in flight on the side stream
@@ -162,6 +162,7 @@ struct oak_ctx {
     bool cond_seen = false;          // ... and cond_mm holds it for the tail's report (oak_sgpr_last_terms slot 7)
     bool stats_fp32 = false;         // the statistics in "stats" came from the fp32 panel path
     bool stats_crt = false;          // ... Phi of the statistics in "stats" was accumulated exactly on the int8 pipe (crt.hip)
+    int64_t crt_info[6] = {0, 0, 0, 0, 0, 0};   // ... and how (oak_bench_crt_info)
     double cond_mm[2] = {1.0, 1.0};  // min / max of diag chol(Kuu), written by the side stream
     hipEvent_t ev2 = nullptr;        // side stream: conditioning estimate ready
     double noise_var = 0, jitter = 0;
@@ -268,7 +269,8 @@ struct CrtPlan {
 };
 bool crt_supported(const oak_ctx* ctx, int64_t M);
 int crt_plan(oak_ctx* ctx, int64_t na, int64_t M, int64_t n_total, CrtPlan* pl);
-int crt_scales(oak_ctx* ctx, const PreparedKernel& pk, const Feat& FZ, int64_t M, const CrtPlan& pl);
+// kdiag_parts: the featurize pass of X ran its tiled form with the K_diag reduction (kappa_done): its per-workgroup maxima serve
+int crt_scales(oak_ctx* ctx, const PreparedKernel& pk, const Feat& FX, const Feat& FZ, int64_t M, const CrtPlan& pl, bool kdiag_parts);
 int crt_convert_panel(oak_ctx* ctx, const CrtPlan& pl, const double* d_panel, int64_t ldp, int64_t na);
 int crt_accumulate(oak_ctx* ctx, const CrtPlan& pl, int64_t M, bool first_chunk, bool last_chunk, double* d_phi);
 bool gram_crt_supported(const PreparedKernel& pk);

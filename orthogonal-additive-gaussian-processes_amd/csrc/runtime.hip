@@ -247,12 +247,16 @@ __global__ void __launch_bounds__(256) featurize_tile_kernel(DevDesc dd, DevMeas
         if (q < R) kd = __builtin_fma(dd.w[q + 1], e[q], kd);
     __syncthreads();                                   // the X tile is no longer needed: reuse it for the reduction
     tile[threadIdx.x] = (i < n) ? kd : 0.0;
+    tile[256 + threadIdx.x] = (i < n) ? kd : 0.0;     // ... and for the largest K_diag of the workgroup's rows (crt.hip: column scales)
     __syncthreads();
     for (int off = 128; off >= 1; off >>= 1) {
-        if ((int)threadIdx.x < off) tile[threadIdx.x] += tile[threadIdx.x + off];
+        if ((int)threadIdx.x < off) {
+            tile[threadIdx.x] += tile[threadIdx.x + off];
+            tile[256 + threadIdx.x] = fmax(tile[256 + threadIdx.x], tile[256 + threadIdx.x + off]);
+        }
         __syncthreads();
     }
-    if (threadIdx.x == 0) kpart[blockIdx.x] = tile[0];
+    if (threadIdx.x == 0) { kpart[blockIdx.x] = tile[0]; kpart[gridDim.x + blockIdx.x] = tile[256]; }
 }
 
 // tmp[k] = w_k * sum_l w_l * bv * exp(-(loc_k-loc_l)^2 / (2 l^2))   (var_s of the empirical measure, :109-120)
@@ -519,10 +523,11 @@ int featurize(oak_ctx* ctx, const PreparedKernel& pk, const double* dX, int64_t 
     out->xs32 = with_grad ? base + (size_t)3 * D * ld : nullptr;
     out->dcs = with_grad ? base + (size_t)4 * D * ld : nullptr;
     if (ldx <= 31 && n >= 4096) {
-        const size_t lds = sizeof(double) * 256 * (size_t)(ldx | 1);
+        size_t lds = sizeof(double) * 256 * (size_t)(ldx | 1);
+        if (d_kdiag_sum != nullptr && lds < sizeof(double) * 512) lds = sizeof(double) * 512;      // the two reductions' scratch
         const unsigned nblk = (unsigned)((ld + 255) / 256);
         double* d_kpart = nullptr;
-        if (d_kdiag_sum != nullptr) OAK_CHECK(get_buf_t(ctx, "feat_kpart", (size_t)nblk, &d_kpart));
+        if (d_kdiag_sum != nullptr) OAK_CHECK(get_buf_t(ctx, "feat_kpart", (size_t)2 * nblk, &d_kpart));      // [sums | maxima] per workgroup
         featurize_tile_kernel<<<nblk, 256, lds, ctx->stream>>>(pk.dd, pk.dm, pk.d_meas, dX, n, ldx, ld, out->xs, out->cn, out->dcn,
                                                              out->xs32, out->dcs, pk.d_tables, d_kpart);
         if (d_kdiag_sum != nullptr) {
@@ -720,7 +725,7 @@ int oak_ctx_create(int device, oak_ctx** out) {
     ctx->main_part = ss.main_part; ctx->side_part = ss.side_part; ctx->part_cus = ss.part_cus;      // a pooled set may bring its pair along
     ctx->part_cus_req = ss.part_cus_req;
     // development / A-B knob: the statistics precision every new context starts with (oak_sgpr_set_precision overrides it)
-    if (const char* e = getenv("OAK_PRECISION")) { const int v = atoi(e); if (v >= 0 && v <= 2) ctx->precision = v; }
+    if (const char* e = getenv("OAK_PRECISION")) { const int v = atoi(e); if (v >= -1 && v <= 2) ctx->precision = v; }
     { std::lock_guard<std::mutex> lock(oak::g_ctx_mu); oak::g_ctxs.insert(ctx); }
     *out = ctx;
     return OAK_OK;

@@ -297,7 +297,10 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     // bound to scale by.  Route known before the Gram launch: the residue planes come out of the Gram kernel's epilogue (and the fp64
     // panel is written only when a gradient or a further output column reads it); route still pending (auto, large problem) or a
     // kernel shape the fused epilogue is not instantiated for: the fp64 panel is converted by a pass of its own once the route is settled.
-    const bool crt_wanted = ctx->precision == 2 && !use32 && crt_supported(ctx, M);
+    // precision -1 (default, "auto"): the int8 route where it pays -- N M^2 >= 2^36 (the headline problem and its row shards down to
+    // N / 16, config 5; not config 2, where the two routes measure the same 1.05 ms) -- and the fp64 kernels elsewhere
+    const bool crt_auto = ctx->precision == -1 && M >= 512 && (double)N * (double)M * (double)M >= 68719476736.0 && getenv("OAK_NO_AUTO_CRT") == nullptr;
+    const bool crt_wanted = (ctx->precision == 2 || crt_auto) && !use32 && crt_supported(ctx, M);
     const bool crt_fused = crt_wanted && !lazy && !whiten && gram_crt_supported(pk) && getenv("OAK_CRT_UNFUSED") == nullptr;
     const bool crt_panel = ctx->keep_kfu || ctx->n_extra > 0;      // fused pass: somebody reads the fp64 panel afterwards
     bool use_crt = false;
@@ -306,7 +309,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
         const int64_t na = (a0 + rows <= N) ? rows : N - a0;
         if (crt_fused) {
             OAK_CHECK(crt_plan(ctx, na, M, N, &cp));
-            if (chunk_idx == 0) OAK_CHECK(crt_scales(ctx, pk, FZ, M, cp));
+            if (chunk_idx == 0) OAK_CHECK(crt_scales(ctx, pk, FX, FZ, M, cp, kappa_done));
         }
         {
             PhaseTimer t(ctx, "gram");
@@ -378,7 +381,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
         if (use_crt) {
             if (!crt_fused) {
                 OAK_CHECK(crt_plan(ctx, na, M, N, &cp));
-                if (chunk_idx == 0) OAK_CHECK(crt_scales(ctx, pk, FZ, M, cp));
+                if (chunk_idx == 0) OAK_CHECK(crt_scales(ctx, pk, FX, FZ, M, cp, kappa_done));
                 OAK_CHECK(crt_convert_panel(ctx, cp, dSy, Mp, na));
             }
             OAK_CHECK(crt_accumulate(ctx, cp, M, chunk_idx == 0, a0 + rows >= N, st.phi));
@@ -414,6 +417,11 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     ctx->stats_whitened = whiten;
     ctx->stats_fp32 = use32;
     ctx->stats_crt = use_crt;
+    for (int q = 0; q < 6; ++q) ctx->crt_info[q] = 0;
+    if (use_crt) {
+        ctx->crt_info[0] = cp.md.L; ctx->crt_info[1] = cp.B; ctx->crt_info[2] = cp.nsplit; ctx->crt_info[3] = cp.rps;
+        ctx->crt_info[4] = crt_fused ? 1 : 0; ctx->crt_info[5] = cp.Mp2;
+    }
     ctx->have_post = false;
     return OAK_OK;
 }
@@ -1053,7 +1061,8 @@ int oak_sgpr_set_route(oak_ctx* ctx, int32_t route) {
 
 int oak_sgpr_set_precision(oak_ctx* ctx, int32_t mode) {
     OAK_CHECK(guard(ctx));
-    OAK_REQUIRE(mode >= 0 && mode <= 2, "precision must be 0 (fp64), 1 (fp32 statistics) or 2 (exact int8 CRT accumulation of Phi)");
+    OAK_REQUIRE(mode >= -1 && mode <= 2, "precision must be -1 (automatic: int8 CRT accumulation of Phi on large phi-route problems, fp64 kernels otherwise), "
+                                         "0 (fp64 kernels), 1 (fp32 statistics) or 2 (int8 CRT accumulation of Phi wherever it is supported)");
     ctx->precision = mode;
     return OAK_OK;
 }
@@ -1062,6 +1071,13 @@ int oak_sgpr_stats_precision(oak_ctx* ctx, int32_t* mode) {
     OAK_CHECK(guard(ctx));
     OAK_REQUIRE(ctx->have_stats && mode, "no statistics available");
     *mode = ctx->stats_fp32 ? 1 : (ctx->stats_crt ? 2 : 0);
+    return OAK_OK;
+}
+
+int oak_bench_crt_info(oak_ctx* ctx, int64_t* info6) {
+    OAK_CHECK(guard(ctx));
+    OAK_REQUIRE(info6 != nullptr, "oak_bench_crt_info: NULL output");
+    for (int q = 0; q < 6; ++q) info6[q] = ctx->have_stats ? ctx->crt_info[q] : 0;
     return OAK_OK;
 }
 

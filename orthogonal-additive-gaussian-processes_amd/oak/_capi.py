@@ -131,6 +131,7 @@ SIGNATURES = {
     "oak_bench_gram_resident": (C.c_int, [_CTX, _DESC, _D]),
     "oak_bench_potrf": (C.c_int, [_CTX, C.c_int64, C.c_int32, _D, _D]),
     "oak_bench_trsm": (C.c_int, [_CTX, _D, C.c_int64, _D, C.c_int64, C.c_int32, C.c_int32, _D]),
+    "oak_bench_crt_info": (C.c_int, [_CTX, C.POINTER(C.c_int64)]),
     "oak_flow_objective": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, _D, _D]),
     "oak_flow_forward": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32, C.c_int32, _I, _D, _D]),
     "oak_kmeans_plusplus": (C.c_int, [_CTX, _D, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int64, _D, C.c_int32, _D,
@@ -505,10 +506,10 @@ class HipContext:
     def sgpr_set_route(self, route):
         _check(self._lib.oak_sgpr_set_route(self._h, self.ROUTES.get(route, route)))
 
-    PRECISIONS = {"fp64": 0, "fp32": 1, "int8crt": 2}
+    PRECISIONS = {"auto": -1, "fp64": 0, "fp32": 1, "int8crt": 2}
 
     def sgpr_set_precision(self, mode):
-        """'fp64' (default, the reference's arithmetic), 'fp32' = fp32 Kfu panel + fp32-MFMA Phi partials (forward, phi route), or
+        """'auto' (default: 'int8crt' on large phi-route problems, the fp64 kernels elsewhere), 'fp64' (fp64 kernels throughout), 'fp32' = fp32 Kfu panel + fp32-MFMA Phi partials (forward, phi route), or
         'int8crt' = Phi accumulated EXACTLY on the int8 matrix pipe from 48-bit scaled integers (residue planes + Chinese
         remainder reconstruction, csrc/crt.hip; phi route): at least as accurate as the fp64 accumulation, not a lower precision."""
         _check(self._lib.oak_sgpr_set_precision(self._h, self.PRECISIONS.get(mode, mode)))
@@ -893,6 +894,12 @@ class HipContext:
         _check(self._lib.oak_bench_gram_resident(self._h, desc.ref, C.byref(b)))
         return b.value
 
+
+    def bench_crt_info(self) -> dict:
+        """Shape of the most recent int8 CRT accumulation of Phi (all zero when the fp64 / fp32 kernels formed the statistics)."""
+        a = (C.c_int64 * 6)()
+        _check(self._lib.oak_bench_crt_info(self._h, a))
+        return dict(zip(("planes", "bits", "row_splits", "rows_per_split", "fused", "plane_columns"), [int(v) for v in a]))
 
     def bench_potrf(self, n: int, reps: int = 10):
         """(mean ms per factorisation, log det) of the library's Cholesky on an n x n exponential-kernel test matrix."""

@@ -1,0 +1,202 @@
+"""GPU: Phi = Kuf Kuf^T accumulated EXACTLY on the int8 matrix pipe (oak_sgpr_set_precision("int8crt"), csrc/crt.hip; the default
+"auto" mode picks it on large phi-route problems).  What the mode changes is HOW the sum over N rows is formed (scaled 48-bit
+integers, residue planes, int8 MFMA, Chinese remainder reconstruction) -- the fp64 Gram entries, psi, kappa and the whole tail are the
+fp64 kernels' -- so it is held to the fp64 contract, not to a looser one:
+  * Phi against an extended-precision (80-bit accumulation) reference: the int8 route's error -- ONE rounding per panel entry, to 2^-48
+    of the column's a-priori bound -- stays below 4e-14 of sqrt(Phi_aa Phi_bb) (measured 1e-15 .. 5e-15 here; the fp64 MFMA
+    accumulation measures 2e-16 .. 2e-15 on the same problems), i.e. four orders inside the 1e-10 contract of the bound's terms;
+  * the ELBO and every kernel-dependent term against the oracle at <= 1e-10 (the fp64 tolerance), all sub-kernel types;
+  * bit-exact identities that follow from integer arithmetic: fused Gram epilogue == stand-alone conversion pass, LDS-DMA SYRK ==
+    register-staged SYRK, one panel chunk == many chunks (residues carried between chunks), repeated evaluation == itself;
+  * row-shard additivity, ragged shapes (N not a multiple of 16 / 128, M not a multiple of 256), extra output columns, gradient calls,
+    the whitened route and too-small problems (the mode steps aside and says so), a description with a negative order variance (the
+    a-priori bound must not rely on positive semi-definiteness).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+from oak import _capi
+from oracle import c_oracle, oak_oracle as o
+
+pytestmark = pytest.mark.gpu
+
+
+def _problem(N, D, M, R, kinds, seed=0, ls=(0.8, 1.6)):
+    rng = np.random.default_rng(1000 * seed + N + D)
+    spec = cases.random_spec(rng, D, R, kinds)
+    for dim in spec["dims"]:
+        if dim["type"] == "rbf":
+            dim["lengthscale"] = float(rng.uniform(*ls))
+    X = cases.random_inputs(rng, spec, N)
+    Z = X[rng.choice(N, M, replace=False)].copy()
+    y = (np.sin(X[:, 0]) + 0.3 * X[:, 1 % D] + 0.1 * rng.standard_normal(N)).reshape(-1, 1)
+    y = (y - y.mean()) / y.std()
+    return spec, X, y, Z
+
+
+def _stats(ctx, d, mode, s2=0.05):
+    ctx.sgpr_set_precision(mode)
+    e = ctx.sgpr_elbo(d, s2)
+    return e, ctx.sgpr_last_terms(), ctx.sgpr_get_stats(), ctx.sgpr_stats_precision()
+
+
+@pytest.mark.parametrize("N,D,M,R,kinds", [(65536, 8, 512, 2, ("gaussian",)),
+                                           (40000, 20, 384, 4, ("gaussian", "binary", "categorical", "uniform")),
+                                           (50001, 6, 300, 3, ("gaussian", "mog"))])
+def test_phi_against_an_extended_precision_accumulation(N, D, M, R, kinds):
+    """Sampled entries of Phi against sums formed in 80-bit arithmetic from the device's own fp64 Gram panel."""
+    spec, X, y, Z = _problem(N, D, M, R, kinds)
+    ctx = _capi.HipContext(0)
+    d = _capi.KernelDesc(spec)
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("phi")
+    e64, t64, s64, u64 = _stats(ctx, d, "fp64")
+    ec, tc, sc, uc = _stats(ctx, d, "int8crt")
+    assert u64 == "fp64" and uc == "int8crt"
+    P64, Pc = s64[:M * M].reshape(M, M), sc[:M * M].reshape(M, M)
+    np.testing.assert_array_equal(Pc, Pc.T)
+    np.testing.assert_array_equal(sc[M * M + M:], s64[M * M + M:])              # kappa, yy, counts: the fp64 kernels' own
+    np.testing.assert_allclose(sc[M * M:M * M + M], s64[M * M:M * M + M], rtol=1e-13, atol=1e-13 * np.abs(s64[M * M:M * M + M]).max())   # psi: same entries, another summation tree
+    cols = np.unique(np.random.default_rng(5).choice(M, 24, replace=False))
+    K = np.empty((N, len(cols)), dtype=np.longdouble)
+    for lo in range(0, N, 8192):
+        K[lo:lo + 8192] = ctx.gram(d, X[lo:lo + 8192], Z[cols])
+    ref = (K.T @ K).astype(np.longdouble)                                        # 64-bit mantissa accumulation
+    dg = np.sqrt(np.outer(np.diag(ref), np.diag(ref))).astype(np.float64)
+    sub = np.ix_(cols, cols)
+    err_c = np.abs((Pc[sub].astype(np.longdouble) - ref).astype(np.float64)) / dg
+    err_64 = np.abs((P64[sub].astype(np.longdouble) - ref).astype(np.float64)) / dg
+    # one rounding of 2^-48 of the column bound per entry: relative to sqrt(Phi_aa Phi_bb) that is 2^-47 (bound / rms) / sqrt(6 N), with
+    # the Cauchy-Schwarz bound a few hundred times the column's rms for these kernels
+    assert err_c.max() <= 4e-14, err_c.max()
+    assert err_64.max() <= 4e-15, err_64.max()                   # (the fp64 MFMA accumulation, for the record)
+    print(f"Phi error vs 80-bit accumulation: int8crt {err_c.max():.2e}, fp64 {err_64.max():.2e}")
+    # (two Phi that differ by 1e-15 relative reach the bound through W = L^-1 Phi L^-T, i.e. amplified by cond(Kuu): the routes are
+    # compared with each other at 1e-9 here and with the ORACLE at the contract's 1e-10 below)
+    assert abs(ec - e64) <= 1e-9 * abs(e64)
+    ctx.close()
+
+
+@pytest.mark.parametrize("case", ["c2", "mixed", "ragged"])
+def test_bound_and_terms_against_the_oracle(case):
+    if case == "c2":                                             # BASELINE config 2 at full size (cond(Kuu) ~ 1e5: the phi route's hard case)
+        X, y, Z = o.synthetic_problem(65536, 8, 512)
+        spec = o.make_spec(8, 2)
+    elif case == "mixed":
+        spec, X, y, Z = _problem(30000, 18, 256, 4, ("gaussian", "binary", "categorical", "mog", "uniform"), seed=3)
+    else:
+        spec, X, y, Z = _problem(20011, 7, 130, 3, ("gaussian", "gauss2"), seed=4)
+    ref, parts = c_oracle.sgpr_elbo_chunked(spec, X, y, Z, 0.02, chunk=8192, return_parts=True)
+    ctx = _capi.HipContext(0)
+    d = _capi.KernelDesc(spec)
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("phi")
+    e, t, s, used = _stats(ctx, d, "int8crt", 0.02)
+    assert used == "int8crt"
+    assert abs(e - ref) <= 1e-10 * abs(ref), (e, ref)
+    cases.assert_terms_match(t, parts["terms"], rtol=1e-10 if case != "c2" else 1e-9, what=f"int8crt, {case}:")
+    assert ctx.sgpr_elbo(d, 0.02) == e and ctx.sgpr_last_terms() == t          # bitwise repeatable
+    ctx.close()
+
+
+def test_integer_identities_between_the_code_paths():
+    """Exact integer accumulation: every route to the residue planes and through the int8 SYRK gives the SAME Phi, bit for bit."""
+    spec, X, y, Z = _problem(70000, 9, 520, 2, ("gaussian",), seed=7)
+    ctx = _capi.HipContext(0)
+    d = _capi.KernelDesc(spec)
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("phi")
+    _, _, base, used = _stats(ctx, d, "int8crt")
+    assert used == "int8crt"
+    M = Z.shape[0]
+    try:
+        os.environ["OAK_CRT_UNFUSED"] = "1"                      # stand-alone conversion of the fp64 panel instead of the Gram epilogue
+        _, _, s1, _ = _stats(ctx, d, "int8crt")
+        del os.environ["OAK_CRT_UNFUSED"]
+        os.environ["OAK_CRT_SYRK"] = "4"                         # register-staged int8 SYRK instead of the LDS-DMA pipeline
+        _, _, s2, _ = _stats(ctx, d, "int8crt")
+        del os.environ["OAK_CRT_SYRK"]
+    finally:
+        os.environ.pop("OAK_CRT_UNFUSED", None); os.environ.pop("OAK_CRT_SYRK", None)
+    np.testing.assert_array_equal(s1[:M * M], base[:M * M])
+    np.testing.assert_array_equal(s2[:M * M], base[:M * M])
+    ctx.sgpr_set_panel_rows(16384)                               # five panel chunks: residues carried from chunk to chunk
+    _, _, s3, used3 = _stats(ctx, d, "int8crt")
+    ctx.sgpr_set_panel_rows(0)
+    assert used3 == "int8crt"
+    np.testing.assert_array_equal(s3[:M * M], base[:M * M])
+    ctx.close()
+
+
+def test_row_shards_extra_outputs_gradient_and_fallbacks():
+    spec, X, y, Z = _problem(48000, 10, 384, 3, ("gaussian", "binary"), seed=9)
+    N, M = X.shape[0], Z.shape[0]
+    ctx = _capi.HipContext(0)
+    d = _capi.KernelDesc(spec)
+    ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("phi"); ctx.sgpr_set_precision("int8crt")
+    ctx.sgpr_set_data(X, y)
+    e_full = ctx.sgpr_elbo(d, 0.05); full = ctx.sgpr_get_stats(); t_full = ctx.sgpr_last_terms()
+    assert ctx.sgpr_stats_precision() == "int8crt"
+    acc = np.zeros_like(full)
+    for lo, hi in ((0, 17001), (17001, 31000), (31000, N)):
+        ctx.sgpr_set_data(X[lo:hi], y[lo:hi]); ctx.sgpr_local_stats(d); acc += ctx.sgpr_get_stats()
+        assert ctx.sgpr_stats_precision() == "int8crt"
+    np.testing.assert_allclose(acc[:-2], full[:-2], rtol=1e-12, atol=1e-12 * np.abs(full).max())
+    # the fp64 kernels on the same data
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_precision("fp64")
+    e64, g64 = ctx.sgpr_elbo_grad(d, 0.05)
+    ctx.sgpr_set_precision("int8crt")
+    eg, g = ctx.sgpr_elbo_grad(d, 0.05)                          # fused pass that also writes the fp64 panel the backward reads
+    assert ctx.sgpr_stats_precision() == "int8crt"
+    assert abs(eg - e64) <= 1e-9 * abs(e64) and eg == e_full
+    np.testing.assert_allclose(g, g64, rtol=1e-9, atol=1e-9 * np.abs(g64).max())
+    # extra output columns read the fp64 panel for their Kuf y
+    ctx.sgpr_set_extra_targets(np.column_stack([np.cos(X[:, 1]), X[:, 2] ** 2]))
+    e3 = ctx.sgpr_elbo(d, 0.05)
+    assert ctx.sgpr_stats_precision() == "int8crt"
+    ctx.sgpr_set_precision("fp64")
+    e3_64 = ctx.sgpr_elbo(d, 0.05)
+    assert abs(e3 - e3_64) <= 1e-9 * abs(e3_64) and e3_64 != e64
+    ctx.sgpr_set_extra_targets(None)
+    # whitened route: no a-priori bound on L^-1 Kuf -- the fp64 kernels run and the context says so
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_precision("int8crt"); ctx.sgpr_set_route("whitened")
+    ew = ctx.sgpr_elbo(d, 0.05)
+    assert ctx.sgpr_stats_precision() == "fp64" and abs(ew - e64) <= 1e-10 * abs(e64)
+    # too few rows: steps aside as well
+    ctx.sgpr_set_route("phi"); ctx.sgpr_set_data(X[:2000], y[:2000])
+    ctx.sgpr_elbo(d, 0.05)
+    assert ctx.sgpr_stats_precision() == "fp64"
+    # default mode: this size stays on the fp64 kernels (N M^2 < 2^36)
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_precision("auto")
+    assert ctx.sgpr_elbo(d, 0.05) == e64 and ctx.sgpr_stats_precision() == "fp64"
+    ctx.close()
+
+
+def test_negative_order_variance_uses_the_entrywise_bound():
+    """A description whose kernel is not positive semi-definite: Cauchy-Schwarz does not bound its entries; the scales fall back to
+    sum_r |w_r| e_r(max k_d) and Phi still matches the fp64 accumulation."""
+    spec, X, y, Z = _problem(30000, 6, 256, 2, ("gaussian",), seed=11)
+    spec["order_variances"] = [0.3, -0.8, 1.1]
+    ctx = _capi.HipContext(0)
+    d = _capi.KernelDesc(spec)
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("phi")
+    M = Z.shape[0]
+    ctx.sgpr_set_precision("fp64"); ctx.sgpr_local_stats(d); s64 = ctx.sgpr_get_stats()
+    ctx.sgpr_set_precision("int8crt"); ctx.sgpr_local_stats(d); sc = ctx.sgpr_get_stats()
+    assert ctx.sgpr_stats_precision() == "int8crt"
+    P64, Pc = s64[:M * M].reshape(M, M), sc[:M * M].reshape(M, M)
+    dg = np.sqrt(np.outer(np.diag(P64), np.diag(P64)))
+    assert (np.abs(Pc - P64) / dg).max() <= 1e-13
+    ctx.close()
+
+
+def test_deep_kernel_takes_the_stand_alone_conversion():
+    """Depth 6 is outside the fused epilogue's instantiations (<= 4): the fp64 panel is converted by its own pass."""
+    spec, X, y, Z = _problem(24000, 7, 256, 6, ("gaussian",), seed=13)
+    ctx = _capi.HipContext(0)
+    d = _capi.KernelDesc(spec)
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("phi")
+    e64, _, _, _ = _stats(ctx, d, "fp64")
+    ec, _, _, used = _stats(ctx, d, "int8crt")
+    assert used == "int8crt" and abs(ec - e64) <= 1e-9 * abs(e64)
+    ctx.close()
