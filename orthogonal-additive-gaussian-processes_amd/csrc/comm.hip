@@ -144,6 +144,13 @@ int comm_allreduce_scalar_side(oak_ctx* ctx, double* value) {
     OAK_CHECK(get_buf_t(ctx, "comm_ctl", 1, &d));
     hipStream_t main_stream = ctx->stream;
     ctx->stream = ctx->side;
+    if (ctx->part_active && ctx->side == ctx->side_part && ctx->side_full != nullptr && !comm_is_loopback(ctx) && ctx->host_allreduce == nullptr) {
+        // partitioned pass under a real RCCL communicator: the collective's kernels go to the UNMASKED side stream (a communicator
+        // serves one stream pair; RCCL kernels on a CU-masked queue have never run on hardware), ordered behind what side_part holds
+        OAK_HIP_CHECK(hipEventRecord(ctx->ev3, ctx->side_part));
+        OAK_HIP_CHECK(hipStreamWaitEvent(ctx->side_full, ctx->ev3, 0));
+        ctx->stream = ctx->side_full;
+    }
     int rc = [&]() -> int {
         set_scalar_kernel<<<1, 1, 0, ctx->stream>>>(d, *value);
         OAK_HIP_CHECK(hipGetLastError());
@@ -227,17 +234,18 @@ int oak_comm_allreduce_stats(oak_ctx* ctx) {
     OAK_REQUIRE(ctx->have_stats, "no local statistics to reduce");
     if (ctx->comm == nullptr || ctx->nranks <= 1) return OAK_OK;
     double* d_stats = (double*)peek_buf(ctx, "stats");
+    // rank-local validation BEFORE the first collective: a rank that fails it must join neither of the two (a rank that left after
+    // the first would leave its peers blocked in the second)
+    double* d_psix = ctx->n_extra > 0 ? (double*)peek_buf(ctx, "psix") : nullptr;
+    if (ctx->n_extra > 0)
+        OAK_REQUIRE(d_psix != nullptr && ctx->psix_valid, "oak_comm_allreduce_stats: the extra target columns' statistics are not those of the "
+                    "packed statistics in place (form both with oak_sgpr_local_stats on every rank)");
     PhaseTimer t(ctx, "allreduce");
     // the two trailing slots (shards that whitened, shards summed) ride along: the tail rejects a mixed sum
     OAK_CHECK(comm_allreduce_dev(ctx, d_stats, oak_sgpr_stats_len(ctx)));
     // extra target columns: [Kuf y_p | y_p^T y_p] is part of the same sum over the row shards -- reduced HERE, so that the documented
     // local_stats -> allreduce_stats -> tail sequence and the fused entry points exchange the same things
-    if (ctx->n_extra > 0) {
-        double* d_psix = (double*)peek_buf(ctx, "psix");
-        OAK_REQUIRE(d_psix != nullptr && ctx->psix_valid, "oak_comm_allreduce_stats: the extra target columns' statistics are not those of the "
-                    "packed statistics in place (form both with oak_sgpr_local_stats on every rank)");
-        OAK_CHECK(comm_allreduce_dev(ctx, d_psix, (int64_t)ctx->n_extra * ctx->M + ctx->n_extra, "comm_stage_x"));
-    }
+    if (ctx->n_extra > 0) OAK_CHECK(comm_allreduce_dev(ctx, d_psix, (int64_t)ctx->n_extra * ctx->M + ctx->n_extra, "comm_stage_x"));
     t.stop();
     return OAK_OK;
 }

@@ -1087,7 +1087,7 @@ int gram_bwd(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
     // row's live in registers; three LDS reads per pair-dimension fewer.  OPT-IN (OAK_BWD_ROWS=1): built because the r04 verdict asked
     // for it, it fits 256 VGPRs without scratch (253) and halves the LDS instructions, but measures 15.1-15.5 ms against 14.8 at the
     // headline shape -- the wait cycles move from LDS to scalar / vector memory (profiles/r05_pmc_pair_kernels.json).
-    bool rows_form = fast && allrbf && unitbv && !want_gk && tablen == 0 && dmax <= 16 && R <= (dmax == 16 ? 3 : 4) && na >= 16384;
+    bool rows_form = fast && allrbf && unitbv && !want_gk && tablen == 0 && (dmax == 8 || dmax == 16) && R >= 1 && R <= (dmax == 16 ? 3 : 4) && na >= 16384;
     { const char* e = getenv("OAK_BWD_ROWS"); rows_form = rows_form && e != nullptr && atoi(e) != 0; }
     if (rows_form) {
         OAK_REQUIRE(A.xs32 != nullptr && B.xs32 != nullptr, "gram_bwd: features were not prepared for the backward pass");

@@ -197,7 +197,7 @@ int gram_bwd_rows_launch(oak_ctx* ctx, const PreparedKernel& pk, int dmax, const
         case 108: OAK_BR(1, 8) break;   case 116: OAK_BR(1, 16) break;
         case 208: OAK_BR(2, 8) break;   case 216: OAK_BR(2, 16) break;
         case 308: OAK_BR(3, 8) break;   case 316: OAK_BR(3, 16) break;
-        case 408: OAK_BR(4, 8) break;   case 416: OAK_BR(4, 16) break;
+        case 408: OAK_BR(4, 8) break;       // (depth 4 at 16 sub-kernels does not fit the register file: the columns kernel serves it)
         default: set_error("gram_bwd_rows: unsupported shape R=%d dmax=%d", R, dmax); return OAK_E_ARG;
     }
 #undef OAK_BR

@@ -634,12 +634,14 @@ gram_crt_kernel(const DevDesc dd, const double* __restrict__ tables, const doubl
                 unsigned b[RT];
 #pragma unroll
                 for (int r = 0; r < RT; ++r) {
-                    const double q = __builtin_fma(xi[r][c], ip, M52) - M52;
+                    const double q = __builtin_rint(xi[r][c] * ip);        // (v_rndne_f64 issues in half the clocks of the add it replaces)
                     b[r] = (unsigned)__double2loint(__builtin_fma(q, -p, xm[r][c]));
                 }
-                const unsigned w01 = __builtin_amdgcn_perm(b[1], b[0], 0x0c0c0400u);      // bytes: b0.0, b1.0, 0, 0
-                const unsigned w23 = __builtin_amdgcn_perm(b[3], b[2], 0x04000c0cu);      // bytes: 0, 0, b2.0, b3.0
-                *reinterpret_cast<unsigned*>(pl + (colbase + 16 * c) * 16) = w01 | w23;
+                // low bytes of b0 .. b3 -> one dword, three byte permutes (selector 0-3: bytes of the second source, 4-7: of the first)
+                unsigned wv = __builtin_amdgcn_perm(b[1], b[0], 0x07060400u);             // b0.0, b1.0, (b1.2, b1.3)
+                wv = __builtin_amdgcn_perm(b[2], wv, 0x07040100u);                        // b0.0, b1.0, b2.0, (b2.3)
+                wv = __builtin_amdgcn_perm(b[3], wv, 0x04020100u);                        // b0.0, b1.0, b2.0, b3.0
+                *reinterpret_cast<unsigned*>(pl + (colbase + 16 * c) * 16) = wv;
             }
         }
     }

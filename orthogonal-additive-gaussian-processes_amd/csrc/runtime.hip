@@ -614,6 +614,9 @@ static int requested_part_cus() {
     if (const char* e = getenv("OAK_PART_CUS")) side_cus = atoi(e);
     return (side_cus <= 0 || side_cus % 8 != 0 || side_cus > 64) ? 0 : side_cus;
 }
+static std::mutex g_orphan_mu;
+static std::vector<hipStream_t> g_orphans;          // streams of a partition pair whose creation failed half-way (destroyed by shutdown_pool)
+static void park_orphan_stream(hipStream_t s) { std::lock_guard<std::mutex> lock(g_orphan_mu); g_orphans.push_back(s); }
 static void create_partition_streams(StreamSet* ss, int num_cu) {
     const int side_cus = requested_part_cus();
     ss->part_cus_req = side_cus;
@@ -621,10 +624,15 @@ static void create_partition_streams(StreamSet* ss, int num_cu) {
     uint32_t ms[8], mm[8];
     for (int w = 0; w < 8; ++w) { ms[w] = 0u; mm[w] = 0xffffffffu; }
     for (int b = 0; b < side_cus; ++b) { ms[b >> 5] |= 1u << (b & 31); mm[b >> 5] &= ~(1u << (b & 31)); }
+    // NB hipExtStreamCreateWithCUMask takes no flags: the pair is created with hipStreamDefault semantics, i.e. it synchronises with the
+    // legacy NULL stream (the unmasked pair is hipStreamNonBlocking).  The library itself never uses the NULL stream; a host process
+    // that does serialises its NULL-stream work with partitioned passes.
+    // A half-created pair is PARKED, not destroyed: this can run in the middle of an evaluation while other threads use the device,
+    // and hipStreamDestroy is the call that deadlocks there (see below); oak_runtime_shutdown destroys the parked streams.
     hipStream_t a = nullptr, b = nullptr;
     if (hipExtStreamCreateWithCUMask(&a, 8, mm) != hipSuccess) { (void)hipGetLastError(); return; }
-    if (hipExtStreamCreateWithCUMask(&b, 8, ms) != hipSuccess) { (void)hipGetLastError(); (void)hipStreamDestroy(a); return; }
-    if (hipEventCreateWithFlags(&ss->ev3, hipEventDisableTiming) != hipSuccess) { (void)hipStreamDestroy(a); (void)hipStreamDestroy(b); return; }
+    if (hipExtStreamCreateWithCUMask(&b, 8, ms) != hipSuccess) { (void)hipGetLastError(); park_orphan_stream(a); return; }
+    if (hipEventCreateWithFlags(&ss->ev3, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); park_orphan_stream(a); park_orphan_stream(b); return; }
     ss->main_part = a; ss->side_part = b; ss->part_cus = side_cus;
 }
 
@@ -650,6 +658,11 @@ static int shutdown_pool() {
             if (ev) (void)hipEventDestroy(ev);
     }
     g_pool.clear();
+    {
+        std::lock_guard<std::mutex> lock2(g_orphan_mu);
+        for (hipStream_t st : g_orphans) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+        g_orphans.clear();
+    }
     return OAK_OK;
 }
 static int acquire_streams(int device, int num_cu, StreamSet* out) {

@@ -269,6 +269,23 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
         }
         if (level >= 1) want32 = false;
     }
+    // int8 CRT candidate (decided for good further down): its residue planes come out of the Gram kernel, so an auto route that is
+    // still pending is settled BEFORE the first Gram launch -- the side stream's estimate arrives while the main stream featurizes
+    // (~0.2 ms of waiting against the 4 ms a stand-alone conversion pass costs a phi evaluation).  Not in a partitioned pass whose
+    // chain is only enqueued behind the first Gram launch.
+    const bool crt_size = M >= 512 && (double)N * (double)M * (double)M >= 68719476736.0 && getenv("OAK_NO_AUTO_CRT") == nullptr;
+    const bool crt_cand = (ctx->precision == 2 || (ctx->precision == -1 && crt_size)) && crt_supported(ctx, M);
+    if (ctx->auto_pending && crt_cand && gram_crt_supported(pk) && !ctx->kuu_deferred) {
+        OAK_HIP_CHECK(hipEventSynchronize(ctx->ev2));
+        const double ratio = ctx->cond_mm[1] / ctx->cond_mm[0];
+        ctx->auto_whiten = (ratio * ratio > AUTO_WHITEN_DIAG_RATIO2) ? 1 : 0;
+        if (ctx->comm != nullptr && ctx->nranks > 1) {          // rank 0's decision is the one all ranks take (as below)
+            double flag = (ctx->rank == 0) ? (double)ctx->auto_whiten : 0.0;
+            OAK_CHECK(comm_allreduce_scalar_side(ctx, &flag));
+            ctx->auto_whiten = flag > 0.5 ? 1 : 0;
+        }
+        ctx->auto_pending = false;
+    }
     const bool lazy = ctx->auto_pending;
     bool whiten = lazy ? false : sgpr_route_whitened(ctx);
     const bool use32 = want32 && !whiten && pk.dd.R <= 16 && !pk.grouped;       // the fp32 Gram kernel is instantiated to depth 16
@@ -299,8 +316,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     // kernel shape the fused epilogue is not instantiated for: the fp64 panel is converted by a pass of its own once the route is settled.
     // precision -1 (default, "auto"): the int8 route where it pays -- N M^2 >= 2^36 (the headline problem and its row shards down to
     // N / 16, config 5; not config 2, where the two routes measure the same 1.05 ms) -- and the fp64 kernels elsewhere
-    const bool crt_auto = ctx->precision == -1 && M >= 512 && (double)N * (double)M * (double)M >= 68719476736.0 && getenv("OAK_NO_AUTO_CRT") == nullptr;
-    const bool crt_wanted = (ctx->precision == 2 || crt_auto) && !use32 && crt_supported(ctx, M);
+    const bool crt_wanted = crt_cand && !use32;
     const bool crt_fused = crt_wanted && !lazy && !whiten && gram_crt_supported(pk) && getenv("OAK_CRT_UNFUSED") == nullptr;
     const bool crt_panel = ctx->keep_kfu || ctx->n_extra > 0;      // fused pass: somebody reads the fp64 panel afterwards
     bool use_crt = false;

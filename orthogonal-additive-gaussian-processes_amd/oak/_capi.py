@@ -176,8 +176,9 @@ def _shutdown_runtime():
     """Interpreter exit.  Only when a profiler is attached (its finaliser crashes on CU-masked queues left alive) or OAK_SHUTDOWN_AT_EXIT=1
     asks for it: close the contexts still alive, then let the library destroy its pooled streams (oak_runtime_shutdown) -- while the process
     is still whole (a C-level exit handler would run after the profiler's per-thread state is gone).  Otherwise nothing is torn down at
-    exit, as before r05: an ordinary process makes no HIP call on its way out (hipStreamDestroy is the call that can deadlock against the
-    runtime's event thread), the driver reclaims streams and memory."""
+    exit, as before r05: this handler makes no HIP call (hipStreamDestroy is the call that can deadlock against the runtime's event thread,
+    DESIGN.md section 6a) and the driver reclaims streams and memory -- a HipContext finalised by the garbage collector still runs
+    oak_ctx_destroy (stream synchronisation, hipFree / hipHostFree; its streams go back to the pool, none is destroyed)."""
     want = os.environ.get("OAK_SHUTDOWN_AT_EXIT")
     if want == "0" or (want is None and not _profiler_attached()):
         return

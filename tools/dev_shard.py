@@ -13,7 +13,7 @@ N, D, M, R = 1 << 20, 16, 1024, 2
 X, y, Z = bench.synthetic(N, D, M)
 spec = bench.make_spec(D, R)
 ctx = _capi.default_context()
-PH = ["featurize", "gram", "syrk", "reduce", "tail", "total"]
+PH = ["featurize", "gram", "syrk", "crt_syrk", "crt_reduce", "reduce", "tail", "total"]
 GS = tuple(int(a) for a in sys.argv[1:]) or (1, 2, 4, 8)      # e.g. `dev_shard.py 8` under rocprofv3 for one shard size
 for g in GS:
     n = N // g
@@ -31,4 +31,4 @@ for g in GS:
     ph = {k: round(ctx.timing(k)[0] / K, 3) for k in PH}
     if g == GS[0]:
         base = dt * g                      # perfect strong scaling measured from the first (largest) shard of this run
-    print(f"g={g} rows={n} wall={dt*1e3:.2f} ms  linear={base*1e3/g:.2f}  {ph}")
+    print(f"g={g} rows={n} wall={dt*1e3:.2f} ms  linear={base*1e3/g:.2f}  precision={ctx.sgpr_stats_precision()}  {ph}")
