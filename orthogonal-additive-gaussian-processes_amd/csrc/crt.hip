@@ -1,10 +1,12 @@
 // Phi = Kuf Kuf^T (oak/utils.py:189-190; GPflow's AAT before whitening) on the INT8 matrix pipe, exactly: the "Ozaki scheme II" /
 // Chinese-remainder construction.  Opt-in (oak_sgpr_set_precision(ctx, 2)), phi route only.
 //
-//   1. every column m of the Kfu panel gets a power-of-two scale 2^s_m from an A-PRIORI bound (no pass over the panel):
-//          |K(x, z_m)| <= sqrt(K(x, x) K(z_m, z_m)) <= sqrt(Kmax * K_diag(z_m))          (K is positive semi-definite)
-//      with Kmax = sum_r w_r e_r(max_x k_1(x, x), .., max_x k_D(x, x)) from the kernel description alone;
-//      A[n, m] = rint(K[n, m] 2^s_m) is an integer of at most B = 48 bits;
+//   1. every column m of the Kfu panel gets a power-of-two scale 2^s_m from a bound that needs no pass over the panel:
+//          |K(x_n, z_m)| <= sqrt(K(x_n, x_n) K(z_m, z_m)) <= sqrt(max_n K_diag(x_n) * K_diag(z_m))       (K is positive semi-definite)
+//      -- max_n K_diag(x_n) falls out of the featurize pass's kappa reduction, K_diag(z_m) is one small launch; both are capped by
+//      Kmax = sum_r |w_r| e_r(sup k_1, .., sup k_D) from the kernel description alone, which also serves a description that is not
+//      positive semi-definite (negative order variance);
+//      A[n, m] = rint(K[n, m] 2^s_m) is an integer of at most B bits, B = 48 .. 50 (what the moduli of step 2 leave room for);
 //   2. L pairwise coprime moduli p_i <= 254 with prod p_i > 2 N 2^(2B-2); residue planes R_i = A mod p_i (int8, |r| <= 127),
 //      laid out [plane][n / 16][m][n % 16] so that an MFMA operand fragment is one 16-byte unit;
 //   3. C_i = R_i^T R_i by v_mfma_i32_32x32x32_i8, int32 accumulation over row splits short enough to be exact, summed (int64) and
@@ -415,10 +417,13 @@ bool crt_supported(const oak_ctx* ctx, int64_t M) {
 // multiple of 8 -- one XCD each --, <= 32768 rows: int32 sums are exact to 2^31 / 128^2 = 131 072 rows, whole 128-row stages) and the
 // buffers (grow-only, so a later, shorter chunk fits).
 int crt_plan(oak_ctx* ctx, int64_t na, int64_t M, int64_t n_total, CrtPlan* pl) {
+    // Integer width: the moduli are chosen for 48-bit integers (prod p_i > 2 N 2^(2B-2)); whatever head room their product then
+    // leaves is spent on wider integers at no cost -- B = 49 at N = 2^20 (15 moduli, 117.9 bits >= 2 x 49 - 1 + 20.25), 50 up to
+    // 2^18 rows (50 is the cap: the conversion's magic-constant arithmetic holds |x| < 2^51).
     pl->B = 48;
-    if (const char* e = getenv("OAK_CRT_BITS")) { const int v = atoi(e); if (v >= 40 && v <= 50) pl->B = v; }      // experiment knob
     pl->Mp2 = pad_to(M, 256);
-    const double need = 2.0 * pl->B - 1.0 + std::log2((double)n_total) + 0.25;
+    const double lgn = std::log2((double)n_total);
+    const double need = 2.0 * pl->B - 1.0 + lgn + 0.25;
     pl->md.L = 0;
     double bits = 0.0;
     while (bits <= need && pl->md.L < CRT_MAXL) {
@@ -426,6 +431,17 @@ int crt_plan(oak_ctx* ctx, int64_t na, int64_t M, int64_t n_total, CrtPlan* pl) 
         bits += std::log2((double)kCrtModuli[pl->md.L]); ++pl->md.L;
     }
     OAK_REQUIRE(bits > need, "int8 CRT statistics: %lld rows need more than %d moduli", (long long)n_total, CRT_MAXL);
+    while (pl->B < 50 && 2.0 * (pl->B + 1) - 1.0 + lgn + 0.25 < bits) ++pl->B;
+    if (const char* e = getenv("OAK_CRT_BITS")) {      // experiment knob: a fixed width (the moduli follow)
+        const int v = atoi(e);
+        if (v >= 40 && v <= 50) {
+            pl->B = v; pl->md.L = 0; bits = 0.0;
+            while (bits <= 2.0 * v - 1.0 + lgn + 0.25 && pl->md.L < CRT_MAXL) {
+                pl->md.p[pl->md.L] = kCrtModuli[pl->md.L]; pl->md.inv[pl->md.L] = 1.0 / kCrtModuli[pl->md.L];
+                bits += std::log2((double)kCrtModuli[pl->md.L]); ++pl->md.L;
+            }
+        }
+    }
     pl->nsplit = (int)pad_to((na + 32767) / 32768, 8);
     pl->rps = pad_to((na + pl->nsplit - 1) / pl->nsplit, CST);
     pl->rows_pad = pl->rps * pl->nsplit;

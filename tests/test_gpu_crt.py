@@ -2,9 +2,10 @@
 "auto" mode picks it on large phi-route problems).  What the mode changes is HOW the sum over N rows is formed (scaled 48-bit
 integers, residue planes, int8 MFMA, Chinese remainder reconstruction) -- the fp64 Gram entries, psi, kappa and the whole tail are the
 fp64 kernels' -- so it is held to the fp64 contract, not to a looser one:
-  * Phi against an extended-precision (80-bit accumulation) reference: the int8 route's error -- ONE rounding per panel entry, to 2^-48
-    of the column's a-priori bound -- stays below 4e-14 of sqrt(Phi_aa Phi_bb) (measured 1e-15 .. 5e-15 here; the fp64 MFMA
-    accumulation measures 2e-16 .. 2e-15 on the same problems), i.e. four orders inside the 1e-10 contract of the bound's terms;
+  * Phi against an extended-precision (80-bit accumulation) reference: the int8 route's error -- ONE rounding per panel entry, to 2^-B
+    of the column's bound, B = 48 .. 50 -- stays below 4e-14 of sqrt(Phi_aa Phi_bb) (measured 2e-16 .. 9e-16 on these problems, the
+    fp64 MFMA accumulation 3e-16 .. 4e-16; at the headline size both are ~1e-15), i.e. four orders inside the 1e-10 contract of the
+    bound's terms;
   * the ELBO and every kernel-dependent term against the oracle at <= 1e-10 (the fp64 tolerance), all sub-kernel types;
   * bit-exact identities that follow from integer arithmetic: fused Gram epilogue == stand-alone conversion pass, LDS-DMA SYRK ==
     register-staged SYRK, one panel chunk == many chunks (residues carried between chunks), repeated evaluation == itself;
