@@ -17,6 +17,9 @@
 #ifndef OAK_GRAM_PREFETCH
 #define OAK_GRAM_PREFETCH 1
 #endif
+#ifndef OAK_GRAM_WAVE_STAGE
+#define OAK_GRAM_WAVE_STAGE 1
+#endif
 
 namespace oak {
 
@@ -97,8 +100,54 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
 #pragma unroll
     for (int c = 0; c < CPT; ++c) psi[c] = 0.0;
 
+#if OAK_GRAM_WAVE_STAGE
+    // WAVE-PRIVATE row staging (r06): wave ty reads only the RT rows it owns (Ax[d * RS + ty * RT + r]), so it also stages only those
+    // -- D * RT values per array, one (<= 16 sub-kernels) or RT (<= 64) per lane -- and the row loop needs NO workgroup barrier: a
+    // wave's LDS operations execute in program order, its writes of step s + 1 follow its reads of step s.  (The cooperative form
+    // below spent two __syncthreads per 16-row step: 17 % of the wave time parked, profiles/r05_pmc_pair_kernels.json.)  The next
+    // step's values are fetched into registers under the current step's arithmetic, raw and from clamped addresses.
+    constexpr int NSW = (CPT == 4) ? 1 : RT;
+    const int lane = tid & 63;
+    double rx[NSW], rc[NSW], ry = 0.0;
+    auto fetch_rows = [&](int64_t i0n) {
+#pragma unroll
+        for (int s4 = 0; s4 < NSW; ++s4) {
+            const int idx = lane + 64 * s4;
+            const int d = idx / RT, r = idx - d * RT;
+            int64_t gi = i0n + ty * RT + r;
+            gi = gi < iend ? gi : iend - 1;
+            const bool in = idx < D * RT;
+            rx[s4] = in ? Axs[(int64_t)d * a_ld + a0 + gi] : 0.0;
+            rc[s4] = in ? Acn[(int64_t)d * a_ld + a0 + gi] : 0.0;
+        }
+        if (yA != nullptr && lane < RT) { const int64_t gi = i0n + ty * RT + lane; ry = yA[a0 + (gi < iend ? gi : iend - 1)]; }
+    };
+    if (ib < iend) fetch_rows(ib);
+    __syncthreads();   // B-side features, exp2 table, discrete tables staged
+    for (int64_t i0 = ib; i0 < iend; i0 += RS) {
+#pragma unroll
+        for (int s4 = 0; s4 < NSW; ++s4) {
+            const int idx = lane + 64 * s4;
+            if (idx < D * RT) {
+                const int d = idx / RT, r = idx - d * RT;
+                const bool ok = i0 + ty * RT + r < iend;
+                const double pre = (ALLRBF || dd.type[d] == OAK_DIM_RBF) ? 0.03125 : 1.0;
+                Ax[d * RS + ty * RT + r] = ok ? rx[s4] * pre : 0.0;
+                Ac[d * RS + ty * RT + r] = ok ? rc[s4] : 0.0;
+            }
+        }
+        if (yA != nullptr && lane < RT) Ay[ty * RT + lane] = (i0 + ty * RT + lane < iend) ? ry : 0.0;
+        if constexpr (GRP) {
+            for (int idx = lane; idx < nx * RT; idx += 64) {
+                const int q = idx / RT, r = idx - q * RT;
+                Aq[q * RS + ty * RT + r] = (i0 + ty * RT + r < iend) ? Axx[(int64_t)q * a_ld + a0 + i0 + ty * RT + r] * 0.03125 : 0.0;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // (compiler ordering only: the wave's own LDS writes before its reads)
+        if (i0 + RS < iend) fetch_rows(i0 + RS);
+#else
 #if OAK_GRAM_PREFETCH
-    // Row-side features of the NEXT row step are fetched into registers while the current one is computed (D * RS <= 1024 values per
+    // (cooperative staging, kept for A/B: -DOAK_GRAM_WAVE_STAGE=0)  Row-side features of the NEXT row step are fetched into registers while the current one is computed (D * RS <= 1024 values per
     // array: at most four per thread), raw and from clamped addresses; mask and pre-scale are applied when they go to LDS.  Without
     // this the global loads sat between the two barriers of a step: every wave of the workgroup waited out an HBM latency per 16 rows.
     // (the launcher pairs CPT = 4 with <= 16 sub-kernels: one value per thread there; CPT = 2 goes to 64)
@@ -156,6 +205,7 @@ gram_kernel(const DevDesc dd, const double* __restrict__ tables, const double* _
         if (i0 + RS < iend) fetch_rows(i0 + RS);
 #endif
 
+#endif   // OAK_GRAM_WAVE_STAGE
         double e[RT][CPT][R > 0 ? R : 1];
 #pragma unroll
         for (int r = 0; r < RT; ++r)
