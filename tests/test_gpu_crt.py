@@ -96,7 +96,7 @@ def test_bound_and_terms_against_the_oracle(case):
     e, t, s, used = _stats(ctx, d, "int8crt", 0.02)
     assert used == "int8crt"
     assert abs(e - ref) <= 1e-10 * abs(ref), (e, ref)
-    cases.assert_terms_match(t, parts["terms"], rtol=1e-10 if case != "c2" else 1e-9, what=f"int8crt, {case}:")
+    cases.assert_terms_match(t, parts["terms"], rtol=1e-10, what=f"int8crt, {case}:")
     assert ctx.sgpr_elbo(d, 0.02) == e and ctx.sgpr_last_terms() == t          # bitwise repeatable
     ctx.close()
 
