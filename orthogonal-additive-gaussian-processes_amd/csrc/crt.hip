@@ -195,11 +195,15 @@ __global__ void __launch_bounds__(512, 1) crt_syrk_i8_kernel(const int8_t* __res
 // limit (1.55-1.75 GHz; the MFMAs alone take 9.8e6 of 1.27e7 cycles), so only work NOT done is time.  Hence the diagonal tiles
 // (bi == bj): one side is fetched (both operands are the same columns) and only the 36 of 64 MFMA tiles per k-step that touch the
 // upper triangle are issued -- by straight-line code per wave role (MASK, bit 2 x + y), not by predicates in one loop (those cost
-// the schedule of EVERY tile: 9.8 ms).  Integer results: any mistake in the hand-written waits shows as a Phi that differs from the
+// the schedule of EVERY tile: 9.8 ms).  The price: diagonal tiles now run ahead of the other tiles of their row split, the split's rows
+// no longer stream through the L2 once (fabric fetch 19-27 GB -> 42-47 GB per launch, L2 hit rate 0.70 -> 0.32) -- and the kernel is
+// still 0.3-0.5 ms faster (9.1-9.3 vs 9.5-9.7 ms with OAK_CRT_DIAG=0).  Spreading a diagonal tile's MFMA tiles evenly over the four SIMDs
+// ({8+0, 8+0, 7+3, 7+3} instead of 3 / 7 / 11 / 15) changed nothing (its stage time is not the matrix pipe's), and neither did dispatching
+// all off-diagonal tiles of an XCD ahead of its diagonal ones (fetch 37 GB, same 9.2-9.3 ms).  Integer results: any mistake in the hand-written waits shows as a Phi that differs from the
 // register-staged kernel's bit for bit (tests/test_gpu_crt.py).
 template <unsigned MASK> struct CrtMask { static constexpr unsigned value = MASK; };
 __global__ void __launch_bounds__(512, 1) crt_syrk_i8_deep_kernel(const int8_t* __restrict__ planes, int64_t rows_pad, int Mp2, int nt2, int64_t rows_per_split,
-                                                                  int nsplit, int* __restrict__ part) {
+                                                                  int nsplit, int* __restrict__ part, int diag_mode) {
     extern __shared__ __attribute__((aligned(16))) crt_v4i crt_lds[];      // [NBUF][2 sides][4 groups][CT2 cols]
     constexpr int NBUF = 4, SGR = 4, SIDE = SGR * CT2, SLOT = 2 * SIDE, D = NBUF - 1;
     const int ntile = nt2 * (nt2 + 1) / 2;
@@ -211,11 +215,11 @@ __global__ void __launch_bounds__(512, 1) crt_syrk_i8_deep_kernel(const int8_t* 
     const int8_t* plane = planes + (int64_t)blockIdx.y * rows_pad * Mp2;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool diag = bi == bj && diag_mode != 0;
     const int wr = wave >> 2, wc = wave & 3;
     const int h = lane >> 5, c = lane & 31;
     const int64_t g0 = (int64_t)split * rows_per_split / 16, g1 = g0 + rows_per_split / 16;
     const crt_v4i* P = reinterpret_cast<const crt_v4i*>(plane);
-    const bool diag = bi == bj;
     crt_v16i acc[4][2];
 #pragma unroll
     for (int x = 0; x < 4; ++x)
@@ -504,10 +508,16 @@ int crt_accumulate(oak_ctx* ctx, const CrtPlan& pl, int64_t M, bool first_chunk,
         // A/B knob (and the reference of tests/test_gpu_crt.py): OAK_CRT_SYRK=4 runs the register-staged kernel
         const char* ev = getenv("OAK_CRT_SYRK");
         const int variant = ev ? atoi(ev) : 64;
-        auto kern = variant == 4 ? crt_syrk_i8_kernel : crt_syrk_i8_deep_kernel;
         const int threads = 512;
-        OAK_CHECK(ensure_max_dynamic_lds((const void*)kern));
-        kern<<<dim3((unsigned)(ntile2 * pl.nsplit), (unsigned)md.L), threads, lds, ctx->stream>>>(pl.d_planes, pl.rows_pad, (int)pl.Mp2, nt2, pl.rps, pl.nsplit, pl.d_part);
+        const int diag_mode = getenv("OAK_CRT_DIAG") ? atoi(getenv("OAK_CRT_DIAG")) : 1;      // A/B knob: 0 = diagonal tiles run like any other tile
+        const dim3 sgrid((unsigned)(ntile2 * pl.nsplit), (unsigned)md.L);
+        if (variant == 4) {
+            OAK_CHECK(ensure_max_dynamic_lds((const void*)crt_syrk_i8_kernel));
+            crt_syrk_i8_kernel<<<sgrid, threads, lds, ctx->stream>>>(pl.d_planes, pl.rows_pad, (int)pl.Mp2, nt2, pl.rps, pl.nsplit, pl.d_part);
+        } else {
+            OAK_CHECK(ensure_max_dynamic_lds((const void*)crt_syrk_i8_deep_kernel));
+            crt_syrk_i8_deep_kernel<<<sgrid, threads, lds, ctx->stream>>>(pl.d_planes, pl.rows_pad, (int)pl.Mp2, nt2, pl.rps, pl.nsplit, pl.d_part, diag_mode);
+        }
         OAK_HIP_CHECK(hipGetLastError());
         t.stop();
     }
