@@ -1,5 +1,6 @@
 // Phi = Kuf Kuf^T (oak/utils.py:189-190; GPflow's AAT before whitening) on the INT8 matrix pipe, exactly: the "Ozaki scheme II" /
-// Chinese-remainder construction.  Opt-in (oak_sgpr_set_precision(ctx, 2)), phi route only.
+// Chinese-remainder construction.  oak_sgpr_set_precision: the automatic default on large phi-route problems (N M^2 >= 2^36), forced
+// by mode 2, off in mode 0; phi route only.
 //
 //   1. every column m of the Kfu panel gets a power-of-two scale 2^s_m from a bound that needs no pass over the panel:
 //          |K(x_n, z_m)| <= sqrt(K(x_n, x_n) K(z_m, z_m)) <= sqrt(max_n K_diag(x_n) * K_diag(z_m))       (K is positive semi-definite)
@@ -12,8 +13,10 @@
 //   3. C_i = R_i^T R_i by v_mfma_i32_32x32x32_i8, int32 accumulation over row splits short enough to be exact, summed (int64) and
 //      reduced mod p_i;
 //   4. Garner / mixed-radix reconstruction of the exact integer X = A^T A from (C_1 .. C_L), Phi[a, b] = X[a, b] 2^(-s_a - s_b).
-// The only error is the rounding of step 1 (|delta| <= 1/2 in the last of 48 bits, independent from entry to entry): the sum over
-// N rows is exact, where the fp64 MFMA SYRK rounds N times (measured r05, tools/ubench/ozaki2_syrk.hip: 3.8e-16 against 1.7e-15).
+// The only error is the rounding of step 1 (|delta| <= 1/2 in the last of B bits, independent from entry to entry): the sum over
+// N rows is exact, where the fp64 MFMA SYRK rounds N times.  Measured against 80-bit accumulation (tests/test_gpu_crt.py): 2e-16 .. 9e-16
+// of sqrt(Phi_aa Phi_bb), the fp64 accumulation 3e-16 .. 4e-16 on the same problems; r05 probe with true column maxima
+// (tools/ubench/ozaki2_syrk.hip): 3.8e-16 against 1.7e-15.
 #include "oak_internal.h"
 #include <algorithm>
 #include <cmath>
@@ -24,8 +27,8 @@ namespace oak {
 typedef int crt_v4i __attribute__((ext_vector_type(4)));
 typedef int crt_v16i __attribute__((ext_vector_type(16)));
 
-// pairwise coprime, largest first; <= 254 so that a residue formed with one sloppy fp32 rounding of the quotient (fused epilogue of
-// the Gram kernel) still fits a signed byte
+// pairwise coprime, largest first; <= 254: every residue -- also one formed from a quotient that is off by one next to a tie -- fits a
+// signed byte with |r| <= 127, so that 32768 rows of products stay below 2^31
 static const int kCrtModuli[CRT_MAXL] = {254, 253, 251, 249, 247, 245, 241, 239, 233, 229, 227, 223, 211, 199, 197, 193, 191, 181, 179, 173};
 
 static int modinv(int a, int p) {
@@ -35,7 +38,6 @@ static int modinv(int a, int p) {
 }
 
 // ---- 1. column scales -------------------------------------------------------------------------------------------------------------
-// sexp[m] = B - 1 - e with bound_m < 2^e; columns beyond M (zero padding) get the scale of column 0 (their entries are exact zeros)
 // kmax_x[0] <- max of x[0 .. n) (one workgroup; n = the featurize pass's per-workgroup maxima of K_diag, or all K_diag values)
 __global__ void __launch_bounds__(256) crt_max_kernel(const double* __restrict__ x, int64_t n, double* __restrict__ out) {
     __shared__ double sh[256];
@@ -50,6 +52,7 @@ __global__ void __launch_bounds__(256) crt_max_kernel(const double* __restrict__
     if (threadIdx.x == 0) out[0] = sh[0];
 }
 
+// sexp[m] = B - 1 - e with bound_m < 2^e; columns beyond M (zero padding) get the scale of column 0 (their entries are exact zeros).
 // psd = 0 (a negative order variance in the description: K need not be positive semi-definite): the entry-wise bound
 // |K| <= sum_r |w_r| e_r(kmax_1 .. kmax_D) = kmax for every column instead of the Cauchy-Schwarz one
 // psd = 1: |K(x, z_m)| <= sqrt(max_n K_diag(x_n) K_diag(z_m)) with the largest K_diag of THIS rank's rows from the device (kmax_x; never
