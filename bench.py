@@ -513,7 +513,10 @@ def main():
                         peak=INT8_PEAK_TOPS, unit="TOP/s", frac=ach / INT8_PEAK_TOPS, traffic=traffic.get(args.config, {}).get("crt_syrk"),
                         traffic_source=traffic_src, avg_launch_ms=syrk_ms, algorithmic_ops_per_launch=ops, planes=planes, crt=crt_info,
                         note="int8 operations (multiply-add = 2), algorithmic = upper triangle; the kernel runs against the 1400 W power "
-                             "limit at 1.55-1.75 GHz (profiles/r06_crt_syrk_clocks.txt, r06_power_crt_step.txt), not at the 2.4 GHz the peak assumes",
+                             "limit at 1.55-1.75 GHz (profiles/r06_crt_syrk_clocks.txt, r06_power_crt_step.txt), not at the 2.4 GHz the peak assumes; "
+                             "an MFMA-only loop over the same tiles (operand fragments read once, no memory traffic) sustains 3.5 POP/s of executed "
+                             "operations at 1.67 GHz (profiles/r05_ubench_ozaki2.txt, probe 4): the kernel executes 1.03x the algorithmic operations",
+                        frac_of_guide_measured_ceiling=ach / 3944.0,
                         fp64_equivalent={"what": "M(M+1)N fp64 flops of Phi / (residue conversion in the Gram epilogue + int8 SYRK + split sums and "
                                                  "reconstruction)", "ms": emu_ms,
                                          "conversion_ms (Gram kernel with epilogue minus without, same run)": conv_ms, "reduce_ms": red_ms,

@@ -3,7 +3,8 @@ stated (order 3: a different instantiation of the fused Gram / backward kernels)
 properties, since the CPU oracle cannot finish that size in seconds:
   * row-shard additivity of the sufficient statistics (the multi-GPU contract) and exact symmetry of Phi;
   * bitwise determinism of repeated evaluations;
-  * a 1/16 row sample against the multi-core oracle at the full M, both routes: the total (<= 1e-10) AND every
+  * a 1/16 row sample against the multi-core oracle at the full M, both routes and -- on the phi route -- both accumulations of Phi
+    (the default exact int8 / CRT one and the fp64 MFMA SYRK): the total (<= 1e-10) AND every
     kernel-dependent term of the bound on its own (sum log diag LB, c^T c, tr AAT, kappa, log det Kuu; <= 1e-10 relative each:
     at this size the total is dominated by the data-only terms, so a bound on the total alone would tolerate ~1e-2 absolute
     error in the kernel-dependent ones);
@@ -42,6 +43,7 @@ def test_fullsize_statistics_additivity_symmetry_determinism(problem):
     ctx.sgpr_set_data(X, y)
     ctx.sgpr_local_stats(d)
     full = ctx.sgpr_get_stats()
+    assert ctx.sgpr_stats_precision() == "int8crt"              # the default at this size: Phi accumulated exactly on the int8 pipe
     e1 = ctx.sgpr_elbo(d, 0.01)
     t1 = ctx.sgpr_last_terms()
     assert ctx.sgpr_elbo(d, 0.01) == e1 and ctx.sgpr_last_terms() == t1      # bitwise repeatable, term by term
@@ -70,11 +72,15 @@ def test_fullsize_sample_against_multicore_oracle(problem):
     ctx = _capi.HipContext(0)
     d = _capi.KernelDesc(spec)
     ctx.sgpr_set_data(X[:ns], y[:ns]); ctx.sgpr_set_inducing(Z)
-    for route in ("phi", "whitened"):
-        ctx.sgpr_set_route(route)
+    # phi route with both accumulations of Phi (the default at this size: exact int8 / CRT, csrc/crt.hip; and the fp64 MFMA SYRK),
+    # whitened route (fp64 kernels): all three at the same 1e-10 on the total and on every term
+    for route, precision, expect in (("phi", "auto", "int8crt"), ("phi", "fp64", "fp64"), ("whitened", "auto", "fp64")):
+        ctx.sgpr_set_route(route); ctx.sgpr_set_precision(precision)
         e = ctx.sgpr_elbo(d, 0.01)
-        assert abs(e - ref) <= 1e-10 * abs(ref), (route, e, ref)
-        cases.assert_terms_match(ctx.sgpr_last_terms(), parts["terms"], rtol=1e-10, what=f"order {R}, route {route}:")
+        assert ctx.sgpr_stats_precision() == expect, (route, precision, ctx.sgpr_stats_precision())
+        assert abs(e - ref) <= 1e-10 * abs(ref), (route, precision, e, ref)
+        cases.assert_terms_match(ctx.sgpr_last_terms(), parts["terms"], rtol=1e-10, what=f"order {R}, route {route}, precision {precision}:")
+    ctx.sgpr_set_precision("auto")
     # explicit Gram on sampled rows
     rows = np.random.default_rng(0).choice(N, 2048, replace=False)
     K = ctx.gram(d, X[rows], Z)
@@ -153,6 +159,11 @@ def test_c5_size_mixed_kernel_properties():
     ctx.sgpr_set_data(X, y)
     ctx.sgpr_local_stats(d)
     full = ctx.sgpr_get_stats()
+    assert ctx.sgpr_stats_precision() == "int8crt"              # mixed kernel at depth 4: the fused residue epilogue's CPT = 2 form
+    ctx.sgpr_set_precision("fp64"); ctx.sgpr_local_stats(d); full64 = ctx.sgpr_get_stats(); ctx.sgpr_set_precision("auto")
+    P, P64 = full[:M5 * M5].reshape(M5, M5), full64[:M5 * M5].reshape(M5, M5)
+    dg = np.sqrt(np.outer(np.diag(P64), np.diag(P64)))
+    assert (np.abs(P - P64) / dg).max() <= 1e-13               # the two accumulations of Phi against each other (measured 8e-15)
     acc = np.zeros_like(full)
     for lo, hi in ((0, 100_003), (100_003, N5)):
         ctx.sgpr_set_data(X[lo:hi], y[lo:hi]); ctx.sgpr_local_stats(d); acc += ctx.sgpr_get_stats()
