@@ -202,7 +202,9 @@ __global__ void __launch_bounds__(512, 1) crt_syrk_i8_kernel(const int8_t* __res
 // no longer stream through the L2 once (fabric fetch 19-27 GB -> 42-47 GB per launch, L2 hit rate 0.70 -> 0.32) -- and the kernel is
 // still 0.3-0.5 ms faster (9.1-9.3 vs 9.5-9.7 ms with OAK_CRT_DIAG=0).  Spreading a diagonal tile's MFMA tiles evenly over the four SIMDs
 // ({8+0, 8+0, 7+3, 7+3} instead of 3 / 7 / 11 / 15) changed nothing (its stage time is not the matrix pipe's), and neither did dispatching
-// all off-diagonal tiles of an XCD ahead of its diagonal ones (fetch 37 GB, same 9.2-9.3 ms).  Integer results: any mistake in the hand-written waits shows as a Phi that differs from the
+// all off-diagonal tiles of an XCD ahead of its diagonal ones (fetch 37 GB, same 9.2-9.3 ms); PACING the diagonal tiles on the progress of
+// an off-diagonal tile of their split (a counter per tile in L2, polled every 16 stages by one lane) cost 0.3 ms and left the fetch at
+// 42 GB.  Integer results: any mistake in the hand-written waits shows as a Phi that differs from the
 // register-staged kernel's bit for bit (tests/test_gpu_crt.py).
 template <unsigned MASK> struct CrtMask { static constexpr unsigned value = MASK; };
 __global__ void __launch_bounds__(512, 1) crt_syrk_i8_deep_kernel(const int8_t* __restrict__ planes, int64_t rows_pad, int Mp2, int nt2, int64_t rows_per_split,
