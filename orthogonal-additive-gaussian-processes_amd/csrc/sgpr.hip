@@ -316,11 +316,16 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     // kernel shape the fused epilogue is not instantiated for: the fp64 panel is converted by a pass of its own once the route is settled.
     // precision -1 (default, "auto"): the int8 route where it pays -- N M^2 >= 2^36 (the headline problem and its row shards down to
     // N / 16, config 5; not config 2, where the two routes measure the same 1.05 ms) -- and the fp64 kernels elsewhere
-    const bool crt_wanted = crt_cand && !use32;
+    bool crt_wanted = crt_cand && !use32;
+    CrtPlan cp;
+    if (crt_wanted && !whiten) {
+        // the route's buffers (residue planes: 15 bytes per panel entry; int32 partials) are claimed up front, for the largest chunk: if the
+        // device cannot provide them this evaluation runs the fp64 kernels (oak_sgpr_stats_precision tells) instead of failing
+        if (crt_plan(ctx, rows, M, N, &cp) != OAK_OK) { crt_wanted = false; (void)hipGetLastError(); }
+    }
     const bool crt_fused = crt_wanted && !lazy && !whiten && gram_crt_supported(pk) && getenv("OAK_CRT_UNFUSED") == nullptr;
     const bool crt_panel = ctx->keep_kfu || ctx->n_extra > 0;      // fused pass: somebody reads the fp64 panel afterwards
     bool use_crt = false;
-    CrtPlan cp;
     for (int64_t a0 = 0; a0 < N; a0 += rows, ++chunk_idx) {
         const int64_t na = (a0 + rows <= N) ? rows : N - a0;
         if (crt_fused) {
