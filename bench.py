@@ -220,6 +220,47 @@ def bounded_fit(X, y, M, R, maxiter):
             "loss_before": loss0, "loss_after": float(res.fun), "cond_estimate_last": float(hip.sgpr_last_terms().get("cond_estimate", 0.0))}
 
 
+def power_sample(step, ctx, seconds=1.5):
+    """rocm-smi power / shader-clock samples on a helper thread while `step` runs back to back for `seconds`."""
+    import re, shutil, subprocess, threading
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    cap = None
+    try:
+        capj = json.loads(subprocess.run([smi, "--showmaxpower", "--json"], capture_output=True, text=True, timeout=10).stdout)
+        cap = next((float(v) for k, v in capj.get("card0", {}).items() if re.match(r"^[0-9.]+$", str(v))), None)
+    except Exception:                                                # noqa: BLE001
+        pass
+    samples, stop = [], threading.Event()
+
+    def sampler():
+        while not stop.is_set():
+            try:
+                d = json.loads(subprocess.run([smi, "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=10).stdout).get("card0", {})
+                pw = next((float(v) for k, v in d.items() if "ower" in k and re.match(r"^[0-9.]+$", str(v))), None)
+                ck = next((int(re.search(r"(\d+)Mhz", str(v)).group(1)) for k, v in d.items() if "sclk" in k.lower() and re.search(r"(\d+)Mhz", str(v))), None)
+                samples.append((pw, ck))
+            except Exception:                                        # noqa: BLE001
+                pass
+            time.sleep(0.03)
+
+    step(); ctx.sync()
+    th = threading.Thread(target=sampler, daemon=True)
+    th.start()
+    t0 = time.perf_counter(); n = 0
+    while time.perf_counter() - t0 < seconds:
+        step(); n += 1
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    stop.set(); th.join(5)
+    busy = [(p, c) for p, c in samples if p is not None and c is not None and p > 600.0]      # samples taken while the GPU was loaded
+    if not busy:
+        return {"samples": len(samples), "note": "no loaded samples"}
+    ps, cs = sorted(p for p, _ in busy), sorted(c for _, c in busy)
+    return {"power_W_median": ps[len(ps) // 2], "power_W_max": ps[-1], "sclk_MHz_median": cs[len(cs) // 2], "sclk_MHz_max": cs[-1],
+            "power_cap_W": cap, "samples": len(busy), "steps": n, "ms_per_step_during_sampling": dt / n * 1e3,
+            "note": "rocm-smi on a helper thread while the step runs back to back (outside the timed region); sclk max of the part is 2400 MHz"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -241,6 +282,9 @@ def main():
                     help="N>1 with --exchange rccl: if the RCCL communicator cannot be created, fall back to the host exchange and "
                          "still print a (degraded) line; without this flag such a run exits non-zero")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--power", action="store_true",
+                    help="after the timed region: rocm-smi power / shader-clock samples (child processes of this one) while the step runs back to "
+                         "back for 1.5 s -- opt-in, never under a profiler")
     ap.add_argument("--no-fit", action="store_true", help="skip the bounded BFGS fit through the model API (the 'fit' sub-record)")
     ap.add_argument("--fit-maxiter", type=int, default=6)
     ap.add_argument("--cpu-sample-rows", type=int, default=1 << 20)
@@ -461,6 +505,15 @@ def main():
             "note": "route=whitened: GPflow's op order (oak/utils.py:187-195), conditioning-independent; same workload as the headline"}
         ctx.sgpr_set_route(args.route)
 
+    # ---- power and shader clock while the step runs back to back (rocm-smi, outside the timed region) ---------------------
+    # The step runs against the board's power limit: the record lets a reader see that in THIS run.
+    power_info = None
+    if world == 1 and args.power and not _capi._profiler_attached():
+        try:
+            power_info = power_sample(step, ctx, seconds=1.5)
+        except Exception as ex:                                     # noqa: BLE001  (no rocm-smi, no permission: a missing record, not a failed run)
+            power_info = {"error": repr(ex)}
+
     # ---- explicit Gram GB/s (the second half of BASELINE's metric) -------------------------------------------
     ctx.reset_timings()
     desc = _capi.KernelDesc(spec)
@@ -599,6 +652,7 @@ def main():
         "forward_plus_gradient": grad_info,
         "whitened": whitened_info,
         "fp64_kernels": fp64_info,
+        "power": power_info,
     }
 
     # ---- Sobol indices of every term of the model (BASELINE configs[4] names the Sobol path) ----------------
