@@ -192,7 +192,7 @@ int oak_sgpr_set_route(oak_ctx* ctx, int32_t route);
 /* Rows over all shards when this ctx holds one shard and the statistics are exchanged outside the library
    (oak_sgpr_get_stats / oak_sgpr_set_stats): the auto route's size rule uses it.  0 = unknown (default). */
 int oak_sgpr_set_global_rows(oak_ctx* ctx, int64_t n_total);
-/* Arithmetic of the N-sized statistics.  -1 (default): mode 2 where it pays (phi route, N M^2 >= 2^36, M >= 512), mode 0 elsewhere.
+/* Arithmetic of the N-sized statistics.  -1 (default): mode 2 where it pays (phi route; M >= 640 and N >= 32768, or M >= 512 and N M^2 >= 2^38), mode 0 elsewhere.
    0: the fp64 kernels throughout, the reference's precision (oak/oak_kernel.py:31-32 sets float64 globally).  1: "fp32 statistics" -- the Kfu panel is generated in fp32 (hardware v_exp_f32) and Phi's row-split
    partials are formed by fp32 MFMA (fp32 accumulation within one split of a few thousand rows only), everything else --
    featurisation, kappa, the cross-split sums, the O(M^3) tail, prediction, Sobol, every gradient -- stays fp64.  Applies to

@@ -1,5 +1,5 @@
 // Phi = Kuf Kuf^T (oak/utils.py:189-190; GPflow's AAT before whitening) on the INT8 matrix pipe, exactly: the "Ozaki scheme II" /
-// Chinese-remainder construction.  oak_sgpr_set_precision: the automatic default on large phi-route problems (N M^2 >= 2^36), forced
+// Chinese-remainder construction.  oak_sgpr_set_precision: the automatic default on phi-route problems with M >= 640 inducing points and N >= 32768 rows (M >= 512: N M^2 >= 2^38), forced
 // by mode 2, off in mode 0; phi route only.
 //
 //   1. every column m of the Kfu panel gets a power-of-two scale 2^s_m from a bound that needs no pass over the panel:

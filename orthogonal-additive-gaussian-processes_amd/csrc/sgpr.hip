@@ -273,7 +273,10 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     // still pending is settled BEFORE the first Gram launch -- the side stream's estimate arrives while the main stream featurizes
     // (~0.2 ms of waiting against the 4 ms a stand-alone conversion pass costs a phi evaluation).  Not in a partitioned pass whose
     // chain is only enqueued behind the first Gram launch.
-    const bool crt_size = M >= 512 && (double)N * (double)M * (double)M >= 68719476736.0 && getenv("OAK_NO_AUTO_CRT") == nullptr;
+    // automatic rule (profiles/r06_crt_size_sweep.txt, D = 16: the gain follows M -- 1.09-1.16x at M = 768, 1.14-1.22x at 1024, 1.24-1.40x at
+    // 2048 -- and hardly N: 1.15x already at 65536 rows; at M = 512 it appears only around 2^20 rows)
+    const bool crt_size = ((M >= 640 && N >= 32768) || (M >= 512 && (double)N * (double)M * (double)M >= 274877906944.0)) &&
+                          getenv("OAK_NO_AUTO_CRT") == nullptr;
     const bool crt_cand = (ctx->precision == 2 || (ctx->precision == -1 && crt_size)) && crt_supported(ctx, M);
     if (ctx->auto_pending && crt_cand && gram_crt_supported(pk) && !ctx->kuu_deferred) {
         OAK_HIP_CHECK(hipEventSynchronize(ctx->ev2));
@@ -314,8 +317,6 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     // bound to scale by.  Route known before the Gram launch: the residue planes come out of the Gram kernel's epilogue (and the fp64
     // panel is written only when a gradient or a further output column reads it); route still pending (auto, large problem) or a
     // kernel shape the fused epilogue is not instantiated for: the fp64 panel is converted by a pass of its own once the route is settled.
-    // precision -1 (default, "auto"): the int8 route where it pays -- N M^2 >= 2^36 (the headline problem and its row shards down to
-    // N / 16, config 5; not config 2, where the two routes measure the same 1.05 ms) -- and the fp64 kernels elsewhere
     bool crt_wanted = crt_cand && !use32;
     CrtPlan cp;
     if (crt_wanted && !whiten) {

@@ -167,7 +167,7 @@ def test_row_shards_extra_outputs_gradient_and_fallbacks():
     ctx.sgpr_set_route("phi"); ctx.sgpr_set_data(X[:2000], y[:2000])
     ctx.sgpr_elbo(d, 0.05)
     assert ctx.sgpr_stats_precision() == "fp64"
-    # default mode: this size stays on the fp64 kernels (N M^2 < 2^36)
+    # default mode: 384 inducing points stay on the fp64 kernels (the automatic rule starts at M = 512)
     ctx.sgpr_set_data(X, y); ctx.sgpr_set_precision("auto")
     assert ctx.sgpr_elbo(d, 0.05) == e64 and ctx.sgpr_stats_precision() == "fp64"
     ctx.close()
