@@ -241,6 +241,7 @@ int oak_comm_allreduce_stats(oak_ctx* ctx) {
         OAK_REQUIRE(d_psix != nullptr && ctx->psix_valid, "oak_comm_allreduce_stats: the extra target columns' statistics are not those of the "
                     "packed statistics in place (form both with oak_sgpr_local_stats on every rank)");
     PhaseTimer t(ctx, "allreduce");
+    ctx->stats_phi_dd = false;      // a sum of shards in fp64 rounds Phi: its low word no longer belongs to it
     // the two trailing slots (shards that whitened, shards summed) ride along: the tail rejects a mixed sum
     OAK_CHECK(comm_allreduce_dev(ctx, d_stats, oak_sgpr_stats_len(ctx)));
     // extra target columns: [Kuf y_p | y_p^T y_p] is part of the same sum over the row shards -- reduced HERE, so that the documented

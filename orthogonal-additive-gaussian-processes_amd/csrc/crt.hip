@@ -318,7 +318,7 @@ struct CrtGarnerF {
 template <int LT>
 __global__ void __launch_bounds__(256) crt_reduce_kernel(const int* __restrict__ part, int nsplit, int64_t M, int64_t Mp2, const CrtGarnerF gr,
                                                          int* __restrict__ res, int first, int last, const int* __restrict__ sexp,
-                                                         double* __restrict__ phi) {
+                                                         double* __restrict__ phi, double* __restrict__ phi_lo) {
     const int64_t a = blockIdx.y;
     const int64_t b0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4 + (a & ~(int64_t)3);      // first column group that touches the diagonal
     if (b0 >= M) return;
@@ -372,24 +372,33 @@ __global__ void __launch_bounds__(256) crt_reduce_kernel(const int* __restrict__
             }
         }
     }
+    // The exact integer as a DOUBLE-DOUBLE (phi_lo != NULL: the whitening of an ill-conditioned Kuu needs Phi to more than one double,
+    // ddgemm.hip): Horner over the digit groups with error-free products (FMA) and two-sums; the power-of-two scale is exact.
     const int sa = sexp[a];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int64_t b = b0 + k;
-        double x = 0.0;
+        double xh = 0.0, xl = 0.0;
 #pragma unroll
         for (int g = (LT + 4) / 5 - 1; g >= 0; --g) {
-            constexpr int dummy = 0; (void)dummy;
             const int lo = 5 * g, hi = (lo + 5 < LT) ? lo + 5 : LT;
             long long G = 0;
 #pragma unroll
             for (int i = hi - 1; i >= lo; --i) G = G * (long long)gr.p[i] + (long long)v[i][k];
-            x = __builtin_fma(x, gr.pg[g], (double)G);
+            const double Gd = (double)G, pgd = gr.pg[g];
+            const double p = xh * pgd;
+            double e = __builtin_fma(xh, pgd, -p) + xl * pgd;
+            const double s = p + Gd, t = s - p;
+            e += (p - (s - t)) + (Gd - t);
+            xh = s + e;
+            xl = e - (xh - s);
         }
         if (b >= a && b < M) {
-            const double out = ldexp(x, -(sa + sexp[b]));
-            phi[a * M + b] = out;
-            phi[b * M + a] = out;
+            const int sh = -(sa + sexp[b]);
+            const double oh = ldexp(xh, sh), ol = ldexp(xl, sh);
+            phi[a * M + b] = oh;
+            phi[b * M + a] = oh;
+            if (phi_lo != nullptr) { phi_lo[a * M + b] = ol; phi_lo[b * M + a] = ol; }
         }
     }
 }
@@ -497,7 +506,7 @@ int crt_convert_panel(oak_ctx* ctx, const CrtPlan& pl, const double* d_panel, in
 }
 
 // int8 SYRK of the chunk's planes, split sums joined to the residues carried so far; on the last chunk Phi (full, symmetric)
-int crt_accumulate(oak_ctx* ctx, const CrtPlan& pl, int64_t M, bool first_chunk, bool last_chunk, double* d_phi) {
+int crt_accumulate(oak_ctx* ctx, const CrtPlan& pl, int64_t M, bool first_chunk, bool last_chunk, double* d_phi, double* d_phi_lo) {
     CrtGarnerF gr;
     const CrtMod& md = pl.md;
     gr.L = md.L; gr.ngroups = (md.L + 4) / 5;
@@ -530,7 +539,7 @@ int crt_accumulate(oak_ctx* ctx, const CrtPlan& pl, int64_t M, bool first_chunk,
         PhaseTimer t(ctx, "crt_reduce");
         const dim3 grid((unsigned)((M + 1023) / 1024), (unsigned)M);
 #define OAK_CRT_RED(LL) case LL: crt_reduce_kernel<LL><<<grid, 256, 0, ctx->stream>>>(pl.d_part, pl.nsplit, M, pl.Mp2, gr, pl.d_res, first_chunk ? 1 : 0, \
-                                                                                      last_chunk ? 1 : 0, pl.d_sexp, d_phi); break;
+                                                                                      last_chunk ? 1 : 0, pl.d_sexp, d_phi, d_phi_lo); break;
         switch (md.L) {
             OAK_CRT_RED(13) OAK_CRT_RED(14) OAK_CRT_RED(15) OAK_CRT_RED(16) OAK_CRT_RED(17) OAK_CRT_RED(18)
             default: set_error("int8 CRT statistics: %d moduli outside the instantiated range 13..18", md.L); return OAK_E_ARG;

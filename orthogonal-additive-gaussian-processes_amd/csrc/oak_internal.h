@@ -162,6 +162,8 @@ struct oak_ctx {
     bool cond_seen = false;          // ... and cond_mm holds it for the tail's report (oak_sgpr_last_terms slot 7)
     bool stats_fp32 = false;         // the statistics in "stats" came from the fp32 panel path
     bool stats_crt = false;          // ... Phi of the statistics in "stats" was accumulated exactly on the int8 pipe (crt.hip)
+    bool last_tail_dd = false;       // the most recent tail whitened Phi in double-double arithmetic (oak_bench_crt_info slot 6)
+    bool stats_phi_dd = false;       // ... and buffer "phi_lo" holds the low word of that Phi (cleared when the statistics are replaced / summed)
     int64_t crt_info[6] = {0, 0, 0, 0, 0, 0};   // ... and how (oak_bench_crt_info)
     double cond_mm[2] = {1.0, 1.0};  // min / max of diag chol(Kuu), written by the side stream
     hipEvent_t ev2 = nullptr;        // side stream: conditioning estimate ready
@@ -272,7 +274,10 @@ int crt_plan(oak_ctx* ctx, int64_t na, int64_t M, int64_t n_total, CrtPlan* pl);
 // kdiag_parts: the featurize pass of X ran its tiled form with the K_diag reduction (kappa_done): its per-workgroup maxima serve
 int crt_scales(oak_ctx* ctx, const PreparedKernel& pk, const Feat& FX, const Feat& FZ, int64_t M, const CrtPlan& pl, bool kdiag_parts);
 int crt_convert_panel(oak_ctx* ctx, const CrtPlan& pl, const double* d_panel, int64_t ldp, int64_t na);
-int crt_accumulate(oak_ctx* ctx, const CrtPlan& pl, int64_t M, bool first_chunk, bool last_chunk, double* d_phi);
+// d_phi_lo (may be NULL): the low word of the double-double Phi (the integer Gram matrix holds ~118 bits)
+int crt_accumulate(oak_ctx* ctx, const CrtPlan& pl, int64_t M, bool first_chunk, bool last_chunk, double* d_phi, double* d_phi_lo);
+// [W ; (L^-1 psi)^T] = [L^-1 Phi L^-T ; (L^-1 psi)^T] in double-double arithmetic from the double-double Phi (ddgemm.hip), one double out
+int dd_whiten(oak_ctx* ctx, const double* d_Linv, const double* d_phi_hi, const double* d_phi_lo, const double* d_psi, int64_t M, double* d_out);
 bool gram_crt_supported(const PreparedKernel& pk);
 int gram_crt(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int64_t na, const Feat& B, double* d_out, int64_t ldo,
              const double* d_yA, double* d_psi, int64_t zero_pad_to, const CrtMod& md, const int* d_sexp, int8_t* d_planes, int64_t rows_pad,

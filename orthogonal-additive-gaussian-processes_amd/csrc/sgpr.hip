@@ -278,7 +278,15 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     const bool crt_size = ((M >= 640 && N >= 32768) || (M >= 512 && (double)N * (double)M * (double)M >= 274877906944.0)) &&
                           getenv("OAK_NO_AUTO_CRT") == nullptr;
     const bool crt_cand = (ctx->precision == 2 || (ctx->precision == -1 && crt_size)) && crt_supported(ctx, M);
-    if (ctx->auto_pending && crt_cand && gram_crt_supported(pk) && !ctx->kuu_deferred) {
+    // With the int8 route Phi is exact (a double-double) and the tail can whiten it in double-double arithmetic (ddgemm.hip): the phi
+    // route then has the whitened route's accuracy at any conditioning, so the auto route never pays the N-sized triangular solve
+    // (the tail looks at the conditioning estimate and picks the fp64 or the double-double M^3 products).  One rank only: a sum of
+    // shards in fp64 would round Phi again.
+    const bool dd_tail = crt_cand && (ctx->comm == nullptr || ctx->nranks <= 1) && ctx->n_extra == 0 && (M % 32) == 0 && getenv("OAK_NO_TAIL_DD") == nullptr;
+    if (ctx->auto_pending && dd_tail) {
+        ctx->auto_whiten = 0;
+        ctx->auto_pending = false;
+    } else if (ctx->auto_pending && crt_cand && gram_crt_supported(pk) && !ctx->kuu_deferred) {
         OAK_HIP_CHECK(hipEventSynchronize(ctx->ev2));
         const double ratio = ctx->cond_mm[1] / ctx->cond_mm[0];
         ctx->auto_whiten = (ratio * ratio > AUTO_WHITEN_DIAG_RATIO2) ? 1 : 0;
@@ -406,7 +414,9 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
                 if (chunk_idx == 0) OAK_CHECK(crt_scales(ctx, pk, FX, FZ, M, cp, kappa_done));
                 OAK_CHECK(crt_convert_panel(ctx, cp, dSy, Mp, na));
             }
-            OAK_CHECK(crt_accumulate(ctx, cp, M, chunk_idx == 0, a0 + rows >= N, st.phi));
+            double* d_phi_lo = nullptr;
+            OAK_CHECK(get_buf_t(ctx, "phi_lo", (size_t)M * M, &d_phi_lo));
+            OAK_CHECK(crt_accumulate(ctx, cp, M, chunk_idx == 0, a0 + rows >= N, st.phi, d_phi_lo));
         } else {
             PhaseTimer t(ctx, "syrk");
             if (use32) OAK_CHECK(syrk_panel_f32(ctx, dPanel32, Mp, na, M, dPart, nsplit, chunk_idx > 0));
@@ -439,6 +449,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     ctx->stats_whitened = whiten;
     ctx->stats_fp32 = use32;
     ctx->stats_crt = use_crt;
+    ctx->stats_phi_dd = use_crt;
     for (int q = 0; q < 6; ++q) ctx->crt_info[q] = 0;
     if (use_crt) {
         ctx->crt_info[0] = cp.md.L; ctx->crt_info[1] = cp.B; ctx->crt_info[2] = cp.nsplit; ctx->crt_info[3] = cp.rps;
@@ -644,7 +655,9 @@ int sgpr_forward(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, doubl
     // every CU the chain's small launches are starved (one Cholesky step measured 1.2 ms beside the Gram kernel,
     // tools/ubench/cumask_probe.hip: 44 ms against 1.3 ms for 40 small kernels) whatever the queue priority.
     PartitionScope part(ctx);
-    const bool want_cond = auto_big || (ctx->precision == 1 && !ctx->keep_kfu && !sgpr_route_whitened(ctx));
+    // (the int8 route's tail chooses between fp64 and double-double whitening by the same estimate: one tiny kernel on the side stream)
+    const bool want_cond = auto_big || (ctx->precision == 1 && !ctx->keep_kfu && !sgpr_route_whitened(ctx)) ||
+                           ((ctx->precision == -1 || ctx->precision == 2) && ctx->route != 2);
     if (partition_wanted(ctx, pk)) {
         OAK_HIP_CHECK(hipEventRecord(ctx->ev0, ctx->main_full));        // everything enqueued so far (uploads, the previous evaluation) is ordered before both
         OAK_HIP_CHECK(hipStreamWaitEvent(ctx->main_part, ctx->ev0, 0));
@@ -760,6 +773,21 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     ctx->have_linv = l_state == 2 || (aug && l_state == 0);      // the side stream always leaves L^-1 / L^-T behind
     // W = L^-1 Phi L^-T  (= sigma^2 * A A^T, utils.py:189-190 without materialising A)
     const bool aug_b = (M % 32) == 0;       // L^-1 psi rides through chol(B) as an extra row (potrf_lower: nrows = M + 1)
+    // Double-double whitening (ddgemm.hip) when the statistics in place carry the exact Phi of the int8 route AND Kuu looks
+    // ill-conditioned -- (max diag L / min diag L)^2 > 1e2, the estimate the auto route whitened on at 1e3; it under-reads cond(Kuu)
+    // by 20-600x -- or OAK_TAIL_DD=1 asks for it (0: never).  The side stream's estimate has long arrived (it ran under the Gram
+    // kernel); one output column (further columns ride as extra rows of the fp64 product).
+    bool tail_dd = false;
+    if (aug && ctx->stats_phi_dd && !ctx->stats_whitened && nx == 0 && peek_buf(ctx, "phi_lo") != nullptr && ctx->have_linv) {
+        const char* e = getenv("OAK_TAIL_DD");
+        if (e != nullptr) tail_dd = atoi(e) != 0;
+        else if (ctx->cond_seen && l_state == 2) {
+            OAK_HIP_CHECK(hipEventSynchronize(ctx->ev2));
+            const double ratio = ctx->cond_mm[1] / ctx->cond_mm[0];
+            tail_dd = ratio * ratio > 1e2;
+        }
+    }
+    ctx->last_tail_dd = tail_dd;
     if (ctx->stats_whitened) {
         OAK_CHECK(copy_d2d(ctx, dT2, st.phi, sizeof(double) * (size_t)M * M));   // statistics already hold W
         double* dv = aug_b ? dT2 + M * M : dv1;
@@ -779,6 +807,9 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
                 OAK_CHECK(trsm_rows(ctx, dL, M, M, dvx, nx, M, 0));
             }
         }
+    } else if (aug && tail_dd) {
+        // exact Phi (double-double, int8 route) whitened in double-double arithmetic: the phi route at the whitened route's accuracy
+        OAK_CHECK(dd_whiten(ctx, (const double*)peek_buf(ctx, "Linv"), st.phi, (const double*)peek_buf(ctx, "phi_lo"), st.psi, M, dT2));
     } else if (aug) {
         // S = L^-1 Phi (rows 0..M-1 of T1; Phi is symmetric, so gemm_nt against it is the plain product), row M = psi^T;
         // [W ; (L^-1 psi)^T] = T1 L^-T in one (M+1) x M x M GEMM
@@ -1100,6 +1131,7 @@ int oak_bench_crt_info(oak_ctx* ctx, int64_t* info6) {
     OAK_CHECK(guard(ctx));
     OAK_REQUIRE(info6 != nullptr, "oak_bench_crt_info: NULL output");
     for (int q = 0; q < 6; ++q) info6[q] = ctx->have_stats ? ctx->crt_info[q] : 0;
+    if (ctx->have_stats && ctx->last_tail_dd) info6[4] |= 2;      // bit 1: the most recent tail whitened Phi in double-double arithmetic
     return OAK_OK;
 }
 
@@ -1132,6 +1164,7 @@ int oak_sgpr_set_stats(oak_ctx* ctx, const double* packed, int32_t whitened) {
     OAK_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     ctx->have_stats = true; ctx->stats_whitened = whitened != 0; ctx->have_post = false;
     ctx->psix_valid = false;               // whatever "psix" holds was formed for other statistics
+    ctx->stats_phi_dd = false;             // ... and so was the low word of Phi
     return OAK_OK;
 }
 

@@ -900,7 +900,10 @@ class HipContext:
         """Shape of the most recent int8 CRT accumulation of Phi (all zero when the fp64 / fp32 kernels formed the statistics)."""
         a = (C.c_int64 * 6)()
         _check(self._lib.oak_bench_crt_info(self._h, a))
-        return dict(zip(("planes", "bits", "row_splits", "rows_per_split", "fused", "plane_columns"), [int(v) for v in a]))
+        d = dict(zip(("planes", "bits", "row_splits", "rows_per_split", "fused", "plane_columns"), [int(v) for v in a]))
+        d["tail_dd"] = (d["fused"] >> 1) & 1          # the most recent tail whitened Phi in double-double arithmetic (csrc/ddgemm.hip)
+        d["fused"] &= 1
+        return d
 
     def bench_potrf(self, n: int, reps: int = 10):
         """(mean ms per factorisation, log det) of the library's Cholesky on an n x n exponential-kernel test matrix."""
