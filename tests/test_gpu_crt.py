@@ -201,3 +201,74 @@ def test_deep_kernel_takes_the_stand_alone_conversion():
     ec, _, _, used = _stats(ctx, d, "int8crt")
     assert used == "int8crt" and abs(ec - e64) <= 1e-9 * abs(e64)
     ctx.close()
+
+
+def _ill_conditioned(N, M, D, ls, seed=0):
+    """Near-duplicate inducing points and a long lengthscale: cond(Kuu + 1e-6 I) ~ 1e6 .. 1e8."""
+    rng = np.random.default_rng(seed)
+    X = rng.standard_normal((N, D))
+    y = (np.sin(X[:, 0]) + 0.5 * X[:, 1] * X[:, 2] + 0.1 * rng.standard_normal(N)).reshape(-1, 1)
+    y = (y - y.mean()) / y.std()
+    Z = X[:M].copy()
+    Z[M // 2:] = Z[:M - M // 2] + 0.02 * rng.standard_normal((M - M // 2, D))
+    return o.make_spec(D, 2, lengthscales=[ls] * D), X, y, Z
+
+
+@pytest.mark.parametrize("ls", [1.5, 3.0])
+def test_ill_conditioned_kuu_stays_on_the_phi_route_with_double_double_whitening(ls):
+    """The automatic route used to send such evaluations through the N-sized triangular solve (GPflow's A = L^-1 Kuf), because the fp64
+    products L^-1 Phi L^-T lose cond(Kuu) eps.  With the exact (double-double) Phi of the int8 route and double-double products
+    (csrc/ddgemm.hip) the phi route meets the same 1e-10 -- on the total and on every term -- and is the one the auto route takes."""
+    spec, X, y, Z = _ill_conditioned(65536, 768, 8, ls)
+    ref, parts = c_oracle.sgpr_elbo_chunked(spec, X, y, Z, 0.01, chunk=8192, return_parts=True)
+    ctx = _capi.HipContext(0)
+    d = _capi.KernelDesc(spec)
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z)                       # route auto, precision auto: the defaults
+    e = ctx.sgpr_elbo(d, 0.01)
+    t = ctx.sgpr_last_terms()
+    info = ctx.bench_crt_info()
+    assert not ctx.sgpr_stats_whitened() and ctx.sgpr_stats_precision() == "int8crt" and info["tail_dd"] == 1
+    assert t["cond_estimate"] > 1e2
+    # every term at 1e-10 of its own size; the total is a difference of terms a few hundred times its size here (0.5 c^T c = 3e6 against
+    # |ELBO| = 1e4), so it is held to 1e-10 of the largest of them (and to 2e-10 |ELBO| against the whitened route below)
+    cases.assert_terms_match(t, parts["terms"], rtol=1e-10, what=f"auto route (int8 Phi, double-double tail), ls {ls}:")
+    scale = max(abs(ref), 0.5 * abs(parts["terms"]["cTc"]), 0.5 * abs(parts["terms"]["tr_AAT"]))
+    assert abs(e - ref) <= 1e-10 * scale, (e, ref)
+    assert ctx.sgpr_elbo(d, 0.01) == e                                          # bitwise repeatable
+    # the same statistics through fp64 products: what the double-double tail is for
+    try:
+        os.environ["OAK_TAIL_DD"] = "0"
+        e64 = ctx.sgpr_elbo(d, 0.01)
+    finally:
+        os.environ.pop("OAK_TAIL_DD", None)
+    assert ctx.bench_crt_info()["tail_dd"] == 0
+    assert abs(e64 - ref) > 20 * abs(e - ref) and abs(e64 - ref) > 1e-9 * abs(ref)
+    # GPflow's own order, for comparison: the two routes agree
+    ctx.sgpr_set_route("whitened")
+    ew = ctx.sgpr_elbo(d, 0.01)
+    assert ctx.sgpr_stats_whitened() and abs(ew - e) <= 2e-10 * abs(ref)
+    # gradient of the auto route (phi statistics, fp64 backward) against the whitened route's
+    _, gw = ctx.sgpr_elbo_grad(d, 0.01)
+    ctx.sgpr_set_route("auto")
+    eg, g = ctx.sgpr_elbo_grad(d, 0.01)
+    assert not ctx.sgpr_stats_whitened() and abs(eg - e) <= 1e-12 * abs(e)
+    np.testing.assert_allclose(g, gw, rtol=1e-5, atol=1e-6 * np.abs(gw).max())
+    # predictions from the phi-route posterior against the whitened one
+    m1, v1 = ctx.sgpr_predict(d, X[:2048])
+    ctx.sgpr_set_route("whitened"); ctx.sgpr_elbo(d, 0.01)
+    m2, v2 = ctx.sgpr_predict(d, X[:2048])
+    np.testing.assert_allclose(m1, m2, rtol=1e-7, atol=1e-8 * np.abs(m2).max())
+    np.testing.assert_allclose(v1, v2, rtol=1e-6, atol=1e-8 * np.abs(v2).max())
+    ctx.close()
+
+
+def test_well_conditioned_kuu_keeps_the_fp64_products():
+    spec, X, y, Z = _problem(65536, 8, 768, 2, ("gaussian",), seed=21, ls=(0.6, 0.9))
+    ctx = _capi.HipContext(0)
+    d = _capi.KernelDesc(spec)
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z)
+    ctx.sgpr_elbo(d, 0.05)
+    t = ctx.sgpr_last_terms()
+    if t["cond_estimate"] <= 1e2:
+        assert ctx.bench_crt_info()["tail_dd"] == 0 and ctx.sgpr_stats_precision() == "int8crt" and not ctx.sgpr_stats_whitened()
+    ctx.close()
