@@ -184,7 +184,10 @@ int oak_sgpr_local_stats(oak_ctx* ctx, const oak_kernel_desc* desc, double jitte
    then holds W = L^-1 Phi L^-T.  0 = auto: whitened while N*M <= 2^24; above that oak_sgpr_elbo and
    oak_sgpr_elbo_grad whiten only when chol(Kuu) looks ill-conditioned, (max diag L / min diag L)^2 > 1e3,
    which keeps the result within ~1e-10 of the literal route (the stand-alone oak_sgpr_local_stats uses the
-   size rule alone).  Under a communicator N is the row count over ALL ranks: what oak_sgpr_set_global_rows declared
+   size rule alone).  Where the int8 route of oak_sgpr_set_precision runs on ONE rank, auto never whitens: Phi is then exact (kept as a
+   double-double) and the tail whitens it with double-double M^3 products when chol(Kuu) looks ill-conditioned (estimate > 1e2;
+   csrc/ddgemm.hip) -- the phi route at the whitened route's accuracy, without the N-sized triangular solve (tests/test_gpu_crt.py).
+   Under a communicator N is the row count over ALL ranks: what oak_sgpr_set_global_rows declared
    (either every rank declares it or none does), else one scalar all-reduce on EVERY auto-route evaluation (never a
    per-rank cache: the sequence of collectives is then the same on all ranks whatever their history); the conditioning
    decision is rank 0's, shared with the other ranks; so all ranks take the same route even when their shards differ. */
