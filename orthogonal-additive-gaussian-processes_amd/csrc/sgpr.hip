@@ -277,7 +277,13 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     // 2048 -- and hardly N: 1.15x already at 65536 rows; at M = 512 it appears only around 2^20 rows)
     const bool crt_size = ((M >= 640 && N >= 32768) || (M >= 512 && (double)N * (double)M * (double)M >= 274877906944.0)) &&
                           getenv("OAK_NO_AUTO_CRT") == nullptr;
-    const bool crt_cand = (ctx->precision == 2 || (ctx->precision == -1 && crt_size)) && crt_supported(ctx, M);
+    bool crt_cand = (ctx->precision == 2 || (ctx->precision == -1 && crt_size)) && crt_supported(ctx, M) && ctx->route != 2;
+    CrtPlan cp;
+    if (crt_cand) {
+        // the route's buffers (residue planes: 15 bytes per panel entry; int32 partials) are claimed up front, for the largest chunk: if the
+        // device cannot provide them this evaluation runs the fp64 kernels and the fp64 route rules (oak_sgpr_stats_precision tells)
+        if (crt_plan(ctx, rows, M, N, &cp) != OAK_OK) { crt_cand = false; (void)hipGetLastError(); }
+    }
     // With the int8 route Phi is exact (a double-double) and the tail can whiten it in double-double arithmetic (ddgemm.hip): the phi
     // route then has the whitened route's accuracy at any conditioning, so the auto route never pays the N-sized triangular solve
     // (the tail looks at the conditioning estimate and picks the fp64 or the double-double M^3 products).  One rank only: a sum of
@@ -325,13 +331,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     // bound to scale by.  Route known before the Gram launch: the residue planes come out of the Gram kernel's epilogue (and the fp64
     // panel is written only when a gradient or a further output column reads it); route still pending (auto, large problem) or a
     // kernel shape the fused epilogue is not instantiated for: the fp64 panel is converted by a pass of its own once the route is settled.
-    bool crt_wanted = crt_cand && !use32;
-    CrtPlan cp;
-    if (crt_wanted && !whiten) {
-        // the route's buffers (residue planes: 15 bytes per panel entry; int32 partials) are claimed up front, for the largest chunk: if the
-        // device cannot provide them this evaluation runs the fp64 kernels (oak_sgpr_stats_precision tells) instead of failing
-        if (crt_plan(ctx, rows, M, N, &cp) != OAK_OK) { crt_wanted = false; (void)hipGetLastError(); }
-    }
+    const bool crt_wanted = crt_cand && !use32;
     const bool crt_fused = crt_wanted && !lazy && !whiten && gram_crt_supported(pk) && getenv("OAK_CRT_UNFUSED") == nullptr;
     const bool crt_panel = ctx->keep_kfu || ctx->n_extra > 0;      // fused pass: somebody reads the fp64 panel afterwards
     bool use_crt = false;
