@@ -123,8 +123,10 @@ __global__ void __launch_bounds__(256) ddgemv_lower_kernel(const double* __restr
     if (lane == 0) out[i] = c.h + c.l;
 }
 
-// [W ; (L^-1 psi)^T] from the double-double Phi: d_out = (M + 1) x M array (rows 0 .. M-1 = W, row M = L^-1 psi), all one double
-int dd_whiten(oak_ctx* ctx, const double* d_Linv, const double* d_phi_hi, const double* d_phi_lo, const double* d_psi, int64_t M, double* d_out) {
+// [W ; (L^-1 psi)^T ; (L^-1 psi_p)^T ..] from the double-double Phi: d_out = (M + 1 + nx) x M array (rows 0 .. M-1 = W, row M = L^-1 psi,
+// rows M + 1 .. the further output columns'), all one double
+int dd_whiten(oak_ctx* ctx, const double* d_Linv, const double* d_phi_hi, const double* d_phi_lo, const double* d_psi, int64_t M, double* d_out,
+              const double* d_psix, int nx) {
     double *d_th = nullptr, *d_tl = nullptr;
     OAK_CHECK(get_buf_t(ctx, "ddT_hi", (size_t)M * M, &d_th));
     OAK_CHECK(get_buf_t(ctx, "ddT_lo", (size_t)M * M, &d_tl));
@@ -135,6 +137,10 @@ int dd_whiten(oak_ctx* ctx, const double* d_Linv, const double* d_phi_hi, const 
     OAK_HIP_CHECK(hipGetLastError());
     ddgemv_lower_kernel<<<(unsigned)((M + 3) / 4), 256, 0, ctx->stream>>>(d_Linv, M, d_psi, d_out + M * M);
     OAK_HIP_CHECK(hipGetLastError());
+    for (int p = 0; p < nx; ++p) {          // further output columns: rows M + 1 .. = (L^-1 psi_p)^T
+        ddgemv_lower_kernel<<<(unsigned)((M + 3) / 4), 256, 0, ctx->stream>>>(d_Linv, M, d_psix + (int64_t)p * M, d_out + (M + 1 + p) * M);
+        OAK_HIP_CHECK(hipGetLastError());
+    }
     return OAK_OK;
 }
 

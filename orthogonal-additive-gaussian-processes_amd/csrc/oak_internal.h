@@ -277,7 +277,8 @@ int crt_convert_panel(oak_ctx* ctx, const CrtPlan& pl, const double* d_panel, in
 // d_phi_lo (may be NULL): the low word of the double-double Phi (the integer Gram matrix holds ~118 bits)
 int crt_accumulate(oak_ctx* ctx, const CrtPlan& pl, int64_t M, bool first_chunk, bool last_chunk, double* d_phi, double* d_phi_lo);
 // [W ; (L^-1 psi)^T] = [L^-1 Phi L^-T ; (L^-1 psi)^T] in double-double arithmetic from the double-double Phi (ddgemm.hip), one double out
-int dd_whiten(oak_ctx* ctx, const double* d_Linv, const double* d_phi_hi, const double* d_phi_lo, const double* d_psi, int64_t M, double* d_out);
+int dd_whiten(oak_ctx* ctx, const double* d_Linv, const double* d_phi_hi, const double* d_phi_lo, const double* d_psi, int64_t M, double* d_out,
+              const double* d_psix, int nx);
 bool gram_crt_supported(const PreparedKernel& pk);
 int gram_crt(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, int64_t na, const Feat& B, double* d_out, int64_t ldo,
              const double* d_yA, double* d_psi, int64_t zero_pad_to, const CrtMod& md, const int* d_sexp, int8_t* d_planes, int64_t rows_pad,

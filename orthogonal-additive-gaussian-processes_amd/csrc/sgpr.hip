@@ -288,7 +288,7 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     // route then has the whitened route's accuracy at any conditioning, so the auto route never pays the N-sized triangular solve
     // (the tail looks at the conditioning estimate and picks the fp64 or the double-double M^3 products).  One rank only: a sum of
     // shards in fp64 would round Phi again.
-    const bool dd_tail = crt_cand && (ctx->comm == nullptr || ctx->nranks <= 1) && ctx->n_extra == 0 && (M % 32) == 0 && getenv("OAK_NO_TAIL_DD") == nullptr;
+    const bool dd_tail = crt_cand && (ctx->comm == nullptr || ctx->nranks <= 1) && (M % 32) == 0 && getenv("OAK_NO_TAIL_DD") == nullptr;
     if (ctx->auto_pending && dd_tail) {
         ctx->auto_whiten = 0;
         ctx->auto_pending = false;
@@ -776,9 +776,9 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
     // Double-double whitening (ddgemm.hip) when the statistics in place carry the exact Phi of the int8 route AND Kuu looks
     // ill-conditioned -- (max diag L / min diag L)^2 > 1e2, the estimate the auto route whitened on at 1e3; it under-reads cond(Kuu)
     // by 20-600x -- or OAK_TAIL_DD=1 asks for it (0: never).  The side stream's estimate has long arrived (it ran under the Gram
-    // kernel); one output column (further columns ride as extra rows of the fp64 product).
+    // kernel).
     bool tail_dd = false;
-    if (aug && ctx->stats_phi_dd && !ctx->stats_whitened && nx == 0 && peek_buf(ctx, "phi_lo") != nullptr && ctx->have_linv) {
+    if (aug && ctx->stats_phi_dd && !ctx->stats_whitened && peek_buf(ctx, "phi_lo") != nullptr && ctx->have_linv) {
         const char* e = getenv("OAK_TAIL_DD");
         if (e != nullptr) tail_dd = atoi(e) != 0;
         else if (ctx->cond_seen && l_state == 2) {
@@ -809,7 +809,7 @@ int sgpr_tail(oak_ctx* ctx, const PreparedKernel& pk, double noise_var, double j
         }
     } else if (aug && tail_dd) {
         // exact Phi (double-double, int8 route) whitened in double-double arithmetic: the phi route at the whitened route's accuracy
-        OAK_CHECK(dd_whiten(ctx, (const double*)peek_buf(ctx, "Linv"), st.phi, (const double*)peek_buf(ctx, "phi_lo"), st.psi, M, dT2));
+        OAK_CHECK(dd_whiten(ctx, (const double*)peek_buf(ctx, "Linv"), st.phi, (const double*)peek_buf(ctx, "phi_lo"), st.psi, M, dT2, d_psix_in, nx));
     } else if (aug) {
         // S = L^-1 Phi (rows 0..M-1 of T1; Phi is symmetric, so gemm_nt against it is the plain product), row M = psi^T;
         // [W ; (L^-1 psi)^T] = T1 L^-T in one (M+1) x M x M GEMM

@@ -262,6 +262,38 @@ def test_ill_conditioned_kuu_stays_on_the_phi_route_with_double_double_whitening
     ctx.close()
 
 
+def test_double_double_whitening_with_several_output_columns():
+    """Further output columns (oak_sgpr_set_extra_targets) ride through the double-double tail as further L^-1 psi_p rows: the
+    P-column bound equals the sum of the P single-column bounds of the oracle."""
+    spec, X, y, Z = _ill_conditioned(65536, 768, 8, 3.0, seed=3)
+    Y = np.column_stack([y[:, 0], np.cos(X[:, 1]) + 0.3 * X[:, 4], np.tanh(X[:, 2] * X[:, 3])])
+    refs = [c_oracle.sgpr_elbo_chunked(spec, X, Y[:, p], Z, 0.01, chunk=8192, return_parts=True) for p in range(3)]
+    ref = sum(r[0] for r in refs)
+    ctx = _capi.HipContext(0)
+    d = _capi.KernelDesc(spec)
+    ctx.sgpr_set_data(X, Y[:, 0]); ctx.sgpr_set_extra_targets(Y[:, 1:]); ctx.sgpr_set_inducing(Z)
+    e = ctx.sgpr_elbo(d, 0.01)
+    assert not ctx.sgpr_stats_whitened() and ctx.sgpr_stats_precision() == "int8crt" and ctx.bench_crt_info()["tail_dd"] == 1
+    scale = max(abs(ref), sum(0.5 * abs(r[1]["terms"]["cTc"]) for r in refs), 1.5 * abs(refs[0][1]["terms"]["tr_AAT"]))
+    assert abs(e - ref) <= 1e-10 * scale, (e, ref)
+    ctx.sgpr_set_route("whitened")
+    ew = ctx.sgpr_elbo(d, 0.01)
+    assert ctx.sgpr_stats_whitened() and abs(ew - e) <= 2e-10 * abs(ref)
+    # the single outputs' posteriors against the whitened route's
+    Xs = X[:1024]
+    pw = []
+    for p in range(3):
+        ctx.sgpr_select_output(p); pw.append(ctx.sgpr_predict(d, Xs))
+    ctx.sgpr_set_route("auto"); ctx.sgpr_elbo(d, 0.01)
+    assert ctx.bench_crt_info()["tail_dd"] == 1
+    for p in range(3):
+        ctx.sgpr_select_output(p)
+        m1, v1 = ctx.sgpr_predict(d, Xs)
+        np.testing.assert_allclose(m1, pw[p][0], rtol=1e-7, atol=1e-8 * np.abs(pw[p][0]).max())
+        np.testing.assert_allclose(v1, pw[p][1], rtol=1e-6, atol=1e-8 * np.abs(pw[p][1]).max())
+    ctx.close()
+
+
 def test_well_conditioned_kuu_keeps_the_fp64_products():
     spec, X, y, Z = _problem(65536, 8, 768, 2, ("gaussian",), seed=21, ls=(0.6, 0.9))
     ctx = _capi.HipContext(0)
