@@ -1422,8 +1422,18 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
     // ---- forward ------------------------------------------------------------------------------------------
     double elbo = 0.0, terms[8];
     ctx->keep_kfu = true;                                   // a whitening forward keeps the raw Kfu panel for the loop below
+    ctx->crt_planes_valid = false;
+    // Where the forward pass takes the int8 route (crt.hip) and converts the whole panel in one chunk, the adjoint panel Kfu H below
+    // is formed from its residue planes on the int8 pipe as well (crt_gemm.hip), and the forward pass need not write the fp64 panel
+    // at all.  OAK_CRT_GEMM=0: the fp64 GEMM throughout.
+    ctx->grad_int8 = getenv("OAK_CRT_GEMM") == nullptr || atoi(getenv("OAK_CRT_GEMM")) != 0;
     const int frc = sgpr_forward(ctx, pk, noise_var, jitter, &elbo, terms);
     ctx->keep_kfu = false;
+    const bool planes_here = ctx->crt_planes_valid && ctx->grad_int8 && !ctx->stats_whitened;
+    const bool panel_here = ctx->crt_panel_written || !ctx->stats_crt;      // an int8-route forward writes the fp64 panel only on request
+    ctx->crt_planes_valid = false;
+    ctx->grad_int8 = false;
+    ctx->crt_gemm_info[0] = ctx->crt_gemm_info[1] = 0;
     OAK_CHECK(frc);
     const int64_t N = ctx->N, M = ctx->M, Mp = ((M + 127) / 128) * 128;
     const double s2 = noise_var;
@@ -1545,15 +1555,28 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
     double *dPanel = nullptr, *dG = nullptr;
     OAK_CHECK(get_buf_t(ctx, "panel", (size_t)rows * Mp, &dPanel));
     OAK_CHECK(get_buf_t(ctx, "gpanel", (size_t)rows * Mp, &dG));
-    const bool reuse_panel = (rows >= N) && (!ctx->stats_whitened || ctx->kfu_kept);    // forward left the raw Kfu panel in place
+    const bool reuse_panel = (rows >= N) && panel_here && (!ctx->stats_whitened || ctx->kfu_kept);    // forward left the raw Kfu panel in place
     for (int64_t a0 = 0; a0 < N; a0 += rows) {
         const int64_t na = (a0 + rows <= N) ? rows : N - a0;
-        if (!reuse_panel) {
+        // int8 route: the adjoint panel from the residue planes of the forward pass (crt_gemm.hip)
+        bool done = false;
+        if (planes_here && rows >= N) {
+            PhaseTimer t(ctx, "bwd_gemm");
+            done = crt_gemm_adjoint(ctx, ctx->crt_pl, M, na, dH, dG, Mp) == OAK_OK;
+            if (!done) (void)hipGetLastError();          // (no room for H' next to the forward's moduli: the fp64 product below)
+            else if (nx > 0) {                          // the other outputs' y_p a_p^T: a pass of its own over the adjoint panel
+                rank_add_kernel<<<dim3((unsigned)((M + 255) / 256), (unsigned)((na + 15) / 16)), 256, 0, ctx->stream>>>(
+                    dG, Mp, na, M, (const double*)peek_buf(ctx, "Yx") + a0, N, d_ax, nx);
+                OAK_HIP_CHECK(hipGetLastError());
+            }
+            t.stop();
+        }
+        if (!reuse_panel && !done) {
             PhaseTimer t(ctx, "gram");
             OAK_CHECK(gram(ctx, pk, FX, a0, na, FZ, dPanel, Mp, nullptr, nullptr, Mp));
             t.stop();
         }
-        {
+        if (!done) {
             PhaseTimer t(ctx, "bwd_gemm");      // Gfu = Kfu H   (scaled by 1/s2 inside the pair kernel)
             int rs = OAK_OK;
             if (nx > 0 && gemm_nt_rankp(ctx, dPanel, dH, dG, na, M, M, Mp, M, Mp, (const double*)peek_buf(ctx, "Yx") + a0, N, d_ax, nx, &rs)) {

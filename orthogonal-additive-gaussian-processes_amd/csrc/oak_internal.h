@@ -122,6 +122,14 @@ struct PreparedKernel {
     // host-side derivative helpers (per RBF dim): d inv_v / d lengthscale etc. are recomputed in grad code
 };
 
+// exact int8 / CRT accumulation (crt.hip): the moduli and the buffers of one panel chunk
+constexpr int CRT_MAXL = 20;
+struct CrtMod { int L; int p[CRT_MAXL]; double inv[CRT_MAXL]; };
+struct CrtPlan {
+    CrtMod md; int B = 48, nsplit = 0; int64_t Mp2 = 0, rows_pad = 0, rps = 0;
+    int* d_sexp = nullptr; int8_t* d_planes = nullptr; int* d_part = nullptr; int* d_res = nullptr;
+};
+
 }  // namespace oak
 
 struct oak_ctx {
@@ -165,6 +173,13 @@ struct oak_ctx {
     bool last_tail_dd = false;       // the most recent tail whitened Phi in double-double arithmetic (oak_bench_crt_info slot 6)
     bool stats_phi_dd = false;       // ... and buffer "phi_lo" holds the low word of that Phi (cleared when the statistics are replaced / summed)
     int64_t crt_info[6] = {0, 0, 0, 0, 0, 0};   // ... and how (oak_bench_crt_info)
+    // The residue planes of the WHOLE Kfu panel are still in "crt_planes" (the forward pass of a gradient call converted all rows in one
+    // chunk): the backward pass forms its adjoint panel from them on the int8 pipe (crt_gemm.hip).  Valid between that forward and the
+    // backward of the same call only.
+    bool crt_planes_valid = false; oak::CrtPlan crt_pl;
+    bool grad_int8 = false;          // set by the gradient entry points around their forward pass: the backward will use those planes
+    bool crt_panel_written = true;   // the int8-route forward pass also wrote the fp64 Kfu panel
+    int64_t crt_gemm_info[2] = {0, 0};           // moduli and bits of H' of the most recent int8 adjoint GEMM (0: the fp64 GEMM ran)
     double cond_mm[2] = {1.0, 1.0};  // min / max of diag chol(Kuu), written by the side stream
     hipEvent_t ev2 = nullptr;        // side stream: conditioning estimate ready
     double noise_var = 0, jitter = 0;
@@ -263,12 +278,6 @@ int gram_f32(oak_ctx* ctx, const PreparedKernel& pk, const Feat& A, int64_t a0, 
 int syrk_panel_f32(oak_ctx* ctx, const float* d_panel, int64_t ldp, int64_t nrows, int64_t M, double* d_part, int nsplit, bool accumulate);
 int syrk_reduce(oak_ctx* ctx, const double* d_part, int nsplit, int64_t M, double* d_phi /*[M*M]*/, bool accumulate);
 // exact int8 / CRT accumulation of Phi (crt.hip; the fused Gram epilogue is gram.hip::gram_crt_kernel)
-constexpr int CRT_MAXL = 20;
-struct CrtMod { int L; int p[CRT_MAXL]; double inv[CRT_MAXL]; };
-struct CrtPlan {
-    CrtMod md; int B = 48, nsplit = 0; int64_t Mp2 = 0, rows_pad = 0, rps = 0;
-    int* d_sexp = nullptr; int8_t* d_planes = nullptr; int* d_part = nullptr; int* d_res = nullptr;
-};
 bool crt_supported(const oak_ctx* ctx, int64_t M);
 int crt_plan(oak_ctx* ctx, int64_t na, int64_t M, int64_t n_total, CrtPlan* pl);
 // kdiag_parts: the featurize pass of X ran its tiled form with the K_diag reduction (kappa_done): its per-workgroup maxima serve
@@ -276,6 +285,8 @@ int crt_scales(oak_ctx* ctx, const PreparedKernel& pk, const Feat& FX, const Fea
 int crt_convert_panel(oak_ctx* ctx, const CrtPlan& pl, const double* d_panel, int64_t ldp, int64_t na);
 // d_phi_lo (may be NULL): the low word of the double-double Phi (the integer Gram matrix holds ~118 bits)
 int crt_accumulate(oak_ctx* ctx, const CrtPlan& pl, int64_t M, bool first_chunk, bool last_chunk, double* d_phi, double* d_phi_lo);
+// adjoint panel G = Kfu H on the int8 pipe from the planes of `pl` (crt_gemm.hip)
+int crt_gemm_adjoint(oak_ctx* ctx, const CrtPlan& pl, int64_t M, int64_t na, const double* d_H, double* d_G, int64_t ldg);
 // [W ; (L^-1 psi)^T] = [L^-1 Phi L^-T ; (L^-1 psi)^T] in double-double arithmetic from the double-double Phi (ddgemm.hip), one double out
 int dd_whiten(oak_ctx* ctx, const double* d_Linv, const double* d_phi_hi, const double* d_phi_lo, const double* d_psi, int64_t M, double* d_out,
               const double* d_psix, int nx);

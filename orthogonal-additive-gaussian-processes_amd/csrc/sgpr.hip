@@ -9,6 +9,7 @@ namespace oak {
 
 static inline int64_t pad128(int64_t m) { return ((m + 127) / 128) * 128; }
 static constexpr double AUTO_WHITEN_DIAG_RATIO2 = 1e3;   // auto route: whiten when (max diag L / min diag L)^2 exceeds this
+static constexpr double CRT_GEMM_MAX_DIAG_RATIO2 = 1e2;  // int8 adjoint GEMM of a gradient call (crt_gemm.hip): only below this value of the same estimate
 // fp32 statistics mode: honoured only below this value of the same estimate.  Measured (tools/dev_fp32.py): estimate 24
 // (headline, cond(Kuu) = 2.3e3) -> ELBO 9e-7 from fp64; 545 (config 2, cond 9e4) -> 2.6e-5: the latter is refused.
 static constexpr double FP32_MAX_DIAG_RATIO2 = 1e2;
@@ -333,7 +334,24 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     // kernel shape the fused epilogue is not instantiated for: the fp64 panel is converted by a pass of its own once the route is settled.
     const bool crt_wanted = crt_cand && !use32;
     const bool crt_fused = crt_wanted && !lazy && !whiten && gram_crt_supported(pk) && getenv("OAK_CRT_UNFUSED") == nullptr;
-    const bool crt_panel = ctx->keep_kfu || ctx->n_extra > 0;      // fused pass: somebody reads the fp64 panel afterwards
+    // fused pass: somebody reads the fp64 panel afterwards -- a further output column's Kuf y, or a backward pass that cannot form its
+    // adjoint panel from the residue planes (more than one chunk; OAK_CRT_GEMM=0)
+    // The int8 adjoint GEMM is for well-conditioned Kuu only: G = Kfu H cancels like cond(Kuu), and its operands are fixed-point numbers
+    // per column (49-51 bits of the column bound) where the fp64 GEMM has 53 bits of every entry.  Same estimate and threshold as the
+    // double-double tail; the side stream's reading arrives while the main stream featurizes (~0.2 ms of waiting in a gradient call).
+    // OAK_CRT_GEMM=1 skips the check (experiments).
+    bool int8_bwd = ctx->keep_kfu && ctx->grad_int8 && crt_fused && rows >= N;
+    if (int8_bwd && !(getenv("OAK_CRT_GEMM") != nullptr && atoi(getenv("OAK_CRT_GEMM")) == 1)) {
+        if (ctx->cond_requested && ctx->kuu_async && !ctx->kuu_deferred) {
+            OAK_HIP_CHECK(hipEventSynchronize(ctx->ev2));
+            const double ratio = ctx->cond_mm[1] / ctx->cond_mm[0];
+            int8_bwd = ratio * ratio <= CRT_GEMM_MAX_DIAG_RATIO2;
+        } else {
+            int8_bwd = false;
+        }
+    }
+    if (ctx->keep_kfu) ctx->grad_int8 = int8_bwd;
+    const bool crt_panel = (ctx->keep_kfu && !int8_bwd) || ctx->n_extra > 0;
     bool use_crt = false;
     for (int64_t a0 = 0; a0 < N; a0 += rows, ++chunk_idx) {
         const int64_t na = (a0 + rows <= N) ? rows : N - a0;
@@ -450,6 +468,9 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     ctx->stats_fp32 = use32;
     ctx->stats_crt = use_crt;
     ctx->stats_phi_dd = use_crt;
+    ctx->crt_panel_written = !crt_fused || crt_panel;
+    ctx->crt_planes_valid = use_crt && chunk_idx == 1;      // one chunk: "crt_planes" holds every row (a gradient call's backward reads them)
+    if (use_crt) ctx->crt_pl = cp;
     for (int q = 0; q < 6; ++q) ctx->crt_info[q] = 0;
     if (use_crt) {
         ctx->crt_info[0] = cp.md.L; ctx->crt_info[1] = cp.B; ctx->crt_info[2] = cp.nsplit; ctx->crt_info[3] = cp.rps;
