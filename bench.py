@@ -472,6 +472,23 @@ def main():
         gt = {k: ctx.timing(k) for k in PHASES}
         grad_info = {"steps_per_sec": gsteps / dtg, "ms_per_step": dtg / gsteps * 1e3, "steps": gsteps,
                      "phase_ms_per_step": {k: v[0] / gsteps for k, v in gt.items() if v[1]}}
+        # the adjoint panel Kfu H of the backward pass: int8 pipe from the forward pass's residue planes (csrc/crt_gemm.hip) where
+        # chol(Kuu) looks well-conditioned, else the fp64 MFMA GEMM
+        ginfo = ctx.bench_crt_info()
+        g_ms = gt["bwd_gemm"][0] / max(gt["bwd_gemm"][1], 1)
+        if ginfo.get("gemm_planes", 0) > 0 and g_ms:
+            g_ops = 2.0 * ginfo["gemm_planes"] * ginfo["plane_columns"] ** 2 * float(hi - lo)
+            grad_info["adjoint_gemm"] = {"kernel": f"crt_gemm_i8_kernel (v_mfma_i32_32x32x32_i8 over {ginfo['gemm_planes']} residue planes, operands via ds_read_b64_tr_b8; "
+                                                   f"H scaled to >= {ginfo['gemm_bits']} bits)", "avg_launch_ms": g_ms, "bound": "mfma",
+                                         "achieved": g_ops / (g_ms * 1e-3) / 1e12, "peak": INT8_PEAK_TOPS, "unit": "TOP/s",
+                                         "frac": g_ops / (g_ms * 1e-3) / 1e12 / INT8_PEAK_TOPS,
+                                         "fp64_equivalent_TFLOPs": 2.0 * M * M * float(hi - lo) / (g_ms * 1e-3) / 1e12,
+                                         "note": "avg_launch_ms includes the two small launches that convert H (phase timer bwd_gemm)"}
+        elif g_ms:
+            g_fl = 2.0 * M * M * float(hi - lo)
+            grad_info["adjoint_gemm"] = {"kernel": "gemm128_nt_kernel (v_mfma_f64_16x16x4_f64)", "avg_launch_ms": g_ms, "bound": "mfma",
+                                         "achieved": g_fl / (g_ms * 1e-3) / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                         "frac": g_fl / (g_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS}
 
     # ---- the route real fits take: GPflow's literal A = L^-1 Kuf (whitened), forward and forward + gradient ----------
     # (with k-means inducing points the conditioning estimate sends most BFGS evaluations of the auto route here)

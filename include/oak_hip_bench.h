@@ -24,7 +24,8 @@ int oak_bench_trsm(oak_ctx* ctx, const double* L, int64_t n, double* B, int64_t 
 
 /* Shape of the most recent int8 CRT accumulation of Phi (oak_sgpr_set_precision 2 / automatic; csrc/crt.hip): info[0] = residue planes
    (moduli), info[1] = bits of the scaled integers, info[2] = row splits, info[3] = rows per split, info[4] bit 0 = the planes came
-   out of the Gram kernel's epilogue (else: stand-alone conversion pass), bit 1 = the most recent tail whitened Phi in double-double arithmetic, info[5] = plane columns (M rounded up to 256).  All zero when
+   out of the Gram kernel's epilogue (else: stand-alone conversion pass), bit 1 = the most recent tail whitened Phi in double-double arithmetic, bits 8-15 / 16-23 = residue planes / bits of H' of the most
+   recent gradient call's int8 adjoint GEMM (csrc/crt_gemm.hip; 0: the fp64 GEMM ran), info[5] = plane columns (M rounded up to 256).  All zero when
    the last statistics were formed by the fp64 / fp32 kernels.  bench.py prices the int8 SYRK with it. */
 int oak_bench_crt_info(oak_ctx* ctx, int64_t* info6);
 

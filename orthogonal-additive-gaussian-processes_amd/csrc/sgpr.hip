@@ -1152,6 +1152,7 @@ int oak_bench_crt_info(oak_ctx* ctx, int64_t* info6) {
     OAK_CHECK(guard(ctx));
     OAK_REQUIRE(info6 != nullptr, "oak_bench_crt_info: NULL output");
     for (int q = 0; q < 6; ++q) info6[q] = ctx->have_stats ? ctx->crt_info[q] : 0;
+    if (ctx->have_stats) info6[4] |= (ctx->crt_gemm_info[0] & 0xff) << 8 | (ctx->crt_gemm_info[1] & 0xff) << 16;   // bits 8-15 / 16-23: the last gradient's int8 adjoint GEMM
     if (ctx->have_stats && ctx->last_tail_dd) info6[4] |= 2;      // bit 1: the most recent tail whitened Phi in double-double arithmetic
     return OAK_OK;
 }

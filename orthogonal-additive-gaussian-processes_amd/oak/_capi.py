@@ -902,6 +902,8 @@ class HipContext:
         _check(self._lib.oak_bench_crt_info(self._h, a))
         d = dict(zip(("planes", "bits", "row_splits", "rows_per_split", "fused", "plane_columns"), [int(v) for v in a]))
         d["tail_dd"] = (d["fused"] >> 1) & 1          # the most recent tail whitened Phi in double-double arithmetic (csrc/ddgemm.hip)
+        d["gemm_planes"] = (d["fused"] >> 8) & 0xff   # the most recent gradient call formed its adjoint panel on the int8 pipe (csrc/crt_gemm.hip) from
+        d["gemm_bits"] = (d["fused"] >> 16) & 0xff    # this many residue planes, H scaled to this many bits (0 / 0: the fp64 GEMM ran)
         d["fused"] &= 1
         return d
 

@@ -304,3 +304,81 @@ def test_well_conditioned_kuu_keeps_the_fp64_products():
     if t["cond_estimate"] <= 1e2:
         assert ctx.bench_crt_info()["tail_dd"] == 0 and ctx.sgpr_stats_precision() == "int8crt" and not ctx.sgpr_stats_whitened()
     ctx.close()
+
+
+def _with_env(name, value, fn):
+    old = os.environ.get(name)
+    try:
+        if value is None: os.environ.pop(name, None)
+        else: os.environ[name] = value
+        return fn()
+    finally:
+        if old is None: os.environ.pop(name, None)
+        else: os.environ[name] = old
+
+
+@pytest.mark.parametrize("N,D,M,kinds,ls", [(50001, 7, 640, ("gaussian", "uniform", "gaussian", "categorical"), (0.3, 0.5)),
+                                              (65536, 8, 1024, ("gaussian",), (0.35, 0.6))])
+def test_int8_adjoint_gemm_of_the_gradient(N, D, M, kinds, ls):
+    """csrc/crt_gemm.hip: a gradient call whose forward pass took the int8 route forms the adjoint panel Kfu H from the residue planes
+    (LDS transpose reads, one int8 GEMM per modulus, fp64 fraction reconstruction) when chol(Kuu) looks well-conditioned.  Its operands
+    are 49-51-bit fixed-point numbers per column: the gradient is held to 1e-10 of its largest entry against the fp64 GEMM and against
+    the fp64 kernels (measured 1e-12 .. 6e-12).  Ragged N and M (plane columns padded to 768), a discrete sub-kernel, further output
+    columns, the gradient w.r.t. the inducing inputs.  (Short lengthscales: the estimate of these problems is 27 and 31.)"""
+    spec, X, y, Z = _problem(N, D, M, 2, kinds, seed=31, ls=ls)
+    ctx = _capi.HipContext(0)
+    d = _capi.KernelDesc(spec)
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("phi"); ctx.sgpr_set_precision("int8crt")
+    e0, g0 = _with_env("OAK_CRT_GEMM", "0", lambda: ctx.sgpr_elbo_grad(d, 0.05))
+    assert ctx.bench_crt_info()["gemm_planes"] == 0 and ctx.sgpr_stats_precision() == "int8crt"
+    e1, g1 = ctx.sgpr_elbo_grad(d, 0.05)
+    info = ctx.bench_crt_info()
+    assert ctx.sgpr_last_terms()["cond_estimate"] <= 1e2 and info["gemm_planes"] >= 13 and info["gemm_bits"] >= 44, info
+    assert e1 == e0                                               # the forward pass is the same arithmetic with or without the fp64 panel
+    tol = 1e-10 * np.abs(g0).max()
+    np.testing.assert_allclose(g1, g0, rtol=0, atol=tol)
+    ctx.sgpr_set_precision("fp64")
+    _, g64 = ctx.sgpr_elbo_grad(d, 0.05)
+    assert ctx.bench_crt_info()["gemm_planes"] == 0
+    np.testing.assert_allclose(g1, g64, rtol=0, atol=tol)
+    ctx.sgpr_set_precision("int8crt")
+    assert ctx.sgpr_elbo_grad(d, 0.05)[1].tobytes() == g1.tobytes()            # repeatable bit for bit
+    # gradient w.r.t. the inducing inputs reads the same adjoint panel
+    _, _, gz0 = _with_env("OAK_CRT_GEMM", "0", lambda: ctx.sgpr_elbo_grad_z(d, 0.05, M, D))
+    _, _, gz1 = ctx.sgpr_elbo_grad_z(d, 0.05, M, D)
+    assert ctx.bench_crt_info()["gemm_planes"] >= 13
+    np.testing.assert_allclose(gz1, gz0, rtol=0, atol=1e-9 * np.abs(gz0).max())
+    # further output columns: y_p a_p^T joins the int8 product in a pass of its own
+    ctx.sgpr_set_extra_targets(np.column_stack([np.cos(X[:, 1]), X[:, 2] ** 2]))
+    ex0, gx0 = _with_env("OAK_CRT_GEMM", "0", lambda: ctx.sgpr_elbo_grad(d, 0.05))
+    ex1, gx1 = ctx.sgpr_elbo_grad(d, 0.05)
+    assert ctx.bench_crt_info()["gemm_planes"] >= 13 and ex1 == ex0 and ex1 != e1
+    np.testing.assert_allclose(gx1, gx0, rtol=0, atol=1e-10 * np.abs(gx0).max())
+    ctx.sgpr_set_extra_targets(None)
+    # several panel chunks: the planes of the last chunk only -- the fp64 product runs
+    ctx.sgpr_set_panel_rows(20000)
+    ec, gc = ctx.sgpr_elbo_grad(d, 0.05)
+    ctx.sgpr_set_panel_rows(0)
+    assert ctx.bench_crt_info()["gemm_planes"] == 0 and ctx.sgpr_stats_precision() == "int8crt"
+    np.testing.assert_allclose(gc, g0, rtol=1e-9, atol=tol)
+    ctx.close()
+
+
+def test_int8_adjoint_gemm_steps_aside_on_ill_conditioned_kuu():
+    """G = Kfu H cancels like cond(Kuu): above the estimate 1e2 the fp64 GEMM runs (measured at estimate 5e5: 1e-5 of the largest gradient
+    entry from the whitened route's with the int8 product, 5e-9 with the fp64 one)."""
+    spec, X, y, Z = _ill_conditioned(65536, 768, 8, 1.5)
+    ctx = _capi.HipContext(0)
+    d = _capi.KernelDesc(spec)
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z)
+    _, g = ctx.sgpr_elbo_grad(d, 0.01)
+    info = ctx.bench_crt_info()
+    assert ctx.sgpr_stats_precision() == "int8crt" and info["tail_dd"] == 1 and info["gemm_planes"] == 0
+    ctx.sgpr_set_route("whitened")
+    _, gw = ctx.sgpr_elbo_grad(d, 0.01)
+    np.testing.assert_allclose(g, gw, rtol=1e-5, atol=1e-7 * np.abs(gw).max())
+    ctx.sgpr_set_route("auto")
+    _, gf = _with_env("OAK_CRT_GEMM", "1", lambda: ctx.sgpr_elbo_grad(d, 0.01))      # forced: runs, and shows why it is not the default here
+    assert ctx.bench_crt_info()["gemm_planes"] >= 13
+    assert np.abs(gf - gw).max() > 10 * np.abs(g - gw).max()
+    ctx.close()

@@ -14,6 +14,7 @@ ap.add_argument("--configs", default="headline")
 ap.add_argument("--reps", type=int, default=4)
 ap.add_argument("--bits", default="")
 ap.add_argument("--rows", type=int, default=0)
+ap.add_argument("--int8-only", action="store_true", help="only the int8 GEMM mode (profiling runs)")
 ap.add_argument("--cond-sweep", action="store_true", help="gradient error of the int8 and the fp64 adjoint GEMM against the whitened route's gradient over a range of conditioning")
 args = ap.parse_args()
 ctx = _capi.default_context()
@@ -48,7 +49,8 @@ for name in args.configs.split(","):
     d = _capi.KernelDesc(spec)
     ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("phi")
     res = {}
-    for label, mode, env in (("fp64 kernels", "fp64", "0"), ("int8 Phi, fp64 GEMM", "int8crt", "0"), ("int8 Phi, int8 GEMM", "int8crt", "1")):
+    modes = (("fp64 kernels", "fp64", "0"), ("int8 Phi, fp64 GEMM", "int8crt", "0"), ("int8 Phi, int8 GEMM", "int8crt", "1"))
+    for label, mode, env in (modes[2:] if args.int8_only else modes):
         ctx.sgpr_set_precision(mode)
         os.environ["OAK_CRT_GEMM"] = env
         if args.bits: os.environ["OAK_CRT_GEMM_BITS"] = args.bits
@@ -67,6 +69,7 @@ for name in args.configs.split(","):
                 pass
         res[label] = (e, g, dt, ph)
         print(f"{name} N={N} M={M}: {label}: {dt * 1e3:.2f} ms  {ph}", flush=True)
+    if args.int8_only: continue
     g0 = res["fp64 kernels"][1]
     for label in ("int8 Phi, fp64 GEMM", "int8 Phi, int8 GEMM"):
         g = res[label][1]
