@@ -212,7 +212,12 @@ int oak_sgpr_set_global_rows(oak_ctx* ctx, int64_t n_total);
    reconstructed by the Chinese remainder theorem.  The one rounding per entry (2^-48 of the column bound) replaces the N
    roundings of an fp64 accumulation: this is not a lower precision (Phi is closer to the exact sum than the fp64 SYRK's).  phi
    route only (a whitened panel has no a-priori bound); M <= 4096, N >= 4096; otherwise the evaluation runs the fp64 kernels --
-   oak_sgpr_stats_precision tells. */
+   oak_sgpr_stats_precision tells.
+   Gradient calls (oak_sgpr_elbo_grad / _grad_z) whose forward pass took this route with the whole panel in one chunk also form the
+   adjoint panel Kfu H of the backward pass from those residue planes on the int8 pipe (csrc/crt_gemm.hip) -- when chol(Kuu) looks
+   well-conditioned ((max diag L / min diag L)^2 <= 1e2): its operands are 49- and 46-49-bit fixed-point numbers per column and the
+   product cancels like cond(Kuu) (gradient within 1e-14 of the fp64 kernels' at the headline size, 3e-13 at an estimate of 200;
+   tests/test_gpu_crt.py).  Otherwise, and with OAK_CRT_GEMM=0 in the environment, the fp64 MFMA GEMM runs (modes 0 and 1: always). */
 int oak_sgpr_set_precision(oak_ctx* ctx, int32_t mode);
 int oak_sgpr_stats_precision(oak_ctx* ctx, int32_t* mode);
 int oak_sgpr_stats_whitened(oak_ctx* ctx, int32_t* flag);

@@ -11,7 +11,7 @@ def find(sub):
     return cpl[ks[0]] if ks else {}
 gram, syrk, bwd, gemm = find("gram_kernel<"), find("syrk_kernel<"), find("gram_bwd_fast_kernel<"), find("gemm128_nt_kernel")
 trsm = find("trsm_fused_kernel")
-gcrt, scrt = find("gram_crt_kernel<"), find("crt_syrk_i8_deep_kernel")
+gcrt, scrt, gemm8 = find("gram_crt_kernel<"), find("crt_syrk_i8_deep_kernel"), find("crt_gemm_i8_kernel")
 src = f"profiles/{tag}_pmc_summary.json (tools/profile_headline.sh {tag})"
 traffic = {"headline": {"syrk": syrk.get("FETCH_SIZE_bytes", 0) + syrk.get("WRITE_SIZE_bytes", 0),
                         "gram": gram.get("FETCH_SIZE_bytes", 0) + gram.get("WRITE_SIZE_bytes", 0),
@@ -19,7 +19,8 @@ traffic = {"headline": {"syrk": syrk.get("FETCH_SIZE_bytes", 0) + syrk.get("WRIT
                         "bwd_gram": bwd.get("FETCH_SIZE_bytes", 0) + bwd.get("WRITE_SIZE_bytes", 0),
                         "trsm": trsm.get("FETCH_SIZE_bytes", 0) + trsm.get("WRITE_SIZE_bytes", 0),
                         "crt_syrk": scrt.get("FETCH_SIZE_bytes", 0) + scrt.get("WRITE_SIZE_bytes", 0),
-                        "gram_crt": gcrt.get("FETCH_SIZE_bytes", 0) + gcrt.get("WRITE_SIZE_bytes", 0)},
+                        "gram_crt": gcrt.get("FETCH_SIZE_bytes", 0) + gcrt.get("WRITE_SIZE_bytes", 0),
+                        "crt_gemm": gemm8.get("FETCH_SIZE_bytes", 0) + gemm8.get("WRITE_SIZE_bytes", 0)},
            "_note": "bytes per launch at the L2<->fabric boundary (TCC_EA requests; Infinity-Cache hits are included), from separate "
                     "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 tallies "
                     "128-B requests at 64 B)",
