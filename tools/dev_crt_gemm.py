@@ -29,14 +29,15 @@ if args.cond_sweep:
         if spread < 1.0: Z[M // 2:] = Z[:M - M // 2] + spread * rng.standard_normal((M - M // 2, D))
         spec = o.make_spec(D, 2, lengthscales=[ls] * D); d = _capi.KernelDesc(spec)
         ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z)
-        ctx.sgpr_set_route("whitened"); ctx.sgpr_set_precision("fp64"); _, gw = ctx.sgpr_elbo_grad(d, 0.01)
-        ctx.sgpr_set_route("phi"); _, g64 = ctx.sgpr_elbo_grad(d, 0.01)
+        ctx.sgpr_set_route("whitened"); ctx.sgpr_set_precision("fp64"); _, gw, zw = ctx.sgpr_elbo_grad_z(d, 0.01, M, D)
+        ctx.sgpr_set_route("phi"); _, g64, z64 = ctx.sgpr_elbo_grad_z(d, 0.01, M, D)
         ctx.sgpr_set_precision("int8crt")
-        os.environ["OAK_CRT_GEMM"] = "0"; _, ga = ctx.sgpr_elbo_grad(d, 0.01); est = ctx.sgpr_last_terms()["cond_estimate"]
-        os.environ["OAK_CRT_GEMM"] = "1"; _, gb = ctx.sgpr_elbo_grad(d, 0.01); info = ctx.bench_crt_info()
-        sc = np.abs(gw).max()
+        os.environ["OAK_CRT_GEMM"] = "0"; _, ga, za = ctx.sgpr_elbo_grad_z(d, 0.01, M, D); est = ctx.sgpr_last_terms()["cond_estimate"]
+        os.environ["OAK_CRT_GEMM"] = "1"; _, gb, zb = ctx.sgpr_elbo_grad_z(d, 0.01, M, D); info = ctx.bench_crt_info()
+        sc, sz = np.abs(gw).max(), np.abs(zw).max()
         print(f"ls {ls} spread {spread}: estimate {est:.3g}  |g - g_whitened| / max|g|: fp64 phi {np.abs(g64 - gw).max() / sc:.1e}, int8 Phi + fp64 GEMM {np.abs(ga - gw).max() / sc:.1e}, "
-              f"int8 Phi + int8 GEMM {np.abs(gb - gw).max() / sc:.1e}   (tail_dd {info['tail_dd']})", flush=True)
+              f"int8 Phi + int8 GEMM {np.abs(gb - gw).max() / sc:.1e}   (tail_dd {info['tail_dd']})\n"
+              f"      gradient w.r.t. Z, same order: {np.abs(z64 - zw).max() / sz:.1e}, {np.abs(za - zw).max() / sz:.1e}, {np.abs(zb - zw).max() / sz:.1e}", flush=True)
     os.environ.pop("OAK_CRT_GEMM", None)
     sys.exit(0)
 PHASES = ("gram", "crt_syrk", "syrk", "tail", "bwd_tail", "bwd_gemm", "bwd_gram", "bwd_small", "total")
