@@ -184,7 +184,9 @@ int oak_sgpr_local_stats(oak_ctx* ctx, const oak_kernel_desc* desc, double jitte
    then holds W = L^-1 Phi L^-T.  0 = auto: whitened while N*M <= 2^24; above that oak_sgpr_elbo and
    oak_sgpr_elbo_grad whiten only when chol(Kuu) looks ill-conditioned, (max diag L / min diag L)^2 > 1e3,
    which keeps the result within ~1e-10 of the literal route (the stand-alone oak_sgpr_local_stats uses the
-   size rule alone).  Where the int8 route of oak_sgpr_set_precision runs on ONE rank, auto never whitens: Phi is then exact (kept as a
+   size rule alone).  Where the int8 route of oak_sgpr_set_precision runs -- on one rank, or under a communicator whose ranks all declared
+   oak_sgpr_set_global_rows (the shards' Phi are then summed exactly: two fixed-point limbs per entry, one more all-reduce of M^2 doubles;
+   RCCL and loopback communicators by default, the host exchange with OAK_COMM_DD=1) -- auto never whitens: Phi is then exact (kept as a
    double-double) and the tail whitens it with double-double M^3 products when chol(Kuu) looks ill-conditioned (estimate > 1e2;
    csrc/ddgemm.hip) -- the phi route at the whitened route's accuracy, without the N-sized triangular solve (tests/test_gpu_crt.py).
    Under a communicator N is the row count over ALL ranks: what oak_sgpr_set_global_rows declared

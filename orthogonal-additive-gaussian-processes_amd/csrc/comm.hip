@@ -241,9 +241,29 @@ int oak_comm_allreduce_stats(oak_ctx* ctx) {
         OAK_REQUIRE(d_psix != nullptr && ctx->psix_valid, "oak_comm_allreduce_stats: the extra target columns' statistics are not those of the "
                     "packed statistics in place (form both with oak_sgpr_local_stats on every rank)");
     PhaseTimer t(ctx, "allreduce");
-    ctx->stats_phi_dd = false;      // a sum of shards in fp64 rounds Phi: its low word no longer belongs to it
+    // Exact sum of the shards' Phi (sgpr.hip::comm_dd_rule; ddgemm.hip): the Phi slot carries the high limbs through the ordinary exchange,
+    // a second vector the low limbs; joined afterwards into Phi and its low word.  Without it: a sum of shards in fp64 rounds Phi, its low
+    // word no longer belongs to it.
+    const int64_t M = ctx->M;
+    const bool dd = ctx->comm_dd && !ctx->stats_whitened && peek_buf(ctx, "dd_eexp") != nullptr;
+    double *d_lo = nullptr, *d_phi_lo = nullptr;
+    if (dd) {
+        OAK_CHECK(get_buf_t(ctx, "dd_lo_limb", (size_t)M * M, &d_lo));
+        const double* lo_in = ctx->stats_phi_dd ? (const double*)peek_buf(ctx, "phi_lo") : nullptr;
+        int en = 0, lr = 0;
+        while (((int64_t)1 << en) < ctx->n_global_user) ++en;
+        while ((1 << lr) < ctx->nranks) ++lr;
+        OAK_CHECK(dd_exchange_split(ctx, d_stats, lo_in, (const int*)peek_buf(ctx, "dd_eexp"), en + 1, 50 - lr, M, d_lo));
+        OAK_CHECK(get_buf_t(ctx, "phi_lo", (size_t)M * M, &d_phi_lo));
+    }
+    ctx->stats_phi_dd = false;
     // the two trailing slots (shards that whitened, shards summed) ride along: the tail rejects a mixed sum
     OAK_CHECK(comm_allreduce_dev(ctx, d_stats, oak_sgpr_stats_len(ctx)));
+    if (dd) {
+        OAK_CHECK(comm_allreduce_dev(ctx, d_lo, M * M, "comm_stage_lo"));
+        OAK_CHECK(dd_exchange_join(ctx, d_stats, d_lo, M, d_phi_lo));
+        ctx->stats_phi_dd = true;
+    }
     // extra target columns: [Kuf y_p | y_p^T y_p] is part of the same sum over the row shards -- reduced HERE, so that the documented
     // local_stats -> allreduce_stats -> tail sequence and the fused entry points exchange the same things
     if (ctx->n_extra > 0) OAK_CHECK(comm_allreduce_dev(ctx, d_psix, (int64_t)ctx->n_extra * ctx->M + ctx->n_extra, "comm_stage_x"));

@@ -495,6 +495,28 @@ int crt_scales(oak_ctx* ctx, const PreparedKernel& pk, const Feat& FX, const Fea
     return OAK_OK;
 }
 
+// e_m = exponent of the a-priori bound on |K(x, z_m)| (no data of this rank's rows in it: every rank of a communicator derives the same)
+__global__ void __launch_bounds__(256) crt_eexp_kernel(const double* __restrict__ kdiagZ, int64_t M, double kmax, int psd, int* __restrict__ eexp) {
+    const int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    const double kd = kdiagZ[m];
+    const double bound = (psd ? sqrt(kmax * (kd > 0.0 ? kd : 0.0)) : kmax) * (1.0 + 0x1p-20) + 0x1p-300;
+    int e = 0;
+    frexp(bound, &e);
+    eexp[m] = e;
+}
+int crt_bound_exponents(oak_ctx* ctx, const PreparedKernel& pk, const Feat& FZ, int64_t M, int* d_eexp) {
+    double* d_kdz = nullptr;
+    OAK_CHECK(get_buf_t(ctx, "crt_kdiagZ", (size_t)M, &d_kdz));
+    OAK_CHECK(gram_diag(ctx, pk, FZ, d_kdz, nullptr));
+    bool psd = true;
+    for (double w : pk.w_full) psd = psd && w >= 0.0;
+    for (int d = 0; d < pk.dd.D; ++d) psd = psd && pk.dd.bv[d] >= 0.0;
+    crt_eexp_kernel<<<(unsigned)((M + 255) / 256), 256, 0, ctx->stream>>>(d_kdz, M, crt_kmax(pk), psd ? 1 : 0, d_eexp);
+    OAK_HIP_CHECK(hipGetLastError());
+    return OAK_OK;
+}
+
 // stand-alone conversion of an fp64 panel chunk (the fallback of the fused Gram epilogue, gram.hip::gram_crt_kernel)
 int crt_convert_panel(oak_ctx* ctx, const CrtPlan& pl, const double* d_panel, int64_t ldp, int64_t na) {
     PhaseTimer t(ctx, "crt_convert");

@@ -144,4 +144,41 @@ int dd_whiten(oak_ctx* ctx, const double* d_Linv, const double* d_phi_hi, const 
     return OAK_OK;
 }
 
+// ---- exact sum of the ranks' Phi through an fp64 all-reduce ------------------------------------------------------------------------------
+// |Phi_total[a][b]| <= N_global bound_a bound_b < 2^E, E = e_a + e_b + en: every rank rounds its Phi[a][b] (a double-double when the int8
+// route formed it, else one double) to the grid 2^(E - 51) -- the HIGH limb, at most 51 bits and a sign -- and the remainder to the grid
+// 2^(E - 51 - lo_bits) -- the LOW limb.  Sums of the high limbs over the ranks stay below 2^52 grid units (the bound is on the total) and sums
+// of the low limbs below 2^52 with lo_bits = 50 - ceil(log2 ranks): both all-reduces are exact, in any order.  Rounding by the
+// add-and-subtract constant 1.5 * 2^(grid + 52).  What is dropped is below 2^(E - 51 - lo_bits): 98 bits under the bound at eight ranks.
+__global__ void __launch_bounds__(256) dd_split_kernel(double* __restrict__ phi, const double* __restrict__ phi_lo, const int* __restrict__ eexp, int en,
+                                                       int lo_bits, int64_t M, double* __restrict__ lo_out) {
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x, a = blockIdx.y;
+    if (b >= M) return;
+    const int E = eexp[a] + eexp[b] + en;
+    const double ch = ldexp(1.5, E - 51 + 52), cl = ldexp(1.5, E - 51 - lo_bits + 52);
+    const double xh = phi[a * M + b], xl = phi_lo != nullptr ? phi_lo[a * M + b] : 0.0;
+    const double hi = (xh + ch) - ch;
+    const double rem = (xh - hi) + xl;
+    phi[a * M + b] = hi;
+    lo_out[a * M + b] = (rem + cl) - cl;
+}
+__global__ void __launch_bounds__(256) dd_join_kernel(double* __restrict__ phi, const double* __restrict__ lo, int64_t n, double* __restrict__ phi_lo) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const double h = phi[i], l = lo[i];
+    const double s = h + l, t = s - h;
+    phi[i] = s;
+    phi_lo[i] = (h - (s - t)) + (l - t);
+}
+int dd_exchange_split(oak_ctx* ctx, double* d_phi, const double* d_phi_lo, const int* d_eexp, int en, int lo_bits, int64_t M, double* d_lo) {
+    dd_split_kernel<<<dim3((unsigned)((M + 255) / 256), (unsigned)M), 256, 0, ctx->stream>>>(d_phi, d_phi_lo, d_eexp, en, lo_bits, M, d_lo);
+    OAK_HIP_CHECK(hipGetLastError());
+    return OAK_OK;
+}
+int dd_exchange_join(oak_ctx* ctx, double* d_phi, const double* d_lo, int64_t M, double* d_phi_lo) {
+    dd_join_kernel<<<(unsigned)((M * M + 255) / 256), 256, 0, ctx->stream>>>(d_phi, d_lo, M * M, d_phi_lo);
+    OAK_HIP_CHECK(hipGetLastError());
+    return OAK_OK;
+}
+
 }  // namespace oak

@@ -172,6 +172,10 @@ struct oak_ctx {
     bool stats_crt = false;          // ... Phi of the statistics in "stats" was accumulated exactly on the int8 pipe (crt.hip)
     bool last_tail_dd = false;       // the most recent tail whitened Phi in double-double arithmetic (oak_bench_crt_info slot 6)
     bool stats_phi_dd = false;       // ... and buffer "phi_lo" holds the low word of that Phi (cleared when the statistics are replaced / summed)
+    // Under a communicator the shards' Phi are summed EXACTLY (comm.hip: two fixed-point limbs per entry on a grid every rank derives from the
+    // same rank-independent bound, summed by the ordinary fp64 all-reduce), so that the double-double tail also serves multi-rank jobs.  Decided
+    // per evaluation by a rule of rank-independent inputs only (sgpr.hip::comm_dd_rule): every rank then runs the same sequence of collectives.
+    bool comm_dd = false;
     int64_t crt_info[6] = {0, 0, 0, 0, 0, 0};   // ... and how (oak_bench_crt_info)
     // The residue planes of the WHOLE Kfu panel are still in "crt_planes" (the forward pass of a gradient call converted all rows in one
     // chunk): the backward pass forms its adjoint panel from them on the int8 pipe (crt_gemm.hip).  Valid between that forward and the
@@ -285,6 +289,13 @@ int crt_scales(oak_ctx* ctx, const PreparedKernel& pk, const Feat& FX, const Fea
 int crt_convert_panel(oak_ctx* ctx, const CrtPlan& pl, const double* d_panel, int64_t ldp, int64_t na);
 // d_phi_lo (may be NULL): the low word of the double-double Phi (the integer Gram matrix holds ~118 bits)
 int crt_accumulate(oak_ctx* ctx, const CrtPlan& pl, int64_t M, bool first_chunk, bool last_chunk, double* d_phi, double* d_phi_lo);
+// exponents e_m with bound_m < 2^e_m for |K(x, z_m)| over ANY x (a-priori: rank-independent), into the int buffer d_eexp[M] (crt.hip)
+bool comm_dd_rule(const oak_ctx* ctx, int64_t M);      // sgpr.hip
+int crt_bound_exponents(oak_ctx* ctx, const PreparedKernel& pk, const Feat& FZ, int64_t M, int* d_eexp);
+// exact exchange of Phi between ranks (ddgemm.hip): split the (double-double) Phi in place into the high limb (the Phi slot itself) and the
+// low limb d_lo on the grid 2^(e_a + e_b + en - 51); after the all-reduce of both, join them into Phi (one double) and its low word
+int dd_exchange_split(oak_ctx* ctx, double* d_phi, const double* d_phi_lo, const int* d_eexp, int en, int lo_bits, int64_t M, double* d_lo);
+int dd_exchange_join(oak_ctx* ctx, double* d_phi, const double* d_lo, int64_t M, double* d_phi_lo);
 // adjoint panel G = Kfu H on the int8 pipe from the planes of `pl` (crt_gemm.hip)
 int crt_gemm_adjoint(oak_ctx* ctx, const CrtPlan& pl, int64_t M, int64_t na, const double* d_H, double* d_G, int64_t ldg);
 // [W ; (L^-1 psi)^T] = [L^-1 Phi L^-T ; (L^-1 psi)^T] in double-double arithmetic from the double-double Phi (ddgemm.hip), one double out

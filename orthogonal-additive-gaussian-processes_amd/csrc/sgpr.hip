@@ -289,7 +289,16 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     // route then has the whitened route's accuracy at any conditioning, so the auto route never pays the N-sized triangular solve
     // (the tail looks at the conditioning estimate and picks the fp64 or the double-double M^3 products).  One rank only: a sum of
     // shards in fp64 would round Phi again.
-    const bool dd_tail = crt_cand && (ctx->comm == nullptr || ctx->nranks <= 1) && (M % 32) == 0 && getenv("OAK_NO_TAIL_DD") == nullptr;
+    // More than one rank: the shards' Phi are summed exactly (comm.hip) when comm_dd_rule -- rank-independent inputs only -- says so; every
+    // rank then follows it whatever its own accumulation turned out to be (a rank that fell back to the fp64 kernels contributes its fp64 Phi).
+    const bool one_rank = ctx->comm == nullptr || ctx->nranks <= 1;
+    ctx->comm_dd = !one_rank && comm_dd_rule(ctx, M);
+    const bool dd_tail = ((crt_cand && one_rank) || ctx->comm_dd) && (M % 32) == 0 && getenv("OAK_NO_TAIL_DD") == nullptr;
+    if (ctx->comm_dd) {
+        int* d_eexp = nullptr;
+        OAK_CHECK(get_buf_t(ctx, "dd_eexp", (size_t)M, &d_eexp));
+        OAK_CHECK(crt_bound_exponents(ctx, pk, FZ, M, d_eexp));
+    }
     if (ctx->auto_pending && dd_tail) {
         ctx->auto_whiten = 0;
         ctx->auto_pending = false;
@@ -487,6 +496,17 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
 // problems measured (tests/dev), so the switch keeps the ELBO within ~1e-10 of the literal route.
 // The size rule looks at the rows of ALL shards (sgpr_route_rows): ranks whose shards differ by a row must not land on
 // opposite sides of the threshold.
+// Exact exchange of Phi under a communicator (and with it the double-double tail, and an auto route that never whitens): decided from what
+// every rank of a job shares -- the mode, the route, M, the declared global row count -- never from this rank's rows or allocations.
+bool comm_dd_rule(const oak_ctx* ctx, int64_t M) {
+    if (ctx->comm == nullptr || ctx->nranks <= 1 || ctx->nranks > 1024 || ctx->n_global_user <= 0 || ctx->route == 2) return false;
+    if (getenv("OAK_NO_TAIL_DD") != nullptr || getenv("OAK_NO_COMM_DD") != nullptr) return false;
+    // the host-exchange communicator (a TCP / gloo control plane: ~0.5 GB/s measured) pays 8 M^2 more bytes per evaluation dearly -- 16 -> 38 ms
+    // at M = 1024 with two ranks: there only on request (OAK_COMM_DD=1; every rank's environment alike)
+    if (ctx->host_allreduce != nullptr && !(getenv("OAK_COMM_DD") != nullptr && atoi(getenv("OAK_COMM_DD")) == 1)) return false;
+    const bool mode = ctx->precision == 2 || (ctx->precision == -1 && M >= 640 && getenv("OAK_NO_AUTO_CRT") == nullptr);
+    return mode && (M % 32) == 0 && ((M + 255) / 256) * 256 <= 4096;
+}
 int64_t sgpr_route_rows(const oak_ctx* ctx) {
     if (ctx->n_global_user > 0) return ctx->n_global_user;
     if (ctx->comm != nullptr && ctx->nranks > 1 && ctx->n_global_comm > 0) return ctx->n_global_comm;

@@ -382,3 +382,119 @@ def test_int8_adjoint_gemm_steps_aside_on_ill_conditioned_kuu():
     assert ctx.bench_crt_info()["gemm_planes"] >= 13
     assert np.abs(gf - gw).max() > 10 * np.abs(g - gw).max()
     ctx.close()
+
+
+def _two_rank_job(spec, X, y, Z, split, fn, route="auto", precision="auto"):
+    """Two host-exchange ranks on one GPU (two threads, the callback is a two-party sum through a barrier): fn(ctx, desc) runs on both.
+    (OAK_COMM_DD=1: the exact exchange of Phi is on request only under the host-exchange communicator -- it doubles the bytes a slow control
+    plane carries; under RCCL and the loopback communicator it is the default.)"""
+    import threading
+    if "OAK_NO_COMM_DD" not in os.environ: os.environ["OAK_COMM_DD"] = "1"
+    d = _capi.KernelDesc(spec)
+    ranks = []
+    for lo, hi in ((0, split), (split, len(X))):
+        c = _capi.HipContext(0)
+        c.sgpr_set_data(X[lo:hi], y[lo:hi]); c.sgpr_set_inducing(Z); c.sgpr_set_route(route); c.sgpr_set_precision(precision)
+        c.sgpr_set_global_rows(len(X))
+        ranks.append(c)
+    bar = threading.Barrier(2)
+    slots = [None, None]
+
+    def make_cb(r):
+        def cb(a):
+            slots[r] = a
+            bar.wait()
+            out = slots[0] + slots[1]
+            bar.wait()
+            return out
+        return cb
+    for r, c in enumerate(ranks):
+        c.comm_init_host(2, r, make_cb(r))
+    res = {}
+
+    def run(r, c):
+        res[r] = fn(c, d)
+    th = [threading.Thread(target=run, args=(r, c)) for r, c in enumerate(ranks)]
+    [t.start() for t in th]; [t.join(300) for t in th]
+    os.environ.pop("OAK_COMM_DD", None)
+    assert not any(t.is_alive() for t in th)
+    return ranks, res
+
+
+def test_two_ranks_sum_phi_exactly_and_keep_the_phi_route_on_ill_conditioned_kuu():
+    """Under a communicator the shards' Phi used to be summed in fp64, so an ill-conditioned Kuu sent every rank through the N-sized
+    triangular solve.  Now each rank splits its exact (double-double) Phi into two fixed-point limbs on a grid all ranks share, the two fp64
+    all-reduces are exact, and the double-double tail serves the sum: the auto route stays on the phi route and meets the oracle to 1e-10 on
+    every term -- bit-identical on both ranks."""
+    spec, X, y, Z = _ill_conditioned(90000, 768, 8, 1.5, seed=5)
+    ref, parts = c_oracle.sgpr_elbo_chunked(spec, X, y, Z, 0.01, chunk=8192, return_parts=True)
+
+    def job(c, d):
+        e, g = c.sgpr_elbo_grad(d, 0.01)
+        return e, g, c.sgpr_last_terms(), c.sgpr_stats_whitened(), c.sgpr_stats_precision(), c.bench_crt_info()
+    ranks, res = _two_rank_job(spec, X, y, Z, 41000, job)
+    for r in (0, 1):
+        e, g, t, whitened, prec, info = res[r]
+        assert not whitened and prec == "int8crt" and info["tail_dd"] == 1 and t["cond_estimate"] > 1e2, (whitened, prec, info)
+        cases.assert_terms_match(t, parts["terms"], rtol=1e-10, what=f"rank {r}, two shards, exact exchange of Phi:")
+        scale = max(abs(ref), 0.5 * abs(parts["terms"]["cTc"]), 0.5 * abs(parts["terms"]["tr_AAT"]))
+        assert abs(e - ref) <= 1e-10 * scale, (e, ref)
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1])
+    for c in ranks: c.close()
+    # the same job with the exchange switched off: the old rule whitens (rank 0's estimate), and agrees
+    try:
+        os.environ["OAK_NO_COMM_DD"] = "1"
+        ranks, res2 = _two_rank_job(spec, X, y, Z, 41000, job)
+    finally:
+        os.environ.pop("OAK_NO_COMM_DD", None)
+    assert res2[0][3] and res2[1][3]
+    assert abs(res2[0][0] - res[0][0]) <= 2e-10 * scale           # (the total is a difference of terms a few hundred times its size)
+    np.testing.assert_allclose(res[0][1], res2[0][1], rtol=1e-5, atol=1e-6 * np.abs(res2[0][1]).max())
+    for c in ranks: c.close()
+
+
+def test_two_ranks_exact_exchange_equals_one_rank_on_a_well_conditioned_problem():
+    """Same protocol, well-conditioned Kuu, ragged shards: the two-rank ELBO / gradient equal the one-rank evaluation of the same rows to
+    rounding, and one rank that cannot take the int8 route (too few rows) still follows the exchange with its fp64 Phi."""
+    spec, X, y, Z = _problem(70001, 8, 768, 2, ("gaussian",), seed=41, ls=(0.4, 0.7))
+    one = _capi.HipContext(0)
+    d1 = _capi.KernelDesc(spec)
+    one.sgpr_set_data(X, y); one.sgpr_set_inducing(Z)
+    e1, g1 = one.sgpr_elbo_grad(d1, 0.05)
+    assert one.sgpr_stats_precision() == "int8crt" and not one.sgpr_stats_whitened()
+    one.close()
+
+    def job(c, d):
+        e, g = c.sgpr_elbo_grad(d, 0.05)
+        return e, g, c.sgpr_stats_whitened(), c.sgpr_stats_precision()
+    for split in (35000, 68001):                   # second: rank 1 holds 2000 rows -- fp64 kernels there
+        ranks, res = _two_rank_job(spec, X, y, Z, split, job)
+        assert not res[0][2] and not res[1][2] and res[0][3] == "int8crt"
+        assert res[1][3] == ("int8crt" if split == 35000 else "fp64")
+        assert abs(res[0][0] - e1) <= 1e-12 * abs(e1) and res[0][0] == res[1][0]
+        np.testing.assert_allclose(res[0][1], g1, rtol=1e-9, atol=1e-10 * np.abs(g1).max())
+        for c in ranks: c.close()
+
+
+def test_loopback_eight_ranks_exact_exchange_on_ill_conditioned_kuu():
+    """The loopback communicator (world 8: every collective returns 8 x the local vector, i.e. eight ranks holding the same shard) runs the
+    exact exchange by default: the limbs are multiplied by 8 without rounding, the double-double tail serves the sum, and the result is the
+    oracle's on the shard repeated eight times."""
+    spec, X, y, Z = _ill_conditioned(36000, 768, 8, 1.5, seed=7)
+    X8, y8 = np.tile(X, (8, 1)), np.tile(y, (8, 1))
+    ref, parts = c_oracle.sgpr_elbo_chunked(spec, X8, y8, Z, 0.01, chunk=16384, return_parts=True)
+    ctx = _capi.HipContext(0)
+    d = _capi.KernelDesc(spec)
+    ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_global_rows(len(X8))
+    ctx.comm_init_loopback(8)
+    e = ctx.sgpr_elbo(d, 0.01)
+    t = ctx.sgpr_last_terms()
+    assert not ctx.sgpr_stats_whitened() and ctx.sgpr_stats_precision() == "int8crt" and ctx.bench_crt_info()["tail_dd"] == 1
+    cases.assert_terms_match(t, parts["terms"], rtol=1e-10, what="loopback x 8, exact exchange:")
+    scale = max(abs(ref), 0.5 * abs(parts["terms"]["cTc"]), 0.5 * abs(parts["terms"]["tr_AAT"]))
+    assert abs(e - ref) <= 1e-10 * scale, (e, ref)
+    # undeclared global row count: no rank-independent bound for the limbs' grid -- the old rule (rank 0's estimate) whitens
+    ctx.sgpr_set_global_rows(0)
+    ew = ctx.sgpr_elbo(d, 0.01)
+    assert ctx.sgpr_stats_whitened() and abs(ew - ref) <= 2e-10 * scale
+    ctx.close()
