@@ -287,8 +287,8 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     }
     // With the int8 route Phi is exact (a double-double) and the tail can whiten it in double-double arithmetic (ddgemm.hip): the phi
     // route then has the whitened route's accuracy at any conditioning, so the auto route never pays the N-sized triangular solve
-    // (the tail looks at the conditioning estimate and picks the fp64 or the double-double M^3 products).  One rank only: a sum of
-    // shards in fp64 would round Phi again.
+    // (the tail looks at the conditioning estimate and picks the fp64 or the double-double M^3 products).  One rank, or several that sum their
+    // shards' Phi exactly (comm_dd below): a sum of shards in fp64 would round Phi again.
     // More than one rank: the shards' Phi are summed exactly (comm.hip) when comm_dd_rule -- rank-independent inputs only -- says so; every
     // rank then follows it whatever its own accumulation turned out to be (a rank that fell back to the fp64 kernels contributes its fp64 Phi).
     const bool one_rank = ctx->comm == nullptr || ctx->nranks <= 1;
