@@ -96,6 +96,17 @@ def test_fullsize_gradient_directional_check(problem):
     ctx = _capi.HipContext(0)
     ctx.sgpr_set_data(X, y); ctx.sgpr_set_inducing(Z); ctx.sgpr_set_route("phi")
     e, g = ctx.sgpr_elbo_grad(_capi.KernelDesc(spec), 0.01)
+    # at this size the default forms the adjoint panel Kfu H on the int8 pipe (csrc/crt_gemm.hip): held against the fp64 GEMM on the same statistics
+    info = ctx.bench_crt_info()
+    assert ctx.sgpr_stats_precision() == "int8crt" and info["gemm_planes"] >= 13 and info["gemm_bits"] >= 44, info
+    import os
+    try:
+        os.environ["OAK_CRT_GEMM"] = "0"
+        e0, g0 = ctx.sgpr_elbo_grad(_capi.KernelDesc(spec), 0.01)
+    finally:
+        os.environ.pop("OAK_CRT_GEMM", None)
+    assert ctx.bench_crt_info()["gemm_planes"] == 0 and e0 == e
+    np.testing.assert_allclose(g, g0, rtol=0, atol=1e-12 * np.abs(g0).max())
     rng = np.random.default_rng(1)
     v_ls, v_ov, v_n = rng.uniform(-1, 1, D), rng.uniform(-1, 1, R + 1), 0.01 * rng.uniform(-1, 1)
 
@@ -178,6 +189,7 @@ def test_c5_size_mixed_kernel_properties():
     import copy
     ctx.sgpr_set_data(X, y); ctx.sgpr_set_route("phi")
     e0, g = ctx.sgpr_elbo_grad(d, 0.01)
+    assert ctx.bench_crt_info()["gemm_planes"] >= 13                     # int8 adjoint GEMM at M = 2048 (two 1024-term folds per plane)
     rng = np.random.default_rng(1)
     v_ls = rng.uniform(-1, 1, D5) * np.array([dm["type"] == "rbf" for dm in spec["dims"]])
     v_ov = rng.uniform(-1, 1, R5 + 1)
