@@ -1429,7 +1429,12 @@ int oak_sgpr_elbo_grad_z(oak_ctx* ctx, const oak_kernel_desc* desc, double noise
     ctx->grad_int8 = getenv("OAK_CRT_GEMM") == nullptr || atoi(getenv("OAK_CRT_GEMM")) != 0;
     const int frc = sgpr_forward(ctx, pk, noise_var, jitter, &elbo, terms);
     ctx->keep_kfu = false;
-    const bool planes_here = ctx->crt_planes_valid && ctx->grad_int8 && !ctx->stats_whitened;
+    bool planes_here = ctx->crt_planes_valid && ctx->grad_int8 && !ctx->stats_whitened;
+    if (planes_here && !(getenv("OAK_CRT_GEMM") != nullptr && atoi(getenv("OAK_CRT_GEMM")) == 1)) {
+        // the conditioning rule of the int8 product (sgpr.hip: the forward pass applied it already when the estimate arrived before its Gram
+        // launch; in a partitioned pass it arrives later)
+        planes_here = ctx->cond_seen && sgpr_cond_estimate_ok_for_int8_gemm(ctx);
+    }
     const bool panel_here = ctx->crt_panel_written || !ctx->stats_crt;      // an int8-route forward writes the fp64 panel only on request
     ctx->crt_planes_valid = false;
     ctx->grad_int8 = false;

@@ -291,6 +291,7 @@ int crt_convert_panel(oak_ctx* ctx, const CrtPlan& pl, const double* d_panel, in
 int crt_accumulate(oak_ctx* ctx, const CrtPlan& pl, int64_t M, bool first_chunk, bool last_chunk, double* d_phi, double* d_phi_lo);
 // exponents e_m with bound_m < 2^e_m for |K(x, z_m)| over ANY x (a-priori: rank-independent), into the int buffer d_eexp[M] (crt.hip)
 bool comm_dd_rule(const oak_ctx* ctx, int64_t M);      // sgpr.hip
+bool sgpr_cond_estimate_ok_for_int8_gemm(oak_ctx* ctx);  // sgpr.hip
 int crt_bound_exponents(oak_ctx* ctx, const PreparedKernel& pk, const Feat& FZ, int64_t M, int* d_eexp);
 // exact exchange of Phi between ranks (ddgemm.hip): split the (double-double) Phi in place into the high limb (the Phi slot itself) and the
 // low limb d_lo on the grid 2^(e_a + e_b + en - 51); after the all-reduce of both, join them into Phi (one double) and its low word

@@ -350,17 +350,22 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
     // double-double tail; the side stream's reading arrives while the main stream featurizes (~0.2 ms of waiting in a gradient call).
     // OAK_CRT_GEMM=1 skips the check (experiments).
     bool int8_bwd = ctx->keep_kfu && ctx->grad_int8 && crt_fused && rows >= N;
+    bool skip_panel = int8_bwd;           // ... and then the forward pass need not write the fp64 panel
     if (int8_bwd && !(getenv("OAK_CRT_GEMM") != nullptr && atoi(getenv("OAK_CRT_GEMM")) == 1)) {
         if (ctx->cond_requested && ctx->kuu_async && !ctx->kuu_deferred) {
             OAK_HIP_CHECK(hipEventSynchronize(ctx->ev2));
             const double ratio = ctx->cond_mm[1] / ctx->cond_mm[0];
-            int8_bwd = ratio * ratio <= CRT_GEMM_MAX_DIAG_RATIO2;
+            int8_bwd = skip_panel = ratio * ratio <= CRT_GEMM_MAX_DIAG_RATIO2;
+        } else if (ctx->cond_requested && ctx->kuu_async) {
+            // partitioned pass (row shards, small N): the factorisation chain is only enqueued behind the first Gram launch, its estimate
+            // is not there yet -- the panel is written (cheap at these sizes) and the backward pass decides with the estimate in hand
+            skip_panel = false;
         } else {
-            int8_bwd = false;
+            int8_bwd = skip_panel = false;
         }
     }
     if (ctx->keep_kfu) ctx->grad_int8 = int8_bwd;
-    const bool crt_panel = (ctx->keep_kfu && !int8_bwd) || ctx->n_extra > 0;
+    const bool crt_panel = (ctx->keep_kfu && !skip_panel) || ctx->n_extra > 0;
     bool use_crt = false;
     for (int64_t a0 = 0; a0 < N; a0 += rows, ++chunk_idx) {
         const int64_t na = (a0 + rows <= N) ? rows : N - a0;
@@ -498,6 +503,12 @@ int sgpr_local_stats(oak_ctx* ctx, const PreparedKernel& pk, double jitter) {
 // opposite sides of the threshold.
 // Exact exchange of Phi under a communicator (and with it the double-double tail, and an auto route that never whitens): decided from what
 // every rank of a job shares -- the mode, the route, M, the declared global row count -- never from this rank's rows or allocations.
+// the side stream's estimate (max diag L / min diag L)^2 of this evaluation against the int8 adjoint GEMM's limit (crt_gemm.hip)
+bool sgpr_cond_estimate_ok_for_int8_gemm(oak_ctx* ctx) {
+    if (hipEventSynchronize(ctx->ev2) != hipSuccess) { (void)hipGetLastError(); return false; }
+    const double ratio = ctx->cond_mm[1] / ctx->cond_mm[0];
+    return ratio * ratio <= CRT_GEMM_MAX_DIAG_RATIO2;
+}
 bool comm_dd_rule(const oak_ctx* ctx, int64_t M) {
     if (ctx->comm == nullptr || ctx->nranks <= 1 || ctx->nranks > 1024 || ctx->n_global_user <= 0 || ctx->route == 2) return false;
     if (getenv("OAK_NO_TAIL_DD") != nullptr || getenv("OAK_NO_COMM_DD") != nullptr) return false;

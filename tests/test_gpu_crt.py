@@ -318,13 +318,15 @@ def _with_env(name, value, fn):
 
 
 @pytest.mark.parametrize("N,D,M,kinds,ls", [(50001, 7, 640, ("gaussian", "uniform", "gaussian", "categorical"), (0.3, 0.5)),
-                                              (65536, 8, 1024, ("gaussian",), (0.35, 0.6))])
+                                              (65536, 8, 1024, ("gaussian",), (0.35, 0.6)),
+                                              (196608, 8, 1024, ("gaussian",), (0.35, 0.6))])      # a row shard's size: the partitioned forward pass
 def test_int8_adjoint_gemm_of_the_gradient(N, D, M, kinds, ls):
     """csrc/crt_gemm.hip: a gradient call whose forward pass took the int8 route forms the adjoint panel Kfu H from the residue planes
     (LDS transpose reads, one int8 GEMM per modulus, fp64 fraction reconstruction) when chol(Kuu) looks well-conditioned.  Its operands
     are 49-51-bit fixed-point numbers per column: the gradient is held to 1e-10 of its largest entry against the fp64 GEMM and against
     the fp64 kernels (measured 1e-12 .. 6e-12).  Ragged N and M (plane columns padded to 768), a discrete sub-kernel, further output
-    columns, the gradient w.r.t. the inducing inputs.  (Short lengthscales: the estimate of these problems is 27 and 31.)"""
+    columns, the gradient w.r.t. the inducing inputs.  (Short lengthscales: the estimate of these problems is 27 and 31.)  In a partitioned
+    forward pass (small N, row shards) the estimate arrives behind the first Gram launch: the fp64 panel is written and the backward decides."""
     spec, X, y, Z = _problem(N, D, M, 2, kinds, seed=31, ls=ls)
     ctx = _capi.HipContext(0)
     d = _capi.KernelDesc(spec)
