@@ -13,7 +13,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 ctx = _capi.default_context()
 KINDS = [("gaussian",), ("gaussian", "binary"), ("gaussian", "categorical", "binary", "uniform"), ("gaussian", "mog"), ("gauss2", "gaussian")]
 for it in range(ncase):
-    N = int(rng.integers(4096, 120000)); M = int(rng.choice([96, 200, 256, 300, 512, 640, 768, 1000, 1024, 1500, 2048])); D = int(rng.integers(2, 24)); R = int(rng.integers(1, min(D, 4) + 1))
+    N = int(rng.integers(4096, 120000)); M = int(rng.choice([96, 200, 256, 300, 512, 640, 768, 1000, 1024, 1500, 2048, 3000, 4096])); D = int(rng.integers(2, 24)); R = int(rng.integers(1, min(D, 4) + 1))
     kinds = KINDS[int(rng.integers(len(KINDS)))]
     spec = cases.random_spec(rng, D, R, kinds, share=bool(rng.integers(2)))
     for dim in spec["dims"]:
